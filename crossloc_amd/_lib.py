@@ -1,0 +1,49 @@
+"""ctypes binding of libcrossloc_hip.so (the C ABI declared in include/*.h).
+
+The product path has no CPU fallback: if the HIP library is missing this raises, loudly.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcrossloc_hip.so")
+_lib = None
+
+c_i32, c_i64, c_u32, c_u64 = ctypes.c_int, ctypes.c_int64, ctypes.c_uint32, ctypes.c_uint64
+c_f, c_vp = ctypes.c_float, ctypes.c_void_p
+
+
+class XlError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise XlError("libcrossloc_hip.so is not built (%s). Run `python -m crossloc_amd.build` "
+                          "(or __graft_entry__.build()); there is no CPU fallback." % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        L.xl_status_string.restype = ctypes.c_char_p
+        L.xl_status_string.argtypes = [c_i32]
+        L.xl_last_hip_error.restype = ctypes.c_char_p
+        L.xl_dsac_forward_rgb_batch.restype = c_i32
+        L.xl_dsac_forward_rgb_batch.argtypes = [c_vp, c_i64, c_i64, c_i64, c_i64, c_i32, c_i32, c_i32, c_vp,
+                                                c_i32, c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_vp,
+                                                c_u64, c_u64, c_u64, c_u32, c_vp, c_vp, c_vp, c_vp, c_vp]
+        L.xl_dsac_forward_rgb_host.restype = c_i32
+        L.xl_dsac_forward_rgb_host.argtypes = [c_vp, c_i64, c_i64, c_i64, c_i32, c_i32, c_vp, c_i32, c_f, c_f, c_f,
+                                               c_f, c_f, c_f, c_i32, c_u64, c_u64, c_u32, c_vp, c_vp, c_vp, c_vp]
+        for name in ("xl_dsac_backward_rgb", "xl_dsac_forward_rgbd", "xl_dsac_backward_rgbd"):
+            getattr(L, name).restype = c_i32
+        _lib = L
+    return _lib
+
+
+def check(status):
+    if status != 0:
+        L = lib()
+        msg = L.xl_status_string(status).decode()
+        if status == -3:
+            msg += ": " + L.xl_last_hip_error().decode()
+        raise XlError("crossloc_hip: %s (status %d)" % (msg, status))

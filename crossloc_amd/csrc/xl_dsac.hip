@@ -1,0 +1,954 @@
+// xl_dsac.hip — MI355X (gfx950) kernel bundle for CrossLoc's DSAC* pose solver.
+//
+// Replaces dsacstar_rgb_forward (/root/reference/dsacstar/dsacstar.cpp:63-178) behind the C ABI of
+// include/crossloc_dsac.h.  One 256-thread workgroup (4 wavefronts) per image, everything in one launch:
+//
+//   stage      scene coordinates -> LDS as SoA planes (64.8 KB for 60x90), read by every later phase
+//   sample     wavefront w owns hypotheses w, w+4, ...; the 64 lanes evaluate 64 consecutive tries of
+//              one hypothesis in parallel (counter-based RNG keyed by try index, one P3P per lane);
+//              __ballot picks the lowest accepted try = the reference's "first accepted try"
+//              (sampleHypotheses, dsacstar_util.h:135-221)
+//   score      the same wavefront projects all cells through the accepted pose (lanes stride the
+//              cells), soft-inlier sigmoid, xor-butterfly reduction (getReproErrs + getHypScores,
+//              dsacstar_util.h:316-343, 356-446); error maps never leave registers
+//   select     argmax with first-maximum-wins across the 4 wavefronts through LDS (softMax/draw,
+//              dsacstar_util.h:684-752)
+//   refine     all 256 threads: inlier set, Levenberg-Marquardt PnP on the inliers (28 wave-reduced
+//              sums per evaluation, 6x6 Cholesky redundantly in every thread so control flow stays
+//              uniform without broadcasts), repeat while the inlier count grows (refineHyp,
+//              dsacstar_util.h:522-597)
+//   write      inverse rigid transform as float 4x4 (pose2trans, dsacstar_util.h:759-770)
+//
+// Arithmetic contract: compiled with -ffp-contract=off; every transcendental is a fixed polynomial in
+// + - * / sqrt; reductions use a fixed order.  tests/test_dsac_gpu.py checks sampled cells, tries,
+// scores, winner and refined pose against oracle/dsac_oracle.c bit for bit.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/crossloc_dsac.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kWaves = kThreads / 64;
+constexpr int kMaxCellsPerThread = 64;
+constexpr int kMaxCells = kThreads * kMaxCellsPerThread;     // 16384
+constexpr int kLmMaxIter = 20;                               // cv::solvePnP ITERATIVE term criteria
+constexpr double kFltEps = 1.1920928955078125e-07;
+
+struct Pose { double R[9]; double t[3]; };                   // world -> camera
+
+// ------------------------------------------------------------------------------ deterministic math
+
+__device__ __forceinline__ double pow2i(int k)
+{
+    return __longlong_as_double((long long)(k + 1023) << 52);
+}
+
+__device__ __forceinline__ double det_exp(double x)
+{
+    if (x != x) return x;
+    if (x > 709.0) return __longlong_as_double(0x7ff0000000000000LL);
+    if (x < -708.0) return 0.0;
+    const double INV_LN2 = 0x1.71547652b82fep+0;
+    const double LN2_HI = 0x1.62e42f8000000p-1;
+    const double LN2_LO = 0x1.be8e7bcd5e4f2p-27;
+    double kf = floor(x * INV_LN2 + 0.5);
+    double r = (x - kf * LN2_HI) - kf * LN2_LO;
+    double p = 1.0 / 87178291200.0;
+    p = p * r + 1.0 / 6227020800.0;
+    p = p * r + 1.0 / 479001600.0;
+    p = p * r + 1.0 / 39916800.0;
+    p = p * r + 1.0 / 3628800.0;
+    p = p * r + 1.0 / 362880.0;
+    p = p * r + 1.0 / 40320.0;
+    p = p * r + 1.0 / 5040.0;
+    p = p * r + 1.0 / 720.0;
+    p = p * r + 1.0 / 120.0;
+    p = p * r + 1.0 / 24.0;
+    p = p * r + 1.0 / 6.0;
+    p = p * r + 0.5;
+    p = p * r + 1.0;
+    p = p * r + 1.0;
+    return p * pow2i((int)kf);
+}
+
+__device__ __forceinline__ void det_sincos(double x, double &s, double &c)
+{
+    const double TWO_OVER_PI = 0x1.45f306dc9c883p-1;
+    const double PIO2_HI = 0x1.921fb50000000p+0;
+    const double PIO2_LO = 0x1.110b4611a6263p-26;
+    double kf = floor(x * TWO_OVER_PI + 0.5);
+    double r = (x - kf * PIO2_HI) - kf * PIO2_LO;
+    double r2 = r * r;
+    double ps = -1.0 / 355687428096000.0;
+    ps = ps * r2 + 1.0 / 1307674368000.0;
+    ps = ps * r2 - 1.0 / 6227020800.0;
+    ps = ps * r2 + 1.0 / 39916800.0;
+    ps = ps * r2 - 1.0 / 362880.0;
+    ps = ps * r2 + 1.0 / 5040.0;
+    ps = ps * r2 - 1.0 / 120.0;
+    ps = ps * r2 + 1.0 / 6.0;
+    double sr = r - r * r2 * ps;
+    double pc = -1.0 / 6402373705728000.0;
+    pc = pc * r2 + 1.0 / 20922789888000.0;
+    pc = pc * r2 - 1.0 / 87178291200.0;
+    pc = pc * r2 + 1.0 / 479001600.0;
+    pc = pc * r2 - 1.0 / 3628800.0;
+    pc = pc * r2 + 1.0 / 40320.0;
+    pc = pc * r2 - 1.0 / 720.0;
+    pc = pc * r2 + 1.0 / 24.0;
+    double cr = 1.0 - r2 * (0.5 - r2 * pc);
+    double q = kf - 4.0 * floor(kf * 0.25);
+    int qi = (int)q;
+    if (qi == 0) { s = sr; c = cr; }
+    else if (qi == 1) { s = cr; c = -sr; }
+    else if (qi == 2) { s = -sr; c = -cr; }
+    else { s = -cr; c = sr; }
+}
+
+// ------------------------------------------------------------------------------ counter-based RNG
+
+__device__ __forceinline__ uint64_t mix64(uint64_t z)
+{
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+    return z ^ (z >> 31);
+}
+
+__device__ __forceinline__ uint64_t try_state(uint64_t imageKey, uint32_t hyp, uint32_t t)
+{
+    return mix64(imageKey ^ (((uint64_t)hyp << 32) | (uint64_t)t));
+}
+
+__device__ __forceinline__ int draw(uint64_t state, int j, int n)
+{
+    uint64_t r = mix64(state + 0x9e3779b97f4a7c15ULL * (uint64_t)(j + 1));
+    uint32_t hi = (uint32_t)(r >> 32);
+    return (int)(((uint64_t)hi * (uint64_t)(uint32_t)n) >> 32);
+}
+
+// ------------------------------------------------------------------------------ camera + coordinates
+
+struct Cam { double f, cx, cy; float thr, alpha, maxReproj; int sub, Ho, Wo, N; };
+
+// scene coordinates of the image: SoA planes in LDS
+struct Coords {
+    const float *sx, *sy, *sz;
+    __device__ __forceinline__ void fetch(int i, double &X, double &Y, double &Z) const
+    {
+        X = (double)sx[i]; Y = (double)sy[i]; Z = (double)sz[i];
+    }
+};
+
+__device__ __forceinline__ void project(const Pose &p, double X, double Y, double Z, const Cam &cam,
+                                        float &u, float &v)
+{
+    double xc = p.R[0] * X + p.R[1] * Y + p.R[2] * Z + p.t[0];
+    double yc = p.R[3] * X + p.R[4] * Y + p.R[5] * Z + p.t[1];
+    double zc = p.R[6] * X + p.R[7] * Y + p.R[8] * Z + p.t[2];
+    double z = (zc != 0.0) ? 1.0 / zc : 1.0;
+    double x = xc * z, y = yc * z;
+    u = (float)(x * cam.f + cam.cx);
+    v = (float)(y * cam.f + cam.cy);
+}
+
+__device__ __forceinline__ float cell_err(const Pose &p, const Coords &co, int i, const Cam &cam)
+{
+    int y = i / cam.Wo, x = i - y * cam.Wo;
+    double X, Y, Z;
+    co.fetch(i, X, Y, Z);
+    float u, v;
+    project(p, X, Y, Z, cam, u, v);
+    float px = (float)(x * cam.sub + cam.sub / 2), py = (float)(y * cam.sub + cam.sub / 2);
+    float dx = px - u, dy = py - v;
+    double n = sqrt((double)dx * (double)dx + (double)dy * (double)dy);
+    float a = (float)n;
+    return (cam.maxReproj < a) ? cam.maxReproj : a;
+}
+
+// ------------------------------------------------------------------------------ quartic (Ferrari)
+
+__device__ __forceinline__ double cubic_pos_root(double c2, double c1, double c0)
+{
+    double m = fabs(c2);
+    if (fabs(c1) > m) m = fabs(c1);
+    if (fabs(c0) > m) m = fabs(c0);
+    double lo = 0.0, hi = 1.0 + m;
+    double z = hi;
+    for (int it = 0; it < 128; ++it) {
+        double g = ((z + c2) * z + c1) * z + c0;
+        double dg = (3.0 * z + 2.0 * c2) * z + c1;
+        if (g > 0.0) hi = z; else lo = z;
+        if (g == 0.0) break;
+        double zn = z - g / dg;
+        if (!(zn > lo && zn < hi)) zn = 0.5 * (lo + hi);
+        if (zn == z || !(hi > lo)) break;
+        z = zn;
+    }
+    return z;
+}
+
+__device__ __forceinline__ bool quadratic(double b, double c, double &r0, double &r1)
+{
+    double disc = b * b - 4.0 * c;
+    if (!(disc >= 0.0)) return false;
+    double sq = sqrt(disc);
+    double q = (b >= 0.0) ? -0.5 * (b + sq) : -0.5 * (b - sq);
+    if (q != 0.0) { r0 = q; r1 = c / q; }
+    else { r0 = 0.0; r1 = 0.0; }
+    return true;
+}
+
+// roots land in four fixed slots (valid mask bit i) in the order the oracle appends them
+__device__ __forceinline__ unsigned quartic(double A4, double A3, double A2, double A1, double A0,
+                                            double &x0, double &x1, double &x2, double &x3)
+{
+    double a = A3 / A4, b = A2 / A4, c = A1 / A4, d = A0 / A4;
+    double a2 = a * a;
+    double p = b - 0.375 * a2;
+    double q = c - 0.5 * a * b + 0.125 * a2 * a;
+    double r = d - 0.25 * a * c + 0.0625 * a2 * b - (3.0 / 256.0) * a2 * a2;
+    double shift = -0.25 * a;
+    unsigned mask = 0;
+    x0 = x1 = x2 = x3 = 0.0;
+    double z0 = cubic_pos_root(2.0 * p, p * p - 4.0 * r, -(q * q));
+    if (z0 > 0.0) {
+        double s = sqrt(z0);
+        double h = 0.5 * (p + z0);
+        double g = 0.5 * q / s;
+        double r0, r1;
+        if (quadratic(s, h - g, r0, r1)) { x0 = r0 + shift; x1 = r1 + shift; mask |= 3u; }
+        if (quadratic(-s, h + g, r0, r1)) { x2 = r0 + shift; x3 = r1 + shift; mask |= 12u; }
+    } else {
+        double w0, w1;
+        if (quadratic(p, r, w0, w1)) {
+            if (w0 >= 0.0) { double y = sqrt(w0); x0 = y + shift; x1 = -y + shift; mask |= 3u; }
+            if (w1 >= 0.0) { double y = sqrt(w1); x2 = y + shift; x3 = -y + shift; mask |= 12u; }
+        }
+    }
+    return mask;
+}
+
+// ------------------------------------------------------------------------------ P3P + 4th point
+
+struct V3 { double x, y, z; };
+
+__device__ __forceinline__ V3 cross3(V3 a, V3 b)
+{
+    return V3{ a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x };
+}
+
+struct Frame { V3 e1, e2, e3; };
+
+__device__ __forceinline__ bool frame_of(V3 A, V3 B, V3 C, Frame &F)
+{
+    V3 ab{ B.x - A.x, B.y - A.y, B.z - A.z };
+    V3 ac{ C.x - A.x, C.y - A.y, C.z - A.z };
+    double n1 = sqrt(ab.x * ab.x + ab.y * ab.y + ab.z * ab.z);
+    if (!(n1 > 0.0)) return false;
+    F.e1 = V3{ ab.x / n1, ab.y / n1, ab.z / n1 };
+    V3 nn = cross3(ab, ac);
+    double n3 = sqrt(nn.x * nn.x + nn.y * nn.y + nn.z * nn.z);
+    if (!(n3 > 0.0)) return false;
+    F.e3 = V3{ nn.x / n3, nn.y / n3, nn.z / n3 };
+    F.e2 = cross3(F.e3, F.e1);
+    return true;
+}
+
+__device__ __forceinline__ V3 bearing(double u, double v, const Cam &cam)
+{
+    double mx = (u - cam.cx) / cam.f, my = (v - cam.cy) / cam.f;
+    double nrm = sqrt(mx * mx + my * my + 1.0);
+    return V3{ mx / nrm, my / nrm, 1.0 / nrm };
+}
+
+// one candidate root of the quartic -> pose + 4th-point error; false if the root is rejected
+__device__ __forceinline__ bool p3p_candidate(double v, double pq, double ca, double cb, double cg,
+                                              double a2, double b2, double c2,
+                                              V3 f0, V3 f1, V3 f2, V3 P0, V3 P1, V3 P2, V3 P3,
+                                              double u3, double v3, const Frame &E, const Cam &cam,
+                                              Pose &cand, double &err)
+{
+    if (!(v > 0.0)) return false;
+    double den = cg - v * ca;
+    if (!(den != 0.0)) return false;
+    double u = ((pq - 1.0) * v * v - 2.0 * pq * cb * v + 1.0 + pq) / (2.0 * den);
+    if (!(u > 0.0)) return false;
+    double w = 1.0 + v * v - 2.0 * v * cb;
+    if (!(w > 0.0)) return false;
+    double s1 = sqrt(b2 / w), s2 = u * s1, s3 = v * s1;
+    for (int it = 0; it < 2; ++it) {
+        double F1 = s2 * s2 + s3 * s3 - 2.0 * s2 * s3 * ca - a2;
+        double F2 = s1 * s1 + s3 * s3 - 2.0 * s1 * s3 * cb - b2;
+        double F3 = s1 * s1 + s2 * s2 - 2.0 * s1 * s2 * cg - c2;
+        double j12 = 2.0 * s2 - 2.0 * s3 * ca, j13 = 2.0 * s3 - 2.0 * s2 * ca;
+        double j21 = 2.0 * s1 - 2.0 * s3 * cb, j23 = 2.0 * s3 - 2.0 * s1 * cb;
+        double j31 = 2.0 * s1 - 2.0 * s2 * cg, j32 = 2.0 * s2 - 2.0 * s1 * cg;
+        double det = j12 * j23 * j31 + j13 * j21 * j32;
+        if (!(det != 0.0)) break;
+        double dx1 = (F1 * (-(j23 * j32)) - j12 * (-(j23 * F3)) + j13 * (F2 * j32)) / det;
+        double dx2 = (-(F1 * (-(j23 * j31))) + j13 * (j21 * F3 - F2 * j31)) / det;
+        double dx3 = (-(j12 * (j21 * F3 - F2 * j31)) + F1 * (j21 * j32)) / det;
+        s1 -= dx1; s2 -= dx2; s3 -= dx3;
+    }
+    if (!(s1 > 0.0) || !(s2 > 0.0) || !(s3 > 0.0)) return false;
+    V3 C0{ s1 * f0.x, s1 * f0.y, s1 * f0.z };
+    V3 C1{ s2 * f1.x, s2 * f1.y, s2 * f1.z };
+    V3 C2{ s3 * f2.x, s3 * f2.y, s3 * f2.z };
+    Frame D;
+    if (!frame_of(C0, C1, C2, D)) return false;
+    // R[i][j] = d1[i] e1[j] + d2[i] e2[j] + d3[i] e3[j]
+    cand.R[0] = D.e1.x * E.e1.x + D.e2.x * E.e2.x + D.e3.x * E.e3.x;
+    cand.R[1] = D.e1.x * E.e1.y + D.e2.x * E.e2.y + D.e3.x * E.e3.y;
+    cand.R[2] = D.e1.x * E.e1.z + D.e2.x * E.e2.z + D.e3.x * E.e3.z;
+    cand.R[3] = D.e1.y * E.e1.x + D.e2.y * E.e2.x + D.e3.y * E.e3.x;
+    cand.R[4] = D.e1.y * E.e1.y + D.e2.y * E.e2.y + D.e3.y * E.e3.y;
+    cand.R[5] = D.e1.y * E.e1.z + D.e2.y * E.e2.z + D.e3.y * E.e3.z;
+    cand.R[6] = D.e1.z * E.e1.x + D.e2.z * E.e2.x + D.e3.z * E.e3.x;
+    cand.R[7] = D.e1.z * E.e1.y + D.e2.z * E.e2.y + D.e3.z * E.e3.y;
+    cand.R[8] = D.e1.z * E.e1.z + D.e2.z * E.e2.z + D.e3.z * E.e3.z;
+    double pwx = (P0.x + P1.x + P2.x) / 3.0, pwy = (P0.y + P1.y + P2.y) / 3.0, pwz = (P0.z + P1.z + P2.z) / 3.0;
+    double pcx = (C0.x + C1.x + C2.x) / 3.0, pcy = (C0.y + C1.y + C2.y) / 3.0, pcz = (C0.z + C1.z + C2.z) / 3.0;
+    cand.t[0] = pcx - (cand.R[0] * pwx + cand.R[1] * pwy + cand.R[2] * pwz);
+    cand.t[1] = pcy - (cand.R[3] * pwx + cand.R[4] * pwy + cand.R[5] * pwz);
+    cand.t[2] = pcz - (cand.R[6] * pwx + cand.R[7] * pwy + cand.R[8] * pwz);
+    double xc = cand.R[0] * P3.x + cand.R[1] * P3.y + cand.R[2] * P3.z + cand.t[0];
+    double yc = cand.R[3] * P3.x + cand.R[4] * P3.y + cand.R[5] * P3.z + cand.t[1];
+    double zc = cand.R[6] * P3.x + cand.R[7] * P3.y + cand.R[8] * P3.z + cand.t[2];
+    double up = cam.cx + cam.f * xc / zc, vp = cam.cy + cam.f * yc / zc;
+    err = (up - u3) * (up - u3) + (vp - v3) * (vp - v3);
+    return true;
+}
+
+__device__ __forceinline__ void pose_identity(Pose &p)
+{
+    p.R[0] = 1.0; p.R[1] = 0.0; p.R[2] = 0.0;
+    p.R[3] = 0.0; p.R[4] = 1.0; p.R[5] = 0.0;
+    p.R[6] = 0.0; p.R[7] = 0.0; p.R[8] = 1.0;
+    p.t[0] = 0.0; p.t[1] = 0.0; p.t[2] = 0.0;
+}
+
+// cv::solvePnP(SOLVEPNP_P3P) call-site contract (dsacstar_util.h:185-193): 3 points solve, 4th selects
+__device__ bool p3p(V3 P0, V3 P1, V3 P2, V3 P3, const double (&uv)[4][2], const Cam &cam, Pose &out)
+{
+    V3 f0 = bearing(uv[0][0], uv[0][1], cam);
+    V3 f1 = bearing(uv[1][0], uv[1][1], cam);
+    V3 f2 = bearing(uv[2][0], uv[2][1], cam);
+    double ca = f1.x * f2.x + f1.y * f2.y + f1.z * f2.z;
+    double cb = f0.x * f2.x + f0.y * f2.y + f0.z * f2.z;
+    double cg = f0.x * f1.x + f0.y * f1.y + f0.z * f1.z;
+    double d0, d1, d2;
+    d0 = P1.x - P2.x; d1 = P1.y - P2.y; d2 = P1.z - P2.z;
+    double a2 = d0 * d0 + d1 * d1 + d2 * d2;
+    d0 = P0.x - P2.x; d1 = P0.y - P2.y; d2 = P0.z - P2.z;
+    double b2 = d0 * d0 + d1 * d1 + d2 * d2;
+    d0 = P0.x - P1.x; d1 = P0.y - P1.y; d2 = P0.z - P1.z;
+    double c2 = d0 * d0 + d1 * d1 + d2 * d2;
+    if (!(a2 > 0.0) || !(b2 > 0.0) || !(c2 > 0.0)) return false;
+    Frame E;
+    if (!frame_of(P0, P1, P2, E)) return false;
+
+    double pq = (a2 - c2) / b2, qq = (a2 + c2) / b2;
+    double c2b = c2 / b2, a2b = a2 / b2;
+    double A4 = (pq - 1.0) * (pq - 1.0) - 4.0 * c2b * ca * ca;
+    double A3 = 4.0 * (pq * (1.0 - pq) * cb - (1.0 - qq) * ca * cg + 2.0 * c2b * ca * ca * cb);
+    double A2 = 2.0 * (pq * pq - 1.0 + 2.0 * pq * pq * cb * cb + 2.0 * ((b2 - c2) / b2) * ca * ca
+                       - 4.0 * qq * ca * cb * cg + 2.0 * ((b2 - a2) / b2) * cg * cg);
+    double A1 = 4.0 * (-pq * (1.0 + pq) * cb + 2.0 * a2b * cg * cg * cb - (1.0 - qq) * ca * cg);
+    double A0 = (1.0 + pq) * (1.0 + pq) - 4.0 * a2b * cg * cg;
+    if (!(A4 != 0.0) || A4 != A4) return false;
+
+    double x0, x1, x2, x3;
+    unsigned mask = quartic(A4, A3, A2, A1, A0, x0, x1, x2, x3);
+    bool found = false;
+    double best = 0.0;
+#pragma unroll 1
+    for (int ri = 0; ri < 4; ++ri) {
+        if (!((mask >> ri) & 1u)) continue;
+        double v = (ri == 0) ? x0 : (ri == 1) ? x1 : (ri == 2) ? x2 : x3;
+        Pose cand;
+        double e;
+        if (!p3p_candidate(v, pq, ca, cb, cg, a2, b2, c2, f0, f1, f2, P0, P1, P2, P3,
+                           uv[3][0], uv[3][1], E, cam, cand, e)) continue;
+        if (!found || e < best) { best = e; out = cand; found = true; }
+    }
+    return found;
+}
+
+// one sampling try (dsacstar_util.h:159-219); returns accept flag, pose = try result (identity if P3P failed)
+__device__ bool sample_try(const Coords &co, const Cam &cam, uint64_t imageKey, uint32_t hyp, uint32_t t,
+                           Pose &pose, int (&cells)[4])
+{
+    uint64_t st = try_state(imageKey, hyp, t);
+    V3 P[4];
+    double uv[4][2];
+    float px[4], py[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int x = draw(st, 2 * j, cam.Wo);
+        int y = draw(st, 2 * j + 1, cam.Ho);
+        cells[j] = y * cam.Wo + x;
+        px[j] = (float)(x * cam.sub + cam.sub / 2);
+        py[j] = (float)(y * cam.sub + cam.sub / 2);
+        uv[j][0] = (double)px[j]; uv[j][1] = (double)py[j];
+        co.fetch(cells[j], P[j].x, P[j].y, P[j].z);
+    }
+    if (!p3p(P[0], P[1], P[2], P[3], uv, cam, pose)) {
+        pose_identity(pose);
+        return false;
+    }
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float u, v;
+        project(pose, P[j].x, P[j].y, P[j].z, cam, u, v);
+        float dx = px[j] - u, dy = py[j] - v;
+        double n = sqrt((double)dx * (double)dx + (double)dy * (double)dy);
+        if (ok && !(n < (double)cam.thr)) ok = false;
+    }
+    return ok;
+}
+
+// ------------------------------------------------------------------------------ wave / block reductions
+
+__device__ __forceinline__ double wave_butterfly(double v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = v + __shfl_xor(v, off);
+    return v;
+}
+
+__device__ __forceinline__ Pose wave_bcast_pose(const Pose &p, int src)
+{
+    Pose o;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) o.R[i] = __shfl(p.R[i], src);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) o.t[i] = __shfl(p.t[i], src);
+    return o;
+}
+
+// ------------------------------------------------------------------------------ LM pieces
+
+// per-thread accumulation of the normal equations over this thread's inlier cells
+__device__ __forceinline__ void normal_eq_thread(const Coords &co, const Cam &cam, const Pose &p,
+                                                 unsigned long long inl, int tid, double (&a)[28])
+{
+#pragma unroll
+    for (int k = 0; k < 28; ++k) a[k] = 0.0;
+    int j = 0;
+    for (int i = tid; i < cam.N; i += kThreads, ++j) {
+        if (!((inl >> j) & 1ull)) continue;
+        int y = i / cam.Wo, x = i - y * cam.Wo;
+        double X, Y, Z;
+        co.fetch(i, X, Y, Z);
+        double qx = p.R[0] * X + p.R[1] * Y + p.R[2] * Z;
+        double qy = p.R[3] * X + p.R[4] * Y + p.R[5] * Z;
+        double qz = p.R[6] * X + p.R[7] * Y + p.R[8] * Z;
+        double xc = qx + p.t[0], yc = qy + p.t[1], zc = qz + p.t[2];
+        double z = (zc != 0.0) ? 1.0 / zc : 1.0;
+        double xn = xc * z, yn = yc * z;
+        double ru = (xn * cam.f + cam.cx) - (double)(float)(x * cam.sub + cam.sub / 2);
+        double rv = (yn * cam.f + cam.cy) - (double)(float)(y * cam.sub + cam.sub / 2);
+        double fa = cam.f * z;
+        double fc = -(fa * xn);
+        double fd = -(fa * yn);
+        double Ju[6], Jv[6];
+        Ju[0] = fc * qy;            Ju[1] = fa * qz - fc * qx;  Ju[2] = -(fa * qy);
+        Ju[3] = fa;                 Ju[4] = 0.0;                Ju[5] = fc;
+        Jv[0] = fd * qy - fa * qz;  Jv[1] = -(fd * qx);         Jv[2] = fa * qx;
+        Jv[3] = 0.0;                Jv[4] = fa;                 Jv[5] = fd;
+        int k = 0;
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int c = r; c < 6; ++c) { a[k] += Ju[r] * Ju[c] + Jv[r] * Jv[c]; ++k; }
+#pragma unroll
+        for (int r = 0; r < 6; ++r) a[21 + r] += Ju[r] * ru + Jv[r] * rv;
+        a[27] += ru * ru + rv * rv;
+    }
+}
+
+// canonical block sum of the 28 per-thread values: butterfly per wave, waves added in order.
+// `red` points at a [kWaves][28] double LDS buffer; the caller alternates two buffers.
+__device__ __forceinline__ void block_reduce28(double (&a)[28], double *red, int wave, int lane)
+{
+#pragma unroll
+    for (int k = 0; k < 28; ++k) {
+        double v = wave_butterfly(a[k]);
+        if (lane == 0) red[wave * 28 + k] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 28; ++k) {
+        double tot = red[k];
+#pragma unroll
+        for (int w = 1; w < kWaves; ++w) tot = tot + red[w * 28 + k];
+        a[k] = tot;
+    }
+}
+
+__device__ __forceinline__ bool solve6(const double (&ne)[28], double lambda, double (&d)[6])
+{
+    double A[6][6];
+    {
+        int k = 0;
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int c = r; c < 6; ++c) { A[r][c] = ne[k]; A[c][r] = ne[k]; ++k; }
+    }
+#pragma unroll
+    for (int r = 0; r < 6; ++r) A[r][r] = A[r][r] * (1.0 + lambda);
+    double L[6][6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) L[i][j] = 0.0;
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        double s = A[j][j];
+#pragma unroll
+        for (int m = 0; m < j; ++m) s -= L[j][m] * L[j][m];
+        if (!(s > 0.0)) ok = false;
+        double ljj = sqrt(s);
+        L[j][j] = ljj;
+#pragma unroll
+        for (int i = j + 1; i < 6; ++i) {
+            double v = A[i][j];
+#pragma unroll
+            for (int m = 0; m < j; ++m) v -= L[i][m] * L[j][m];
+            L[i][j] = v / ljj;
+        }
+    }
+    if (!ok) return false;
+    double yv[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        double v = ne[21 + i];
+#pragma unroll
+        for (int m = 0; m < i; ++m) v -= L[i][m] * yv[m];
+        yv[i] = v / L[i][i];
+    }
+#pragma unroll
+    for (int i = 5; i >= 0; --i) {
+        double v = yv[i];
+#pragma unroll
+        for (int m = i + 1; m < 6; ++m) v -= L[m][i] * d[m];
+        d[i] = v / L[i][i];
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+        if (!(d[i] == d[i]) || fabs(d[i]) > 1.0e300) ok = false;
+    return ok;
+}
+
+__device__ __forceinline__ void apply_step(const Pose &prev, const double (&d)[6], Pose &out)
+{
+    double wx = -d[0], wy = -d[1], wz = -d[2];
+    double th2 = wx * wx + wy * wy + wz * wz;
+    double th = sqrt(th2);
+    double E[9];
+    if (!(th > 1.0e-300)) {
+        E[0] = 1.0; E[1] = -wz; E[2] = wy;
+        E[3] = wz;  E[4] = 1.0; E[5] = -wx;
+        E[6] = -wy; E[7] = wx;  E[8] = 1.0;
+    } else {
+        double s, c;
+        det_sincos(th, s, c);
+        double kx = wx / th, ky = wy / th, kz = wz / th;
+        double c1 = 1.0 - c;
+        E[0] = c + c1 * kx * kx;      E[1] = c1 * kx * ky - s * kz; E[2] = c1 * kx * kz + s * ky;
+        E[3] = c1 * kx * ky + s * kz; E[4] = c + c1 * ky * ky;      E[5] = c1 * ky * kz - s * kx;
+        E[6] = c1 * kx * kz - s * ky; E[7] = c1 * ky * kz + s * kx; E[8] = c + c1 * kz * kz;
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            out.R[3 * i + j] = E[3 * i] * prev.R[j] + E[3 * i + 1] * prev.R[3 + j] + E[3 * i + 2] * prev.R[6 + j];
+    out.t[0] = prev.t[0] - d[3];
+    out.t[1] = prev.t[1] - d[4];
+    out.t[2] = prev.t[2] - d[5];
+}
+
+__device__ __forceinline__ double lambda_of(int lg)
+{
+    // 10^lg for lg in [-16, 16]; decimal literals, identical constants on host and device
+    switch (lg) {
+        case -16: return 1e-16; case -15: return 1e-15; case -14: return 1e-14; case -13: return 1e-13;
+        case -12: return 1e-12; case -11: return 1e-11; case -10: return 1e-10; case -9: return 1e-9;
+        case -8: return 1e-8; case -7: return 1e-7; case -6: return 1e-6; case -5: return 1e-5;
+        case -4: return 1e-4; case -3: return 1e-3; case -2: return 1e-2; case -1: return 1e-1;
+        case 0: return 1e0; case 1: return 1e1; case 2: return 1e2; case 3: return 1e3; case 4: return 1e4;
+        case 5: return 1e5; case 6: return 1e6; case 7: return 1e7; case 8: return 1e8; case 9: return 1e9;
+        case 10: return 1e10; case 11: return 1e11; case 12: return 1e12; case 13: return 1e13;
+        case 14: return 1e14; case 15: return 1e15; default: return 1e16;
+    }
+}
+
+struct Params {
+    const float *coords; int64_t sb, sc, sy, sx;
+    float *outPoses;
+    const float *focals;
+    int32_t *cells; int32_t *tries; double *scores; double *dbg;
+    uint64_t seed, image0, imageStride;
+    uint32_t maxTries;
+    int nHyp, Ho, Wo, sub, Npad;
+    float thr, focal, ppx, ppy, alpha, maxReproj;
+};
+
+// LDS carve (all dynamic, 16-byte aligned pieces)
+struct Smem {
+    double red[2][kWaves * 28];
+    double bestPose[kWaves][12];
+    double pose0[12];
+    double bestScore[kWaves];
+    int bestIdx[kWaves];
+    int anyNan[kWaves];
+    unsigned cnt[2][kWaves];
+    int pad[4];
+};
+
+__global__ __launch_bounds__(kThreads)
+void xl_dsac_forward_kernel(Params P)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    Smem &S = *reinterpret_cast<Smem *>(smem_raw);
+    float *sCo = reinterpret_cast<float *>(smem_raw + ((sizeof(Smem) + 15) & ~size_t(15)));
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.x;
+    const int N = P.Ho * P.Wo;
+
+    Cam cam;
+    cam.f = (double)(P.focals ? P.focals[b] : P.focal);
+    cam.cx = (double)P.ppx; cam.cy = (double)P.ppy;
+    cam.thr = P.thr; cam.alpha = P.alpha; cam.maxReproj = P.maxReproj;
+    cam.sub = P.sub; cam.Ho = P.Ho; cam.Wo = P.Wo; cam.N = N;
+
+    // ---- stage coordinates into LDS planes
+    {
+        const float *g = P.coords + (int64_t)b * P.sb;
+        for (int i = tid; i < N; i += kThreads) {
+            int y = i / P.Wo, x = i - y * P.Wo;
+            const float *q = g + (int64_t)y * P.sy + (int64_t)x * P.sx;
+            sCo[i] = q[0];
+            sCo[P.Npad + i] = q[P.sc];
+            sCo[2 * P.Npad + i] = q[2 * P.sc];
+        }
+    }
+    __syncthreads();
+    Coords co{ sCo, sCo + P.Npad, sCo + 2 * P.Npad };
+
+    const uint64_t imageIdx = P.image0 + (uint64_t)b * P.imageStride;
+    const uint64_t imageKey = mix64(P.seed + 0x9e3779b97f4a7c15ULL * (imageIdx + 1));
+
+    // ---- sample + score: this wave's hypotheses
+    double bestScore = 0.0;
+    int bestIdx = -1;
+    int anyNan = 0;
+    const float beta = 5.0f / cam.thr;
+    const float fac = cam.alpha / (float)cam.Wo / (float)cam.Ho;
+
+    for (int h = wave; h < P.nHyp; h += kWaves) {
+        Pose pose;
+        int c4[4] = { 0, 0, 0, 0 };
+        int triesUsed = 0;
+        for (uint32_t t0 = 0; t0 < P.maxTries; t0 += 64) {
+            uint32_t t = t0 + (uint32_t)lane;
+            Pose p;
+            int cc[4] = { 0, 0, 0, 0 };
+            bool ok = false;
+            if (t < P.maxTries) ok = sample_try(co, cam, imageKey, (uint32_t)h, t, p, cc);
+            else pose_identity(p);
+            unsigned long long m = __ballot(ok);
+            int src;
+            if (m != 0ull) { src = __ffsll((long long)m) - 1; triesUsed = (int)t0 + src + 1; }
+            else if (t0 + 64u >= P.maxTries) { src = (int)(P.maxTries - 1u - t0); triesUsed = -(int)P.maxTries; }
+            else continue;
+            pose = wave_bcast_pose(p, src);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) c4[j] = __shfl(cc[j], src);
+            break;
+        }
+
+        double acc = 0.0;
+        for (int i = lane; i < N; i += 64) {
+            float e = cell_err(pose, co, i, cam);
+            float stf = beta * (e - cam.thr);
+            double st = (double)stf;
+            st = 1.0 / (1.0 + det_exp(-st));
+            acc += 1.0 - st;
+        }
+        double total = wave_butterfly(acc);
+        double score = total * (double)fac;
+
+        if (lane == 0) {
+            if (P.cells) {
+                int32_t *o = P.cells + ((int64_t)b * P.nHyp + h) * 4;
+                o[0] = c4[0]; o[1] = c4[1]; o[2] = c4[2]; o[3] = c4[3];
+            }
+            if (P.tries) P.tries[(int64_t)b * P.nHyp + h] = triesUsed;
+            if (P.scores) P.scores[(int64_t)b * P.nHyp + h] = score;
+        }
+        if (score != score) anyNan = 1;
+        bool better = (bestIdx < 0) || (score > bestScore);
+        if (h == 0 && lane == 0) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) S.pose0[i] = pose.R[i];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) S.pose0[9 + i] = pose.t[i];
+        }
+        if (better) {
+            bestScore = score; bestIdx = h;
+            if (lane == 0) {
+#pragma unroll
+                for (int i = 0; i < 9; ++i) S.bestPose[wave][i] = pose.R[i];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) S.bestPose[wave][9 + i] = pose.t[i];
+            }
+        }
+    }
+    if (lane == 0) { S.bestScore[wave] = bestScore; S.bestIdx[wave] = bestIdx; S.anyNan[wave] = anyNan; }
+    __syncthreads();
+
+    // ---- select: first maximum wins (draw(probs,false), dsacstar_util.h:727-752)
+    int win = -1, winWave = 0, nanAny = 0;
+    {
+        double ws = 0.0;
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) {
+            nanAny |= S.anyNan[w];
+            int idx = S.bestIdx[w];
+            if (idx < 0) continue;
+            double s = S.bestScore[w];
+            if (win < 0 || s > ws || (s == ws && idx < win)) { win = idx; ws = s; winWave = w; }
+        }
+        if (nanAny) win = 0;        // any NaN score makes every softmax prob NaN -> draw() returns 0
+    }
+    Pose pose;
+    {
+        const double *src = nanAny ? S.pose0 : S.bestPose[winWave];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) pose.R[i] = src[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) pose.t[i] = src[9 + i];
+    }
+    if (tid == 0 && P.dbg) {
+        double *o = P.dbg + (int64_t)b * XL_DSAC_DBG_DOUBLES;
+        o[0] = (double)win;
+        for (int i = 0; i < 9; ++i) o[4 + i] = pose.R[i];
+        for (int i = 0; i < 3; ++i) o[13 + i] = pose.t[i];
+    }
+
+    // ---- refine (refineHyp, dsacstar_util.h:522-597)
+    unsigned best = 4;
+    int rounds = 0, evals = 0;
+    unsigned finalInl = 0;
+    int redSel = 0, cntSel = 0;
+    for (int step = 0; step < XL_DSAC_MAX_REF_STEPS; ++step) {
+        unsigned long long inl = 0ull;
+        {
+            int j = 0;
+            for (int i = tid; i < N; i += kThreads, ++j) {
+                float e = cell_err(pose, co, i, cam);
+                if (e < cam.thr) inl |= (1ull << j);
+            }
+        }
+        unsigned cnt = (unsigned)__popcll(inl);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) cnt += (unsigned)__shfl_xor((int)cnt, off);
+        if (lane == 0) S.cnt[cntSel][wave] = cnt;
+        __syncthreads();
+        cnt = S.cnt[cntSel][0] + S.cnt[cntSel][1] + S.cnt[cntSel][2] + S.cnt[cntSel][3];
+        cntSel ^= 1;
+        if (cnt <= best) break;
+        best = cnt;
+
+        // Levenberg-Marquardt on the inliers (cv::solvePnP ITERATIVE + extrinsic guess)
+        Pose cur = pose, prev;
+        double ne[28], neNew[28];
+        int lg = -3, iters = 0;
+        bool failed = false;
+        normal_eq_thread(co, cam, cur, inl, tid, ne);
+        block_reduce28(ne, S.red[redSel], wave, lane); redSel ^= 1; ++evals;
+        for (;;) {
+            double d[6];
+            prev = cur;
+            if (!solve6(ne, lambda_of(lg), d)) { failed = true; break; }
+            apply_step(prev, d, cur);
+            double prevErr = ne[27];
+            normal_eq_thread(co, cam, cur, inl, tid, neNew);
+            block_reduce28(neNew, S.red[redSel], wave, lane); redSel ^= 1; ++evals;
+            while (neNew[27] > prevErr) {
+                if (++lg <= 16) {
+                    if (!solve6(ne, lambda_of(lg), d)) { failed = true; break; }
+                    apply_step(prev, d, cur);
+                    normal_eq_thread(co, cam, cur, inl, tid, neNew);
+                    block_reduce28(neNew, S.red[redSel], wave, lane); redSel ^= 1; ++evals;
+                } else break;
+            }
+            if (failed) break;
+            lg = (lg - 1 > -16) ? lg - 1 : -16;
+            double dn = d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3] + d[4] * d[4] + d[5] * d[5];
+            double pn = (3.0 - (prev.R[0] + prev.R[4] + prev.R[8]))
+                        + prev.t[0] * prev.t[0] + prev.t[1] * prev.t[1] + prev.t[2] * prev.t[2];
+            ++iters;
+            if (iters >= kLmMaxIter || dn < kFltEps * kFltEps * pn) break;
+#pragma unroll
+            for (int k = 0; k < 28; ++k) ne[k] = neNew[k];
+        }
+        if (!failed) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) if (!(cur.R[i] == cur.R[i])) failed = true;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) if (!(cur.t[i] == cur.t[i])) failed = true;
+        }
+        if (failed) break;
+        pose = cur;
+        finalInl = cnt;
+        ++rounds;
+    }
+
+    // ---- write (pose2trans): inverse rigid transform, float row-major
+    if (tid == 0) {
+        float *o = P.outPoses + (int64_t)b * 16;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) o[4 * i + j] = (float)pose.R[3 * j + i];
+            o[4 * i + 3] = (float)(-(pose.R[i] * pose.t[0] + pose.R[3 + i] * pose.t[1] + pose.R[6 + i] * pose.t[2]));
+        }
+        o[12] = 0.0f; o[13] = 0.0f; o[14] = 0.0f; o[15] = 1.0f;
+        if (P.dbg) {
+            double *q = P.dbg + (int64_t)b * XL_DSAC_DBG_DOUBLES;
+            q[1] = (double)rounds; q[2] = (double)finalInl; q[3] = (double)evals;
+            for (int i = 0; i < 9; ++i) q[16 + i] = pose.R[i];
+            for (int i = 0; i < 3; ++i) q[25 + i] = pose.t[i];
+        }
+    }
+}
+
+thread_local char g_hipErr[256] = "";
+
+int hip_fail(hipError_t e, const char *what)
+{
+    snprintf(g_hipErr, sizeof(g_hipErr), "%s: %s", what, hipGetErrorString(e));
+    return XL_ERR_HIP;
+}
+
+#define XL_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return hip_fail(e_, #call); } while (0)
+
+}  // namespace
+
+extern "C" {
+
+int xl_dsac_forward_rgb_batch(const float *coords_dev, int64_t sb, int64_t sc, int64_t sy, int64_t sx,
+                              int B, int Ho, int Wo, float *out_poses_dev,
+                              int n_hyp, float thr, float focal, float ppx, float ppy,
+                              float alpha, float max_reproj, int sub, const float *focals_dev,
+                              uint64_t seed, uint64_t image0, uint64_t image_stride, uint32_t max_tries,
+                              void *stream,
+                              int32_t *cells_dev, int32_t *tries_dev, double *scores_dev, double *dbg_dev)
+{
+    if (!coords_dev || !out_poses_dev || B <= 0 || Ho <= 0 || Wo <= 0 || n_hyp <= 0 || sub <= 0 || max_tries == 0)
+        return XL_ERR_ARG;
+    const int N = Ho * Wo;
+    if (N > kMaxCells) return XL_ERR_GRID;
+    Params P;
+    P.coords = coords_dev; P.sb = sb; P.sc = sc; P.sy = sy; P.sx = sx;
+    P.outPoses = out_poses_dev; P.focals = focals_dev;
+    P.cells = cells_dev; P.tries = tries_dev; P.scores = scores_dev; P.dbg = dbg_dev;
+    P.seed = seed; P.image0 = image0; P.imageStride = image_stride; P.maxTries = max_tries;
+    P.nHyp = n_hyp; P.Ho = Ho; P.Wo = Wo; P.sub = sub; P.Npad = (N + 3) & ~3;
+    P.thr = thr; P.focal = focal; P.ppx = ppx; P.ppy = ppy; P.alpha = alpha; P.maxReproj = max_reproj;
+
+    size_t lds = ((sizeof(Smem) + 15) & ~size_t(15)) + (size_t)3 * P.Npad * sizeof(float);
+    if (lds > 160 * 1024) return XL_ERR_GRID;
+    static size_t configured = 0;
+    if (lds > configured) {
+        XL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(xl_dsac_forward_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured = lds;
+    }
+    hipLaunchKernelGGL(xl_dsac_forward_kernel, dim3(B), dim3(kThreads), lds, (hipStream_t)stream, P);
+    XL_HIP(hipGetLastError());
+    return XL_OK;
+}
+
+int xl_dsac_forward_rgb_host(const float *coords_host, int64_t sc, int64_t sy, int64_t sx, int Ho, int Wo,
+                             float *out_pose_host, int n_hyp, float thr, float focal, float ppx, float ppy,
+                             float alpha, float max_reproj, int sub,
+                             uint64_t seed, uint64_t image, uint32_t max_tries,
+                             int32_t *cells_host, int32_t *tries_host, double *scores_host, double *dbg_host)
+{
+    if (!coords_host || !out_pose_host || Ho <= 0 || Wo <= 0 || n_hyp <= 0) return XL_ERR_ARG;
+    const int N = Ho * Wo;
+    // pack to a contiguous [3,Ho,Wo] staging buffer (honours arbitrary host strides)
+    float *stage = (float *)malloc(sizeof(float) * 3 * (size_t)N);
+    if (!stage) return XL_ERR_ARG;
+    for (int c = 0; c < 3; ++c)
+        for (int y = 0; y < Ho; ++y)
+            for (int x = 0; x < Wo; ++x)
+                stage[((size_t)c * Ho + y) * Wo + x] = coords_host[c * sc + y * sy + x * sx];
+    float *dCo = nullptr, *dPose = nullptr;
+    int32_t *dCells = nullptr, *dTries = nullptr;
+    double *dScores = nullptr, *dDbg = nullptr;
+    int rc = XL_OK;
+    hipError_t e;
+#define XL_TRY(call) do { e = (call); if (e != hipSuccess) { rc = hip_fail(e, #call); goto done; } } while (0)
+    XL_TRY(hipMalloc(&dCo, sizeof(float) * 3 * (size_t)N));
+    XL_TRY(hipMalloc(&dPose, sizeof(float) * 16));
+    XL_TRY(hipMemcpy(dCo, stage, sizeof(float) * 3 * (size_t)N, hipMemcpyHostToDevice));
+    if (cells_host) XL_TRY(hipMalloc(&dCells, sizeof(int32_t) * 4 * (size_t)n_hyp));
+    if (tries_host) XL_TRY(hipMalloc(&dTries, sizeof(int32_t) * (size_t)n_hyp));
+    if (scores_host) XL_TRY(hipMalloc(&dScores, sizeof(double) * (size_t)n_hyp));
+    if (dbg_host) XL_TRY(hipMalloc(&dDbg, sizeof(double) * XL_DSAC_DBG_DOUBLES));
+    rc = xl_dsac_forward_rgb_batch(dCo, (int64_t)3 * N, N, Wo, 1, 1, Ho, Wo, dPose, n_hyp, thr, focal, ppx, ppy,
+                                   alpha, max_reproj, sub, nullptr, seed, image, 1, max_tries, nullptr,
+                                   dCells, dTries, dScores, dDbg);
+    if (rc != XL_OK) goto done;
+    XL_TRY(hipDeviceSynchronize());
+    XL_TRY(hipMemcpy(out_pose_host, dPose, sizeof(float) * 16, hipMemcpyDeviceToHost));
+    if (cells_host) XL_TRY(hipMemcpy(cells_host, dCells, sizeof(int32_t) * 4 * (size_t)n_hyp, hipMemcpyDeviceToHost));
+    if (tries_host) XL_TRY(hipMemcpy(tries_host, dTries, sizeof(int32_t) * (size_t)n_hyp, hipMemcpyDeviceToHost));
+    if (scores_host) XL_TRY(hipMemcpy(scores_host, dScores, sizeof(double) * (size_t)n_hyp, hipMemcpyDeviceToHost));
+    if (dbg_host) XL_TRY(hipMemcpy(dbg_host, dDbg, sizeof(double) * XL_DSAC_DBG_DOUBLES, hipMemcpyDeviceToHost));
+done:
+#undef XL_TRY
+    free(stage);
+    if (dCo) (void)hipFree(dCo);
+    if (dPose) (void)hipFree(dPose);
+    if (dCells) (void)hipFree(dCells);
+    if (dTries) (void)hipFree(dTries);
+    if (dScores) (void)hipFree(dScores);
+    if (dDbg) (void)hipFree(dDbg);
+    return rc;
+}
+
+int xl_dsac_backward_rgb(void) { return XL_ERR_UNSUPPORTED; }
+int xl_dsac_forward_rgbd(void) { return XL_ERR_UNSUPPORTED; }
+int xl_dsac_backward_rgbd(void) { return XL_ERR_UNSUPPORTED; }
+
+const char *xl_status_string(int status)
+{
+    switch (status) {
+        case XL_OK: return "ok";
+        case XL_ERR_ARG: return "invalid argument (null pointer or non-positive size)";
+        case XL_ERR_GRID: return "coordinate grid too large for the kernel (Ho*Wo > 16384 or LDS exceeded)";
+        case XL_ERR_HIP: return "HIP runtime error (see xl_last_hip_error)";
+        case XL_ERR_UNSUPPORTED: return "entry point exported for interface parity but not implemented";
+        default: return "unknown status";
+    }
+}
+
+const char *xl_last_hip_error(void) { return g_hipErr; }
+
+}  // extern "C"

@@ -1,0 +1,147 @@
+"""GPU parity: HIP DSAC* bundle (through the C ABI) vs oracle/dsac_oracle.c on the same seeded inputs.
+Integer outputs (sampled cells, tries, winner, rounds, inlier counts) and every float/double output
+must be bit-identical; poses are additionally checked against ground truth."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from crossloc_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+def _gpu_batch(coords_np, n_hyp, image0=0, stride=1, max_tries=None, focal=480.0, ppx=360.0, ppy=240.0, sub=8):
+    import dsacstar
+    co = torch.from_numpy(coords_np).cuda()
+    out = torch.zeros((co.shape[0], 4, 4), dtype=torch.float32, device="cuda")
+    d = dsacstar.forward_rgb_batch(co, out, n_hyp, 10.0, focal, ppx, ppy, 100.0, 100.0, sub,
+                                   image0=image0, image_stride=stride, max_tries=max_tries, debug=True)
+    torch.cuda.synchronize()
+    return out.cpu().numpy(), {k: v.cpu().numpy() for k, v in d.items()}
+
+
+def _assert_same(oracle, coords, pose_g, dg, b, n_hyp, image, max_tries=1000000, focal=480.0, ppx=360.0, ppy=240.0):
+    pose_o, do = oracle.forward_rgb(coords, n_hyp, 10.0, focal, ppx, ppy, 100.0, 100.0, 8, image=image,
+                                    max_tries=max_tries, debug=True)
+    assert np.array_equal(dg["cells"][b], do["cells"]), "sampled cells differ"
+    assert np.array_equal(dg["tries"][b], do["tries"]), "tries differ"
+    assert np.array_equal(dg["scores"][b].view(np.int64), do["scores"].view(np.int64)), "scores differ (bits)"
+    assert int(dg["dbg"][b, 0]) == do["winner"]
+    assert np.array_equal(dg["dbg"][b, 4:16].view(np.int64), do["pose0"].view(np.int64)), "winner pose differs"
+    assert (int(dg["dbg"][b, 1]), int(dg["dbg"][b, 2]), int(dg["dbg"][b, 3])) == (do["rounds"], do["inliers"], do["lm_evals"])
+    assert np.array_equal(dg["dbg"][b, 16:28].view(np.int64), do["pose1"].view(np.int64)), "refined pose differs"
+    assert np.array_equal(pose_g[b].view(np.int32), pose_o.view(np.int32)), "output pose differs (bits)"
+
+
+@pytest.mark.parametrize("rho,n_hyp", [(0.0, 64), (0.3, 64), (0.6, 64), (0.3, 256)])
+def test_bit_exact_vs_oracle(oracle, rho, n_hyp):
+    B = 6
+    coords, _, poses = synth.make_batch(2021, B, noise=0.5, outlier_ratio=rho)
+    pose_g, dg = _gpu_batch(coords, n_hyp, image0=10)
+    for b in range(B):
+        _assert_same(oracle, coords[b], pose_g, dg, b, n_hyp, image=10 + b)
+        t, r = synth.pose_error(poses[b], pose_g[b])
+        assert t < 0.5 and r < 0.1
+
+
+def test_gt_coordinates_give_zero_error():
+    coords, _, poses = synth.make_batch(300, 8, noise=0.0, outlier_ratio=0.0)
+    pose_g, _ = _gpu_batch(coords, 64)
+    for b in range(8):
+        t, r = synth.pose_error(poses[b], pose_g[b])
+        assert t < 1e-3 and r < 1e-3
+
+
+def test_batch_composition_and_stride_invariance():
+    coords, _, _ = synth.make_batch(500, 8, noise=0.5, outlier_ratio=0.3)
+    full, dfull = _gpu_batch(coords, 64, image0=0, stride=1)
+    # images 1,3,5,7 as a rank-1-of-2 shard: same per-image results
+    shard, dshard = _gpu_batch(np.ascontiguousarray(coords[1::2]), 64, image0=1, stride=2)
+    assert np.array_equal(full[1::2], shard)
+    assert np.array_equal(dfull["cells"][1::2], dshard["cells"])
+
+
+def test_degenerate_inputs(oracle):
+    nodata = np.full((2, 3, 60, 90), -1.0, np.float32)
+    pose_g, dg = _gpu_batch(nodata, 8, max_tries=100)
+    assert np.array_equal(pose_g[0], np.eye(4, dtype=np.float32))
+    assert (dg["tries"] == -100).all()
+    _assert_same(oracle, nodata[0], pose_g, dg, 0, 8, image=0, max_tries=100)
+    rng = np.random.default_rng(3)
+    garbage = rng.uniform(-500, 500, size=(2, 3, 60, 90)).astype(np.float32)
+    pose_g, dg = _gpu_batch(garbage, 8, max_tries=200)
+    assert np.isfinite(pose_g).all()
+    for b in range(2):
+        _assert_same(oracle, garbage[b], pose_g, dg, b, 8, image=b, max_tries=200)
+    # max_tries not a multiple of the wave size
+    pose_g, dg = _gpu_batch(garbage, 5, max_tries=77)
+    _assert_same(oracle, garbage[0], pose_g, dg, 0, 5, image=0, max_tries=77)
+
+
+@pytest.mark.parametrize("Ho,Wo", [(8, 12), (7, 13), (33, 17)])
+def test_small_and_ragged_grids(oracle, Ho, Wo):
+    sc = synth.make_scene(50, noise=0.2, outlier_ratio=0.2, Ho=Ho, Wo=Wo)
+    pose_g, dg = _gpu_batch(sc["coords"][None], 16, ppx=sc["ppx"], ppy=sc["ppy"])
+    _assert_same(oracle, sc["coords"], pose_g, dg, 0, 16, image=0, ppx=sc["ppx"], ppy=sc["ppy"])
+
+
+def test_strided_device_input(oracle):
+    import dsacstar
+    sc = synth.make_scene(13, noise=0.5, outlier_ratio=0.3)
+    big = torch.zeros((1, 3, 64, 100), dtype=torch.float32, device="cuda")
+    big[0, :, 2:62, 5:95] = torch.from_numpy(sc["coords"]).cuda()
+    view = big[:, :, 2:62, 5:95]
+    assert not view.is_contiguous()
+    out = torch.zeros((1, 4, 4), dtype=torch.float32, device="cuda")
+    d = dsacstar.forward_rgb_batch(view, out, 32, 10.0, 480.0, 360.0, 240.0, 100.0, 100.0, 8, debug=True)
+    torch.cuda.synchronize()
+    _assert_same(oracle, sc["coords"], out.cpu().numpy(), {k: v.cpu().numpy() for k, v in d.items()}, 0, 32, image=0)
+
+
+def test_reference_shaped_call_cpu_and_gpu_tensors(oracle):
+    """The exact call of utils/evaluation.py:160-172: CPU tensors, in-place 4x4 output."""
+    import dsacstar
+    sc = synth.make_scene(21, noise=0.5, outlier_ratio=0.3)
+    scene_coords = torch.from_numpy(sc["coords"])[None]
+    dsacstar.set_image_index(7)
+    out_pose = torch.zeros((4, 4))
+    ret = dsacstar.forward_rgb(scene_coords, out_pose, 64, 10.0, 480.0, float(720 / 2), float(480 / 2), 100.0, 100.0, 8)
+    assert ret is None
+    ref = oracle.forward_rgb(sc["coords"], 64, 10.0, 480.0, 360.0, 240.0, 100.0, 100.0, 8, image=7)
+    assert np.array_equal(out_pose.numpy(), ref)
+    # the module counter advanced: the next call is image 8
+    out2 = torch.zeros((4, 4))
+    dsacstar.forward_rgb(scene_coords, out2, 64, 10.0, 480.0, 360.0, 240.0, 100.0, 100.0, 8)
+    assert np.array_equal(out2.numpy(), oracle.forward_rgb(sc["coords"], 64, 10.0, 480.0, 360.0, 240.0, 100.0, 100.0, 8, image=8))
+    # GPU tensors in, GPU pose out
+    dsacstar.set_image_index(7)
+    out3 = torch.zeros((4, 4), device="cuda")
+    dsacstar.forward_rgb(scene_coords.cuda(), out3, 64, 10.0, 480.0, 360.0, 240.0, 100.0, 100.0, 8)
+    assert np.array_equal(out3.cpu().numpy(), ref)
+    with pytest.raises(RuntimeError):
+        dsacstar.forward_rgb(scene_coords[0], out_pose, 64, 10.0, 480.0, 360.0, 240.0, 100.0, 100.0, 8)
+    with pytest.raises(RuntimeError):
+        dsacstar.forward_rgb(scene_coords.double(), out_pose, 64, 10.0, 480.0, 360.0, 240.0, 100.0, 100.0, 8)
+    with pytest.raises(NotImplementedError):
+        dsacstar.backward_rgb()
+
+
+def test_full_size_batch_properties():
+    """BASELINE size (256 hypotheses, 60x90) on a larger batch: size-independent properties."""
+    B = 64
+    coords, _, poses = synth.make_batch(9000, B, noise=0.5, outlier_ratio=0.3)
+    pose_g, dg = _gpu_batch(coords, 256)
+    errs = np.array([synth.pose_error(poses[b], pose_g[b]) for b in range(B)])
+    assert np.median(errs[:, 0]) < 0.15 and np.median(errs[:, 1]) < 0.03
+    assert (errs[:, 0] < 1.0).all()
+    R = pose_g[:, :3, :3].astype(np.float64)
+    assert np.allclose(R @ R.transpose(0, 2, 1), np.eye(3), atol=1e-5)           # rigid output
+    assert np.allclose(pose_g[:, 3], [0, 0, 0, 1])
+    assert (dg["scores"] >= 0).all() and (dg["scores"] <= 100).all()
+    assert np.array_equal(dg["dbg"][:, 0].astype(int), dg["scores"].argmax(1))   # first-max winner
+    assert (dg["dbg"][:, 1] >= 1).all() and (dg["dbg"][:, 1] <= 100).all()       # refinement rounds
+    again, _ = _gpu_batch(coords, 256)
+    assert np.array_equal(again, pose_g)                                          # deterministic
