@@ -1,0 +1,502 @@
+// xl_cnn.hip — MI355X (gfx950) kernels for CrossLoc's scene-coordinate CNN forward.
+//
+// What PyTorch dispatched for TransPoseNet.forward (/root/reference/networks/networks.py:466-502) is
+// re-designed here as five kernels executed from an op list (include/crossloc_cnn.h):
+//
+//   conv1_direct   3x3 s1 conv on the 3-channel NCHW image -> NHWC (HBM-bound: 44 MB out per 480x720 image)
+//   igemm_conv     every other conv as an implicit GEMM on exact-fp32 MFMA (v_mfma_f32_32x32x2_f32):
+//                  M = B*Ho*Wo output pixels, N = Cout, K = k*k*Cin; 128xBN block tile, BK = 32,
+//                  A (im2col gather, zero-filled padding) and B (weights [Cout][K]) staged through LDS with
+//                  a 36-float row pitch (conflict-free ds_read_b128), register-prefetched double buffer,
+//                  one barrier per K-step; 4 wavefronts as 2x2, each 64 x BN/2 of the tile (2 x BN/64 MFMA
+//                  tiles of 32x32); XCD-aware tile order so the n-tiles of one m-tile share an L2.
+//   gn_stats       GroupNorm statistics, coalesced: a workgroup reads a pixel chunk of all channels, fp64
+//                  per-thread partials, fixed-order LDS combine -> per-(image, chunk, group) (sum, sumsq)
+//   gn_apply       finalises mean/rstd from the chunk partials (fixed order) into per-channel scale/shift
+//                  in LDS, then streams y = x*scale + shift with fused ReLU / residual add / ReLU
+//   head           fc3 (512 -> 4) + mean offset + exp(hardtanh), one wavefront per pixel, NCHW out
+//
+// fp32 end to end: the MFMA used is bitwise an fmaf chain, so parity with the fp32 reference is at
+// summation-order level (tests compare against torch fp32 on CPU and the golden vectors).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/crossloc_cnn.h"
+#include "../../include/crossloc_dsac.h"   // status codes
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------------------------- conv1
+
+// in NCHW [B,Cin,H,W]; w [(ky*3+kx)*Cin + c][Cout]; out NHWC.  Thread = (pixel, 8 output channels).
+__global__ __launch_bounds__(256)
+void conv1_direct_kernel(const float *__restrict__ in, const float *__restrict__ w, const float *__restrict__ bias,
+                         float *__restrict__ out, int B, int Cin, int H, int W, int Cout, int ldOut)
+{
+    extern __shared__ __attribute__((aligned(16))) float sW[];      // [9*Cin][Cout] + bias[Cout]
+    const int nW = 9 * Cin * Cout;
+    for (int i = threadIdx.x; i < nW; i += 256) sW[i] = w[i];
+    for (int i = threadIdx.x; i < Cout; i += 256) sW[nW + i] = bias[i];
+    __syncthreads();
+    const int tpp = Cout >> 3;                                       // threads per pixel
+    const int pixPerBlock = 256 / tpp;
+    const long long HW = (long long)H * W;
+    const long long total = (long long)B * HW;
+    const int cg = threadIdx.x % tpp;
+    for (long long p = (long long)blockIdx.x * pixPerBlock + threadIdx.x / tpp; p < total;
+         p += (long long)gridDim.x * pixPerBlock) {
+        const int n = (int)(p / HW);
+        const int rem = (int)(p - (long long)n * HW);
+        const int y = rem / W, x = rem - y * W;
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = sW[nW + cg * 8 + j];
+        const float *img = in + (long long)n * Cin * HW;
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = y + ky - 1;
+            if ((unsigned)iy >= (unsigned)H) continue;
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = x + kx - 1;
+                if ((unsigned)ix >= (unsigned)W) continue;
+                for (int c = 0; c < Cin; ++c) {
+                    const float v = img[(long long)c * HW + (long long)iy * W + ix];
+                    const float *wr = sW + ((ky * 3 + kx) * Cin + c) * Cout + cg * 8;
+                    const f32x4 w0 = *reinterpret_cast<const f32x4 *>(wr);
+                    const f32x4 w1 = *reinterpret_cast<const f32x4 *>(wr + 4);
+                    acc[0] = fmaf(v, w0.x, acc[0]); acc[1] = fmaf(v, w0.y, acc[1]);
+                    acc[2] = fmaf(v, w0.z, acc[2]); acc[3] = fmaf(v, w0.w, acc[3]);
+                    acc[4] = fmaf(v, w1.x, acc[4]); acc[5] = fmaf(v, w1.y, acc[5]);
+                    acc[6] = fmaf(v, w1.z, acc[6]); acc[7] = fmaf(v, w1.w, acc[7]);
+                }
+            }
+        }
+        float *o = out + p * ldOut + cg * 8;
+        *reinterpret_cast<f32x4 *>(o) = f32x4{ acc[0], acc[1], acc[2], acc[3] };
+        *reinterpret_cast<f32x4 *>(o + 4) = f32x4{ acc[4], acc[5], acc[6], acc[7] };
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- igemm conv
+
+constexpr int kBM = 128, kBK = 32, kPitch = 36;   // LDS row pitch in floats (32 + 4): conflict-free b128 reads
+
+struct ConvArgs {
+    const float *in; const float *w; const float *bias; float *out;
+    int B, Hi, Wi, Cin, Ho, Wo, Cout, ldIn, ldOut;
+    int M, K, nbm, nbn;
+};
+
+// bijective XCD remap: block b runs on XCD b%8; give each XCD a contiguous run of tiles
+__device__ __forceinline__ int xcd_remap(int b, int nwg)
+{
+    const int q = nwg >> 3, r = nwg & 7;
+    const int xcd = b & 7, local = b >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+}
+
+template <int KS, int STRIDE, int BN>
+__global__ __launch_bounds__(256, 2)
+void igemm_conv_kernel(ConvArgs a)
+{
+    constexpr int PAD = (KS == 3) ? 1 : 0;
+    constexpr int NJ = BN / 64;                 // 32-wide MFMA tiles per wave along N
+    constexpr int BROWS = BN / 32;              // B-tile rows loaded per thread
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *As = smem;                           // [2][kBM][kPitch]
+    float *Bs = smem + 2 * kBM * kPitch;        // [2][BN][kPitch]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int tile = xcd_remap(blockIdx.x, a.nbm * a.nbn);
+    const int mt = tile / a.nbn, nt = tile - mt * a.nbn;
+    const int m0 = mt * kBM, n0 = nt * BN;
+
+    // ---- per-thread load coordinates: 4 A rows (and BROWS B rows) at float4 column kq
+    const int lrow = tid >> 3, kq = tid & 7;
+    long long aOff[4];
+    int aIy[4], aIx[4];
+    const int HoWo = a.Ho * a.Wo;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int m = m0 + lrow + 32 * p;
+        if (m < a.M) {
+            const int n = m / HoWo;
+            const int rem = m - n * HoWo;
+            const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
+            aIy[p] = oy * STRIDE - PAD;
+            aIx[p] = ox * STRIDE - PAD;
+            aOff[p] = (((long long)n * a.Hi + aIy[p]) * a.Wi + aIx[p]) * a.ldIn + 4 * kq;
+        } else {
+            aIy[p] = -100000; aIx[p] = -100000; aOff[p] = 0;
+        }
+    }
+    const float *wBase = a.w + (long long)(n0 + lrow) * a.K + 4 * kq;
+
+    f32x4 ra[4], rb[BROWS];
+    auto load_global = [&](int kk) {
+        const int kbase = kk * kBK;
+        const int tap = kbase / a.Cin;
+        const int c0 = kbase - tap * a.Cin;
+        const int ky = tap / KS, kx = tap - ky * KS;
+        const long long tapOff = ((long long)ky * a.Wi + kx) * a.ldIn + c0;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const bool ok = (unsigned)(aIy[p] + ky) < (unsigned)a.Hi && (unsigned)(aIx[p] + kx) < (unsigned)a.Wi;
+            ra[p] = ok ? *reinterpret_cast<const f32x4 *>(a.in + aOff[p] + tapOff) : f32x4{ 0.f, 0.f, 0.f, 0.f };
+        }
+#pragma unroll
+        for (int p = 0; p < BROWS; ++p)
+            rb[p] = *reinterpret_cast<const f32x4 *>(wBase + (long long)(32 * p) * a.K + kbase);
+    };
+    auto store_lds = [&](int buf) {
+        float *Ad = As + buf * kBM * kPitch + lrow * kPitch + 4 * kq;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) *reinterpret_cast<f32x4 *>(Ad + 32 * p * kPitch) = ra[p];
+        float *Bd = Bs + buf * BN * kPitch + lrow * kPitch + 4 * kq;
+#pragma unroll
+        for (int p = 0; p < BROWS; ++p) *reinterpret_cast<f32x4 *>(Bd + 32 * p * kPitch) = rb[p];
+    };
+
+    f32x16 acc[2][NJ];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = a.K / kBK;
+    load_global(0);
+    store_lds(0);
+    __syncthreads();
+
+    const int fragRow = lane & 31, fragK = (lane >> 5) * 4;
+    for (int kk = 0; kk < nk; ++kk) {
+        const int buf = kk & 1;
+        if (kk + 1 < nk) load_global(kk + 1);
+        const float *Ab = As + buf * kBM * kPitch + (wm * 64 + fragRow) * kPitch + fragK;
+        const float *Bb = Bs + buf * BN * kPitch + (wn * (BN / 2) + fragRow) * kPitch + fragK;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            f32x4 fa[2], fb[NJ];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const f32x4 *>(Ab + i * 32 * kPitch + c * 8);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) fb[j] = *reinterpret_cast<const f32x4 *>(Bb + j * 32 * kPitch + c * 8);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+        }
+        if (kk + 1 < nk) store_lds(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: bias + store. C layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const int col = lane & 31, rhalf = (lane >> 5) * 4;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int n = n0 + wn * (BN / 2) + j * 32 + col;
+        const float bv = a.bias[n];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + rhalf;
+                if (m < a.M) a.out[(long long)m * a.ldOut + n] = acc[i][j][r] + bv;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- GroupNorm
+
+// grid (nchunks, B); T threads with T % (C/4) == 0.  stats[((n*nchunks + chunk)*G + g)*2 + {0,1}] = sum, sumsq
+__global__ void gn_stats_kernel(const float *__restrict__ x, double *__restrict__ stats, int HW, int C, int ld,
+                                int G, int nchunks)
+{
+    extern __shared__ __attribute__((aligned(16))) double sPart[];     // [T][8]
+    const int T = blockDim.x, tid = threadIdx.x;
+    const int C4 = C >> 2;
+    const int c4 = tid % C4, prow = tid / C4, rows = T / C4;
+    const int chunk = blockIdx.x, n = blockIdx.y;
+    const int per = (HW + nchunks - 1) / nchunks;
+    const int p0 = chunk * per;
+    int p1 = p0 + per; if (p1 > HW) p1 = HW;
+    double s[4] = { 0, 0, 0, 0 }, ss[4] = { 0, 0, 0, 0 };
+    const float *base = x + ((long long)n * HW) * ld + 4 * c4;
+    for (int p = p0 + prow; p < p1; p += rows) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(base + (long long)p * ld);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const double d = (double)v[j]; s[j] += d; ss[j] += d * d; }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { sPart[tid * 8 + j] = s[j]; sPart[tid * 8 + 4 + j] = ss[j]; }
+    __syncthreads();
+    if (tid < G) {
+        const int cpg = C / G;
+        double a = 0.0, b = 0.0;
+        for (int r = 0; r < rows; ++r)
+            for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) {
+                const int th = r * C4 + (c >> 2), sl = c & 3;
+                a += sPart[th * 8 + sl];
+                b += sPart[th * 8 + 4 + sl];
+            }
+        double *o = stats + (((long long)n * nchunks + chunk) * G + tid) * 2;
+        o[0] = a; o[1] = b;
+    }
+}
+
+// grid (achunks, B), 256 threads. v = x*scale + shift; flags as in crossloc_cnn.h
+__global__ __launch_bounds__(256)
+void gn_apply_kernel(const float *__restrict__ x, const double *__restrict__ stats, const float *__restrict__ gamma,
+                     const float *__restrict__ beta, const float *__restrict__ aux, float *__restrict__ out,
+                     int HW, int C, int ldIn, int ldOut, int ldAux, int G, int nchunks, float eps, int flags)
+{
+    extern __shared__ __attribute__((aligned(16))) float sSS[];        // scale[C], shift[C]
+    const int tid = threadIdx.x, n = blockIdx.y;
+    const int cpg = C / G;
+    for (int c = tid; c < C; c += 256) {
+        const int g = c / cpg;
+        double a = 0.0, b = 0.0;
+        const double *st = stats + ((long long)n * nchunks * G + g) * 2;
+        for (int k = 0; k < nchunks; ++k) { a += st[(long long)k * G * 2]; b += st[(long long)k * G * 2 + 1]; }
+        const double cnt = (double)HW * (double)cpg;
+        const double mean = a / cnt;
+        double var = b / cnt - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const double rstd = 1.0 / sqrt(var + (double)eps);
+        const double sc = (double)gamma[c] * rstd;
+        sSS[c] = (float)sc;
+        sSS[C + c] = (float)((double)beta[c] - mean * sc);
+    }
+    __syncthreads();
+    const int C4 = C >> 2;
+    const int achunks = gridDim.x;
+    const int per = (HW + achunks - 1) / achunks;
+    const int p0 = blockIdx.x * per;
+    int p1 = p0 + per; if (p1 > HW) p1 = HW;
+    const long long nElem4 = (long long)(p1 - p0) * C4;
+    const bool reluIn = flags & XL_GN_RELU_IN, add = flags & XL_GN_ADD, reluOut = flags & XL_GN_RELU_OUT;
+    for (long long f = tid; f < nElem4; f += 256) {
+        const int p = p0 + (int)(f / C4);
+        const int c = (int)(f - (long long)(p - p0) * C4) * 4;
+        const long long pix = (long long)n * HW + p;
+        f32x4 v = *reinterpret_cast<const f32x4 *>(x + pix * ldIn + c);
+        const f32x4 sc = *reinterpret_cast<const f32x4 *>(sSS + c);
+        const f32x4 sh = *reinterpret_cast<const f32x4 *>(sSS + C + c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float t = v[j] * sc[j] + sh[j];
+            if (reluIn) t = fmaxf(t, 0.f);
+            v[j] = t;
+        }
+        if (add) {
+            const f32x4 r = *reinterpret_cast<const f32x4 *>(aux + pix * ldAux + c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] += r[j];
+        }
+        if (reluOut) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+        }
+        *reinterpret_cast<f32x4 *>(out + pix * ldOut + c) = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- head
+
+// in NHWC [B*HW][Cin], w [Cout][Cin], out NCHW [B][Cout][HW]; one wavefront per pixel (grid-stride)
+template <int COUT_MAX>
+__global__ __launch_bounds__(256)
+void head_kernel(const float *__restrict__ in, const float *__restrict__ w, const float *__restrict__ bias,
+                 const float *__restrict__ mean, float *__restrict__ out, int B, int HW, int Cin, int ldIn,
+                 int Cout, int nTask, float lo, float hi)
+{
+    const int lane = threadIdx.x & 63;
+    const int waveGlobal = (blockIdx.x * 256 + threadIdx.x) >> 6;
+    const int nWaves = (gridDim.x * 256) >> 6;
+    const int nq = Cin >> 8;                                  // float4 per lane (Cin / 256), <= 8
+    const long long total = (long long)B * HW;
+    for (long long p = waveGlobal; p < total; p += nWaves) {
+        float acc[COUT_MAX];
+#pragma unroll
+        for (int o = 0; o < COUT_MAX; ++o) acc[o] = 0.f;
+        for (int q = 0; q < nq; ++q) {
+            const int c = q * 256 + lane * 4;
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(in + p * ldIn + c);
+#pragma unroll
+            for (int o = 0; o < COUT_MAX; ++o) {
+                if (o < Cout) {
+                    const f32x4 wv = *reinterpret_cast<const f32x4 *>(w + (long long)o * Cin + c);
+                    acc[o] = fmaf(v.x, wv.x, acc[o]); acc[o] = fmaf(v.y, wv.y, acc[o]);
+                    acc[o] = fmaf(v.z, wv.z, acc[o]); acc[o] = fmaf(v.w, wv.w, acc[o]);
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < COUT_MAX; ++o)
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) acc[o] += __shfl_xor(acc[o], off);
+        if (lane < Cout) {
+            float v = 0.f;
+#pragma unroll
+            for (int o = 0; o < COUT_MAX; ++o) if (o == lane) v = acc[o];
+            v += bias[lane];
+            if (lane < nTask) v += mean[lane];                               // networks.py:351
+            else v = expf(fminf(fmaxf(v, lo), hi));                          // networks.py:355-358
+            const int n = (int)(p / HW);
+            const int pix = (int)(p - (long long)n * HW);
+            out[((long long)n * Cout + lane) * HW + pix] = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- weight pack
+
+__global__ void pack_weight_kernel(const float *__restrict__ src, float *__restrict__ dst, int Cout, int Cin, int k)
+{
+    const long long total = (long long)Cout * Cin * k * k;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        // dst index i = ((o*k + ky)*k + kx)*Cin + c
+        const int c = (int)(i % Cin);
+        long long t = i / Cin;
+        const int kx = (int)(t % k); t /= k;
+        const int ky = (int)(t % k);
+        const int o = (int)(t / k);
+        dst[i] = src[(((long long)o * Cin + c) * k + ky) * k + kx];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- host side
+
+thread_local char g_err[256] = "";
+
+template <int KS, int STRIDE, int BN>
+int launch_igemm(const xl_op &op, hipStream_t st)
+{
+    ConvArgs a;
+    a.in = (const float *)op.in; a.w = (const float *)op.w; a.bias = (const float *)op.bias; a.out = (float *)op.out;
+    a.B = op.B; a.Hi = op.Hi; a.Wi = op.Wi; a.Cin = op.Cin; a.Ho = op.Ho; a.Wo = op.Wo; a.Cout = op.Cout;
+    a.ldIn = op.ld_in; a.ldOut = op.ld_out;
+    a.M = op.B * op.Ho * op.Wo; a.K = op.ksize * op.ksize * op.Cin;
+    a.nbm = (a.M + kBM - 1) / kBM; a.nbn = op.Cout / BN;
+    const size_t lds = sizeof(float) * 2 * (kBM + BN) * kPitch;
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(igemm_conv_kernel<KS, STRIDE, BN>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { snprintf(g_err, sizeof(g_err), "hipFuncSetAttribute: %s", hipGetErrorString(e)); return XL_ERR_HIP; }
+        configured = true;
+    }
+    hipLaunchKernelGGL((igemm_conv_kernel<KS, STRIDE, BN>), dim3(a.nbm * a.nbn), dim3(256), lds, st, a);
+    return XL_OK;
+}
+
+int run_conv(const xl_op &op, hipStream_t st)
+{
+    if (op.Cin % 32 != 0 || op.Cout % 64 != 0 || op.ld_in % 4 != 0) return XL_ERR_ARG;
+    const bool wide = (op.Cout % 128 == 0);
+    if (op.ksize == 3 && op.stride == 1) return wide ? launch_igemm<3, 1, 128>(op, st) : launch_igemm<3, 1, 64>(op, st);
+    if (op.ksize == 3 && op.stride == 2) return wide ? launch_igemm<3, 2, 128>(op, st) : launch_igemm<3, 2, 64>(op, st);
+    if (op.ksize == 1 && op.stride == 1) return wide ? launch_igemm<1, 1, 128>(op, st) : launch_igemm<1, 1, 64>(op, st);
+    return XL_ERR_UNSUPPORTED;
+}
+
+int run_op(const xl_op &op, hipStream_t st)
+{
+    switch (op.type) {
+        case XL_OP_CONV1: {
+            if (op.Cout % 8 != 0 || op.Cout > 64 || 256 % (op.Cout / 8) != 0 || op.ld_out % 4 != 0) return XL_ERR_ARG;
+            const size_t lds = sizeof(float) * (size_t)(9 * op.Cin * op.Cout + op.Cout);
+            const long long pix = (long long)op.B * op.Hi * op.Wi;
+            const int ppb = 256 / (op.Cout / 8);
+            long long blocks = (pix + ppb - 1) / ppb;
+            if (blocks > 65536) blocks = 65536;
+            hipLaunchKernelGGL(conv1_direct_kernel, dim3((unsigned)blocks), dim3(256), lds, st,
+                               (const float *)op.in, (const float *)op.w, (const float *)op.bias, (float *)op.out,
+                               op.B, op.Cin, op.Hi, op.Wi, op.Cout, op.ld_out);
+            return XL_OK;
+        }
+        case XL_OP_CONV:
+            return run_conv(op, st);
+        case XL_OP_GN_STATS: {
+            const int C4 = op.Cin / 4;
+            if (op.Cin % 4 != 0 || op.Cin % op.groups != 0 || op.ld_in % 4 != 0) return XL_ERR_ARG;
+            int T = 256;
+            if (C4 > 256) T = C4; else if (256 % C4 != 0) return XL_ERR_ARG;
+            if (T > 1024 || T % 64 != 0 || op.groups > T) return XL_ERR_ARG;
+            hipLaunchKernelGGL(gn_stats_kernel, dim3(op.nchunks, op.B), dim3(T), sizeof(double) * 8 * T, st,
+                               (const float *)op.in, (double *)op.stats, op.Hi * op.Wi, op.Cin, op.ld_in, op.groups,
+                               op.nchunks);
+            return XL_OK;
+        }
+        case XL_OP_GN_APPLY: {
+            if (op.Cin % 4 != 0 || op.ld_in % 4 != 0 || op.ld_out % 4 != 0) return XL_ERR_ARG;
+            const int HW = op.Hi * op.Wi;
+            int achunks = (HW * (op.Cin / 4) + 256 * 16 - 1) / (256 * 16);     // ~16 float4 per thread
+            if (achunks < 1) achunks = 1;
+            if (achunks > 1024) achunks = 1024;
+            hipLaunchKernelGGL(gn_apply_kernel, dim3(achunks, op.B), dim3(256), sizeof(float) * 2 * op.Cin, st,
+                               (const float *)op.in, (const double *)op.stats, (const float *)op.w,
+                               (const float *)op.bias, (const float *)op.aux, (float *)op.out, HW, op.Cin, op.ld_in,
+                               op.ld_out, op.ld_aux, op.groups, op.nchunks, op.eps, op.flags);
+            return XL_OK;
+        }
+        case XL_OP_HEAD: {
+            if (op.Cin % 256 != 0 || op.Cin > 2048 || op.Cout > 8 || op.Cout < 1 || op.ld_in % 4 != 0) return XL_ERR_ARG;
+            const long long pix = (long long)op.B * op.Hi * op.Wi;
+            long long blocks = (pix + 3) / 4;
+            if (blocks > 4096) blocks = 4096;
+            hipLaunchKernelGGL(head_kernel<8>, dim3((unsigned)blocks), dim3(256), 0, st, (const float *)op.in,
+                               (const float *)op.w, (const float *)op.bias, (const float *)op.aux, (float *)op.out,
+                               op.B, op.Hi * op.Wi, op.Cin, op.ld_in, op.Cout, op.n_task, op.clamp_lo, op.clamp_hi);
+            return XL_OK;
+        }
+        default:
+            return XL_ERR_UNSUPPORTED;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int xl_cnn_run(const xl_op *ops, int n_ops, void *stream)
+{
+    if (!ops || n_ops < 0) return XL_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    for (int i = 0; i < n_ops; ++i) {
+        const int rc = run_op(ops[i], st);
+        if (rc != XL_OK) return rc;
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { snprintf(g_err, sizeof(g_err), "kernel launch: %s", hipGetErrorString(e)); return XL_ERR_HIP; }
+    return XL_OK;
+}
+
+int xl_cnn_op_size(void) { return (int)sizeof(xl_op); }
+
+int xl_cnn_pack_conv_weight(const float *w_oihw_dev, float *w_ohwi_dev, int Cout, int Cin, int k, void *stream)
+{
+    if (!w_oihw_dev || !w_ohwi_dev || Cout <= 0 || Cin <= 0 || k <= 0) return XL_ERR_ARG;
+    const long long total = (long long)Cout * Cin * k * k;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w_oihw_dev,
+                       w_ohwi_dev, Cout, Cin, k);
+    return hipGetLastError() == hipSuccess ? XL_OK : XL_ERR_HIP;
+}
+
+const char *xl_cnn_last_error(void) { return g_err; }
+
+}  // extern "C"

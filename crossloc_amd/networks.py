@@ -1,0 +1,483 @@
+"""MI355X-native `TransPoseNet` — same constructor, attributes and state_dict keys as the reference
+(/root/reference/networks/networks.py:375-502) so `load_state_dict` on reference checkpoints is strict-clean
+(116 tensors single-task, 270 for the 3-encoder CrossLoc net), but `forward` does not run PyTorch ops: it is
+lowered once per input shape to an op list (include/crossloc_cnn.h) of hand-written HIP kernels — implicit-GEMM
+convolutions on fp32 MFMA, two-pass GroupNorm with fused ReLU/residual epilogues, fused decoder head — and
+executed with one C call on the current HIP stream.  NCHW at the module boundary, NHWC inside.
+
+The nn.Conv2d / nn.GroupNorm children are parameter containers only (they give identical keys, shapes and
+default initialisation); they are never called.  There is no CPU/eager fallback: forward on a non-GPU tensor
+raises.  Inference only in this round (no autograd graph is built).
+"""
+import ctypes
+import math
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+XL_OP_CONV1, XL_OP_CONV, XL_OP_GN_STATS, XL_OP_GN_APPLY, XL_OP_HEAD = 0, 1, 2, 3, 4
+GN_RELU_IN, GN_ADD, GN_RELU_OUT = 1, 2, 4
+
+
+class XlOp(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in
+                ("type", "B", "Hi", "Wi", "Cin", "Ho", "Wo", "Cout", "ksize", "stride", "groups", "nchunks",
+                 "flags", "ld_in", "ld_out", "ld_aux", "n_task", "n_pos")] + \
+               [(n, ctypes.c_float) for n in ("eps", "clamp_lo", "clamp_hi", "reserved")] + \
+               [(n, ctypes.c_void_p) for n in ("in_", "w", "bias", "aux", "stats", "out")]
+
+
+def _bind():
+    L = _lib.lib()
+    if not hasattr(L, "_cnn_bound"):
+        L.xl_cnn_run.restype = ctypes.c_int
+        L.xl_cnn_run.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        L.xl_cnn_op_size.restype = ctypes.c_int
+        L.xl_cnn_pack_conv_weight.restype = ctypes.c_int
+        L.xl_cnn_pack_conv_weight.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                              ctypes.c_int, ctypes.c_void_p]
+        L.xl_cnn_last_error.restype = ctypes.c_char_p
+        if L.xl_cnn_op_size() != ctypes.sizeof(XlOp):
+            raise _lib.XlError("xl_op layout mismatch: C %d vs ctypes %d" % (L.xl_cnn_op_size(), ctypes.sizeof(XlOp)))
+        L._cnn_bound = True
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        L = _lib.lib()
+        raise _lib.XlError("crossloc_hip cnn: %s %s (status %d)" % (
+            L.xl_status_string(rc).decode(), L.xl_cnn_last_error().decode(), rc))
+
+
+# ------------------------------------------------------------------------------------------ parameter containers
+
+def _create_res_block(tiny, num_gn_channel, ch_down_factor=1):
+    """networks.py:133-146 (ReLU entries keep the Sequential indices 0,1,3,4,6,7 of the reference keys)."""
+    num_ch = (512, 128)[tiny] // ch_down_factor
+    g = min(num_gn_channel, num_ch)
+    return nn.Sequential(nn.Conv2d(num_ch, num_ch, 3, 1, 1), nn.GroupNorm(g, num_ch), nn.ReLU(),
+                         nn.Conv2d(num_ch, num_ch, 1, 1, 0), nn.GroupNorm(g, num_ch), nn.ReLU(),
+                         nn.Conv2d(num_ch, num_ch, 3, 1, 1), nn.GroupNorm(g, num_ch), nn.ReLU())
+
+
+def _create_mlr_concatenator(num_mlr, tiny, num_gn_channel):
+    """networks.py:149-163"""
+    cin, cout = (512, 128)[tiny] * num_mlr, (512, 128)[tiny]
+    return nn.Sequential(nn.Conv2d(cin, cout, 3, 1, 1), nn.GroupNorm(num_gn_channel, cout), nn.ReLU(),
+                         nn.Conv2d(cout, cout, 1, 1, 0), nn.GroupNorm(num_gn_channel, cout), nn.ReLU(),
+                         nn.Conv2d(cout, cout, 3, 1, 1), nn.GroupNorm(num_gn_channel, cout), nn.ReLU())
+
+
+def _create_mlr_skip_layer(num_mlr, tiny, num_gn_channel):
+    """networks.py:166-172"""
+    cin, cout = (512, 128)[tiny] * num_mlr, (512, 128)[tiny]
+    return nn.Sequential(nn.Conv2d(cin, cout, 1, 1, 0), nn.GroupNorm(num_gn_channel, cout))
+
+
+class TransPoseNetEncoder(nn.Module):
+    """Parameter layout of networks.py:175-219."""
+
+    def __init__(self, tiny, grayscale, enc_add_res_block=0, num_gn_channel=32):
+        super().__init__()
+        self.tiny, self.grayscale = tiny, grayscale
+        self.enc_add_res_block, self.num_gn_channel = enc_add_res_block, num_gn_channel
+        g = num_gn_channel
+        c4, c5 = (256, 128)[tiny], (512, 128)[tiny]
+        self.conv1 = nn.Conv2d(1 if grayscale else 3, g, 3, 1, 1)
+        self.norm1 = nn.GroupNorm(g, g)
+        self.conv2 = nn.Conv2d(g, 64, 3, 2, 1)
+        self.norm2 = nn.GroupNorm(g, 64)
+        self.conv3 = nn.Conv2d(64, 128, 3, 2, 1)
+        self.norm3 = nn.GroupNorm(g, 128)
+        self.conv4 = nn.Conv2d(128, c4, 3, 2, 1)
+        self.norm4 = nn.GroupNorm(g, c4)
+        self.res1_conv1 = nn.Conv2d(c4, c4, 3, 1, 1)
+        self.res1_norm1 = nn.GroupNorm(g, c4)
+        self.res1_conv2 = nn.Conv2d(c4, c4, 1, 1, 0)
+        self.res1_norm2 = nn.GroupNorm(g, c4)
+        self.res1_conv3 = nn.Conv2d(c4, c4, 3, 1, 1)
+        self.res1_norm3 = nn.GroupNorm(g, c4)
+        self.res2_conv1 = nn.Conv2d(c4, c5, 3, 1, 1)
+        self.res2_norm1 = nn.GroupNorm(g, c5)
+        self.res2_conv2 = nn.Conv2d(c5, c5, 1, 1, 0)
+        self.res2_norm2 = nn.GroupNorm(g, c5)
+        self.res2_conv3 = nn.Conv2d(c5, c5, 3, 1, 1)
+        self.res2_norm3 = nn.GroupNorm(g, c5)
+        if not tiny:
+            self.res2_skip = nn.Conv2d(256, 512, 1, 1, 0)
+            self.res2_skip_norm = nn.GroupNorm(g, 512)
+        self.enc_add_res_block_ls = [_create_res_block(tiny, g) for _ in range(enc_add_res_block)]
+        for i, block in enumerate(self.enc_add_res_block_ls):
+            self.add_module('enc_add_res_block{:d}'.format(i + 1), block)
+
+
+class TransPoseNetDecoder(nn.Module):
+    """Parameter layout of networks.py:276-317 (full_size_output / DUC branch is out of scope)."""
+
+    def __init__(self, mean, tiny, dec_add_res_block=0, num_task_channel=3, num_pos_channel=1, num_gn_channel=32,
+                 full_size_output=False):
+        super().__init__()
+        if full_size_output:
+            raise NotImplementedError("full_size_output (semantics DUC head) is outside the hot path (SURVEY.md §8f f4)")
+        self.register_buffer('mean', mean.clone().float())
+        self.tiny, self.dec_add_res_block = tiny, dec_add_res_block
+        self.num_task_channel, self.num_pos_channel = num_task_channel, num_pos_channel
+        self.num_gn_channel, self.full_size_output = num_gn_channel, full_size_output
+        c = (512, 128)[tiny]
+        g = num_gn_channel
+        self.dec_add_res_block_ls = [_create_res_block(tiny, g) for _ in range(dec_add_res_block)]
+        for i, block in enumerate(self.dec_add_res_block_ls):
+            self.add_module('dec_add_res_block{:d}'.format(i + 1), block)
+        self.res3_conv1 = nn.Conv2d(c, c, 1, 1, 0)
+        self.res3_norm1 = nn.GroupNorm(g, c)
+        self.res3_conv2 = nn.Conv2d(c, c, 1, 1, 0)
+        self.res3_norm2 = nn.GroupNorm(g, c)
+        self.res3_conv3 = nn.Conv2d(c, c, 1, 1, 0)
+        self.res3_norm3 = nn.GroupNorm(g, c)
+        self.fc1 = nn.Conv2d(c, c, 1, 1, 0)
+        self.fc1_norm = nn.GroupNorm(min(c, g), c)
+        self.fc2 = nn.Conv2d(c, c, 1, 1, 0)
+        self.fc2_norm = nn.GroupNorm(min(c, g), c)
+        assert num_task_channel > 0 and num_pos_channel >= 0
+        assert num_task_channel == len(mean)
+        self.fc3 = nn.Conv2d(c, num_task_channel + num_pos_channel, 1, 1, 0)
+
+
+# ------------------------------------------------------------------------------------------ lowering
+
+class _Plan:
+    """One forward pass for a fixed (B, H, W): op array + workspace, replayed on every call."""
+
+    def __init__(self, net, B, H, W, device):
+        self.B, self.H, self.W, self.device = B, H, W, device
+        self.ops = []
+        self.keep = []                      # tensors the op pointers reference
+        self.free = {}                      # numel -> [tensor]
+        self.packed = {}                    # id(param) -> packed weight tensor
+        self.net = net
+        self.stats = None
+        self.max_stats = 0
+        self.out_op_index = None
+        self.image_op_indices = []
+        self._lower(net)
+        n = len(self.ops)
+        self.op_array = (XlOp * n)(*self.ops)
+        self.stats = torch.zeros(max(self.max_stats, 1), dtype=torch.float64, device=device)
+        for i, op in enumerate(self.ops):
+            if op.type in (XL_OP_GN_STATS, XL_OP_GN_APPLY):
+                self.op_array[i].stats = self.stats.data_ptr()
+
+    # -- workspace
+    def alloc(self, numel):
+        lst = self.free.get(numel)
+        if lst:
+            return lst.pop()
+        t = torch.empty(numel, dtype=torch.float32, device=self.device)
+        self.keep.append(t)
+        return t
+
+    def release(self, t):
+        self.free.setdefault(t.numel(), []).append(t)
+
+    # -- weights
+    def pack_conv(self, conv):
+        w = conv.weight
+        key = id(w)
+        if key not in self.packed:
+            L = _bind()
+            src = w.detach().to(device=self.device, dtype=torch.float32).contiguous()
+            cout, cin, k, _ = src.shape
+            if cin in (1, 3) and k == 3:        # conv1: [(ky*3+kx)*Cin + c][Cout]
+                dst = src.permute(2, 3, 1, 0).contiguous()
+            else:
+                dst = torch.empty_like(src)
+                stream = torch.cuda.current_stream().cuda_stream
+                _check(L.xl_cnn_pack_conv_weight(src.data_ptr(), dst.data_ptr(), cout, cin, k, ctypes.c_void_p(stream)))
+            self.packed[key] = dst
+            self.keep.append(src)
+        return self.packed[key]
+
+    def dev(self, p):
+        t = p.detach().to(device=self.device, dtype=torch.float32).contiguous()
+        self.keep.append(t)
+        return t
+
+    # -- op emitters; an activation is (tensor, H, W, C, ld, channel_offset)
+    def conv(self, act, conv, out=None, out_ld=None, out_off=0):
+        t, H, W, C, ld, off = act
+        k, s = conv.kernel_size[0], conv.stride[0]
+        cout = conv.out_channels
+        Ho = (H + 2 * (k // 2) - k) // s + 1
+        Wo = (W + 2 * (k // 2) - k) // s + 1
+        if out is None:
+            out = self.alloc(self.B * Ho * Wo * cout)
+            out_ld = cout
+        op = XlOp()
+        op.type = XL_OP_CONV
+        op.B, op.Hi, op.Wi, op.Cin, op.Ho, op.Wo, op.Cout = self.B, H, W, C, Ho, Wo, cout
+        op.ksize, op.stride, op.ld_in, op.ld_out = k, s, ld, out_ld
+        op.in_ = t.data_ptr() + 4 * off
+        op.w = self.pack_conv(conv).data_ptr()
+        op.bias = self.dev(conv.bias).data_ptr()
+        op.out = out.data_ptr() + 4 * out_off
+        self.ops.append(op)
+        return (out, Ho, Wo, cout, out_ld, out_off)
+
+    def gn(self, act, norm, flags, aux=None, out=None):
+        """GroupNorm (+fused epilogue) of `act`; in place unless `out` (tensor, ld, off) is given."""
+        t, H, W, C, ld, off = act
+        G = norm.num_groups
+        HW = H * W
+        nchunks = max(1, min(128, (HW + 255) // 256))
+        self.max_stats = max(self.max_stats, self.B * nchunks * G * 2)
+        st = XlOp()
+        st.type = XL_OP_GN_STATS
+        st.B, st.Hi, st.Wi, st.Cin, st.groups, st.nchunks, st.ld_in = self.B, H, W, C, G, nchunks, ld
+        st.in_ = t.data_ptr() + 4 * off
+        self.ops.append(st)
+        ap = XlOp()
+        ap.type = XL_OP_GN_APPLY
+        ap.B, ap.Hi, ap.Wi, ap.Cin, ap.groups, ap.nchunks, ap.ld_in = self.B, H, W, C, G, nchunks, ld
+        ap.flags, ap.eps = flags, norm.eps
+        ap.in_ = t.data_ptr() + 4 * off
+        ap.w = self.dev(norm.weight).data_ptr()
+        ap.bias = self.dev(norm.bias).data_ptr()
+        if aux is not None:
+            ap.aux = aux[0].data_ptr() + 4 * aux[5]
+            ap.ld_aux = aux[4]
+        if out is None:
+            ap.out, ap.ld_out = ap.in_, ld
+            res = act
+        else:
+            ot, old, ooff = out
+            ap.out, ap.ld_out = ot.data_ptr() + 4 * ooff, old
+            res = (ot, H, W, C, old, ooff)
+        self.ops.append(ap)
+        return res
+
+    def cgr(self, act, conv, norm, flags=GN_RELU_IN, aux=None):
+        y = self.conv(act, conv)
+        return self.gn(y, norm, flags, aux)
+
+    def res_block(self, res, block):
+        """relu(res + block(res)), networks.py:252-254 / :332-334"""
+        x = self.cgr(res, block[0], block[1])
+        x2 = self.cgr(x, block[3], block[4])
+        self.release(x[0])
+        x3 = self.cgr(x2, block[6], block[7], GN_RELU_IN | GN_ADD | GN_RELU_OUT, aux=res)
+        self.release(x2[0])
+        self.release(res[0])
+        return x3
+
+    def encoder(self, enc, image, out=None):
+        """networks.py:221-256.  `out` = (tensor, ld, off): write the final activation into a channel slice."""
+        B, H, W = self.B, self.H, self.W
+        cin = enc.conv1.in_channels
+        c1 = enc.conv1.out_channels
+        t1 = self.alloc(B * H * W * c1)
+        op = XlOp()
+        op.type = XL_OP_CONV1
+        op.B, op.Hi, op.Wi, op.Cin, op.Ho, op.Wo, op.Cout, op.ld_out = B, H, W, cin, H, W, c1, c1
+        op.in_ = image.data_ptr()
+        op.w = self.pack_conv(enc.conv1).data_ptr()
+        op.bias = self.dev(enc.conv1.bias).data_ptr()
+        op.out = t1.data_ptr()
+        self.ops.append(op)
+        self.image_op_indices.append(len(self.ops) - 1)
+        x = self.gn((t1, H, W, c1, c1, 0), enc.norm1, GN_RELU_IN)
+        x2 = self.cgr(x, enc.conv2, enc.norm2); self.release(x[0])
+        x3 = self.cgr(x2, enc.conv3, enc.norm3); self.release(x2[0])
+        res = self.cgr(x3, enc.conv4, enc.norm4); self.release(x3[0])
+        a = self.cgr(res, enc.res1_conv1, enc.res1_norm1)
+        b = self.cgr(a, enc.res1_conv2, enc.res1_norm2); self.release(a[0])
+        c = self.cgr(b, enc.res1_conv3, enc.res1_norm3, GN_RELU_IN | GN_ADD | GN_RELU_OUT, aux=res)
+        self.release(b[0]); self.release(res[0])
+        res = c
+        a = self.cgr(res, enc.res2_conv1, enc.res2_norm1)
+        b = self.cgr(a, enc.res2_conv2, enc.res2_norm2); self.release(a[0])
+        c = self.cgr(b, enc.res2_conv3, enc.res2_norm3); self.release(b[0])
+        n_add = len(enc.enc_add_res_block_ls)
+        last_out = out if n_add == 0 else None
+        if not enc.tiny:
+            sk = self.conv(res, enc.res2_skip)
+            self.release(res[0])
+            res = self.gn(sk, enc.res2_skip_norm, GN_ADD | GN_RELU_OUT, aux=c, out=last_out)
+            self.release(c[0])
+            if last_out is not None:
+                self.release(sk[0])
+        else:
+            # tiny: res = relu(res + x) without a skip projection -> plain add is folded as GN-free path
+            raise NotImplementedError("tiny=True is not used by CrossLoc (utils/learning.py:302-305)")
+        for i, block in enumerate(enc.enc_add_res_block_ls):
+            if i == n_add - 1 and out is not None:
+                x = self.cgr(res, block[0], block[1])
+                x2 = self.cgr(x, block[3], block[4]); self.release(x[0])
+                y = self.conv(x2, block[6]); self.release(x2[0])
+                r = self.gn(y, block[7], GN_RELU_IN | GN_ADD | GN_RELU_OUT, aux=res, out=out)
+                self.release(y[0]); self.release(res[0])
+                res = r
+            else:
+                res = self.res_block(res, block)
+        return res
+
+    def _lower(self, net):
+        dec = net.decoder
+        if net.num_mlr == 0:
+            res = self.encoder(net.encoder, _DUMMY)
+        else:
+            Ho = Wo = None
+            c = (512, 128)[net.tiny]
+            # encoders write straight into channel slices of the concat buffer (networks.py:485-488)
+            h, w = self.H, self.W
+            for _ in range(3):
+                h, w = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+            Ho, Wo = h, w
+            ctot = c * net.num_mlr
+            cat = self.alloc(self.B * Ho * Wo * ctot)
+            for i, enc in enumerate(net.mlr_encoder_ls):
+                self.encoder(enc, _DUMMY, out=(cat, ctot, i * c))
+            mlr = (cat, Ho, Wo, ctot, ctot, 0)
+            sk = self.conv(mlr, net.mlr_skip[0])
+            sk = self.gn(sk, net.mlr_skip[1], 0)
+            mlr = self.gn(mlr, net.mlr_norm, 0)
+            f = net.mlr_forward
+            a = self.cgr(mlr, f[0], f[1]); self.release(cat)
+            b = self.cgr(a, f[3], f[4]); self.release(a[0])
+            res = self.cgr(b, f[6], f[7], GN_RELU_IN | GN_ADD | GN_RELU_OUT, aux=sk)
+            self.release(b[0]); self.release(sk[0])
+        for block in dec.dec_add_res_block_ls:
+            res = self.res_block(res, block)
+        a = self.cgr(res, dec.res3_conv1, dec.res3_norm1)
+        b = self.cgr(a, dec.res3_conv2, dec.res3_norm2); self.release(a[0])
+        c = self.cgr(b, dec.res3_conv3, dec.res3_norm3, GN_RELU_IN | GN_ADD | GN_RELU_OUT, aux=res)
+        self.release(b[0]); self.release(res[0])
+        res = c
+        a = self.cgr(res, dec.fc1, dec.fc1_norm); self.release(res[0])
+        b = self.cgr(a, dec.fc2, dec.fc2_norm); self.release(a[0])
+        t, H, W, C, ld, off = b
+        op = XlOp()
+        op.type = XL_OP_HEAD
+        op.B, op.Hi, op.Wi, op.Cin, op.Ho, op.Wo = self.B, H, W, C, H, W
+        op.Cout = dec.num_task_channel + dec.num_pos_channel
+        op.n_task, op.n_pos, op.ld_in = dec.num_task_channel, dec.num_pos_channel, ld
+        op.clamp_lo, op.clamp_hi = -16.10, 13.82
+        op.in_ = t.data_ptr() + 4 * off
+        w3 = dec.fc3.weight.detach().to(device=self.device, dtype=torch.float32).reshape(op.Cout, C).contiguous()
+        self.keep.append(w3)
+        op.w = w3.data_ptr()
+        op.bias = self.dev(dec.fc3.bias).data_ptr()
+        op.aux = self.dev(dec.mean).data_ptr()
+        self.ops.append(op)
+        self.out_op_index = len(self.ops) - 1
+        self.out_shape = (self.B, op.Cout, H, W)
+
+    def run(self, image):
+        out = torch.empty(self.out_shape, dtype=torch.float32, device=self.device)
+        for i in self.image_op_indices:
+            self.op_array[i].in_ = image.data_ptr()
+        self.op_array[self.out_op_index].out = out.data_ptr()
+        stream = torch.cuda.current_stream().cuda_stream
+        _check(_bind().xl_cnn_run(self.op_array, len(self.op_array), ctypes.c_void_p(stream)))
+        return out
+
+
+class _Dummy:
+    @staticmethod
+    def data_ptr():
+        return 0
+
+
+_DUMMY = _Dummy()
+
+
+class TransPoseNet(nn.Module):
+    """Drop-in for networks.py:362-502.  forward(inputs[B,C,H,W] on the GPU) -> [B, n_task+n_pos, H/8, W/8]."""
+
+    def __init__(self, mean, tiny, grayscale, enc_add_res_block=0, dec_add_res_block=0, num_task_channel=3,
+                 num_pos_channel=1, num_gn_channel=32, num_mlr=0, num_unfrozen_encoder=0, full_size_output=False):
+        super().__init__()
+        if tiny:
+            raise NotImplementedError("tiny=True is never instantiated by CrossLoc (utils/learning.py:302-305)")
+        mean = torch.as_tensor(mean, dtype=torch.float32)
+        self.register_buffer('mean', mean.clone())
+        self.tiny, self.grayscale = tiny, grayscale
+        self.enc_add_res_block, self.dec_add_res_block = enc_add_res_block, dec_add_res_block
+        self.num_task_channel, self.num_pos_channel = num_task_channel, num_pos_channel
+        self.num_gn_channel, self.num_mlr, self.full_size_output = num_gn_channel, num_mlr, full_size_output
+        self.OUTPUT_SUBSAMPLE = 1 if full_size_output else 8
+        if num_mlr == 0:
+            self.encoder = TransPoseNetEncoder(tiny, grayscale, enc_add_res_block, num_gn_channel)
+            self.encoder_ls = [self.encoder]
+            self.mlr_encoder_ls = [nn.Identity()]
+            self.mlr_norm, self.mlr_forward, self.mlr_skip = nn.Identity(), nn.Identity(), nn.Identity()
+        else:
+            assert isinstance(num_mlr, int) and 0 <= num_unfrozen_encoder <= num_mlr
+            self.encoder = nn.Identity()
+            self.encoder_ls = [self.encoder]
+            self.mlr_encoder_ls = [TransPoseNetEncoder(tiny, grayscale, enc_add_res_block, num_gn_channel)
+                                   for _ in range(num_mlr)]
+            for i, block in enumerate(self.mlr_encoder_ls):
+                if i >= num_unfrozen_encoder:                       # networks.py:424-428
+                    for p in block.parameters():
+                        p.requires_grad = False
+                self.add_module('mlr_encoder_{:d}'.format(i + 1), block)
+            self.mlr_norm = nn.GroupNorm(num_gn_channel, (512, 128)[tiny] * num_mlr)
+            self.mlr_forward = _create_mlr_concatenator(num_mlr, tiny, num_gn_channel)
+            self.mlr_skip = _create_mlr_skip_layer(num_mlr, tiny, num_gn_channel)
+        self.decoder = TransPoseNetDecoder(mean, tiny, dec_add_res_block, num_task_channel, num_pos_channel,
+                                           num_gn_channel, full_size_output)
+        self.decoder_ls = [self.decoder]
+        self._plans = {}
+        self._plan_version = None
+
+    def _version(self):
+        return sum(p._version for p in self.parameters()) + sum(b._version for b in self.buffers())
+
+    def invalidate(self):
+        """Drop cached plans (packed weights); called automatically when a parameter changes in place."""
+        self._plans = {}
+
+    def _apply(self, fn, *a, **k):
+        self._plans = {}
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._plans = {}
+        return super().load_state_dict(*a, **k)
+
+    def forward(self, inputs):
+        if not isinstance(inputs, torch.Tensor) or inputs.dim() != 4:
+            raise RuntimeError("TransPoseNet.forward expects a 4D tensor [B,C,H,W]")
+        if not inputs.is_cuda:
+            raise RuntimeError("crossloc_amd.TransPoseNet runs on the MI355X only (no CPU fallback); got a CPU tensor")
+        x = inputs.detach().to(torch.float32).contiguous()
+        B, C, H, W = x.shape
+        if C != (1 if self.grayscale else 3):
+            raise RuntimeError("expected %d input channels, got %d" % (1 if self.grayscale else 3, C))
+        ver = self._version()
+        if ver != self._plan_version:
+            self._plans = {}
+            self._plan_version = ver
+        key = (B, H, W, x.device.index)
+        with torch.cuda.device(x.device):
+            plan = self._plans.get(key)
+            if plan is None:
+                plan = _Plan(self, B, H, W, x.device)
+                self._plans[key] = plan
+            return plan.run(x)
+
+
+def smoke_check(device):
+    """Tiny forward against the fp32 torch restatement (used by __graft_entry__.smoke)."""
+    from .weights import seeded_state_dict
+    from oracle import cnn_oracle
+    net = TransPoseNet(torch.tensor([-455.934, 417.50, 520.31]), False, False, 1, 1, 3, 1)
+    net.load_state_dict(seeded_state_dict(net, seed=7))
+    x = torch.rand(1, 3, 64, 96)
+    ref = cnn_oracle.transposenet_forward(net.state_dict(), x, 0, 1, 1)
+    got = net.to(device)(x.to(device)).cpu()
+    err = (got - ref).abs().max().item()
+    assert err < 2e-3 * max(1.0, ref.abs().max().item()), "CNN forward mismatch: %g" % err

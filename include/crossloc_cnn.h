@@ -1,0 +1,75 @@
+/*
+ * crossloc_cnn.h — C ABI of the MI355X-native scene-coordinate CNN kernels (libcrossloc_hip.so).
+ *
+ * Replaces what PyTorch dispatches for TransPoseNet.forward
+ * (/root/reference/networks/networks.py:466-502; encoder :221-256, decoder :319-360,
+ * MLR fusion :483-494): nn.Conv2d 3x3/1x1 stride 1/2, nn.GroupNorm(32, C) + ReLU + residual add,
+ * and the decoder head epilogue (mean offset, exp(hardtanh)).
+ *
+ * The host side (crossloc_amd/networks.py) lowers one forward pass to an array of xl_op records and
+ * executes it with ONE call to xl_cnn_run on a HIP stream.  All tensors are float32 device memory.
+ * Activations are NHWC inside the network ([B, H, W, C], pixel stride `ld` floats so a tensor can
+ * be a channel slice of a wider buffer — the MLR concat is free); the module boundary is NCHW:
+ * XL_OP_CONV1 reads the NCHW image, XL_OP_HEAD writes the NCHW [B,4,Ho,Wo] prediction.
+ */
+#ifndef CROSSLOC_CNN_H
+#define CROSSLOC_CNN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+    XL_OP_CONV1 = 0,     /* 3x3 s1 p1 conv, Cin in {1,3} NCHW input -> NHWC, + bias (networks.py:186-189) */
+    XL_OP_CONV = 1,      /* 3x3 (pad 1) or 1x1 conv, stride 1 or 2, NHWC, implicit GEMM on fp32 MFMA, + bias */
+    XL_OP_GN_STATS = 2,  /* per-(image, chunk, group) partial sums of x and x^2 (fp64) */
+    XL_OP_GN_APPLY = 3,  /* GroupNorm affine from the partial sums, fused ReLU / residual add / ReLU */
+    XL_OP_HEAD = 4       /* fc3 1x1 conv to (n_task + n_pos) channels + mean offset + exp(hardtanh), NCHW out */
+};
+
+/* xl_op.flags for XL_OP_GN_APPLY:  v = gn(x); RELU_IN: v = max(v,0); ADD: v += aux; RELU_OUT: v = max(v,0) */
+#define XL_GN_RELU_IN 1
+#define XL_GN_ADD 2
+#define XL_GN_RELU_OUT 4
+
+typedef struct xl_op {
+    int32_t type;
+    int32_t B, Hi, Wi, Cin;        /* input geometry (XL_OP_GN_*: Hi*Wi pixels of Cin channels) */
+    int32_t Ho, Wo, Cout;          /* output geometry */
+    int32_t ksize, stride;         /* XL_OP_CONV: 3 or 1; 1 or 2 */
+    int32_t groups, nchunks;       /* GroupNorm groups; pixel chunks of the stats pass */
+    int32_t flags;
+    int32_t ld_in, ld_out, ld_aux; /* pixel strides in floats of in / out / aux (NHWC tensors) */
+    int32_t n_task, n_pos;         /* XL_OP_HEAD: task channels (mean added) and positive channels */
+    float eps;                     /* GroupNorm epsilon (1e-5) */
+    float clamp_lo, clamp_hi;      /* XL_OP_HEAD hardtanh bounds (-16.10, 13.82), networks.py:355-356 */
+    float reserved;
+    const void *in;                /* input activations (image for CONV1) */
+    const void *w;                 /* CONV: [Cout][k*k*Cin] (tap-major, channel-minor); CONV1: [27 or 9][Cout];
+                                      GN_APPLY: gamma[C]; HEAD: [Cout][Cin] */
+    const void *bias;              /* CONV*/
+    const void *aux;               /* GN_APPLY: residual tensor; HEAD: mean[n_task] */
+    void *stats;                   /* GN_*: fp64 partial sums [B][nchunks][groups][2] */
+    void *out;
+} xl_op;
+
+/* Execute ops[0..n_ops) in order on `stream` (hipStream_t; NULL = default). Asynchronous.
+ * Returns 0 or a negative xl status (include/crossloc_dsac.h); on error nothing further is launched. */
+int xl_cnn_run(const xl_op *ops, int n_ops, void *stream);
+
+/* sizeof(xl_op) as compiled, so a binding can verify its struct layout. */
+int xl_cnn_op_size(void);
+
+/* Weight layout transform used at load time: PyTorch conv weight [Cout][Cin][k][k] (device) ->
+ * [Cout][k][k][Cin] (device). */
+int xl_cnn_pack_conv_weight(const float *w_oihw_dev, float *w_ohwi_dev, int Cout, int Cin, int k, void *stream);
+
+/* Text of the last HIP failure reported by an xl_cnn_* call on this thread. */
+const char *xl_cnn_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,219 @@
+"""GPU parity of the CNN kernels (through the C ABI op list) against plain PyTorch fp32 on the CPU and
+against the golden outputs of the imported reference network.  Tolerances are fp32 summation-order level:
+|err| <= 2e-4 * max|ref| per op, 1e-3 end to end (29 convs + 28 GroupNorms)."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+import torch.nn as nn                      # noqa: E402
+import torch.nn.functional as F            # noqa: E402
+
+from crossloc_amd import networks          # noqa: E402
+from crossloc_amd.weights import seeded_state_dict   # noqa: E402
+from oracle import cnn_oracle              # noqa: E402
+
+pytestmark = pytest.mark.gpu
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "net_forward.npz"))
+MEAN = torch.tensor([-455.934, 417.50, 520.31])
+
+
+def _run(ops):
+    L = networks._bind()
+    arr = (networks.XlOp * len(ops))(*ops)
+    networks._check(L.xl_cnn_run(arr, len(ops), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+
+
+def _nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def _close(got, ref, tol=2e-4):
+    err = (got - ref).abs().max().item()
+    scale = max(ref.abs().max().item(), 1e-6)
+    assert err <= tol * scale, "max err %g vs scale %g" % (err, scale)
+
+
+@pytest.mark.parametrize("cin,cout,k,s,B,H,W", [
+    (32, 64, 3, 2, 2, 20, 28), (64, 128, 3, 2, 2, 18, 22), (128, 256, 3, 2, 1, 16, 24),
+    (256, 256, 3, 1, 2, 9, 13), (256, 512, 3, 1, 1, 8, 12), (512, 512, 3, 1, 3, 9, 13),
+    (256, 256, 1, 1, 2, 9, 13), (256, 512, 1, 1, 1, 8, 12), (512, 512, 1, 1, 2, 15, 9),
+    (1536, 512, 3, 1, 1, 8, 12), (1536, 512, 1, 1, 1, 8, 12), (512, 512, 3, 1, 1, 60, 90)])
+def test_igemm_conv_vs_torch(cin, cout, k, s, B, H, W):
+    g = torch.Generator().manual_seed(cin * 7 + cout + k + s)
+    x = torch.randn(B, cin, H, W, generator=g)
+    conv = nn.Conv2d(cin, cout, k, s, k // 2)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) * (2.0 / (cin * k * k)) ** 0.5)
+        conv.bias.copy_(torch.randn(cout, generator=g))
+        ref = conv(x)
+    L = networks._bind()
+    xd = _nhwc(x).cuda()
+    wsrc = conv.weight.detach().cuda().contiguous()
+    wd = torch.empty_like(wsrc)
+    networks._check(L.xl_cnn_pack_conv_weight(wsrc.data_ptr(), wd.data_ptr(), cout, cin, k, None))
+    bd = conv.bias.detach().cuda()
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    out = torch.full((B, Ho, Wo, cout), float("nan"), device="cuda")
+    op = networks.XlOp()
+    op.type = networks.XL_OP_CONV
+    op.B, op.Hi, op.Wi, op.Cin, op.Ho, op.Wo, op.Cout = B, H, W, cin, Ho, Wo, cout
+    op.ksize, op.stride, op.ld_in, op.ld_out = k, s, cin, cout
+    op.in_, op.w, op.bias, op.out = xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), out.data_ptr()
+    _run([op])
+    _close(out.cpu().permute(0, 3, 1, 2), ref)
+
+
+def test_conv_reads_and_writes_channel_slices():
+    """ld/offset addressing used by the concat-free MLR fusion."""
+    g = torch.Generator().manual_seed(3)
+    B, H, W = 1, 6, 10
+    wide = torch.randn(B, H, W, 96, generator=g)
+    x = wide[..., 32:64].permute(0, 3, 1, 2).contiguous()
+    conv = nn.Conv2d(32, 64, 3, 1, 1)
+    with torch.no_grad():
+        ref = conv(x)
+    L = networks._bind()
+    wd = torch.empty(conv.weight.shape, device="cuda")
+    ws = conv.weight.detach().cuda().contiguous()
+    networks._check(L.xl_cnn_pack_conv_weight(ws.data_ptr(), wd.data_ptr(), 64, 32, 3, None))
+    xin = wide.cuda()
+    outw = torch.zeros(B, H, W, 192, device="cuda")
+    op = networks.XlOp()
+    op.type = networks.XL_OP_CONV
+    op.B, op.Hi, op.Wi, op.Cin, op.Ho, op.Wo, op.Cout = B, H, W, 32, H, W, 64
+    op.ksize, op.stride, op.ld_in, op.ld_out = 3, 1, 96, 192
+    bd = conv.bias.detach().cuda()
+    op.in_, op.w, op.bias, op.out = xin.data_ptr() + 4 * 32, wd.data_ptr(), bd.data_ptr(), outw.data_ptr() + 4 * 64
+    _run([op])
+    got = outw.cpu()
+    _close(got[..., 64:128].permute(0, 3, 1, 2), ref)
+    assert got[..., :64].abs().max() == 0 and got[..., 128:].abs().max() == 0
+
+
+@pytest.mark.parametrize("cin", [3, 1])
+def test_conv1_vs_torch(cin):
+    g = torch.Generator().manual_seed(5)
+    B, H, W = 2, 24, 40
+    x = torch.rand(B, cin, H, W, generator=g)
+    conv = nn.Conv2d(cin, 32, 3, 1, 1)
+    with torch.no_grad():
+        ref = conv(x)
+    wd = conv.weight.detach().permute(2, 3, 1, 0).contiguous().cuda()
+    bd = conv.bias.detach().cuda()
+    xd = x.cuda()
+    out = torch.empty(B, H, W, 32, device="cuda")
+    op = networks.XlOp()
+    op.type = networks.XL_OP_CONV1
+    op.B, op.Hi, op.Wi, op.Cin, op.Ho, op.Wo, op.Cout, op.ld_out = B, H, W, cin, H, W, 32, 32
+    op.in_, op.w, op.bias, op.out = xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), out.data_ptr()
+    _run([op])
+    _close(out.cpu().permute(0, 3, 1, 2), ref, 1e-5)
+
+
+@pytest.mark.parametrize("C,H,W,flags", [(32, 24, 40, 1), (64, 12, 20, 1), (128, 6, 10, 1), (256, 9, 13, 7),
+                                          (512, 9, 13, 6), (512, 60, 90, 7), (1536, 8, 12, 0), (32, 480, 720, 1)])
+def test_groupnorm_vs_torch(C, H, W, flags):
+    g = torch.Generator().manual_seed(C + H)
+    B = 2
+    x = torch.randn(B, C, H, W, generator=g) * 3.0 + 1.5
+    aux = torch.randn(B, C, H, W, generator=g)
+    gamma = 1.0 + 0.2 * torch.randn(C, generator=g)
+    beta = 0.3 * torch.randn(C, generator=g)
+    ref = F.group_norm(x, 32, gamma, beta, eps=1e-5)
+    if flags & 1:
+        ref = F.relu(ref)
+    if flags & 2:
+        ref = ref + aux
+    if flags & 4:
+        ref = F.relu(ref)
+    xd, ad = _nhwc(x).cuda(), _nhwc(aux).cuda()
+    gd, bd = gamma.cuda(), beta.cuda()
+    nch = max(1, min(128, (H * W + 255) // 256))
+    stats = torch.zeros(B * nch * 32 * 2, dtype=torch.float64, device="cuda")
+    out = torch.empty_like(xd)
+    st = networks.XlOp()
+    st.type = networks.XL_OP_GN_STATS
+    st.B, st.Hi, st.Wi, st.Cin, st.groups, st.nchunks, st.ld_in = B, H, W, C, 32, nch, C
+    st.in_, st.stats = xd.data_ptr(), stats.data_ptr()
+    ap = networks.XlOp()
+    ap.type = networks.XL_OP_GN_APPLY
+    ap.B, ap.Hi, ap.Wi, ap.Cin, ap.groups, ap.nchunks, ap.ld_in, ap.ld_out, ap.ld_aux = B, H, W, C, 32, nch, C, C, C
+    ap.flags, ap.eps = flags, 1e-5
+    ap.in_, ap.w, ap.bias, ap.aux, ap.stats, ap.out = (xd.data_ptr(), gd.data_ptr(), bd.data_ptr(), ad.data_ptr(),
+                                                       stats.data_ptr(), out.data_ptr())
+    _run([st, ap])
+    _close(out.cpu().permute(0, 3, 1, 2), ref, 2e-5)
+
+
+def test_head_vs_torch():
+    g = torch.Generator().manual_seed(9)
+    B, H, W, C = 2, 9, 13, 512
+    x = torch.randn(B, C, H, W, generator=g)
+    fc3 = nn.Conv2d(C, 4, 1)
+    with torch.no_grad():
+        fc3.weight.mul_(20.0)                                     # reach both hardtanh bounds
+        sc = fc3(x)
+        ref = torch.cat([sc[:, :3] + MEAN[None, :, None, None], torch.exp(F.hardtanh(sc[:, 3:], -16.10, 13.82))], 1)
+    xd = _nhwc(x).cuda()
+    wd = fc3.weight.detach().reshape(4, C).contiguous().cuda()
+    bd, md = fc3.bias.detach().cuda(), MEAN.cuda()
+    out = torch.empty(B, 4, H, W, device="cuda")
+    op = networks.XlOp()
+    op.type = networks.XL_OP_HEAD
+    op.B, op.Hi, op.Wi, op.Cin, op.Ho, op.Wo, op.Cout, op.n_task, op.n_pos, op.ld_in = B, H, W, C, H, W, 4, 3, 1, C
+    op.clamp_lo, op.clamp_hi = -16.10, 13.82
+    op.in_, op.w, op.bias, op.aux, op.out = xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), md.data_ptr(), out.data_ptr()
+    _run([op])
+    got = out.cpu()
+    _close(got[:, :3] - MEAN[None, :, None, None], ref[:, :3] - MEAN[None, :, None, None], 1e-4)
+    assert torch.allclose(got[:, 3], ref[:, 3], rtol=2e-4)
+    assert (got[:, 3] >= np.exp(-16.10) * 0.999).all() and (got[:, 3] <= np.exp(13.82) * 1.001).all()
+
+
+@pytest.mark.parametrize("tag,num_mlr", [("single", 0), ("mlr3", 3)])
+def test_network_matches_reference_golden(tag, num_mlr):
+    net = networks.TransPoseNet(MEAN, False, False, 2, 2, 3, 1, 32, num_mlr, 0, False)
+    net.load_state_dict(seeded_state_dict(net, seed=2021), strict=True)
+    net = net.cuda().eval()
+    with torch.no_grad():
+        y = net(torch.from_numpy(GOLD[tag + "_x"]).cuda()).cpu()
+    ref = torch.from_numpy(GOLD[tag + "_y"])
+    assert y.shape == ref.shape
+    _close(y[:, :3] - MEAN[None, :, None, None], ref[:, :3] - MEAN[None, :, None, None], 1e-3)
+    assert torch.allclose(y[:, 3], ref[:, 3], rtol=2e-3)
+
+
+def test_network_full_size_vs_oracle_and_determinism():
+    """480x720 (the BASELINE frame size), batch 2: fp32 restatement on the CPU as the checker."""
+    net = networks.TransPoseNet(MEAN, False, False, 2, 2, 3, 1)
+    net.load_state_dict(seeded_state_dict(net, seed=3))
+    x = torch.rand(2, 3, 480, 720, generator=torch.Generator().manual_seed(1))
+    ref = cnn_oracle.transposenet_forward(net.state_dict(), x, 0, 2, 2)
+    net = net.cuda()
+    y = net(x.cuda())
+    y2 = net(x.cuda())
+    assert y.shape == (2, 4, 60, 90)
+    assert torch.equal(y, y2)                                       # fixed-order reductions: bitwise repeatable
+    y = y.cpu()
+    _close(y[:, :3] - MEAN[None, :, None, None], ref[:, :3] - MEAN[None, :, None, None], 1e-3)
+    assert torch.allclose(y[:, 3], ref[:, 3], rtol=2e-3)
+    # batch-size independence of per-image results
+    y1 = net(x[1:].cuda()).cpu()
+    assert torch.equal(y1[0], y[1])
+
+
+def test_weight_update_invalidates_packed_weights():
+    net = networks.TransPoseNet(MEAN, False, False, 0, 0).cuda()
+    x = torch.rand(1, 3, 64, 96, device="cuda")
+    y0 = net(x)
+    with torch.no_grad():
+        net.decoder.fc2.weight.mul_(1.5)
+        net.encoder.conv3.weight.mul_(0.5)
+    y1 = net(x)
+    ref = cnn_oracle.transposenet_forward(net.state_dict(), x, 0, 0, 0)
+    assert not torch.equal(y0, y1)
+    _close(y1.cpu()[:, :3] - MEAN[None, :, None, None], ref[:, :3] - MEAN[None, :, None, None], 1e-3)

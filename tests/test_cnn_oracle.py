@@ -1,0 +1,45 @@
+"""CPU: the fp32 restatement of the network graph (oracle/cnn_oracle.py) against golden outputs captured from
+the imported reference (tests/golden/make_golden.py), and the parameter containers of crossloc_amd.networks
+against the reference's state_dict keys/shapes."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from crossloc_amd import networks
+from crossloc_amd.weights import seeded_state_dict
+from oracle import cnn_oracle
+
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "net_forward.npz"))
+MEAN = torch.tensor([-455.934, 417.50, 520.31])
+
+
+@pytest.mark.parametrize("tag,num_mlr", [("single", 0), ("mlr3", 3)])
+def test_state_dict_keys_match_reference(tag, num_mlr):
+    net = networks.TransPoseNet(MEAN, False, False, 2, 2, 3, 1, 32, num_mlr, 0, False)
+    ours = ["%s:%s" % (k, "x".join(map(str, v.shape))) for k, v in net.state_dict().items()]
+    assert ours == list(GOLD[tag + "_keys"])                       # same keys, order and shapes (116 / 270)
+    assert sum(p.numel() for p in net.parameters()) == int(GOLD[tag + "_nparams"])
+    assert net.OUTPUT_SUBSAMPLE == 8 and net.num_task_channel == 3 and net.num_pos_channel == 1
+    if num_mlr:
+        assert not any(p.requires_grad for p in net.mlr_encoder_1.parameters())     # frozen, networks.py:424-428
+
+
+@pytest.mark.parametrize("tag,num_mlr", [("single", 0), ("mlr3", 3)])
+def test_oracle_matches_reference_golden(tag, num_mlr):
+    net = networks.TransPoseNet(MEAN, False, False, 2, 2, 3, 1, 32, num_mlr, 0, False)
+    sd = seeded_state_dict(net, seed=2021)
+    y = cnn_oracle.transposenet_forward(sd, torch.from_numpy(GOLD[tag + "_x"]), num_mlr, 2, 2)
+    ref = torch.from_numpy(GOLD[tag + "_y"])
+    # coordinates carry a +-500 m offset: compare the offset-free part tightly
+    assert torch.allclose(y[:, :3] - MEAN[None, :, None, None], ref[:, :3] - MEAN[None, :, None, None], atol=2e-4)
+    assert torch.allclose(y[:, 3], ref[:, 3], rtol=1e-4)
+
+
+def test_forward_requires_gpu_no_fallback():
+    net = networks.TransPoseNet(MEAN, False, False, 0, 0)
+    with pytest.raises(RuntimeError):
+        net(torch.zeros(1, 3, 64, 96))
+    with pytest.raises(NotImplementedError):
+        networks.TransPoseNet(MEAN, True, False)
