@@ -1,0 +1,210 @@
+#!/usr/bin/env python
+"""Benchmark of the CrossLoc localisation hot path on MI355X (BASELINE.json metric: images/s localised,
+480x720 frames, 256 RANSAC hypotheses; median pose error in cm / deg).
+
+A step = one batch of synthetic frames through the whole path on one GPU:
+    single-task scene-coordinate CNN forward (fp32 MFMA kernels)  ->  HIP dsacstar, 256 hypotheses per image.
+No trained weights or datasets exist offline: the CNN runs seeded random weights on uniform-random images and
+the solver consumes synthetic scene-coordinate maps (ray-cast terrain, 0.5 m noise, 30 % outliers) that are
+resident in HBM before the timed region; both stages execute in full for every image of every step.
+Multi-GPU (driver: torch.distributed.run, one rank per GPU): images shard as independent batches (weak
+scaling, no data-path collective); one RCCL all-gather of the per-image errors for the median.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) including
+    roofline     — the dominant kernel (3x3 512->512 implicit-GEMM conv, 78 % of forward FLOPs) timed with HIP
+                   events on its launch stream inside the timed region, against the fp32 MFMA peak;
+    cpu_baseline — the CPU oracle (restated reference path: OpenMP C solver + PyTorch-CPU network) on a bounded
+                   sample, rank 0 at N=1 only.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md: fp32-input MFMA = vector fp32 peak
+FWD_GFLOP_PER_IMAGE = 295.41        # SURVEY.md §8(d), single-task net, 480x720
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=16, help="images per step per GPU")
+    ap.add_argument("--hyps", type=int, default=256)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    from crossloc_amd import networks, synth, evaluation
+    from crossloc_amd.weights import seeded_state_dict
+    import dsacstar
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    B, K, W, H, IMW, NH = args.batch, args.steps, args.warmup, 480, 720, args.hyps
+    mean = torch.tensor(synth.SCENE_MEAN, dtype=torch.float32)
+    net = networks.TransPoseNet(mean, False, False, 2, 2, 3, 1)          # utils/learning.py:302-305 sizes
+    net.load_state_dict(seeded_state_dict(net, seed=2021))
+    net = net.to(dev).eval()
+
+    g = torch.Generator(device="cpu").manual_seed(2021 + rank)
+    images = torch.rand((B, 3, H, IMW), generator=g).to(dev)             # un-normalised [0,1] RGB at eval
+    coords_np, _, poses_np = synth.make_batch(2021 + 1000 * rank, B, noise=0.5, outlier_ratio=0.3)
+    coords = torch.from_numpy(coords_np).to(dev)
+    gt_poses = torch.from_numpy(poses_np).to(dev)
+
+    def step(s):
+        image0 = (s * world + rank) * B                                   # global image index keys the sampler
+        return evaluation.localize_batch(net, images, NH, synth.FOCAL, H, IMW, image0=image0, scene_coords=coords)
+
+    for s in range(W):
+        step(s)
+    torch.cuda.synchronize()
+
+    L = networks._bind()
+    L.xl_cnn_prof_begin.argtypes = [ctypes.c_int]
+    L.xl_cnn_prof_end.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+    plan = net._plans[(B, H, IMW, dev.index)]
+    n_ops = len(plan.op_array)
+    L.xl_cnn_prof_begin(n_ops * K)
+
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+          for _ in range(K)]
+    all_poses = []
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in range(K):
+        ev[s][0].record()
+        with torch.no_grad():
+            pred = net(images)
+        ev[s][1].record()
+        poses = torch.zeros((B, 4, 4), dtype=torch.float32, device=dev)
+        dsacstar.forward_rgb_batch(coords, poses, NH, 10.0, synth.FOCAL, IMW / 2.0, H / 2.0, 100.0, 100.0, 8,
+                                   image0=(s * world + rank) * B)
+        ev[s][2].record()
+        all_poses.append(poses)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    # ---- per-kernel durations from the HIP events recorded inside the timed region
+    cap = n_ops * K
+    idx = (ctypes.c_int32 * cap)()
+    typ = (ctypes.c_int32 * cap)()
+    ms = (ctypes.c_float * cap)()
+    nrec = L.xl_cnn_prof_end(idx, typ, ms, cap)
+    conv_ms, by_type = [], {}
+    for i in range(max(nrec, 0)):
+        op = plan.op_array[idx[i]]
+        by_type[typ[i]] = by_type.get(typ[i], 0.0) + ms[i]
+        if typ[i] == networks.XL_OP_CONV and op.ksize == 3 and op.Cin == 512 and op.Cout == 512 and op.stride == 1:
+            conv_ms.append(ms[i])
+    conv_avg_ms = float(np.mean(conv_ms)) if conv_ms else float("nan")
+    conv_flop = 2.0 * (B * 60 * 90) * 512 * (9 * 512)
+    conv_tflops = conv_flop / (conv_avg_ms * 1e-3) / 1e12 if conv_ms else float("nan")
+    cnn_ms = float(np.mean([ev[s][0].elapsed_time(ev[s][1]) for s in range(K)]))
+    dsac_ms = float(np.mean([ev[s][1].elapsed_time(ev[s][2]) for s in range(K)]))
+
+    # ---- pose errors: every image of every step, gathered over ranks with one all-gather
+    est = torch.cat(all_poses, 0)
+    t_err, r_err = evaluation.pose_errors(gt_poses.repeat(K, 1, 1), est)
+    local = torch.stack([t_err, r_err], 1)
+    total_imgs = world * B * K
+    if world > 1:
+        gathered = [torch.empty_like(local) for _ in range(world)]
+        dist.all_gather(gathered, local)
+        allerr = torch.cat(gathered, 0)
+    else:
+        allerr = local
+    med_t_cm = float(torch.median(allerr[:, 0]).item() * 100.0)
+    med_r_deg = float(torch.median(allerr[:, 1]).item())
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(net, images, coords_np, NH)
+
+    if rank == 0:
+        value = total_imgs / elapsed
+        out = {
+            "metric": "images/sec localized (480x720, 256 hyps)", "value": round(value, 2), "unit": "images/s",
+            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(elapsed / K * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]: single-task coord CNN forward (2+2 extra res blocks) + HIP "
+                                   "dsacstar.forward_rgb, 480x720 frames, 60x90 coordinate grid",
+                       "hypotheses": NH, "batch_per_gpu": B, "global_batch": B * world,
+                       "parallelism": "images sharded over %d GPU(s), no data-path collective" % world,
+                       "solver_input": "synthetic scene coordinates (0.5 m noise, 30% outliers); CNN runs seeded "
+                                       "random weights on random images (no trained weights offline)",
+                       "cnn_ms_per_batch": round(cnn_ms, 3), "dsac_ms_per_batch": round(dsac_ms, 3),
+                       "cnn_fwd_tflops": round(FWD_GFLOP_PER_IMAGE * B / cnn_ms, 2),
+                       "median_err_cm": round(med_t_cm, 3), "median_err_deg": round(med_r_deg, 5)},
+            "roofline": {"bound": "mfma", "kernel": "igemm_conv_kernel<3,1,128> 512->512 @60x90 x%d" % B,
+                         "achieved": round(conv_tflops, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(conv_tflops / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                         "avg_launch_ms": round(conv_avg_ms, 4), "launches_timed": len(conv_ms),
+                         "algorithmic_gflop_per_launch": round(conv_flop / 1e9, 2)},
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(net, images, coords_np, n_hyp):
+    """The restated reference CPU path on this box's host cores: PyTorch-CPU fp32 network + OpenMP C solver.
+    Bounded sample (a few frames) so the default run stays within minutes."""
+    import torch
+    from oracle import cnn_oracle, dsac_oracle
+    dsac_oracle.build()
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    x = images[:1].detach().cpu()
+    cnn_oracle.transposenet_forward(sd, x, 0, 2, 2)                      # warm-up
+    n_cnn = 3
+    t0 = time.perf_counter()
+    for _ in range(n_cnn):
+        cnn_oracle.transposenet_forward(sd, x, 0, 2, 2)
+    t_cnn = (time.perf_counter() - t0) / n_cnn
+    n_dsac = min(16, coords_np.shape[0])
+    dsac_oracle.forward_rgb(coords_np[0], n_hyp, 10.0, 480.0, 360.0, 240.0, 100.0, 100.0, 8)   # warm-up
+    t0 = time.perf_counter()
+    for b in range(n_dsac):
+        dsac_oracle.forward_rgb(coords_np[b], n_hyp, 10.0, 480.0, 360.0, 240.0, 100.0, 100.0, 8, image=b)
+    t_dsac = (time.perf_counter() - t0) / n_dsac
+    return {"value": round(1.0 / (t_cnn + t_dsac), 3), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": "%d frames CNN forward (PyTorch CPU fp32, batch 1) + %d frames oracle dsacstar %d hyps "
+                      "(C/OpenMP, %d threads); reference binary unbuildable (needs OpenCV)" % (
+                          n_cnn, n_dsac, n_hyp, dsac_oracle.num_threads()),
+            "cnn_s_per_image": round(t_cnn, 4), "dsac_s_per_image": round(t_dsac, 5)}
+
+
+if __name__ == "__main__":
+    main()

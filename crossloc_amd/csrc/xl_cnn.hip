@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "../../include/crossloc_cnn.h"
 #include "../../include/crossloc_dsac.h"   // status codes
@@ -381,6 +382,13 @@ __global__ void pack_weight_kernel(const float *__restrict__ src, float *__restr
 
 thread_local char g_err[256] = "";
 
+// ---- optional per-op HIP-event timing (bench.py roofline leg): events are recorded on the launch stream
+// around every op while profiling is on, and resolved after the caller has synchronised.
+struct ProfRec { hipEvent_t a, b; int opIndex; int type; };
+ProfRec *g_prof = nullptr;
+int g_profCap = 0, g_profCount = 0;
+bool g_profOn = false;
+
 template <int KS, int STRIDE, int BN>
 int launch_igemm(const xl_op &op, hipStream_t st)
 {
@@ -476,8 +484,15 @@ int xl_cnn_run(const xl_op *ops, int n_ops, void *stream)
     if (!ops || n_ops < 0) return XL_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     for (int i = 0; i < n_ops; ++i) {
+        const bool rec = g_profOn && g_profCount < g_profCap;
+        if (rec) (void)hipEventRecord(g_prof[g_profCount].a, st);
         const int rc = run_op(ops[i], st);
         if (rc != XL_OK) return rc;
+        if (rec) {
+            (void)hipEventRecord(g_prof[g_profCount].b, st);
+            g_prof[g_profCount].opIndex = i; g_prof[g_profCount].type = ops[i].type;
+            ++g_profCount;
+        }
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { snprintf(g_err, sizeof(g_err), "kernel launch: %s", hipGetErrorString(e)); return XL_ERR_HIP; }
@@ -498,5 +513,37 @@ int xl_cnn_pack_conv_weight(const float *w_oihw_dev, float *w_ohwi_dev, int Cout
 }
 
 const char *xl_cnn_last_error(void) { return g_err; }
+
+int xl_cnn_prof_begin(int max_records)
+{
+    if (max_records <= 0) return XL_ERR_ARG;
+    if (g_prof) return XL_ERR_ARG;
+    g_prof = (ProfRec *)calloc((size_t)max_records, sizeof(ProfRec));
+    if (!g_prof) return XL_ERR_ARG;
+    for (int i = 0; i < max_records; ++i) {
+        if (hipEventCreate(&g_prof[i].a) != hipSuccess || hipEventCreate(&g_prof[i].b) != hipSuccess) return XL_ERR_HIP;
+    }
+    g_profCap = max_records; g_profCount = 0; g_profOn = true;
+    return XL_OK;
+}
+
+int xl_cnn_prof_pause(int on) { g_profOn = (on != 0) && g_prof; return XL_OK; }
+
+int xl_cnn_prof_end(int32_t *op_index, int32_t *op_type, float *ms, int capacity)
+{
+    if (!g_prof) return XL_ERR_ARG;
+    g_profOn = false;
+    int n = g_profCount < capacity ? g_profCount : capacity;
+    for (int i = 0; i < n; ++i) {
+        float t = 0.f;
+        if (hipEventSynchronize(g_prof[i].b) != hipSuccess || hipEventElapsedTime(&t, g_prof[i].a, g_prof[i].b) != hipSuccess) t = -1.f;
+        if (op_index) op_index[i] = g_prof[i].opIndex;
+        if (op_type) op_type[i] = g_prof[i].type;
+        if (ms) ms[i] = t;
+    }
+    for (int i = 0; i < g_profCap; ++i) { (void)hipEventDestroy(g_prof[i].a); (void)hipEventDestroy(g_prof[i].b); }
+    free(g_prof); g_prof = nullptr; g_profCap = 0; g_profCount = 0;
+    return n;
+}
 
 }  // extern "C"

@@ -66,6 +66,14 @@ int xl_cnn_op_size(void);
  * [Cout][k][k][Cin] (device). */
 int xl_cnn_pack_conv_weight(const float *w_oihw_dev, float *w_ohwi_dev, int Cout, int Cin, int k, void *stream);
 
+/* Per-op HIP-event timing for measurement (bench.py): between prof_begin and prof_end every op launched by
+ * xl_cnn_run is bracketed by two events on its own stream (up to max_records ops).  prof_end waits for the
+ * recorded events, writes (index in the op list, op type, elapsed ms) per record and returns the record count
+ * (or a negative status); prof_pause(0/1) suspends/resumes recording. */
+int xl_cnn_prof_begin(int max_records);
+int xl_cnn_prof_pause(int on);
+int xl_cnn_prof_end(int32_t *op_index, int32_t *op_type, float *ms, int capacity);
+
 /* Text of the last HIP failure reported by an xl_cnn_* call on this thread. */
 const char *xl_cnn_last_error(void);
 
