@@ -38,7 +38,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=16, help="images per step per GPU")
+    ap.add_argument("--batch", type=int, default=24,
+                    help="images per step per GPU (24 -> 4052 conv tiles = 7.9 full waves of 512 resident workgroups)")
     ap.add_argument("--hyps", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -125,6 +126,16 @@ def main():
         by_type[typ[i]] = by_type.get(typ[i], 0.0) + ms[i]
         if typ[i] == networks.XL_OP_CONV and op.ksize == 3 and op.Cin == 512 and op.Cout == 512 and op.stride == 1:
             conv_ms.append(ms[i])
+    if rank == 0 and os.environ.get("XL_BENCH_VERBOSE"):
+        per_op = {}
+        for i in range(max(nrec, 0)):
+            per_op.setdefault(idx[i], []).append(ms[i])
+        names = {0: "conv1", 1: "conv", 2: "gn_stats", 3: "gn_apply", 4: "head"}
+        for i in sorted(per_op):
+            op = plan.op_array[i]
+            sys.stderr.write("op %3d %-8s k%d s%d %4d->%4d %3dx%3d  %.4f ms\n" % (
+                i, names[op.type], op.ksize, op.stride, op.Cin, op.Cout, op.Hi, op.Wi, float(np.mean(per_op[i]))))
+        sys.stderr.write("by type (ms/step): %s\n" % {names[k]: round(v / K, 3) for k, v in by_type.items()})
     conv_avg_ms = float(np.mean(conv_ms)) if conv_ms else float("nan")
     conv_flop = 2.0 * (B * 60 * 90) * 512 * (9 * 512)
     conv_tflops = conv_flop / (conv_avg_ms * 1e-3) / 1e12 if conv_ms else float("nan")
@@ -164,7 +175,7 @@ def main():
                        "cnn_ms_per_batch": round(cnn_ms, 3), "dsac_ms_per_batch": round(dsac_ms, 3),
                        "cnn_fwd_tflops": round(FWD_GFLOP_PER_IMAGE * B / cnn_ms, 2),
                        "median_err_cm": round(med_t_cm, 3), "median_err_deg": round(med_r_deg, 5)},
-            "roofline": {"bound": "mfma", "kernel": "igemm_conv_kernel<3,1,128> 512->512 @60x90 x%d" % B,
+            "roofline": {"bound": "mfma", "kernel": "igemm_conv_kernel<3,1,128,512> (3x3 512->512 @60x90 x%d images)" % B,
                          "achieved": round(conv_tflops, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(conv_tflops / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
                          "avg_launch_ms": round(conv_avg_ms, 4), "launches_timed": len(conv_ms),

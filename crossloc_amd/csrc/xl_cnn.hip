@@ -22,6 +22,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <type_traits>
 
 #include "../../include/crossloc_cnn.h"
 #include "../../include/crossloc_dsac.h"   // status codes
@@ -89,6 +90,8 @@ struct ConvArgs {
     const float *in; const float *w; const float *bias; float *out;
     int B, Hi, Wi, Cin, Ho, Wo, Cout, ldIn, ldOut;
     int M, K, nbm, nbn;
+    unsigned inBytes, wBytes;       // extents for the buffer descriptors (hardware bounds check)
+    int dbg;                        // diagnostics only (XL_CONV_DBG): 1 = skip global loads, 2 = skip LDS refill
 };
 
 // bijective XCD remap: block b runs on XCD b%8; give each XCD a contiguous run of tiles
@@ -99,13 +102,25 @@ __device__ __forceinline__ int xcd_remap(int b, int nwg)
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
 }
 
-template <int KS, int STRIDE, int BN>
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff)
+{
+    u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, (int)soff, 0);
+    return __builtin_bit_cast(f32x4, v);
+}
+
+// Global->register loads go through buffer descriptors: a padding tap gets an out-of-range offset and the
+// hardware returns zeros (no branch, no select on the data); destinations and offsets never alias, so the
+// eight loads of a K-step stay in flight together under the MFMAs of the previous one.
+template <int KS, int STRIDE, int BN, int CIN>     // CIN = compile-time Cin (0: runtime)
 __global__ __launch_bounds__(256, 2)
 void igemm_conv_kernel(ConvArgs a)
 {
     constexpr int PAD = (KS == 3) ? 1 : 0;
     constexpr int NJ = BN / 64;                 // 32-wide MFMA tiles per wave along N
     constexpr int BROWS = BN / 32;              // B-tile rows loaded per thread
+    constexpr unsigned OOB = 0x80000000u;       // > any legal extent: forces the zero-fill path
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *As = smem;                           // [2][kBM][kPitch]
     float *Bs = smem + 2 * kBM * kPitch;        // [2][BN][kPitch]
@@ -113,14 +128,18 @@ void igemm_conv_kernel(ConvArgs a)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
+    const int Cin = CIN ? CIN : a.Cin;
 
     const int tile = xcd_remap(blockIdx.x, a.nbm * a.nbn);
     const int mt = tile / a.nbn, nt = tile - mt * a.nbn;
     const int m0 = mt * kBM, n0 = nt * BN;
 
+    const __amdgpu_buffer_rsrc_t srdA = __builtin_amdgcn_make_buffer_rsrc((void *)a.in, 0, (int)a.inBytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srdB = __builtin_amdgcn_make_buffer_rsrc((void *)a.w, 0, (int)a.wBytes, 0x00020000);
+
     // ---- per-thread load coordinates: 4 A rows (and BROWS B rows) at float4 column kq
     const int lrow = tid >> 3, kq = tid & 7;
-    long long aOff[4];
+    unsigned aOff[4];                           // byte offset of (n, iy0, ix0, 4*kq); wraps for padding rows
     int aIy[4], aIx[4];
     const int HoWo = a.Ho * a.Wo;
 #pragma unroll
@@ -132,28 +151,30 @@ void igemm_conv_kernel(ConvArgs a)
             const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
             aIy[p] = oy * STRIDE - PAD;
             aIx[p] = ox * STRIDE - PAD;
-            aOff[p] = (((long long)n * a.Hi + aIy[p]) * a.Wi + aIx[p]) * a.ldIn + 4 * kq;
+            aOff[p] = (unsigned)(((n * a.Hi + aIy[p]) * a.Wi + aIx[p]) * a.ldIn + 4 * kq) * 4u;
         } else {
             aIy[p] = -100000; aIx[p] = -100000; aOff[p] = 0;
         }
     }
-    const float *wBase = a.w + (long long)(n0 + lrow) * a.K + 4 * kq;
+    unsigned bOff[BROWS];
+#pragma unroll
+    for (int p = 0; p < BROWS; ++p) bOff[p] = (unsigned)((n0 + lrow + 32 * p) * a.K + 4 * kq) * 4u;
 
     f32x4 ra[4], rb[BROWS];
     auto load_global = [&](int kk) {
         const int kbase = kk * kBK;
-        const int tap = kbase / a.Cin;
-        const int c0 = kbase - tap * a.Cin;
+        int tap;
+        if constexpr (CIN != 0) tap = kbase / CIN; else tap = kbase / Cin;
+        const int c0 = kbase - tap * Cin;
         const int ky = tap / KS, kx = tap - ky * KS;
-        const long long tapOff = ((long long)ky * a.Wi + kx) * a.ldIn + c0;
+        const unsigned tapOff = (unsigned)((ky * a.Wi + kx) * a.ldIn + c0) * 4u;
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const bool ok = (unsigned)(aIy[p] + ky) < (unsigned)a.Hi && (unsigned)(aIx[p] + kx) < (unsigned)a.Wi;
-            ra[p] = ok ? *reinterpret_cast<const f32x4 *>(a.in + aOff[p] + tapOff) : f32x4{ 0.f, 0.f, 0.f, 0.f };
+            ra[p] = buf_load4(srdA, ok ? aOff[p] + tapOff : OOB, 0);
         }
 #pragma unroll
-        for (int p = 0; p < BROWS; ++p)
-            rb[p] = *reinterpret_cast<const f32x4 *>(wBase + (long long)(32 * p) * a.K + kbase);
+        for (int p = 0; p < BROWS; ++p) rb[p] = buf_load4(srdB, bOff[p], (unsigned)kbase * 4u);
     };
     auto store_lds = [&](int buf) {
         float *Ad = As + buf * kBM * kPitch + lrow * kPitch + 4 * kq;
@@ -178,28 +199,57 @@ void igemm_conv_kernel(ConvArgs a)
     __syncthreads();
 
     const int fragRow = lane & 31, fragK = (lane >> 5) * 4;
+    const float *Afrag = As + (wm * 64 + fragRow) * kPitch + fragK;
+    const float *Bfrag = Bs + (wn * (BN / 2) + fragRow) * kPitch + fragK;
     for (int kk = 0; kk < nk; ++kk) {
         const int buf = kk & 1;
-        if (kk + 1 < nk) load_global(kk + 1);
-        const float *Ab = As + buf * kBM * kPitch + (wm * 64 + fragRow) * kPitch + fragK;
-        const float *Bb = Bs + buf * BN * kPitch + (wn * (BN / 2) + fragRow) * kPitch + fragK;
+        if (kk + 1 < nk && !(a.dbg & 1)) load_global(kk + 1);
+        const float *Ab = Afrag + buf * kBM * kPitch;
+        const float *Bb = Bfrag + buf * BN * kPitch;
+        // fragments ping-pong between two register sets: chunk c+1 is read from LDS while chunk c multiplies.
+        // The sched_group_barrier sequence pins that order (hipcc otherwise re-merges the two sets and exposes
+        // the LDS latency once per chunk).
+        f32x4 fa[2][2], fb[2][NJ];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            f32x4 fa[2], fb[NJ];
+        for (int i = 0; i < 2; ++i) fa[0][i] = *reinterpret_cast<const f32x4 *>(Ab + i * 32 * kPitch);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const f32x4 *>(Ab + i * 32 * kPitch + c * 8);
+        for (int j = 0; j < NJ; ++j) fb[0][j] = *reinterpret_cast<const f32x4 *>(Bb + j * 32 * kPitch);
+        auto chunk = [&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            constexpr int cur = c & 1, nxt = cur ^ 1;
+            if constexpr (c < 3) {
+                if (!(a.dbg & 8)) {
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) fb[j] = *reinterpret_cast<const f32x4 *>(Bb + j * 32 * kPitch + c * 8);
+                for (int i = 0; i < 2; ++i) fa[nxt][i] = *reinterpret_cast<const f32x4 *>(Ab + i * 32 * kPitch + (c + 1) * 8);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) fb[nxt][j] = *reinterpret_cast<const f32x4 *>(Bb + j * 32 * kPitch + (c + 1) * 8);
+                } else {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) fa[nxt][i] = fa[cur][i];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) fb[nxt][j] = fb[cur][j];
+                }
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < NJ; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
-        }
-        if (kk + 1 < nk) store_lds(buf ^ 1);
-        __syncthreads();
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i][e], fb[cur][j][e], acc[i][j], 0, 0, 0);
+        };
+        chunk(std::integral_constant<int, 0>{});
+        chunk(std::integral_constant<int, 1>{});
+        chunk(std::integral_constant<int, 2>{});
+        chunk(std::integral_constant<int, 3>{});
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 * (2 + NJ), 0);     // chunk 0 + chunk 1 fragments
+        __builtin_amdgcn_sched_group_barrier(0x008, 8 * NJ, 0);           // chunk 0 MFMAs
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 + NJ, 0);           // chunk 2 fragments
+        __builtin_amdgcn_sched_group_barrier(0x008, 8 * NJ, 0);           // chunk 1 MFMAs
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 + NJ, 0);           // chunk 3 fragments
+        __builtin_amdgcn_sched_group_barrier(0x008, 16 * NJ, 0);          // chunk 2 + 3 MFMAs
+        if (kk + 1 < nk && !(a.dbg & 2)) store_lds(buf ^ 1);
+        if (!(a.dbg & 4)) __syncthreads();
     }
 
     // ---- epilogue: bias + store. C layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -389,7 +439,7 @@ ProfRec *g_prof = nullptr;
 int g_profCap = 0, g_profCount = 0;
 bool g_profOn = false;
 
-template <int KS, int STRIDE, int BN>
+template <int KS, int STRIDE, int BN, int CIN>
 int launch_igemm(const xl_op &op, hipStream_t st)
 {
     ConvArgs a;
@@ -398,15 +448,25 @@ int launch_igemm(const xl_op &op, hipStream_t st)
     a.ldIn = op.ld_in; a.ldOut = op.ld_out;
     a.M = op.B * op.Ho * op.Wo; a.K = op.ksize * op.ksize * op.Cin;
     a.nbm = (a.M + kBM - 1) / kBM; a.nbn = op.Cout / BN;
-    const size_t lds = sizeof(float) * 2 * (kBM + BN) * kPitch;
+    const long long inBytes = (((long long)op.B * op.Hi * op.Wi - 1) * op.ld_in + op.Cin) * 4;
+    const long long wBytes = (long long)op.Cout * a.K * 4;
+    if (inBytes >= 0x7fffffffLL || wBytes >= 0x7fffffffLL) {
+        snprintf(g_err, sizeof(g_err), "conv input of %lld bytes exceeds 32-bit buffer addressing; split the batch", inBytes);
+        return XL_ERR_ARG;
+    }
+    a.inBytes = (unsigned)inBytes; a.wBytes = (unsigned)wBytes;
+    static const int dbgFlags = getenv("XL_CONV_DBG") ? atoi(getenv("XL_CONV_DBG")) : 0;
+    static const int ldsPad = getenv("XL_CONV_LDS_PAD") ? atoi(getenv("XL_CONV_LDS_PAD")) : 0;
+    a.dbg = dbgFlags;
+    const size_t lds = sizeof(float) * 2 * (kBM + BN) * kPitch + (size_t)ldsPad;
     static bool configured = false;
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(igemm_conv_kernel<KS, STRIDE, BN>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(igemm_conv_kernel<KS, STRIDE, BN, CIN>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { snprintf(g_err, sizeof(g_err), "hipFuncSetAttribute: %s", hipGetErrorString(e)); return XL_ERR_HIP; }
         configured = true;
     }
-    hipLaunchKernelGGL((igemm_conv_kernel<KS, STRIDE, BN>), dim3(a.nbm * a.nbn), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((igemm_conv_kernel<KS, STRIDE, BN, CIN>), dim3(a.nbm * a.nbn), dim3(256), lds, st, a);
     return XL_OK;
 }
 
@@ -414,9 +474,15 @@ int run_conv(const xl_op &op, hipStream_t st)
 {
     if (op.Cin % 32 != 0 || op.Cout % 64 != 0 || op.ld_in % 4 != 0) return XL_ERR_ARG;
     const bool wide = (op.Cout % 128 == 0);
-    if (op.ksize == 3 && op.stride == 1) return wide ? launch_igemm<3, 1, 128>(op, st) : launch_igemm<3, 1, 64>(op, st);
-    if (op.ksize == 3 && op.stride == 2) return wide ? launch_igemm<3, 2, 128>(op, st) : launch_igemm<3, 2, 64>(op, st);
-    if (op.ksize == 1 && op.stride == 1) return wide ? launch_igemm<1, 1, 128>(op, st) : launch_igemm<1, 1, 64>(op, st);
+    if (op.ksize == 3 && op.stride == 1) {
+        if (wide && op.Cin == 512) return launch_igemm<3, 1, 128, 512>(op, st);      // 78 % of the forward FLOPs
+        return wide ? launch_igemm<3, 1, 128, 0>(op, st) : launch_igemm<3, 1, 64, 0>(op, st);
+    }
+    if (op.ksize == 3 && op.stride == 2) return wide ? launch_igemm<3, 2, 128, 0>(op, st) : launch_igemm<3, 2, 64, 0>(op, st);
+    if (op.ksize == 1 && op.stride == 1) {
+        if (wide && op.Cin == 512) return launch_igemm<1, 1, 128, 512>(op, st);
+        return wide ? launch_igemm<1, 1, 128, 0>(op, st) : launch_igemm<1, 1, 64, 0>(op, st);
+    }
     return XL_ERR_UNSUPPORTED;
 }
 

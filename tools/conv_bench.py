@@ -1,0 +1,55 @@
+"""Micro-benchmark of one implicit-GEMM conv op (default: the dominant 3x3 512->512 @ 60x90 x16) with HIP
+events; used standalone and under rocprofv3 --pmc to diagnose the kernel.  Not part of the product path."""
+import argparse
+import ctypes
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from crossloc_amd import networks  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cin", type=int, default=512)
+    ap.add_argument("--cout", type=int, default=512)
+    ap.add_argument("--k", type=int, default=3)
+    ap.add_argument("--s", type=int, default=1)
+    ap.add_argument("--B", type=int, default=16)
+    ap.add_argument("--H", type=int, default=60)
+    ap.add_argument("--W", type=int, default=90)
+    ap.add_argument("--iters", type=int, default=20)
+    a = ap.parse_args()
+    L = networks._bind()
+    Ho = (a.H + 2 * (a.k // 2) - a.k) // a.s + 1
+    Wo = (a.W + 2 * (a.k // 2) - a.k) // a.s + 1
+    x = torch.randn(a.B, a.H, a.W, a.cin, device="cuda")
+    w = torch.randn(a.cout, a.k, a.k, a.cin, device="cuda") * 0.02
+    b = torch.randn(a.cout, device="cuda")
+    out = torch.empty(a.B, Ho, Wo, a.cout, device="cuda")
+    op = networks.XlOp()
+    op.type = networks.XL_OP_CONV
+    op.B, op.Hi, op.Wi, op.Cin, op.Ho, op.Wo, op.Cout = a.B, a.H, a.W, a.cin, Ho, Wo, a.cout
+    op.ksize, op.stride, op.ld_in, op.ld_out = a.k, a.s, a.cin, a.cout
+    op.in_, op.w, op.bias, op.out = x.data_ptr(), w.data_ptr(), b.data_ptr(), out.data_ptr()
+    arr = (networks.XlOp * 1)(op)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for _ in range(3):
+        networks._check(L.xl_cnn_run(arr, 1, st))
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(a.iters):
+        L.xl_cnn_run(arr, 1, st)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / a.iters
+    flop = 2.0 * a.B * Ho * Wo * a.cout * a.k * a.k * a.cin
+    print("conv %dx%d s%d %d->%d B%d %dx%d: %.4f ms  %.1f TFLOP/s (%.1f%% of 157.3)" % (
+        a.k, a.k, a.s, a.cin, a.cout, a.B, a.H, a.W, ms, flop / ms / 1e9, flop / ms / 1e9 / 157.3 * 100))
+
+
+if __name__ == "__main__":
+    main()
