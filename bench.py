@@ -194,8 +194,11 @@ def cpu_baseline(net, images, coords_np, n_hyp):
     import torch
     from oracle import cnn_oracle, dsac_oracle
     dsac_oracle.build()
-    cores = os.cpu_count() or 1
+    # all hardware threads of a 2-socket host oversubscribe both OpenMP runtimes badly (measured 22 s per
+    # frame at 256 threads); use up to 64 and report that number as `cores`
+    cores = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 64)
     torch.set_num_threads(cores)
+    dsac_oracle.set_num_threads(cores)
     sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
     x = images[:1].detach().cpu()
     cnn_oracle.transposenet_forward(sd, x, 0, 2, 2)                      # warm-up

@@ -1,0 +1,111 @@
+"""Evaluation entry point shaped like the reference's test_single_task.py (main loop :328-366, report
+utils/evaluation.py:193-244) for the coord task, on the MI355X path:
+
+    python -m crossloc_amd.test_single_task --synthetic 256 --hypotheses 256 [--network_in model.net]
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 -m crossloc_amd.test_single_task ...
+
+Differences from the reference loop: images are localised in batches (CNN forward + HIP dsacstar per batch)
+instead of one at a time with a .cpu() round trip; with WORLD_SIZE > 1 image i goes to rank i % R and one
+RCCL all-gather collects the per-image errors; dataset/checkpoint discovery (test_single_task.py:118-256)
+is out of scope — frames come from crossloc_amd.synth, weights from --network_in (a reference state_dict) or
+the seeded generator.  Without trained weights the network output is not a scene, so `--solver_input
+synthetic` (default) feeds the solver the synthetic scene-coordinate maps while the CNN still runs.
+"""
+import argparse
+import os
+import random
+import time
+
+import numpy as np
+import torch
+
+from . import evaluation, networks, synth
+from .weights import seeded_state_dict
+
+
+def set_random_seed(random_seed):
+    """utils/learning.py:74-81"""
+    torch.manual_seed(random_seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(random_seed)
+    random.seed(random_seed)
+    np.random.seed(random_seed)
+
+
+def _parse():
+    p = argparse.ArgumentParser(description="CrossLoc coord-task evaluation on MI355X")
+    p.add_argument('--hypotheses', '-hyps', type=int, default=64)            # test_single_task.py:76-89 defaults
+    p.add_argument('--threshold', '-t', type=float, default=10)
+    p.add_argument('--inlieralpha', '-ia', type=float, default=100)
+    p.add_argument('--maxpixelerror', '-maxerrr', type=float, default=100)
+    p.add_argument('--network_in', type=str, default=None, help='reference-format state_dict (.net)')
+    p.add_argument('--synthetic', type=int, default=64, help='number of synthetic frames')
+    p.add_argument('--batch', type=int, default=16)
+    p.add_argument('--noise', type=float, default=0.5)
+    p.add_argument('--outliers', type=float, default=0.3)
+    p.add_argument('--solver_input', choices=['synthetic', 'network'], default='synthetic')
+    p.add_argument('--num_mlr', type=int, default=0, help='3 = CrossLoc three-encoder network')
+    p.add_argument('--testing_log', type=str, default=None)
+    return p.parse_args()
+
+
+def main():
+    opt = _parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+    set_random_seed(2021)                                                       # test_single_task.py:265
+
+    mean = torch.tensor(synth.SCENE_MEAN, dtype=torch.float32)
+    net = networks.TransPoseNet(mean, False, False, 2, 2, 3, 1, 32, opt.num_mlr, 0, False)   # evaluation.py:105-109
+    if opt.network_in:
+        net.load_state_dict(torch.load(opt.network_in, map_location="cpu"), strict=True)     # evaluation.py:113
+    else:
+        net.load_state_dict(seeded_state_dict(net, seed=2021))
+    net = net.to(dev).eval()
+
+    K = opt.synthetic
+    mine = evaluation.shard_indices(K, rank, world)
+    H, W = synth.IMAGE_H, synth.IMAGE_W
+    g = torch.Generator().manual_seed(2021)
+    rows, coord_errs = [], []
+    t0 = time.time()
+    for s in range(0, len(mine), opt.batch):
+        idx = mine[s:s + opt.batch]
+        scenes = [synth.make_scene(2021 + i, noise=opt.noise, outlier_ratio=opt.outliers) for i in idx]
+        images = torch.rand((len(idx), 3, H, W), generator=g).to(dev)           # raw_image=True: un-normalised [0,1]
+        coords = torch.from_numpy(np.stack([sc["coords"] for sc in scenes])).to(dev)
+        gt_pose = torch.from_numpy(np.stack([sc["pose"] for sc in scenes])).to(dev)
+        gt_coords = torch.from_numpy(np.stack([sc["gt_coords"] for sc in scenes])).to(dev)
+        # image0/stride reproduce the i % R sharding in the sampler key
+        poses, pred = evaluation.localize_batch(net, images, opt.hypotheses, synth.FOCAL, H, W, image0=idx[0],
+                                                image_stride=world, threshold=opt.threshold,
+                                                inlier_alpha=opt.inlieralpha, max_pixel_error=opt.maxpixelerror,
+                                                scene_coords=coords if opt.solver_input == 'synthetic' else None)
+        t_err, r_err = evaluation.pose_errors(gt_pose, poses)
+        rows.append(torch.stack([t_err, r_err], 1))
+        used = coords if opt.solver_input == 'synthetic' else pred[:, :3]
+        mask = evaluation.pick_valid_points(gt_coords.flatten(2), synth.NODATA)
+        coord_errs.append(torch.norm(gt_coords.flatten(2) - used.flatten(2), dim=1)[mask].cpu())
+    torch.cuda.synchronize()
+    local = torch.cat(rows, 0) if rows else torch.empty((0, 2), dtype=torch.float64, device=dev)
+    allv = evaluation.gather_errors(local, K, rank, world).cpu().numpy()
+    elapsed = time.time() - t0
+    if rank == 0:
+        print("Localised %d frames on %d GPU(s) in %.2f s (%.1f images/s incl. scene generation)" % (
+            K, world, elapsed, K / elapsed))
+        evaluation.scene_coords_printout(allv[:, 0], allv[:, 1], None, [torch.cat(coord_errs).numpy()],
+                                         testing_log=opt.testing_log)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

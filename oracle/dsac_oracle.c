@@ -802,6 +802,14 @@ void xo_test_draws(uint64_t seed, uint64_t image, uint32_t hyp, uint32_t t, int 
     uint64_t st = xo_try_state(seed, image, hyp, t);
     for (int j = 0; j < 4; ++j) { xy8[2 * j] = xo_draw(st, 2 * j, Wo); xy8[2 * j + 1] = xo_draw(st, 2 * j + 1, Ho); }
 }
+void xo_set_num_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
 int xo_num_threads(void)
 {
 #ifdef _OPENMP

@@ -125,3 +125,7 @@ def draws(seed, image, hyp, t, Wo, Ho):
 
 def num_threads():
     return lib().xo_num_threads()
+
+
+def set_num_threads(n):
+    lib().xo_set_num_threads(int(n))

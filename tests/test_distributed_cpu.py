@@ -1,0 +1,89 @@
+"""The N>1 path on CPU (gloo, world_size 2): image-level sharding i % R, ONE all-gather of per-image
+(t_err, r_err) padded with NaN for ragged shards, identical global order / median for every rank count
+(SURVEY.md §8e).  The per-image localisation itself is done by the CPU oracle here — the product path
+needs a GPU — so this exercises exactly the distributed logic of crossloc_amd.evaluation."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from crossloc_amd import evaluation, synth
+
+K = 5            # ragged over 2 ranks: 3 + 2 images
+N_HYP = 16
+
+
+def _localize(indices):
+    from oracle import dsac_oracle
+    rows = []
+    for i in indices:
+        sc = synth.make_scene(3000 + i, noise=0.5, outlier_ratio=0.3)
+        pose = dsac_oracle.forward_rgb(sc["coords"], N_HYP, 10.0, 480.0, 360.0, 240.0, 100.0, 100.0, 8, image=i)
+        rows.append(evaluation.get_pose_err(sc["pose"], pose))
+    return torch.tensor(rows, dtype=torch.float64).reshape(-1, 2)
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    local = _localize(evaluation.shard_indices(K, rank, world))
+    allv = evaluation.gather_errors(local, K, rank, world)
+    np.save(os.path.join(out_dir, "rank%d.npy" % rank), allv.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_shard_indices_cover_every_image_once():
+    for world in (1, 2, 4, 8):
+        got = sorted(i for r in range(world) for i in evaluation.shard_indices(1024 + 3, r, world))
+        assert got == list(range(1027))
+
+
+def test_two_rank_gather_equals_single_process(tmp_path):
+    single = evaluation.gather_errors(_localize(range(K)), K, 0, 1).numpy()
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0 = np.load(tmp_path / "rank0.npy")
+    r1 = np.load(tmp_path / "rank1.npy")
+    assert r0.shape == (K, 2) and not np.isnan(r0).any()
+    assert np.array_equal(r0, r1)                       # every rank holds the same gathered table
+    assert np.array_equal(r0, single)                   # and it is bit-identical to the 1-rank run
+    assert np.median(r0[:, 0]) == np.median(single[:, 0]) and np.median(r0[:, 1]) == np.median(single[:, 1])
+
+
+def test_accuracy_report_matches_reference_format():
+    t = [0.5, 2.0, 4.0, 12.0, 40.0]
+    r = [0.1, 2.5, 4.9, 8.0, 20.0]
+    stats, text = evaluation.accuracy_report(t, r, [1.0, 2.0, 3.0])
+    assert stats["3m3deg"] == pytest.approx(40.0) and stats["5m5deg"] == pytest.approx(60.0)      # strict <
+    assert stats["30m10deg"] == pytest.approx(80.0) and stats["10m7deg"] == pytest.approx(60.0)
+    assert "Median Error: 4.9 deg, 4.00 m" in text                                               # evaluation.py:226
+    assert "Coordinate regression error: mean 2.0, std 0.8, median 2.0" in text
+
+
+def test_get_pose_err_rotation_identities():
+    def rot_z(deg):
+        a = np.radians(deg)
+        T = np.eye(4)
+        T[:2, :2] = [[np.cos(a), -np.sin(a)], [np.sin(a), np.cos(a)]]
+        return T
+    for deg in (0.0, 1e-3, 90.0, 179.999):
+        t, r = evaluation.get_pose_err(rot_z(deg), np.eye(4))
+        assert t == 0.0 and r == pytest.approx(deg, abs=1e-9)
+    T = np.eye(4)
+    T[:3, 3] = [3.0, 4.0, 12.0]
+    assert evaluation.get_pose_err(T, np.eye(4))[0] == pytest.approx(13.0)
+    te, re = evaluation.pose_errors(torch.tensor(np.stack([rot_z(30.0), T])), torch.eye(4).repeat(2, 1, 1))
+    assert re[0].item() == pytest.approx(30.0, abs=1e-9) and te[1].item() == pytest.approx(13.0)

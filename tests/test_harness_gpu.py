@@ -1,0 +1,50 @@
+"""GPU: the evaluation harness around the solver — reference-shaped scene_coords_eval, batched
+localize_batch, and the test_single_task-shaped entry point."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+from crossloc_amd import evaluation, networks, synth          # noqa: E402
+from crossloc_amd.weights import seeded_state_dict            # noqa: E402
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_scene_coords_eval_with_ground_truth_coordinates():
+    """The `predictions = gt_label  # debug only!` switch of test_single_task.py:361."""
+    sc = synth.make_scene(42, noise=0.0, outlier_ratio=0.0)
+    coords = torch.from_numpy(sc["coords"])[None]
+    gt = torch.from_numpy(sc["gt_coords"])[None]
+    pose = torch.from_numpy(sc["pose"])[None]
+    for dev in ("cpu", "cuda"):
+        t_err, r_err, xyz, cerr, out_pose = evaluation.scene_coords_eval(
+            coords.to(dev), gt.to(dev), pose, -1, 480.0, 480, 720, 64, 10.0, 100.0, 100.0, 8)
+        assert t_err < 1e-3 and r_err < 1e-3
+        assert len(xyz) == 3 and out_pose.shape == (4, 4)
+        assert len(cerr) == int((sc["gt_coords"][0] != -1).sum()) and max(cerr) < 1e-3
+
+
+def test_localize_batch_runs_both_stages():
+    net = networks.TransPoseNet(torch.tensor(synth.SCENE_MEAN, dtype=torch.float32), False, False, 1, 1)
+    net.load_state_dict(seeded_state_dict(net, seed=5))
+    net = net.cuda().eval()
+    coords, _, poses = synth.make_batch(60, 3, noise=0.5, outlier_ratio=0.3)
+    images = torch.rand(3, 3, 480, 720, device="cuda")
+    est, pred = evaluation.localize_batch(net, images, 64, 480.0, 480, 720, image0=5,
+                                          scene_coords=torch.from_numpy(coords).cuda())
+    torch.cuda.synchronize()
+    assert pred.shape == (3, 4, 60, 90) and est.shape == (3, 4, 4)
+    t, r = evaluation.pose_errors(torch.from_numpy(poses).cuda(), est)
+    assert (t < 0.5).all() and (r < 0.1).all()
+
+
+def test_single_task_entry_point():
+    out = subprocess.check_output([sys.executable, "-m", "crossloc_amd.test_single_task", "--synthetic", "8",
+                                   "--batch", "4", "--hypotheses", "64"], cwd=ROOT, stderr=subprocess.STDOUT).decode()
+    assert "Median Error:" in out and "5m5deg: 100.0%" in out and "Coordinate regression error" in out
