@@ -30,6 +30,10 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md: fp32-input MFMA = vector fp32 peak
+# HBM-side bytes per launch of the dominant kernel from rocprofv3 PMC passes (profiles/r1_conv512_pmc.csv):
+# FETCH_SIZE (KB, doubled per the gfx950 note of MI355X_MICROARCH.md §HBM) + WRITE_SIZE (KB), batch 24.
+# PMC counters cannot be read from inside the process, so the profiled value is recorded per batch size.
+CONV512_TRAFFIC_BYTES = {24: (692294 * 2 + 259200) * 1024}
 FWD_GFLOP_PER_IMAGE = 295.41        # SURVEY.md §8(d), single-task net, 480x720
 
 
@@ -177,7 +181,8 @@ def main():
                        "median_err_cm": round(med_t_cm, 3), "median_err_deg": round(med_r_deg, 5)},
             "roofline": {"bound": "mfma", "kernel": "igemm_conv_kernel<3,1,128,512> (3x3 512->512 @60x90 x%d images)" % B,
                          "achieved": round(conv_tflops, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(conv_tflops / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                         "frac": round(conv_tflops / PEAK_F32_MFMA_TFLOPS, 4), "traffic": CONV512_TRAFFIC_BYTES.get(B),
+                         "algorithmic_bytes_per_launch": 2 * B * 5400 * 512 * 4 + 512 * 4608 * 4,
                          "avg_launch_ms": round(conv_avg_ms, 4), "launches_timed": len(conv_ms),
                          "algorithmic_gflop_per_launch": round(conv_flop / 1e9, 2)},
             "cpu_baseline": cpu,

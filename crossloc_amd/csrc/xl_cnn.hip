@@ -9,7 +9,8 @@
 //                  A (im2col gather, zero-filled padding) and B (weights [Cout][K]) staged through LDS with
 //                  a 36-float row pitch (conflict-free ds_read_b128), register-prefetched double buffer,
 //                  one barrier per K-step; 4 wavefronts as 2x2, each 64 x BN/2 of the tile (2 x BN/64 MFMA
-//                  tiles of 32x32); XCD-aware tile order so the n-tiles of one m-tile share an L2.
+//                  tiles of 32x32); XCD-aware tile order so the n-tiles of one m-tile share an L2; K runs
+//                  chunk-major/tap-minor so the 9 shifted reads of an input chunk are cache hits.
 //   gn_stats       GroupNorm statistics, coalesced: a workgroup reads a pixel chunk of all channels, fp64
 //                  per-thread partials, fixed-order LDS combine -> per-(image, chunk, group) (sum, sumsq)
 //   gn_apply       finalises mean/rstd from the chunk partials (fixed order) into per-channel scale/shift
@@ -128,7 +129,6 @@ void igemm_conv_kernel(ConvArgs a)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    const int Cin = CIN ? CIN : a.Cin;
 
     const int tile = xcd_remap(blockIdx.x, a.nbm * a.nbn);
     const int mt = tile / a.nbn, nt = tile - mt * a.nbn;
@@ -162,10 +162,12 @@ void igemm_conv_kernel(ConvArgs a)
 
     f32x4 ra[4], rb[BROWS];
     auto load_global = [&](int kk) {
+        // K order is (channel chunk of 32, tap, channel-in-chunk): the 9 taps of one chunk run back to back, so
+        // the shifted re-reads of the same input pixels hit L1/L2 instead of going back to HBM 9 times
         const int kbase = kk * kBK;
-        int tap;
-        if constexpr (CIN != 0) tap = kbase / CIN; else tap = kbase / Cin;
-        const int c0 = kbase - tap * Cin;
+        const int chunk = kk / (KS * KS);
+        const int tap = kk - chunk * (KS * KS);
+        const int c0 = chunk * kBK;
         const int ky = tap / KS, kx = tap - ky * KS;
         const unsigned tapOff = (unsigned)((ky * a.Wi + kx) * a.ldIn + c0) * 4u;
 #pragma unroll
@@ -418,12 +420,13 @@ __global__ void pack_weight_kernel(const float *__restrict__ src, float *__restr
 {
     const long long total = (long long)Cout * Cin * k * k;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        // dst index i = ((o*k + ky)*k + kx)*Cin + c
-        const int c = (int)(i % Cin);
-        long long t = i / Cin;
-        const int kx = (int)(t % k); t /= k;
-        const int ky = (int)(t % k);
-        const int o = (int)(t / k);
+        // dst index i = ((o*(Cin/32) + chunk)*k*k + tap)*32 + cl   (chunk-major, tap, channel-in-chunk)
+        const int cl = (int)(i % 32);
+        long long t = i / 32;
+        const int tap = (int)(t % (k * k)); t /= (k * k);
+        const int chunk = (int)(t % (Cin / 32));
+        const int o = (int)(t / (Cin / 32));
+        const int c = chunk * 32 + cl, ky = tap / k, kx = tap - ky * k;
         dst[i] = src[(((long long)o * Cin + c) * k + ky) * k + kx];
     }
 }

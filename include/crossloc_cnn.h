@@ -47,7 +47,7 @@ typedef struct xl_op {
     float clamp_lo, clamp_hi;      /* XL_OP_HEAD hardtanh bounds (-16.10, 13.82), networks.py:355-356 */
     float reserved;
     const void *in;                /* input activations (image for CONV1) */
-    const void *w;                 /* CONV: [Cout][k*k*Cin] (tap-major, channel-minor); CONV1: [27 or 9][Cout];
+    const void *w;                 /* CONV: [Cout][Cin/32][k*k][32] (xl_cnn_pack_conv_weight); CONV1: [27 or 9][Cout];
                                       GN_APPLY: gamma[C]; HEAD: [Cout][Cin] */
     const void *bias;              /* CONV*/
     const void *aux;               /* GN_APPLY: residual tensor; HEAD: mean[n_task] */
@@ -63,7 +63,7 @@ int xl_cnn_run(const xl_op *ops, int n_ops, void *stream);
 int xl_cnn_op_size(void);
 
 /* Weight layout transform used at load time: PyTorch conv weight [Cout][Cin][k][k] (device) ->
- * [Cout][k][k][Cin] (device). */
+ * [Cout][Cin/32][k*k][32] (device): 32-channel chunk major, tap, channel within chunk; Cin % 32 == 0. */
 int xl_cnn_pack_conv_weight(const float *w_oihw_dev, float *w_ohwi_dev, int Cout, int Cin, int k, void *stream);
 
 /* Per-op HIP-event timing for measurement (bench.py): between prof_begin and prof_end every op launched by
