@@ -87,7 +87,7 @@ def main():
     L = networks._bind()
     L.xl_cnn_prof_begin.argtypes = [ctypes.c_int]
     L.xl_cnn_prof_end.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
-    plan = net._plans[(B, H, IMW, dev.index)]
+    plan = net._plans[(B, H, IMW, dev.index, False)]
     n_ops = len(plan.op_array)
     L.xl_cnn_prof_begin(n_ops * K)
 

@@ -28,6 +28,8 @@
 #include "../../include/crossloc_cnn.h"
 #include "../../include/crossloc_dsac.h"   // status codes
 
+int xl_run_bwd_op(const xl_op &op, hipStream_t st);   // xl_cnn_bwd.hip
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -93,6 +95,7 @@ struct ConvArgs {
     int M, K, nbm, nbn;
     unsigned inBytes, wBytes;       // extents for the buffer descriptors (hardware bounds check)
     int dbg;                        // diagnostics only (XL_CONV_DBG): 1 = skip global loads, 2 = skip LDS refill
+    int accumulate;                 // epilogue: out += result (XL_CONV_ACCUMULATE)
 };
 
 // bijective XCD remap: block b runs on XCD b%8; give each XCD a contiguous run of tiles
@@ -114,7 +117,10 @@ __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t rsrc, unsigned
 // Global->register loads go through buffer descriptors: a padding tap gets an out-of-range offset and the
 // hardware returns zeros (no branch, no select on the data); destinations and offsets never alias, so the
 // eight loads of a K-step stay in flight together under the MFMAs of the previous one.
-template <int KS, int STRIDE, int BN, int CIN>     // CIN = compile-time Cin (0: runtime)
+// MODE 0: forward convolution.  MODE 1: data gradient — `in` is dY [B,Hi,Wi,Cin] (the forward OUTPUT, Cin = forward
+// Cout), the result is dX [B,Ho,Wo,Cout] (forward input); output pixel (iy,ix) gathers dY[(iy+PAD-ky)/S][(ix+PAD-kx)/S]
+// for the taps whose offset is divisible by the forward stride S (others are zero-filled by the bounds check).
+template <int KS, int STRIDE, int BN, int CIN, int MODE = 0>     // CIN = compile-time Cin tag (0: runtime)
 __global__ __launch_bounds__(256, 2)
 void igemm_conv_kernel(ConvArgs a)
 {
@@ -149,9 +155,15 @@ void igemm_conv_kernel(ConvArgs a)
             const int n = m / HoWo;
             const int rem = m - n * HoWo;
             const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
-            aIy[p] = oy * STRIDE - PAD;
-            aIx[p] = ox * STRIDE - PAD;
-            aOff[p] = (unsigned)(((n * a.Hi + aIy[p]) * a.Wi + aIx[p]) * a.ldIn + 4 * kq) * 4u;
+            if constexpr (MODE == 0) {
+                aIy[p] = oy * STRIDE - PAD;
+                aIx[p] = ox * STRIDE - PAD;
+                aOff[p] = (unsigned)(((n * a.Hi + aIy[p]) * a.Wi + aIx[p]) * a.ldIn + 4 * kq) * 4u;
+            } else {
+                aIy[p] = oy + PAD;                   // numerators of the source row / column
+                aIx[p] = ox + PAD;
+                aOff[p] = (unsigned)(n * a.Hi * a.Wi * a.ldIn + 4 * kq) * 4u;
+            }
         } else {
             aIy[p] = -100000; aIx[p] = -100000; aOff[p] = 0;
         }
@@ -172,8 +184,15 @@ void igemm_conv_kernel(ConvArgs a)
         const unsigned tapOff = (unsigned)((ky * a.Wi + kx) * a.ldIn + c0) * 4u;
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
-            const bool ok = (unsigned)(aIy[p] + ky) < (unsigned)a.Hi && (unsigned)(aIx[p] + kx) < (unsigned)a.Wi;
-            ra[p] = buf_load4(srdA, ok ? aOff[p] + tapOff : OOB, 0);
+            if constexpr (MODE == 0) {
+                const bool ok = (unsigned)(aIy[p] + ky) < (unsigned)a.Hi && (unsigned)(aIx[p] + kx) < (unsigned)a.Wi;
+                ra[p] = buf_load4(srdA, ok ? aOff[p] + tapOff : OOB, 0);
+            } else {
+                const int ty = aIy[p] - ky, tx = aIx[p] - kx;
+                const int sy = ty / STRIDE, sx = tx / STRIDE;               // STRIDE is 1 or 2 (shift)
+                const bool ok = ty >= 0 && tx >= 0 && (STRIDE == 1 || (((ty | tx) & 1) == 0)) && sy < a.Hi && sx < a.Wi;
+                ra[p] = buf_load4(srdA, ok ? aOff[p] + (unsigned)((sy * a.Wi + sx) * a.ldIn + c0) * 4u : OOB, 0);
+            }
         }
 #pragma unroll
         for (int p = 0; p < BROWS; ++p) rb[p] = buf_load4(srdB, bOff[p], (unsigned)kbase * 4u);
@@ -259,13 +278,18 @@ void igemm_conv_kernel(ConvArgs a)
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const int n = n0 + wn * (BN / 2) + j * 32 + col;
-        const float bv = a.bias[n];
+        if (n >= a.Cout) continue;                      // narrow outputs (Cout < BN): columns beyond Cout are padding
+        const float bv = a.bias ? a.bias[n] : 0.f;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + rhalf;
-                if (m < a.M) a.out[(long long)m * a.ldOut + n] = acc[i][j][r] + bv;
+                if (m < a.M) {
+                    float *o = a.out + (long long)m * a.ldOut + n;
+                    const float v = acc[i][j][r] + bv;
+                    *o = a.accumulate ? *o + v : v;
+                }
             }
         }
     }
@@ -431,6 +455,21 @@ __global__ void pack_weight_kernel(const float *__restrict__ src, float *__restr
     }
 }
 
+// dgrad operand: dst[((c*(Cout/32) + ochunk)*k*k + tap)*32 + ol] = src[o][c][ky][kx], o = ochunk*32 + ol
+__global__ void pack_weight_dgrad_kernel(const float *__restrict__ src, float *__restrict__ dst, int Cout, int Cin, int k)
+{
+    const long long total = (long long)Cout * Cin * k * k;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int ol = (int)(i % 32);
+        long long t = i / 32;
+        const int tap = (int)(t % (k * k)); t /= (k * k);
+        const int ochunk = (int)(t % (Cout / 32));
+        const int c = (int)(t / (Cout / 32));
+        const int o = ochunk * 32 + ol, ky = tap / k, kx = tap - ky * k;
+        dst[i] = src[(((long long)o * Cin + c) * k + ky) * k + kx];
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- host side
 
 thread_local char g_err[256] = "";
@@ -442,7 +481,7 @@ ProfRec *g_prof = nullptr;
 int g_profCap = 0, g_profCount = 0;
 bool g_profOn = false;
 
-template <int KS, int STRIDE, int BN, int CIN>
+template <int KS, int STRIDE, int BN, int CIN, int MODE = 0>
 int launch_igemm(const xl_op &op, hipStream_t st)
 {
     ConvArgs a;
@@ -450,7 +489,7 @@ int launch_igemm(const xl_op &op, hipStream_t st)
     a.B = op.B; a.Hi = op.Hi; a.Wi = op.Wi; a.Cin = op.Cin; a.Ho = op.Ho; a.Wo = op.Wo; a.Cout = op.Cout;
     a.ldIn = op.ld_in; a.ldOut = op.ld_out;
     a.M = op.B * op.Ho * op.Wo; a.K = op.ksize * op.ksize * op.Cin;
-    a.nbm = (a.M + kBM - 1) / kBM; a.nbn = op.Cout / BN;
+    a.nbm = (a.M + kBM - 1) / kBM; a.nbn = (op.Cout + BN - 1) / BN;   // weight rows past Cout read as zero (bounds check)
     const long long inBytes = (((long long)op.B * op.Hi * op.Wi - 1) * op.ld_in + op.Cin) * 4;
     const long long wBytes = (long long)op.Cout * a.K * 4;
     if (inBytes >= 0x7fffffffLL || wBytes >= 0x7fffffffLL) {
@@ -461,22 +500,29 @@ int launch_igemm(const xl_op &op, hipStream_t st)
     static const int dbgFlags = getenv("XL_CONV_DBG") ? atoi(getenv("XL_CONV_DBG")) : 0;
     static const int ldsPad = getenv("XL_CONV_LDS_PAD") ? atoi(getenv("XL_CONV_LDS_PAD")) : 0;
     a.dbg = dbgFlags;
+    a.accumulate = (op.flags & XL_CONV_ACCUMULATE) ? 1 : 0;
     const size_t lds = sizeof(float) * 2 * (kBM + BN) * kPitch + (size_t)ldsPad;
     static bool configured = false;
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(igemm_conv_kernel<KS, STRIDE, BN, CIN>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(igemm_conv_kernel<KS, STRIDE, BN, CIN, MODE>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { snprintf(g_err, sizeof(g_err), "hipFuncSetAttribute: %s", hipGetErrorString(e)); return XL_ERR_HIP; }
         configured = true;
     }
-    hipLaunchKernelGGL((igemm_conv_kernel<KS, STRIDE, BN, CIN>), dim3(a.nbm * a.nbn), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((igemm_conv_kernel<KS, STRIDE, BN, CIN, MODE>), dim3(a.nbm * a.nbn), dim3(256), lds, st, a);
     return XL_OK;
 }
 
 int run_conv(const xl_op &op, hipStream_t st)
 {
-    if (op.Cin % 32 != 0 || op.Cout % 64 != 0 || op.ld_in % 4 != 0) return XL_ERR_ARG;
+    if (op.Cin % 32 != 0 || op.Cout % 32 != 0 || op.ld_in % 4 != 0) return XL_ERR_ARG;
     const bool wide = (op.Cout % 128 == 0);
+    if (op.flags & XL_CONV_DGRAD) {
+        if (op.ksize == 3 && op.stride == 1) return wide ? launch_igemm<3, 1, 128, 0, 1>(op, st) : launch_igemm<3, 1, 64, 0, 1>(op, st);
+        if (op.ksize == 3 && op.stride == 2) return wide ? launch_igemm<3, 2, 128, 0, 1>(op, st) : launch_igemm<3, 2, 64, 0, 1>(op, st);
+        if (op.ksize == 1 && op.stride == 1) return wide ? launch_igemm<1, 1, 128, 0, 1>(op, st) : launch_igemm<1, 1, 64, 0, 1>(op, st);
+        return XL_ERR_UNSUPPORTED;
+    }
     if (op.ksize == 3 && op.stride == 1) {
         if (wide && op.Cin == 512) return launch_igemm<3, 1, 128, 512>(op, st);      // 78 % of the forward FLOPs
         return wide ? launch_igemm<3, 1, 128, 0>(op, st) : launch_igemm<3, 1, 64, 0>(op, st);
@@ -540,7 +586,7 @@ int run_op(const xl_op &op, hipStream_t st)
             return XL_OK;
         }
         default:
-            return XL_ERR_UNSUPPORTED;
+            return xl_run_bwd_op(op, st);
     }
 }
 
@@ -578,6 +624,17 @@ int xl_cnn_pack_conv_weight(const float *w_oihw_dev, float *w_ohwi_dev, int Cout
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w_oihw_dev,
                        w_ohwi_dev, Cout, Cin, k);
+    return hipGetLastError() == hipSuccess ? XL_OK : XL_ERR_HIP;
+}
+
+int xl_cnn_pack_conv_weight_dgrad(const float *w_oihw_dev, float *w_dgrad_dev, int Cout, int Cin, int k, void *stream)
+{
+    if (!w_oihw_dev || !w_dgrad_dev || Cout <= 0 || Cin <= 0 || k <= 0 || Cout % 32 != 0) return XL_ERR_ARG;
+    const long long total = (long long)Cout * Cin * k * k;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(pack_weight_dgrad_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w_oihw_dev,
+                       w_dgrad_dev, Cout, Cin, k);
     return hipGetLastError() == hipSuccess ? XL_OK : XL_ERR_HIP;
 }
 

@@ -1,0 +1,620 @@
+// xl_cnn_bwd.hip — backward kernels of the scene-coordinate CNN (what autograd + cuDNN dgrad/wgrad + native
+// GroupNorm backward did for `loss.backward()`, /root/reference/train_single_task.py:298).
+//
+//   data gradient      the forward implicit-GEMM kernel in MODE 1 (xl_cnn.hip): same MFMA core, mirrored tap offsets,
+//                      transposed weight operand, optional accumulate epilogue for gradients with two producers
+//   wgrad_kernel       dW[o][tap][c] = sum_m dY[m][o] * X[m @ tap][c]: implicit GEMM with the PIXEL dimension as K,
+//                      split-K over pixel ranges, fp32 MFMA 32x32x2 with operands read transposed from LDS
+//                      ([pixel][channel] tiles, ds_read_b32 rows are conflict-free), fixed-order reduce -> OIHW
+//   gnb_*              GroupNorm backward fused with the forward epilogue (ReLU / residual add / ReLU):
+//                      pass 1 per-(image, chunk, channel) sums of dv, dv*xhat, xhat; pass 2 dx (+ d residual);
+//                      then d gamma, d beta and the conv-bias gradient in closed form from the sums (no extra pass)
+//   head_bwd_kernel    backward of fc3 + mean + exp(hardtanh)
+//   conv1_wgrad_kernel weight/bias gradient of the 3-channel first conv
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/crossloc_cnn.h"
+#include "../../include/crossloc_dsac.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t rsrc, unsigned voff)
+{
+    u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, 0, 0);
+    return __builtin_bit_cast(f32x4, v);
+}
+
+// ---------------------------------------------------------------------------------------------- wgrad
+
+struct WgradArgs {
+    const float *x; const float *dy; float *partial;
+    int B, Hi, Wi, Cin, Ho, Wo, Cout, ldX, ldY, ksize, stride;
+    int M, splits, mPerSplit, nbo, nbc;
+    unsigned xBytes, dyBytes;
+};
+
+// tile BO (output channels) x BC (input channels) of ONE tap; K = output pixels of this split.
+// waves WO x WC, wave tile (BO/WO) x (BC/WC) = TI x TJ MFMA tiles of 32x32.
+template <int BO, int BC, int WO, int WC>
+__global__ __launch_bounds__(64 * WO * WC)
+void wgrad_kernel(WgradArgs a)
+{
+    constexpr int NT = 64 * WO * WC;
+    constexpr int TI = BO / WO / 32, TJ = BC / WC / 32;
+    constexpr int KB = 32;                                  // pixels per K-step
+    constexpr int LA = (KB * BO / 4) / NT, LB = (KB * BC / 4) / NT;   // float4 loads per thread
+    __shared__ __attribute__((aligned(16))) float sA[2][KB * BO];     // dY tile  [pixel][o]
+    __shared__ __attribute__((aligned(16))) float sB[2][KB * BC];     // X tile   [pixel][c]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wo = wave / WC, wc = wave - wo * WC;
+    const int PAD = (a.ksize == 3) ? 1 : 0;
+
+    int t = blockIdx.x;
+    const int split = t % a.splits; t /= a.splits;
+    const int cb = t % a.nbc; t /= a.nbc;
+    const int ob = t % a.nbo; t /= a.nbo;
+    const int tap = t;
+    const int ky = tap / a.ksize, kx = tap - ky * a.ksize;
+    const int o0 = ob * BO, c0 = cb * BC;
+    const int mBeg = split * a.mPerSplit;
+    int mEnd = mBeg + a.mPerSplit; if (mEnd > a.M) mEnd = a.M;
+
+    const __amdgpu_buffer_rsrc_t srdX = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, (int)a.xBytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srdY = __builtin_amdgcn_make_buffer_rsrc((void *)a.dy, 0, (int)a.dyBytes, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+    const int HoWo = a.Ho * a.Wo;
+
+    f32x4 ra[LA], rb[LB];
+    auto load_global = [&](int m0) {
+#pragma unroll
+        for (int q = 0; q < LA; ++q) {
+            const int f = tid + q * NT;                     // float4 index in the [KB][BO/4] tile
+            const int row = f / (BO / 4), col = f - row * (BO / 4);
+            const int m = m0 + row;
+            ra[q] = buf_load4(srdY, m < mEnd ? (unsigned)(m * a.ldY + o0 + 4 * col) * 4u : OOB);
+        }
+#pragma unroll
+        for (int q = 0; q < LB; ++q) {
+            const int f = tid + q * NT;
+            const int row = f / (BC / 4), col = f - row * (BC / 4);
+            const int m = m0 + row;
+            unsigned off = OOB;
+            if (m < mEnd) {
+                const int n = m / HoWo;
+                const int rem = m - n * HoWo;
+                const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
+                const int iy = oy * a.stride - PAD + ky, ix = ox * a.stride - PAD + kx;
+                if ((unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi)
+                    off = (unsigned)(((n * a.Hi + iy) * a.Wi + ix) * a.ldX + c0 + 4 * col) * 4u;
+            }
+            rb[q] = buf_load4(srdX, off);
+        }
+    };
+    auto store_lds = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < LA; ++q) *reinterpret_cast<f32x4 *>(&sA[buf][(tid + q * NT) * 4]) = ra[q];
+#pragma unroll
+        for (int q = 0; q < LB; ++q) *reinterpret_cast<f32x4 *>(&sB[buf][(tid + q * NT) * 4]) = rb[q];
+    };
+
+    f32x16 acc[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = (mEnd - mBeg + KB - 1) / KB;
+    if (nk > 0) {
+        load_global(mBeg);
+        store_lds(0);
+    }
+    __syncthreads();
+    const int fr = lane & 31, fk = lane >> 5;
+    for (int kk = 0; kk < nk; ++kk) {
+        const int buf = kk & 1;
+        if (kk + 1 < nk) load_global(mBeg + (kk + 1) * KB);
+        const float *Ab = &sA[buf][wo * (BO / WO) + fr];
+        const float *Bb = &sB[buf][wc * (BC / WC) + fr];
+#pragma unroll
+        for (int kp = 0; kp < KB / 2; ++kp) {
+            float fa[TI], fb[TJ];
+#pragma unroll
+            for (int i = 0; i < TI; ++i) fa[i] = Ab[(2 * kp + fk) * BO + i * 32];
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) fb[j] = Bb[(2 * kp + fk) * BC + j * 32];
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+        if (kk + 1 < nk) store_lds(buf ^ 1);
+        __syncthreads();
+    }
+    // partial[split][tap][o][c]
+    const int col = lane & 31, rhalf = (lane >> 5) * 4;
+    float *P = a.partial + ((long long)split * a.ksize * a.ksize + tap) * a.Cout * a.Cin;
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = o0 + wo * (BO / WO) + i * 32 + (r & 3) + 8 * (r >> 2) + rhalf;
+                const int c = c0 + wc * (BC / WC) + j * 32 + col;
+                P[(long long)o * a.Cin + c] = acc[i][j][r];
+            }
+}
+
+// dW[o][c][ky][kx] = sum over splits (fixed order) of partial[s][tap][o][c]
+__global__ void wgrad_reduce_kernel(const float *__restrict__ partial, float *__restrict__ dw, int splits, int taps,
+                                    int Cout, int Cin)
+{
+    const long long total = (long long)taps * Cout * Cin;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int k = 0; k < splits; ++k) s += partial[(long long)k * total + i];
+        const int c = (int)(i % Cin);
+        long long t = i / Cin;
+        const int o = (int)(t % Cout);
+        const int tap = (int)(t / Cout);
+        dw[((long long)o * Cin + c) * taps + tap] = s;
+    }
+}
+
+template <int BO, int BC, int WO, int WC>
+int launch_wgrad(const xl_op &op, hipStream_t st)
+{
+    WgradArgs a;
+    a.x = (const float *)op.in; a.dy = (const float *)op.aux; a.partial = (float *)op.stats2;
+    a.B = op.B; a.Hi = op.Hi; a.Wi = op.Wi; a.Cin = op.Cin; a.Ho = op.Ho; a.Wo = op.Wo; a.Cout = op.Cout;
+    a.ldX = op.ld_in; a.ldY = op.ld_aux; a.ksize = op.ksize; a.stride = op.stride;
+    a.M = op.B * op.Ho * op.Wo; a.splits = op.nchunks2;
+    a.mPerSplit = ((a.M + a.splits - 1) / a.splits + 31) / 32 * 32;
+    a.nbo = op.Cout / BO; a.nbc = op.Cin / BC;
+    const long long xb = (((long long)op.B * op.Hi * op.Wi - 1) * op.ld_in + op.Cin) * 4;
+    const long long yb = (((long long)a.M - 1) * op.ld_aux + op.Cout) * 4;
+    if (xb >= 0x7fffffffLL || yb >= 0x7fffffffLL) return XL_ERR_ARG;
+    a.xBytes = (unsigned)xb; a.dyBytes = (unsigned)yb;
+    const int taps = op.ksize * op.ksize;
+    hipLaunchKernelGGL((wgrad_kernel<BO, BC, WO, WC>), dim3(taps * a.nbo * a.nbc * a.splits), dim3(64 * WO * WC), 0, st, a);
+    const long long total = (long long)taps * op.Cout * op.Cin;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float *)op.stats2,
+                       (float *)op.out, a.splits, taps, op.Cout, op.Cin);
+    return XL_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- GroupNorm backward
+
+// per-channel forward coefficients of image n from the forward fp64 partial sums
+__device__ __forceinline__ void gn_coeffs(const double *fstats, int n, int nchunks, int G, int c, int cpg, int HW,
+                                          float eps, const float *gamma, const float *beta,
+                                          float &mean, float &rstd, float &sc, float &sh)
+{
+    const int g = c / cpg;
+    double s = 0.0, ss = 0.0;
+    const double *st = fstats + ((long long)n * nchunks * G + g) * 2;
+    for (int k = 0; k < nchunks; ++k) { s += st[(long long)k * G * 2]; ss += st[(long long)k * G * 2 + 1]; }
+    const double cnt = (double)HW * (double)cpg;
+    const double mu = s / cnt;
+    double var = ss / cnt - mu * mu;
+    if (var < 0.0) var = 0.0;
+    const double r = 1.0 / sqrt(var + (double)eps);
+    const double scd = (double)gamma[c] * r;
+    mean = (float)mu; rstd = (float)r; sc = (float)scd; sh = (float)((double)beta[c] - mu * scd);
+}
+
+struct GnbArgs {
+    const float *x, *dout, *outAct, *gamma, *beta;
+    const double *fstats;
+    double *bstats;          // [B][nchunks2][C][3]  (sum dv, sum dv*xhat, sum xhat)
+    float *dx, *daux;
+    double *ncsums;          // [B][C][5]: A, Bc, Xh, S1, S2 (written by apply block 0 of each image)
+    int HW, C, ldX, ldD, ldO, ldDx, ldAux, G, nchunks, nchunks2, flags;
+    float eps;
+};
+
+// dv (gradient w.r.t. v = gn(x)) of one element
+__device__ __forceinline__ float gnb_dv(float dout, float outAct, float v, int flags)
+{
+    float t = dout;
+    if ((flags & XL_GN_RELU_OUT) && !(outAct > 0.f)) t = 0.f;
+    if ((flags & XL_GN_RELU_IN) && !(v > 0.f)) t = 0.f;
+    return t;
+}
+
+// grid (nchunks2, B), T threads, T % (C/4) == 0
+__global__ void gnb_stats_kernel(GnbArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) double smemD[];
+    const int T = blockDim.x, tid = threadIdx.x;
+    const int C4 = a.C >> 2, cpg = a.C / a.G;
+    float *sCo = reinterpret_cast<float *>(smemD + (size_t)T * 12);          // mean, rstd, sc, sh per channel
+    const int n = blockIdx.y, chunk = blockIdx.x;
+    for (int c = tid; c < a.C; c += T) {
+        float mu, rs, sc, sh;
+        gn_coeffs(a.fstats, n, a.nchunks, a.G, c, cpg, a.HW, a.eps, a.gamma, a.beta, mu, rs, sc, sh);
+        sCo[c] = mu; sCo[a.C + c] = rs; sCo[2 * a.C + c] = sc; sCo[3 * a.C + c] = sh;
+    }
+    __syncthreads();
+    const int c4 = tid % C4, prow = tid / C4, rows = T / C4;
+    const int per = (a.HW + a.nchunks2 - 1) / a.nchunks2;
+    const int p0 = chunk * per;
+    int p1 = p0 + per; if (p1 > a.HW) p1 = a.HW;
+    double sA[4] = { 0, 0, 0, 0 }, sB[4] = { 0, 0, 0, 0 }, sX[4] = { 0, 0, 0, 0 };
+    const int c = 4 * c4;
+    for (int p = p0 + prow; p < p1; p += rows) {
+        const long long pix = (long long)n * a.HW + p;
+        const f32x4 xv = *reinterpret_cast<const f32x4 *>(a.x + pix * a.ldX + c);
+        const f32x4 dv4 = *reinterpret_cast<const f32x4 *>(a.dout + pix * a.ldD + c);
+        f32x4 ov = { 1.f, 1.f, 1.f, 1.f };
+        if (a.flags & XL_GN_RELU_OUT) ov = *reinterpret_cast<const f32x4 *>(a.outAct + pix * a.ldO + c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float v = xv[j] * sCo[2 * a.C + c + j] + sCo[3 * a.C + c + j];
+            const float xh = (xv[j] - sCo[c + j]) * sCo[a.C + c + j];
+            const float dv = gnb_dv(dv4[j], ov[j], v, a.flags);
+            sA[j] += (double)dv; sB[j] += (double)dv * (double)xh; sX[j] += (double)xh;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { smemD[tid * 12 + j] = sA[j]; smemD[tid * 12 + 4 + j] = sB[j]; smemD[tid * 12 + 8 + j] = sX[j]; }
+    __syncthreads();
+    for (int ch = tid; ch < a.C; ch += T) {
+        double A = 0.0, Bc = 0.0, X = 0.0;
+        for (int r = 0; r < rows; ++r) {
+            const int th = r * C4 + (ch >> 2), sl = ch & 3;
+            A += smemD[th * 12 + sl]; Bc += smemD[th * 12 + 4 + sl]; X += smemD[th * 12 + 8 + sl];
+        }
+        double *o = a.bstats + (((long long)n * a.nchunks2 + chunk) * a.C + ch) * 3;
+        o[0] = A; o[1] = Bc; o[2] = X;
+    }
+}
+
+// grid (achunks, B), 256 threads
+__global__ __launch_bounds__(256)
+void gnb_apply_kernel(GnbArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float sK[];      // per channel: mean, rstd, sc, sh, k1, k2, k3
+    __shared__ double sS[2 * 64];                                    // S1, S2 per group (G <= 64)
+    const int tid = threadIdx.x, n = blockIdx.y;
+    const int C = a.C, cpg = C / a.G;
+    double *dA = reinterpret_cast<double *>(sK + 7 * C);            // A, Bc, Xh totals per channel (fp64)
+    for (int c = tid; c < C; c += 256) {
+        float mu, rs, sc, sh;
+        gn_coeffs(a.fstats, n, a.nchunks, a.G, c, cpg, a.HW, a.eps, a.gamma, a.beta, mu, rs, sc, sh);
+        sK[c] = mu; sK[C + c] = rs; sK[2 * C + c] = sc; sK[3 * C + c] = sh;
+        double A = 0.0, Bc = 0.0, X = 0.0;
+        const double *bs = a.bstats + ((long long)n * a.nchunks2 * C + c) * 3;
+        for (int k = 0; k < a.nchunks2; ++k) { A += bs[(long long)k * C * 3]; Bc += bs[(long long)k * C * 3 + 1]; X += bs[(long long)k * C * 3 + 2]; }
+        dA[3 * c] = A; dA[3 * c + 1] = Bc; dA[3 * c + 2] = X;
+    }
+    __syncthreads();
+    for (int g = tid; g < a.G; g += 256) {
+        double S1 = 0.0, S2 = 0.0;
+        for (int c = g * cpg; c < (g + 1) * cpg; ++c) { S1 += (double)a.gamma[c] * dA[3 * c]; S2 += (double)a.gamma[c] * dA[3 * c + 1]; }
+        sS[2 * g] = S1; sS[2 * g + 1] = S2;
+    }
+    __syncthreads();
+    const double m = (double)cpg * (double)a.HW;
+    for (int c = tid; c < C; c += 256) {
+        const int g = c / cpg;
+        const double rs = (double)sK[C + c];
+        sK[4 * C + c] = (float)(rs * (double)a.gamma[c]);
+        sK[5 * C + c] = (float)(rs * sS[2 * g] / m);
+        sK[6 * C + c] = (float)(rs * sS[2 * g + 1] / m);
+        if (blockIdx.x == 0 && a.ncsums) {
+            double *o = a.ncsums + ((long long)n * C + c) * 5;
+            o[0] = dA[3 * c]; o[1] = dA[3 * c + 1]; o[2] = dA[3 * c + 2]; o[3] = sS[2 * g]; o[4] = sS[2 * g + 1];
+        }
+    }
+    __syncthreads();
+    const int C4 = C >> 2;
+    const int achunks = gridDim.x;
+    const int per = (a.HW + achunks - 1) / achunks;
+    const int p0 = blockIdx.x * per;
+    int p1 = p0 + per; if (p1 > a.HW) p1 = a.HW;
+    const long long nElem4 = (long long)(p1 - p0) * C4;
+    for (long long f = tid; f < nElem4; f += 256) {
+        const int p = p0 + (int)(f / C4);
+        const int c = (int)(f - (long long)(p - p0) * C4) * 4;
+        const long long pix = (long long)n * a.HW + p;
+        const f32x4 xv = *reinterpret_cast<const f32x4 *>(a.x + pix * a.ldX + c);
+        const f32x4 d4 = *reinterpret_cast<const f32x4 *>(a.dout + pix * a.ldD + c);
+        f32x4 ov = { 1.f, 1.f, 1.f, 1.f };
+        if (a.flags & XL_GN_RELU_OUT) ov = *reinterpret_cast<const f32x4 *>(a.outAct + pix * a.ldO + c);
+        f32x4 dx, t4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float v = xv[j] * sK[2 * C + c + j] + sK[3 * C + c + j];
+            const float xh = (xv[j] - sK[c + j]) * sK[C + c + j];
+            float t = d4[j];
+            if ((a.flags & XL_GN_RELU_OUT) && !(ov[j] > 0.f)) t = 0.f;
+            t4[j] = t;
+            const float dv = ((a.flags & XL_GN_RELU_IN) && !(v > 0.f)) ? 0.f : t;
+            dx[j] = sK[4 * C + c + j] * dv - sK[5 * C + c + j] - xh * sK[6 * C + c + j];
+        }
+        if (a.flags & XL_GN_ADD) {
+            float *q = a.daux + pix * a.ldAux + c;
+            if (a.flags & XL_GN_ACC_AUX) {
+                const f32x4 old = *reinterpret_cast<const f32x4 *>(q);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) t4[j] += old[j];
+            }
+            *reinterpret_cast<f32x4 *>(q) = t4;
+        }
+        *reinterpret_cast<f32x4 *>(a.dx + pix * a.ldDx + c) = dx;
+    }
+}
+
+// d gamma, d beta, d conv-bias from the per-(image, channel) sums; one thread per channel
+__global__ void gnb_params_kernel(const double *ncsums, const double *fstats, const float *gamma, int B, int C, int G,
+                                  int HW, int nchunks, float eps, float *dgamma, float *dbeta, float *dbias)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const int cpg = C / G, g = c / cpg;
+    const double m = (double)cpg * (double)HW;
+    double dg = 0.0, db = 0.0, dbi = 0.0;
+    for (int n = 0; n < B; ++n) {
+        const double *o = ncsums + ((long long)n * C + c) * 5;
+        dg += o[1]; db += o[0];
+        if (dbias) {
+            double s = 0.0, ss = 0.0;
+            const double *st = fstats + ((long long)n * nchunks * G + g) * 2;
+            for (int k = 0; k < nchunks; ++k) { s += st[(long long)k * G * 2]; ss += st[(long long)k * G * 2 + 1]; }
+            const double mu = s / m;
+            double var = ss / m - mu * mu;
+            if (var < 0.0) var = 0.0;
+            const double rs = 1.0 / sqrt(var + (double)eps);
+            // sum over pixels of dx = rstd*(gamma*A - (HW*S1 + S2*sum_xhat)/m)
+            dbi += rs * ((double)gamma[c] * o[0] - ((double)HW * o[3] + o[4] * o[2]) / m);
+        }
+    }
+    dgamma[c] = (float)dg; dbeta[c] = (float)db;
+    // one channel per group = instance norm: a per-channel bias cancels exactly, its gradient is identically 0
+    if (dbias) dbias[c] = (cpg == 1) ? 0.f : (float)dbi;
+}
+
+// ---------------------------------------------------------------------------------------------- head backward
+
+// forward: s_o = w_o . x + b_o; out_o = s_o + mean (o < nTask); out_o = exp(clamp(s_o, lo, hi)) otherwise.
+// dout/fout NCHW [B][Cout][HW]; x NHWC; dx NHWC; partial dW [blocks*4 waves][Cout][Cin], partial db [..][Cout]
+template <int COUT_MAX, int NQ_MAX>
+__global__ __launch_bounds__(256)
+void head_bwd_kernel(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ dout,
+                     const float *__restrict__ fout, float *__restrict__ dx, float *__restrict__ pW,
+                     float *__restrict__ pB, int B, int HW, int Cin, int ldX, int ldDx, int Cout, int nTask,
+                     float lo, float hi)
+{
+    const int lane = threadIdx.x & 63;
+    const int waveGlobal = (blockIdx.x * 256 + threadIdx.x) >> 6;
+    const int nWaves = (gridDim.x * 256) >> 6;
+    const int nq = Cin >> 8;
+    const long long total = (long long)B * HW;
+    const float elo = expf(lo), ehi = expf(hi);
+    f32x4 aw[COUT_MAX][NQ_MAX];
+    float ab[COUT_MAX];
+#pragma unroll
+    for (int o = 0; o < COUT_MAX; ++o) {
+        ab[o] = 0.f;
+#pragma unroll
+        for (int q = 0; q < NQ_MAX; ++q) aw[o][q] = f32x4{ 0.f, 0.f, 0.f, 0.f };
+    }
+    for (long long p = waveGlobal; p < total; p += nWaves) {
+        const int n = (int)(p / HW);
+        const int pix = (int)(p - (long long)n * HW);
+        float ds[COUT_MAX];
+#pragma unroll
+        for (int o = 0; o < COUT_MAX; ++o) {
+            ds[o] = 0.f;
+            if (o < Cout) {
+                const long long idx = ((long long)n * Cout + o) * HW + pix;
+                float g = dout[idx];
+                if (o >= nTask) {
+                    const float fo = fout[idx];
+                    g = (fo > elo && fo < ehi) ? g * fo : 0.f;            // d exp(clamp(s)) / ds
+                }
+                ds[o] = g;
+                ab[o] += g;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NQ_MAX; ++q) {
+            if (q < nq) {
+                const int c = q * 256 + lane * 4;
+                const f32x4 xv = *reinterpret_cast<const f32x4 *>(x + p * ldX + c);
+                f32x4 d = { 0.f, 0.f, 0.f, 0.f };
+#pragma unroll
+                for (int o = 0; o < COUT_MAX; ++o) {
+                    if (o < Cout) {
+                        const f32x4 wv = *reinterpret_cast<const f32x4 *>(w + (long long)o * Cin + c);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { d[j] = fmaf(ds[o], wv[j], d[j]); aw[o][q][j] = fmaf(ds[o], xv[j], aw[o][q][j]); }
+                    }
+                }
+                *reinterpret_cast<f32x4 *>(dx + p * ldDx + c) = d;
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < COUT_MAX; ++o) {
+        if (o < Cout) {
+#pragma unroll
+            for (int q = 0; q < NQ_MAX; ++q)
+                if (q < nq) *reinterpret_cast<f32x4 *>(pW + ((long long)waveGlobal * Cout + o) * Cin + q * 256 + lane * 4) = aw[o][q];
+            if (lane == 0) pB[(long long)waveGlobal * Cout + o] = ab[o];
+        }
+    }
+}
+
+// sums `count` partial vectors of length `len` in fixed order
+__global__ void partial_sum_kernel(const float *__restrict__ partial, float *__restrict__ out, int count, int len)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < len; i += gridDim.x * blockDim.x) {
+        double s = 0.0;
+        for (int k = 0; k < count; ++k) s += (double)partial[(long long)k * len + i];
+        out[i] = (float)s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- conv1 wgrad
+
+// dW[o][c][ky][kx] = sum dY[n,y,x,o] * img[n,c,y+ky-1,x+kx-1]; db[o] = sum dY.  Thread = (o, pixel lane j of 8).
+// partial [blocks][(9*Cin + 1)][Cout]
+__global__ __launch_bounds__(256)
+void conv1_wgrad_kernel(const float *__restrict__ img, const float *__restrict__ dy, float *__restrict__ partial,
+                        int B, int Cin, int H, int W, int Cout, int ldY)
+{
+    __shared__ float sRed[8 * 32 * 28];
+    const int o = threadIdx.x % Cout, j = threadIdx.x / Cout, lanes = 256 / Cout;
+    const long long HW = (long long)H * W, total = (long long)B * HW;
+    const long long per = (total + gridDim.x - 1) / gridDim.x;
+    const long long pBeg = (long long)blockIdx.x * per;
+    long long pEnd = pBeg + per; if (pEnd > total) pEnd = total;
+    float acc[28];
+#pragma unroll
+    for (int k = 0; k < 28; ++k) acc[k] = 0.f;
+    for (long long p = pBeg + j; p < pEnd; p += lanes) {
+        const int n = (int)(p / HW);
+        const int rem = (int)(p - (long long)n * HW);
+        const int y = rem / W, x = rem - y * W;
+        const float g = dy[p * ldY + o];
+        acc[27] += g;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int iy = y + ky - 1, ix = x + kx - 1;
+                const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    if (c < Cin) {
+                        const float v = ok ? img[((long long)n * Cin + c) * HW + (long long)iy * W + ix] : 0.f;
+                        acc[(ky * 3 + kx) * 3 + c] = fmaf(g, v, acc[(ky * 3 + kx) * 3 + c]);
+                    }
+                }
+            }
+    }
+    // reduce over the pixel lanes j in fixed order
+#pragma unroll
+    for (int k = 0; k < 28; ++k) sRed[(j * Cout + o) * 28 + k] = acc[k];
+    __syncthreads();
+    if (j == 0) {
+        for (int k = 0; k < 28; ++k) {
+            float s = 0.f;
+            for (int jj = 0; jj < lanes; ++jj) s += sRed[(jj * Cout + o) * 28 + k];
+            partial[((long long)blockIdx.x * 28 + k) * Cout + o] = s;
+        }
+    }
+}
+
+// out: dW OIHW [Cout][Cin][3][3] and db[Cout] from the block partials
+__global__ void conv1_wgrad_reduce_kernel(const float *__restrict__ partial, float *__restrict__ dw, float *__restrict__ db,
+                                          int blocks, int Cin, int Cout)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;          // over 28*Cout
+    if (i >= 28 * Cout) return;
+    const int k = i / Cout, o = i - k * Cout;
+    double s = 0.0;
+    for (int b = 0; b < blocks; ++b) s += (double)partial[((long long)b * 28 + k) * Cout + o];
+    if (k == 27) { db[o] = (float)s; return; }
+    const int tap = k / 3, c = k - tap * 3;
+    if (c < Cin) dw[((long long)o * Cin + c) * 9 + tap] = (float)s;
+}
+
+int gnb_threads(int C)
+{
+    const int C4 = C / 4;
+    if (C4 > 256) return C4;
+    return (256 % C4 == 0) ? 256 : -1;
+}
+
+}  // namespace
+
+int xl_run_bwd_op(const xl_op &op, hipStream_t st)
+{
+    switch (op.type) {
+        case XL_OP_WGRAD: {
+            if (op.nchunks2 < 1 || op.ld_in % 4 != 0 || op.ld_aux % 4 != 0) return XL_ERR_ARG;
+            if (op.Cout % 128 == 0 && op.Cin % 128 == 0) return launch_wgrad<128, 128, 2, 2>(op, st);
+            if (op.Cout % 128 == 0 && op.Cin % 64 == 0) return launch_wgrad<128, 64, 2, 2>(op, st);
+            if (op.Cout % 64 == 0 && op.Cin % 32 == 0) return launch_wgrad<64, 32, 2, 1>(op, st);
+            return XL_ERR_UNSUPPORTED;
+        }
+        case XL_OP_GNB_STATS:
+        case XL_OP_GNB_APPLY: {
+            if (op.Cin % 4 != 0 || op.Cin % op.groups != 0 || op.groups > 64) return XL_ERR_ARG;
+            GnbArgs a;
+            a.x = (const float *)op.in; a.dout = (const float *)op.aux; a.outAct = (const float *)op.aux2;
+            a.gamma = (const float *)op.w; a.beta = (const float *)op.bias; a.fstats = (const double *)op.stats;
+            a.bstats = (double *)op.stats2; a.dx = (float *)op.out; a.daux = (float *)op.out2; a.ncsums = nullptr;
+            a.HW = op.Hi * op.Wi; a.C = op.Cin; a.ldX = op.ld_in; a.ldD = op.ld_aux; a.ldO = op.ld_out; a.ldDx = op.ld_in;
+            a.ldAux = op.ld_out; a.G = op.groups; a.nchunks = op.nchunks; a.nchunks2 = op.nchunks2; a.flags = op.flags;
+            a.eps = op.eps;
+            if (op.type == XL_OP_GNB_STATS) {
+                const int T = gnb_threads(op.Cin);
+                if (T < 0 || T > 1024) return XL_ERR_ARG;
+                const size_t lds = sizeof(double) * 12 * T + sizeof(float) * 4 * op.Cin;
+                hipLaunchKernelGGL(gnb_stats_kernel, dim3(op.nchunks2, op.B), dim3(T), lds, st, a);
+            } else {
+                // ncsums lives behind the per-chunk sums in the same scratch buffer
+                a.ncsums = a.bstats + (long long)op.B * op.nchunks2 * op.Cin * 3;
+                int achunks = (a.HW * (op.Cin / 4) + 256 * 16 - 1) / (256 * 16);
+                if (achunks < 1) achunks = 1;
+                if (achunks > 1024) achunks = 1024;
+                const size_t lds = sizeof(float) * 7 * op.Cin + sizeof(double) * 3 * op.Cin;
+                hipLaunchKernelGGL(gnb_apply_kernel, dim3(achunks, op.B), dim3(256), lds, st, a);
+            }
+            return XL_OK;
+        }
+        case XL_OP_GNB_PARAMS: {
+            const double *nc = (const double *)op.stats2 + (long long)op.B * op.nchunks2 * op.Cin * 3;
+            float *dbias = (op.flags & XL_GN_NO_CONV_BIAS) ? nullptr : (float *)op.aux2;
+            hipLaunchKernelGGL(gnb_params_kernel, dim3((op.Cin + 63) / 64), dim3(64), 0, st, nc, (const double *)op.stats,
+                               (const float *)op.w, op.B, op.Cin, op.groups, op.Hi * op.Wi, op.nchunks, op.eps,
+                               (float *)op.out, (float *)op.out2, dbias);
+            return XL_OK;
+        }
+        case XL_OP_HEAD_BWD: {
+            if (op.Cin % 256 != 0 || op.Cin > 1024 || op.Cout > 4 || op.Cout < 1) return XL_ERR_ARG;
+            const long long pix = (long long)op.B * op.Hi * op.Wi;
+            long long blocks = (pix + 63) / 64;
+            if (blocks > 256) blocks = 256;
+            if (blocks < 1) blocks = 1;
+            const int waves = (int)blocks * 4;
+            float *pW = (float *)op.stats2;
+            float *pB = pW + (long long)waves * op.Cout * op.Cin;
+            hipLaunchKernelGGL((head_bwd_kernel<4, 4>), dim3((unsigned)blocks), dim3(256), 0, st, (const float *)op.in,
+                               (const float *)op.w, (const float *)op.aux, (const float *)op.aux2, (float *)op.out, pW, pB,
+                               op.B, op.Hi * op.Wi, op.Cin, op.ld_in, op.ld_out, op.Cout, op.n_task, op.clamp_lo, op.clamp_hi);
+            hipLaunchKernelGGL(partial_sum_kernel, dim3(8), dim3(256), 0, st, (const float *)pW, (float *)op.out2, waves,
+                               op.Cout * op.Cin);
+            hipLaunchKernelGGL(partial_sum_kernel, dim3(1), dim3(64), 0, st, (const float *)pB, (float *)op.stats, waves, op.Cout);
+            return XL_OK;
+        }
+        case XL_OP_CONV1_WGRAD: {
+            if (op.Cout != 32 || op.Cin > 3) return XL_ERR_UNSUPPORTED;
+            const int blocks = 1024;
+            hipLaunchKernelGGL(conv1_wgrad_kernel, dim3(blocks), dim3(256), 0, st, (const float *)op.in, (const float *)op.aux,
+                               (float *)op.stats2, op.B, op.Cin, op.Hi, op.Wi, op.Cout, op.ld_aux);
+            hipLaunchKernelGGL(conv1_wgrad_reduce_kernel, dim3((28 * op.Cout + 255) / 256), dim3(256), 0, st,
+                               (const float *)op.stats2, (float *)op.out, (float *)op.out2, blocks, op.Cin, op.Cout);
+            return XL_OK;
+        }
+        default:
+            return XL_ERR_UNSUPPORTED;
+    }
+}

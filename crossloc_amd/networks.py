@@ -3,11 +3,13 @@
 (116 tensors single-task, 270 for the 3-encoder CrossLoc net), but `forward` does not run PyTorch ops: it is
 lowered once per input shape to an op list (include/crossloc_cnn.h) of hand-written HIP kernels — implicit-GEMM
 convolutions on fp32 MFMA, two-pass GroupNorm with fused ReLU/residual epilogues, fused decoder head — and
-executed with one C call on the current HIP stream.  NCHW at the module boundary, NHWC inside.
+executed with one C call on the current HIP stream.  NCHW at the module boundary, NHWC inside.  With autograd enabled
+and trainable parameters, forward keeps the activations and `loss.backward()` runs a second op list (data
+gradients through the same MFMA kernel, split-K weight gradients, fused GroupNorm/ReLU/residual backward).
 
 The nn.Conv2d / nn.GroupNorm children are parameter containers only (they give identical keys, shapes and
 default initialisation); they are never called.  There is no CPU/eager fallback: forward on a non-GPU tensor
-raises.  Inference only in this round (no autograd graph is built).
+raises.  The backward pass covers the single-task network (3-encoder MLR backward: not yet).
 """
 import ctypes
 import math
@@ -18,15 +20,17 @@ import torch.nn as nn
 from . import _lib
 
 XL_OP_CONV1, XL_OP_CONV, XL_OP_GN_STATS, XL_OP_GN_APPLY, XL_OP_HEAD = 0, 1, 2, 3, 4
-GN_RELU_IN, GN_ADD, GN_RELU_OUT = 1, 2, 4
+GN_RELU_IN, GN_ADD, GN_RELU_OUT, GN_ACC_AUX, GN_NO_CONV_BIAS = 1, 2, 4, 8, 16
+XL_OP_WGRAD, XL_OP_GNB_STATS, XL_OP_GNB_APPLY, XL_OP_GNB_PARAMS, XL_OP_HEAD_BWD, XL_OP_CONV1_WGRAD = 5, 6, 7, 8, 9, 10
+CONV_DGRAD, CONV_ACCUMULATE = 1, 2
 
 
 class XlOp(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in
                 ("type", "B", "Hi", "Wi", "Cin", "Ho", "Wo", "Cout", "ksize", "stride", "groups", "nchunks",
-                 "flags", "ld_in", "ld_out", "ld_aux", "n_task", "n_pos")] + \
+                 "flags", "ld_in", "ld_out", "ld_aux", "n_task", "n_pos", "nchunks2", "reserved_i")] + \
                [(n, ctypes.c_float) for n in ("eps", "clamp_lo", "clamp_hi", "reserved")] + \
-               [(n, ctypes.c_void_p) for n in ("in_", "w", "bias", "aux", "stats", "out")]
+               [(n, ctypes.c_void_p) for n in ("in_", "w", "bias", "aux", "stats", "out", "aux2", "out2", "stats2")]
 
 
 def _bind():
@@ -38,6 +42,8 @@ def _bind():
         L.xl_cnn_pack_conv_weight.restype = ctypes.c_int
         L.xl_cnn_pack_conv_weight.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
                                               ctypes.c_int, ctypes.c_void_p]
+        L.xl_cnn_pack_conv_weight_dgrad.restype = ctypes.c_int
+        L.xl_cnn_pack_conv_weight_dgrad.argtypes = L.xl_cnn_pack_conv_weight.argtypes
         L.xl_cnn_last_error.restype = ctypes.c_char_p
         if L.xl_cnn_op_size() != ctypes.sizeof(XlOp):
             raise _lib.XlError("xl_op layout mismatch: C %d vs ctypes %d" % (L.xl_cnn_op_size(), ctypes.sizeof(XlOp)))
@@ -149,26 +155,32 @@ class TransPoseNetDecoder(nn.Module):
 # ------------------------------------------------------------------------------------------ lowering
 
 class _Plan:
-    """One forward pass for a fixed (B, H, W): op array + workspace, replayed on every call."""
+    """One pass for a fixed (B, H, W): op array + workspace, replayed on every call.
 
-    def __init__(self, net, B, H, W, device):
-        self.B, self.H, self.W, self.device = B, H, W, device
+    train=False: inference plan (GroupNorm in place, buffers recycled as soon as they are dead).
+    train=True:  every conv output (pre-norm) and every activation is kept, a tape of the layers is recorded and a
+                 second op array for the backward pass is lowered from it (data gradients through the same
+                 implicit-GEMM kernel, weight gradients, GroupNorm/epilogue backward, head backward)."""
+
+    def __init__(self, net, B, H, W, device, train=False):
+        self.B, self.H, self.W, self.device, self.train = B, H, W, device, train
         self.ops = []
         self.keep = []                      # tensors the op pointers reference
         self.free = {}                      # numel -> [tensor]
-        self.packed = {}                    # id(param) -> packed weight tensor
+        self.packed = {}                    # (id(param), kind) -> packed weight tensor
         self.net = net
-        self.stats = None
         self.max_stats = 0
+        self.stats_ops = []                 # (op index) of GN ops using the shared stats scratch (inference)
         self.out_op_index = None
         self.image_op_indices = []
+        self.tape = []
         self._lower(net)
-        n = len(self.ops)
-        self.op_array = (XlOp * n)(*self.ops)
+        self.op_array = (XlOp * len(self.ops))(*self.ops)
         self.stats = torch.zeros(max(self.max_stats, 1), dtype=torch.float64, device=device)
-        for i, op in enumerate(self.ops):
-            if op.type in (XL_OP_GN_STATS, XL_OP_GN_APPLY):
-                self.op_array[i].stats = self.stats.data_ptr()
+        for i in self.stats_ops:
+            self.op_array[i].stats = self.stats.data_ptr()
+        if train:
+            self._lower_backward()
 
     # -- workspace
     def alloc(self, numel):
@@ -180,22 +192,29 @@ class _Plan:
         return t
 
     def release(self, t):
+        if not self.train:                  # training keeps every forward tensor for the backward pass
+            self.free.setdefault(t.numel(), []).append(t)
+
+    def release_grad(self, t):
         self.free.setdefault(t.numel(), []).append(t)
 
     # -- weights
-    def pack_conv(self, conv):
+    def pack_conv(self, conv, dgrad=False):
         w = conv.weight
-        key = id(w)
+        key = (id(w), dgrad)
         if key not in self.packed:
             L = _bind()
             src = w.detach().to(device=self.device, dtype=torch.float32).contiguous()
             cout, cin, k, _ = src.shape
+            stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
             if cin in (1, 3) and k == 3:        # conv1: [(ky*3+kx)*Cin + c][Cout]
                 dst = src.permute(2, 3, 1, 0).contiguous()
+            elif dgrad:
+                dst = torch.empty_like(src)
+                _check(L.xl_cnn_pack_conv_weight_dgrad(src.data_ptr(), dst.data_ptr(), cout, cin, k, stream))
             else:
                 dst = torch.empty_like(src)
-                stream = torch.cuda.current_stream().cuda_stream
-                _check(L.xl_cnn_pack_conv_weight(src.data_ptr(), dst.data_ptr(), cout, cin, k, ctypes.c_void_p(stream)))
+                _check(L.xl_cnn_pack_conv_weight(src.data_ptr(), dst.data_ptr(), cout, cin, k, stream))
             self.packed[key] = dst
             self.keep.append(src)
         return self.packed[key]
@@ -224,30 +243,41 @@ class _Plan:
         op.bias = self.dev(conv.bias).data_ptr()
         op.out = out.data_ptr() + 4 * out_off
         self.ops.append(op)
-        return (out, Ho, Wo, cout, out_ld, out_off)
+        res = (out, Ho, Wo, cout, out_ld, out_off)
+        self.tape.append(dict(kind="conv", conv=conv, x=act, raw=res))
+        return res
 
     def gn(self, act, norm, flags, aux=None, out=None):
-        """GroupNorm (+fused epilogue) of `act`; in place unless `out` (tensor, ld, off) is given."""
+        """GroupNorm (+fused epilogue) of `act`; in place unless `out` (tensor, ld, off) is given or training."""
         t, H, W, C, ld, off = act
         G = norm.num_groups
         HW = H * W
         nchunks = max(1, min(128, (HW + 255) // 256))
-        self.max_stats = max(self.max_stats, self.B * nchunks * G * 2)
         st = XlOp()
         st.type = XL_OP_GN_STATS
         st.B, st.Hi, st.Wi, st.Cin, st.groups, st.nchunks, st.ld_in = self.B, H, W, C, G, nchunks, ld
         st.in_ = t.data_ptr() + 4 * off
-        self.ops.append(st)
         ap = XlOp()
         ap.type = XL_OP_GN_APPLY
         ap.B, ap.Hi, ap.Wi, ap.Cin, ap.groups, ap.nchunks, ap.ld_in = self.B, H, W, C, G, nchunks, ld
         ap.flags, ap.eps = flags, norm.eps
         ap.in_ = t.data_ptr() + 4 * off
-        ap.w = self.dev(norm.weight).data_ptr()
-        ap.bias = self.dev(norm.bias).data_ptr()
+        gamma, beta = self.dev(norm.weight), self.dev(norm.bias)
+        ap.w, ap.bias = gamma.data_ptr(), beta.data_ptr()
+        stats_t = None
+        if self.train:                      # the forward statistics are inputs of the backward pass: keep them
+            stats_t = torch.zeros(self.B * nchunks * G * 2, dtype=torch.float64, device=self.device)
+            self.keep.append(stats_t)
+            st.stats = ap.stats = stats_t.data_ptr()
+        else:
+            self.max_stats = max(self.max_stats, self.B * nchunks * G * 2)
+            self.stats_ops += [len(self.ops), len(self.ops) + 1]
+        self.ops.append(st)
         if aux is not None:
             ap.aux = aux[0].data_ptr() + 4 * aux[5]
             ap.ld_aux = aux[4]
+        if out is None and self.train:
+            out = (self.alloc(self.B * HW * C), C, 0)
         if out is None:
             ap.out, ap.ld_out = ap.in_, ld
             res = act
@@ -256,11 +286,16 @@ class _Plan:
             ap.out, ap.ld_out = ot.data_ptr() + 4 * ooff, old
             res = (ot, H, W, C, old, ooff)
         self.ops.append(ap)
+        self.tape.append(dict(kind="gn", norm=norm, raw=act, out=res, aux=aux, flags=flags, stats=stats_t,
+                              nchunks=nchunks, gamma=gamma, beta=beta))
         return res
 
     def cgr(self, act, conv, norm, flags=GN_RELU_IN, aux=None):
         y = self.conv(act, conv)
-        return self.gn(y, norm, flags, aux)
+        r = self.gn(y, norm, flags, aux)
+        if r[0] is not y[0]:
+            self.release(y[0])
+        return r
 
     def res_block(self, res, block):
         """relu(res + block(res)), networks.py:252-254 / :332-334"""
@@ -287,7 +322,9 @@ class _Plan:
         op.out = t1.data_ptr()
         self.ops.append(op)
         self.image_op_indices.append(len(self.ops) - 1)
-        x = self.gn((t1, H, W, c1, c1, 0), enc.norm1, GN_RELU_IN)
+        raw1 = (t1, H, W, c1, c1, 0)
+        self.tape.append(dict(kind="conv1", conv=enc.conv1, raw=raw1))
+        x = self.gn(raw1, enc.norm1, GN_RELU_IN)
         x2 = self.cgr(x, enc.conv2, enc.norm2); self.release(x[0])
         x3 = self.cgr(x2, enc.conv3, enc.norm3); self.release(x2[0])
         res = self.cgr(x3, enc.conv4, enc.norm4); self.release(x3[0])
@@ -301,16 +338,12 @@ class _Plan:
         c = self.cgr(b, enc.res2_conv3, enc.res2_norm3); self.release(b[0])
         n_add = len(enc.enc_add_res_block_ls)
         last_out = out if n_add == 0 else None
-        if not enc.tiny:
-            sk = self.conv(res, enc.res2_skip)
-            self.release(res[0])
-            res = self.gn(sk, enc.res2_skip_norm, GN_ADD | GN_RELU_OUT, aux=c, out=last_out)
-            self.release(c[0])
-            if last_out is not None:
-                self.release(sk[0])
-        else:
-            # tiny: res = relu(res + x) without a skip projection -> plain add is folded as GN-free path
-            raise NotImplementedError("tiny=True is not used by CrossLoc (utils/learning.py:302-305)")
+        sk = self.conv(res, enc.res2_skip)
+        self.release(res[0])
+        res = self.gn(sk, enc.res2_skip_norm, GN_ADD | GN_RELU_OUT, aux=c, out=last_out)
+        self.release(c[0])
+        if res[0] is not sk[0]:
+            self.release(sk[0])
         for i, block in enumerate(enc.enc_add_res_block_ls):
             if i == n_add - 1 and out is not None:
                 x = self.cgr(res, block[0], block[1])
@@ -328,7 +361,8 @@ class _Plan:
         if net.num_mlr == 0:
             res = self.encoder(net.encoder, _DUMMY)
         else:
-            Ho = Wo = None
+            if self.train:
+                raise NotImplementedError("backward through the 3-encoder MLR network is not implemented yet")
             c = (512, 128)[net.tiny]
             # encoders write straight into channel slices of the concat buffer (networks.py:485-488)
             h, w = self.H, self.W
@@ -373,6 +407,154 @@ class _Plan:
         self.ops.append(op)
         self.out_op_index = len(self.ops) - 1
         self.out_shape = (self.B, op.Cout, H, W)
+        self.tape.append(dict(kind="head", fc3=dec.fc3, x=b, w3=w3, cout=op.Cout, n_task=op.n_task))
+
+    # ------------------------------------------------------------------ backward lowering (train plans)
+    @staticmethod
+    def _key(act):
+        return (act[0].data_ptr(), act[5])
+
+    def _lower_backward(self):
+        B, dev = self.B, self.device
+        bops = []
+        grads = {}                # activation key -> gradient tensor (same layout as the activation, ld = C)
+        graw = {}                 # conv-output key -> gradient tensor
+        self.param_grads = []     # (parameter, tensor) in production order
+        scratch_f = 0             # fp32 scratch (wgrad split-K partials, head / conv1 partials)
+        scratch_d = 0             # fp64 scratch (GroupNorm backward sums)
+        patch_f, patch_d = [], []
+        producers = {self._key(e["raw"]): e for e in self.tape if e["kind"] in ("conv", "conv1")}
+
+        def pgrad(param):
+            t = torch.zeros(param.numel(), dtype=torch.float32, device=dev)
+            self.param_grads.append((param, t))
+            return t
+
+        for e in reversed(self.tape):
+            kind = e["kind"]
+            if kind == "head":
+                t, H, W, C, ld, off = e["x"]
+                gin = self.alloc(B * H * W * C)
+                op = XlOp()
+                op.type = XL_OP_HEAD_BWD
+                op.B, op.Hi, op.Wi, op.Cin, op.Cout, op.n_task = B, H, W, C, e["cout"], e["n_task"]
+                op.ld_in, op.ld_out = ld, C
+                op.clamp_lo, op.clamp_hi = -16.10, 13.82
+                op.in_, op.w, op.out = t.data_ptr() + 4 * off, e["w3"].data_ptr(), gin.data_ptr()
+                op.out2 = pgrad(e["fc3"].weight).data_ptr()
+                op.stats = pgrad(e["fc3"].bias).data_ptr()
+                waves = 4 * max(1, min(256, (B * H * W + 63) // 64))
+                scratch_f = max(scratch_f, waves * e["cout"] * (C + 1))
+                patch_f.append(len(bops))
+                self.head_bwd_index = len(bops)
+                bops.append(op)
+                grads[self._key(e["x"])] = gin
+            elif kind == "gn":
+                t, H, W, C, ld, off = e["raw"]
+                gout = grads.pop(self._key(e["out"]))
+                dx = self.alloc(B * H * W * C)
+                flags = e["flags"]
+                daux = None
+                if e["aux"] is not None:
+                    ak = self._key(e["aux"])
+                    if ak in grads:
+                        flags |= GN_ACC_AUX
+                        daux = grads[ak]
+                    else:
+                        daux = self.alloc(B * H * W * C)
+                        grads[ak] = daux
+                prod = producers.get(self._key(e["raw"]))
+                G = e["norm"].num_groups
+                nch2 = max(1, min(128, (H * W + 255) // 256))
+                scratch_d = max(scratch_d, B * nch2 * C * 3 + B * C * 5)
+                for typ in (XL_OP_GNB_STATS, XL_OP_GNB_APPLY, XL_OP_GNB_PARAMS):
+                    op = XlOp()
+                    op.type = typ
+                    op.B, op.Hi, op.Wi, op.Cin, op.groups = B, H, W, C, G
+                    op.nchunks, op.nchunks2, op.flags, op.eps = e["nchunks"], nch2, flags, e["norm"].eps
+                    op.ld_in, op.ld_aux, op.ld_out = ld, C, e["out"][4]
+                    op.in_ = t.data_ptr() + 4 * off
+                    op.w, op.bias = e["gamma"].data_ptr(), e["beta"].data_ptr()
+                    op.stats = e["stats"].data_ptr()
+                    op.aux = gout.data_ptr()
+                    op.aux2 = e["out"][0].data_ptr() + 4 * e["out"][5]
+                    if typ == XL_OP_GNB_APPLY:
+                        op.out = dx.data_ptr()
+                        op.out2 = daux.data_ptr() if daux is not None else None
+                    elif typ == XL_OP_GNB_PARAMS:
+                        op.out = pgrad(e["norm"].weight).data_ptr()
+                        op.out2 = pgrad(e["norm"].bias).data_ptr()
+                        if prod is not None:
+                            op.aux2 = pgrad(prod["conv"].bias).data_ptr()
+                        else:
+                            op.flags = flags | GN_NO_CONV_BIAS
+                    patch_d.append(len(bops))
+                    bops.append(op)
+                graw[self._key(e["raw"])] = dx
+                self.release_grad(gout)
+            elif kind == "conv":
+                conv = e["conv"]
+                t, H, W, C, ld, off = e["x"]
+                rt, Ho, Wo, Cout, rld, roff = e["raw"]
+                dy = graw.pop(self._key(e["raw"]))
+                k, s = conv.kernel_size[0], conv.stride[0]
+                op = XlOp()
+                op.type = XL_OP_WGRAD
+                op.B, op.Hi, op.Wi, op.Cin, op.Ho, op.Wo, op.Cout = B, H, W, C, Ho, Wo, Cout
+                op.ksize, op.stride, op.ld_in, op.ld_aux = k, s, ld, Cout
+                bo = 128 if Cout % 128 == 0 else 64
+                bc = 128 if C % 128 == 0 else (64 if C % 64 == 0 else 32)
+                tiles = k * k * (Cout // bo) * (C // bc)
+                M = B * Ho * Wo
+                splits = max(1, min(64, -(-1536 // tiles), M // 256))
+                op.nchunks2 = splits
+                op.in_, op.aux = t.data_ptr() + 4 * off, dy.data_ptr()
+                op.out = pgrad(conv.weight).data_ptr()
+                scratch_f = max(scratch_f, splits * k * k * Cout * C)
+                patch_f.append(len(bops))
+                bops.append(op)
+                # data gradient into grads[x]
+                xk = self._key(e["x"])
+                op = XlOp()
+                op.type = XL_OP_CONV
+                op.flags = CONV_DGRAD
+                if xk in grads:
+                    op.flags |= CONV_ACCUMULATE
+                    gx = grads[xk]
+                else:
+                    gx = self.alloc(B * H * W * C)
+                    grads[xk] = gx
+                op.B, op.Hi, op.Wi, op.Cin, op.Ho, op.Wo, op.Cout = B, Ho, Wo, Cout, H, W, C
+                op.ksize, op.stride, op.ld_in, op.ld_out = k, s, Cout, C
+                op.in_, op.out = dy.data_ptr(), gx.data_ptr()
+                op.w = self.pack_conv(conv, dgrad=True).data_ptr()
+                bops.append(op)      # 32 result channels (conv2): the kernel masks the padded half of its 64-wide tile
+                self.release_grad(dy)
+            elif kind == "conv1":
+                conv = e["conv"]
+                rt, H, W, Cout, rld, roff = e["raw"]
+                dy = graw.pop(self._key(e["raw"]))
+                op = XlOp()
+                op.type = XL_OP_CONV1_WGRAD
+                op.B, op.Hi, op.Wi, op.Cin, op.Cout, op.ld_aux = B, H, W, conv.in_channels, Cout, Cout
+                op.aux = dy.data_ptr()
+                op.out = pgrad(conv.weight).data_ptr()
+                # the bias gradient of conv1 comes from the GroupNorm backward sums (fp64 closed form); the sum this
+                # kernel also produces goes to a scratch vector
+                self.conv1_db_unused = torch.empty(Cout, dtype=torch.float32, device=dev)
+                op.out2 = self.conv1_db_unused.data_ptr()
+                scratch_f = max(scratch_f, 1024 * 28 * Cout)
+                patch_f.append(len(bops))
+                self.conv1_wgrad_index = len(bops)
+                bops.append(op)
+                self.release_grad(dy)
+        self.bwd_scratch_f = torch.empty(max(scratch_f, 1), dtype=torch.float32, device=dev)
+        self.bwd_scratch_d = torch.empty(max(scratch_d, 1), dtype=torch.float64, device=dev)
+        self.bwd_array = (XlOp * len(bops))(*bops)
+        for i in patch_f:
+            self.bwd_array[i].stats2 = self.bwd_scratch_f.data_ptr()
+        for i in patch_d:
+            self.bwd_array[i].stats2 = self.bwd_scratch_d.data_ptr()
 
     def run(self, image):
         out = torch.empty(self.out_shape, dtype=torch.float32, device=self.device)
@@ -381,7 +563,36 @@ class _Plan:
         self.op_array[self.out_op_index].out = out.data_ptr()
         stream = torch.cuda.current_stream().cuda_stream
         _check(_bind().xl_cnn_run(self.op_array, len(self.op_array), ctypes.c_void_p(stream)))
+        self.last_image, self.last_out = image, out
         return out
+
+    def run_backward(self, dout):
+        """dout [B, Cout, Ho, Wo] (NCHW, like the forward output).  Returns [(parameter, flat gradient)]."""
+        dout = dout.detach().to(torch.float32).contiguous()
+        hb = self.bwd_array[self.head_bwd_index]
+        hb.aux, hb.aux2 = dout.data_ptr(), self.last_out.data_ptr()
+        self.bwd_array[self.conv1_wgrad_index].in_ = self.last_image.data_ptr()
+        stream = torch.cuda.current_stream().cuda_stream
+        _check(_bind().xl_cnn_run(self.bwd_array, len(self.bwd_array), ctypes.c_void_p(stream)))
+        return self.param_grads
+
+
+class _NetFunction(torch.autograd.Function):
+    """Connects the HIP forward/backward plans to autograd: the parameters are passed as inputs so that
+    `loss.backward()` (train_single_task.py:298) routes the output gradient into run_backward and accumulates the
+    returned parameter gradients into `.grad` like any other op.  The image gradient is not computed."""
+
+    @staticmethod
+    def forward(ctx, plan, x, *params):
+        ctx.plan, ctx.params = plan, params
+        return plan.run(x)
+
+    @staticmethod
+    def backward(ctx, gout):
+        produced = {id(p): g for p, g in ctx.plan.run_backward(gout)}
+        grads = tuple(produced[id(p)].view_as(p).clone() if (p.requires_grad and id(p) in produced) else None
+                      for p in ctx.params)
+        return (None, None) + grads
 
 
 class _Dummy:
@@ -461,13 +672,18 @@ class TransPoseNet(nn.Module):
         if ver != self._plan_version:
             self._plans = {}
             self._plan_version = ver
-        key = (B, H, W, x.device.index)
+        params = [p for p in self.parameters()]
+        train = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        key = (B, H, W, x.device.index, train)
         with torch.cuda.device(x.device):
             plan = self._plans.get(key)
             if plan is None:
-                plan = _Plan(self, B, H, W, x.device)
+                plan = _Plan(self, B, H, W, x.device, train=train)
                 self._plans[key] = plan
-            return plan.run(x)
+            if not train:
+                return plan.run(x)
+            # one forward may be outstanding per plan: its activations live in the plan until backward
+            return _NetFunction.apply(plan, x, *params)
 
 
 def smoke_check(device):

@@ -26,8 +26,23 @@ enum {
     XL_OP_CONV = 1,      /* 3x3 (pad 1) or 1x1 conv, stride 1 or 2, NHWC, implicit GEMM on fp32 MFMA, + bias */
     XL_OP_GN_STATS = 2,  /* per-(image, chunk, group) partial sums of x and x^2 (fp64) */
     XL_OP_GN_APPLY = 3,  /* GroupNorm affine from the partial sums, fused ReLU / residual add / ReLU */
-    XL_OP_HEAD = 4       /* fc3 1x1 conv to (n_task + n_pos) channels + mean offset + exp(hardtanh), NCHW out */
+    XL_OP_HEAD = 4,      /* fc3 1x1 conv to (n_task + n_pos) channels + mean offset + exp(hardtanh), NCHW out */
+    /* ---- backward (what autograd + cuDNN dgrad/wgrad did for loss.backward(), train_single_task.py:298) */
+    XL_OP_WGRAD = 5,     /* conv weight gradient: split-K implicit GEMM over pixels + fixed-order reduce -> OIHW */
+    XL_OP_GNB_STATS = 6, /* GroupNorm(+fused epilogue) backward, pass 1: per-(image, chunk, channel) sums */
+    XL_OP_GNB_APPLY = 7, /* pass 2: dx, optional d(residual), per-(image, channel) sums for the parameter grads */
+    XL_OP_GNB_PARAMS = 8,/* d gamma, d beta and the bias gradient of the preceding conv */
+    XL_OP_HEAD_BWD = 9,  /* backward of XL_OP_HEAD: d(input) NHWC, d(fc3 weight), d(fc3 bias) */
+    XL_OP_CONV1_WGRAD = 10 /* weight + bias gradient of the NCHW-input first conv */
 };
+
+/* xl_op.flags for XL_OP_CONV */
+#define XL_CONV_DGRAD 1        /* data gradient: `in` is dY (Hi x Wi x Cin = forward output), result is dX; weights
+                                  packed with xl_cnn_pack_conv_weight_dgrad; `stride` is the forward stride */
+#define XL_CONV_ACCUMULATE 2   /* out += result (second writer of a gradient buffer) */
+/* extra xl_op.flags for XL_OP_GNB_* */
+#define XL_GN_ACC_AUX 8        /* d(residual) is accumulated into out2 instead of written */
+#define XL_GN_NO_CONV_BIAS 16  /* no conv precedes this GroupNorm: skip the bias gradient */
 
 /* xl_op.flags for XL_OP_GN_APPLY:  v = gn(x); RELU_IN: v = max(v,0); ADD: v += aux; RELU_OUT: v = max(v,0) */
 #define XL_GN_RELU_IN 1
@@ -43,6 +58,7 @@ typedef struct xl_op {
     int32_t flags;
     int32_t ld_in, ld_out, ld_aux; /* pixel strides in floats of in / out / aux (NHWC tensors) */
     int32_t n_task, n_pos;         /* XL_OP_HEAD: task channels (mean added) and positive channels */
+    int32_t nchunks2, reserved_i;  /* backward: pixel chunks of the GNB stats pass / split-K factor of WGRAD */
     float eps;                     /* GroupNorm epsilon (1e-5) */
     float clamp_lo, clamp_hi;      /* XL_OP_HEAD hardtanh bounds (-16.10, 13.82), networks.py:355-356 */
     float reserved;
@@ -53,6 +69,9 @@ typedef struct xl_op {
     const void *aux;               /* GN_APPLY: residual tensor; HEAD: mean[n_task] */
     void *stats;                   /* GN_*: fp64 partial sums [B][nchunks][groups][2] */
     void *out;
+    const void *aux2;              /* GNB_*: forward output of the fused epilogue (ReLU mask); HEAD_BWD: forward out */
+    void *out2;                    /* GNB_APPLY: d(residual); GNB_PARAMS: d beta; HEAD_BWD: d weight */
+    void *stats2;                  /* GNB_*: fp64 backward sums; WGRAD: fp32 split-K partials; GNB_PARAMS out3 = d bias */
 } xl_op;
 
 /* Execute ops[0..n_ops) in order on `stream` (hipStream_t; NULL = default). Asynchronous.
@@ -65,6 +84,10 @@ int xl_cnn_op_size(void);
 /* Weight layout transform used at load time: PyTorch conv weight [Cout][Cin][k][k] (device) ->
  * [Cout][Cin/32][k*k][32] (device): 32-channel chunk major, tap, channel within chunk; Cin % 32 == 0. */
 int xl_cnn_pack_conv_weight(const float *w_oihw_dev, float *w_ohwi_dev, int Cout, int Cin, int k, void *stream);
+
+/* Weight layout for XL_CONV_DGRAD: [Cout][Cin][k][k] -> [Cin][Cout/32][k*k][32] (the transposed operand of the
+ * same implicit GEMM; taps are NOT flipped, the kernel mirrors the offsets).  Cout % 32 == 0. */
+int xl_cnn_pack_conv_weight_dgrad(const float *w_oihw_dev, float *w_dgrad_dev, int Cout, int Cin, int k, void *stream);
 
 /* Per-op HIP-event timing for measurement (bench.py): between prof_begin and prof_end every op launched by
  * xl_cnn_run is bracketed by two events on its own stream (up to max_records ops).  prof_end waits for the

@@ -1,0 +1,226 @@
+"""GPU parity of the CNN backward pass (loss.backward() through crossloc_amd.TransPoseNet) against PyTorch
+autograd on the fp32 CPU restatement of the reference graph (oracle/cnn_oracle.py, itself pinned to reference
+goldens).  Every parameter gradient (116 tensors) is compared; tolerance 2e-4 * max|ref| per tensor (observed:
+<1e-5; fp32, different summation orders through 29 convs + 28 GroupNorms, forward and backward).
+
+ReLU'(0) caveat: a pre-activation that lies within fp32 rounding of zero can get a different ReLU mask on the
+GPU than on the CPU (different conv summation order).  One such flip changes one channel of one d beta by
+O(1 %) and its GroupNorm group accordingly — seen once while choosing these seeds ((1,96,128) input: exactly
+1 of 512 channels of one layer differed, everything else agreed to 1e-6).  The kernels are deterministic, so
+the configurations below, which contain no such element, are stable; the per-op backward tests cover the
+arithmetic of every kernel independently of this effect."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+from crossloc_amd import networks                      # noqa: E402
+from crossloc_amd.weights import seeded_state_dict     # noqa: E402
+from oracle import cnn_oracle                          # noqa: E402
+
+pytestmark = pytest.mark.gpu
+MEAN = torch.tensor([-455.934, 417.50, 520.31])
+
+
+def _reference_grads(sd, x, wgt, enc_add, dec_add):
+    sd = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and not k.endswith("mean") else v)
+          for k, v in sd.items()}
+
+    class _Id(dict):
+        pass
+    leaves = {k: v for k, v in sd.items() if v.requires_grad}
+    # cnn_oracle detaches its inputs; re-implement the call with live tensors
+    orig = cnn_oracle.transposenet_forward
+    res = cnn_oracle.encoder_forward(sd, x, "encoder", enc_add, 32)
+    y = cnn_oracle.decoder_forward(sd, res, dec_add, 3, 1, 32)
+    (y * wgt).sum().backward()
+    return y.detach(), {k: v.grad for k, v in leaves.items()}
+
+
+@pytest.mark.parametrize("B,H,W,enc_add,dec_add", [(2, 64, 96, 1, 1), (1, 64, 128, 2, 2), (3, 40, 56, 0, 0)])
+def test_parameter_gradients_vs_autograd(B, H, W, enc_add, dec_add):
+    net = networks.TransPoseNet(MEAN, False, False, enc_add, dec_add, 3, 1)
+    net.load_state_dict(seeded_state_dict(net, seed=11))
+    g = torch.Generator().manual_seed(B * 100 + H)
+    x = torch.rand(B, 3, H, W, generator=g)
+    Ho, Wo = H // 8, W // 8
+    wgt = torch.randn(B, 4, Ho, Wo, generator=g)
+    wgt[:, 3] *= 0.1
+    yref, gref = _reference_grads(net.state_dict(), x, wgt, enc_add, dec_add)
+
+    net = net.cuda().train()
+    y = net(x.cuda())
+    assert y.requires_grad
+    (y * wgt.cuda()).sum().backward()
+    torch.cuda.synchronize()
+    scale = max(1.0, (yref[:, :3] - MEAN[None, :, None, None]).abs().max().item())
+    assert (y.detach().cpu()[:, :3] - yref[:, :3]).abs().max().item() <= 1e-3 * scale
+    worst = []
+    gmax = max(v.abs().max().item() for v in gref.values())
+    for name, p in net.named_parameters():
+        assert p.grad is not None, name
+        ref = gref[name]
+        err = (p.grad.cpu() - ref).abs().max().item()
+        # per-tensor scale, floored at 1e-4 of the largest gradient in the network: conv1.bias is exactly 0 in
+        # exact arithmetic (GroupNorm(32,32) is an instance norm), so both sides hold rounding noise only
+        sc = max(ref.abs().max().item(), 1e-4 * gmax)
+        worst.append((err / sc, name))
+    worst.sort(reverse=True)
+    worst = [w for w in worst if w[1] != "encoder.conv1.bias"]   # exactly 0 here; the reference holds noise
+    assert worst[0][0] <= 2e-4, worst[:5]
+    assert net.encoder.conv1.bias.grad.abs().max().item() == 0.0
+
+
+def test_gradients_accumulate_and_second_step_matches():
+    net = networks.TransPoseNet(MEAN, False, False, 0, 0, 3, 1)
+    net.load_state_dict(seeded_state_dict(net, seed=3))
+    net = net.cuda().train()
+    x = torch.rand(1, 3, 64, 96, device="cuda")
+    net(x).sum().backward()
+    g1 = {n: p.grad.clone() for n, p in net.named_parameters()}
+    net(x).sum().backward()                              # accumulates
+    for n, p in net.named_parameters():
+        assert torch.allclose(p.grad, 2 * g1[n], rtol=1e-5, atol=1e-6 * g1[n].abs().max().item() + 1e-12), n
+    # an SGD step changes the weights -> the plan repacks and the next forward differs
+    with torch.no_grad():
+        for p in net.parameters():
+            p -= 1e-3 * p.grad
+    net.zero_grad()
+    y2 = net(x)
+    y2.sum().backward()
+    assert all(torch.isfinite(p.grad).all() for p in net.parameters())
+
+
+def test_frozen_parameters_and_no_grad_inference():
+    net = networks.TransPoseNet(MEAN, False, False, 0, 0, 3, 1).cuda()
+    for p in net.encoder.parameters():
+        p.requires_grad = False
+    x = torch.rand(1, 3, 64, 96, device="cuda")
+    net(x).sum().backward()
+    assert all(p.grad is None for p in net.encoder.parameters())
+    assert all(p.grad is not None for p in net.decoder.parameters())
+    with torch.no_grad():
+        y = net(x)
+    assert not y.requires_grad
+
+
+def _nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def _run(ops):
+    import ctypes
+    L = networks._bind()
+    arr = (networks.XlOp * len(ops))(*ops)
+    networks._check(L.xl_cnn_run(arr, len(ops), None))
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("cin,cout,k,s,B,H,W", [(512, 512, 1, 1, 1, 12, 16), (512, 512, 3, 1, 2, 9, 13), (256, 512, 3, 1, 1, 8, 12),
+                                                (128, 256, 3, 2, 2, 17, 23), (64, 128, 3, 2, 1, 32, 48), (32, 64, 3, 2, 2, 40, 56)])
+def test_conv_dgrad_and_wgrad_vs_autograd(cin, cout, k, s, B, H, W):
+    import torch.nn as nn
+    L = networks._bind()
+    g = torch.Generator().manual_seed(cin + cout + k + s)
+    x = torch.randn(B, cin, H, W, generator=g, requires_grad=True)
+    conv = nn.Conv2d(cin, cout, k, s, k // 2)
+    y = conv(x)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    Ho, Wo = y.shape[2], y.shape[3]
+    ws = conv.weight.detach().cuda().contiguous()
+    wd = torch.empty_like(ws)
+    networks._check(L.xl_cnn_pack_conv_weight_dgrad(ws.data_ptr(), wd.data_ptr(), cout, cin, k, None))
+    dyd = _nhwc(dy).cuda()
+    gx = torch.full((B, H, W, cin), float("nan"), device="cuda")
+    op = networks.XlOp()
+    op.type, op.flags = networks.XL_OP_CONV, networks.CONV_DGRAD
+    op.B, op.Hi, op.Wi, op.Cin, op.Ho, op.Wo, op.Cout = B, Ho, Wo, cout, H, W, cin
+    op.ksize, op.stride, op.ld_in, op.ld_out = k, s, cout, cin
+    op.in_, op.w, op.out = dyd.data_ptr(), wd.data_ptr(), gx.data_ptr()
+    _run([op])
+    ref = x.grad
+    assert ((gx.cpu().permute(0, 3, 1, 2) - ref).abs().max() / ref.abs().max()).item() < 2e-5
+    # accumulate epilogue: a second launch doubles the result
+    op.flags |= networks.CONV_ACCUMULATE
+    _run([op])
+    assert ((gx.cpu().permute(0, 3, 1, 2) - 2 * ref).abs().max() / ref.abs().max()).item() < 4e-5
+    xd = _nhwc(x.detach()).cuda()
+    for splits in (1, 3):
+        dw = torch.full(conv.weight.shape, float("nan"), device="cuda")
+        scratch = torch.empty(splits * k * k * cout * cin, device="cuda")
+        op = networks.XlOp()
+        op.type = networks.XL_OP_WGRAD
+        op.B, op.Hi, op.Wi, op.Cin, op.Ho, op.Wo, op.Cout = B, H, W, cin, Ho, Wo, cout
+        op.ksize, op.stride, op.ld_in, op.ld_aux, op.nchunks2 = k, s, cin, cout, splits
+        op.in_, op.aux, op.out, op.stats2 = xd.data_ptr(), dyd.data_ptr(), dw.data_ptr(), scratch.data_ptr()
+        _run([op])
+        ref = conv.weight.grad
+        assert ((dw.cpu() - ref).abs().max() / ref.abs().max()).item() < 2e-5
+
+
+@pytest.mark.parametrize("B,H,W,C", [(1, 12, 16, 512), (2, 8, 12, 256), (2, 24, 32, 64), (1, 48, 64, 32), (1, 8, 12, 1536)])
+@pytest.mark.parametrize("flags", [1, 7, 6, 0])
+def test_groupnorm_backward_vs_autograd(B, H, W, C, flags):
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(C + flags)
+    x = (torch.randn(B, C, H, W, generator=g) * 2 + 0.5).requires_grad_(True)
+    aux = torch.randn(B, C, H, W, generator=g).requires_grad_(True)
+    gamma = (1 + 0.2 * torch.randn(C, generator=g)).requires_grad_(True)
+    beta = (0.3 * torch.randn(C, generator=g)).requires_grad_(True)
+    o = F.group_norm(x, 32, gamma, beta, 1e-5)
+    if flags & 1:
+        o = F.relu(o)
+    if flags & 2:
+        o = o + aux
+    if flags & 4:
+        o = F.relu(o)
+    dout = torch.randn(o.shape, generator=g)
+    o.backward(dout)
+    HW = H * W
+    nch = max(1, min(128, (HW + 255) // 256))
+    xd, ad, dd = _nhwc(x.detach()).cuda(), _nhwc(aux.detach()).cuda(), _nhwc(dout).cuda()
+    gd, bd = gamma.detach().cuda(), beta.detach().cuda()
+    stats = torch.zeros(B * nch * 32 * 2, dtype=torch.float64, device="cuda")
+    outf = torch.empty_like(xd)
+    st = networks.XlOp()
+    st.type = networks.XL_OP_GN_STATS
+    st.B, st.Hi, st.Wi, st.Cin, st.groups, st.nchunks, st.ld_in = B, H, W, C, 32, nch, C
+    st.in_, st.stats = xd.data_ptr(), stats.data_ptr()
+    ap = networks.XlOp()
+    ap.type = networks.XL_OP_GN_APPLY
+    ap.B, ap.Hi, ap.Wi, ap.Cin, ap.groups, ap.nchunks, ap.ld_in, ap.ld_out, ap.ld_aux = B, H, W, C, 32, nch, C, C, C
+    ap.flags, ap.eps = flags, 1e-5
+    ap.in_, ap.w, ap.bias, ap.aux, ap.stats, ap.out = (xd.data_ptr(), gd.data_ptr(), bd.data_ptr(), ad.data_ptr(),
+                                                       stats.data_ptr(), outf.data_ptr())
+    scratch = torch.zeros(B * nch * C * 3 + B * C * 5, dtype=torch.float64, device="cuda")
+    dx = torch.full_like(xd, float("nan"))
+    daux = torch.full_like(xd, float("nan"))
+    dg, db, dbias = (torch.empty(C, device="cuda") for _ in range(3))
+    ops = [st, ap]
+    for typ in (networks.XL_OP_GNB_STATS, networks.XL_OP_GNB_APPLY, networks.XL_OP_GNB_PARAMS):
+        op = networks.XlOp()
+        op.type = typ
+        op.B, op.Hi, op.Wi, op.Cin, op.groups = B, H, W, C, 32
+        op.nchunks, op.nchunks2, op.flags, op.eps = nch, nch, flags, 1e-5
+        op.ld_in, op.ld_aux, op.ld_out = C, C, C
+        op.in_, op.w, op.bias, op.stats, op.aux, op.aux2 = (xd.data_ptr(), gd.data_ptr(), bd.data_ptr(), stats.data_ptr(),
+                                                            dd.data_ptr(), outf.data_ptr())
+        op.stats2 = scratch.data_ptr()
+        if typ == networks.XL_OP_GNB_APPLY:
+            op.out, op.out2 = dx.data_ptr(), daux.data_ptr()
+        if typ == networks.XL_OP_GNB_PARAMS:
+            op.out, op.out2, op.aux2 = dg.data_ptr(), db.data_ptr(), dbias.data_ptr()
+        ops.append(op)
+    _run(ops)
+
+    def rel(a, b):
+        return ((a - b).abs().max() / b.abs().max()).item()
+    assert rel(dx.cpu().permute(0, 3, 1, 2), x.grad) < 5e-6
+    assert rel(dg.cpu(), gamma.grad) < 5e-6 and rel(db.cpu(), beta.grad) < 5e-6
+    if flags & 2:
+        assert torch.equal(daux.cpu().permute(0, 3, 1, 2), aux.grad)
+    if C > 32:
+        assert rel(dbias.cpu(), x.grad.sum((0, 2, 3))) < 2e-5        # closed-form conv-bias gradient
+    else:
+        assert dbias.abs().max().item() == 0.0                        # instance norm: exactly zero
