@@ -96,6 +96,8 @@ struct ConvArgs {
     unsigned inBytes, wBytes;       // extents for the buffer descriptors (hardware bounds check)
     int dbg;                        // diagnostics only (XL_CONV_DBG): 1 = skip global loads, 2 = skip LDS refill
     int accumulate;                 // epilogue: out += result (XL_CONV_ACCUMULATE)
+    // MODE 2 (stride-2 data gradient, one parity class of result pixels per launch)
+    int py, px, Hj, Wj, ntaps; unsigned tapList;
 };
 
 // bijective XCD remap: block b runs on XCD b%8; give each XCD a contiguous run of tiles
@@ -120,6 +122,8 @@ __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t rsrc, unsigned
 // MODE 0: forward convolution.  MODE 1: data gradient — `in` is dY [B,Hi,Wi,Cin] (the forward OUTPUT, Cin = forward
 // Cout), the result is dX [B,Ho,Wo,Cout] (forward input); output pixel (iy,ix) gathers dY[(iy+PAD-ky)/S][(ix+PAD-kx)/S]
 // for the taps whose offset is divisible by the forward stride S (others are zero-filled by the bounds check).
+// MODE 2: the stride-2 data gradient split by result-pixel parity (py,px): only the 1/2/2/4 taps that can reach a
+// pixel of that class are multiplied (9 tap-GEMMs in total over the four launches instead of 36).
 template <int KS, int STRIDE, int BN, int CIN, int MODE = 0>     // CIN = compile-time Cin tag (0: runtime)
 __global__ __launch_bounds__(256, 2)
 void igemm_conv_kernel(ConvArgs a)
@@ -147,21 +151,26 @@ void igemm_conv_kernel(ConvArgs a)
     const int lrow = tid >> 3, kq = tid & 7;
     unsigned aOff[4];                           // byte offset of (n, iy0, ix0, 4*kq); wraps for padding rows
     int aIy[4], aIx[4];
-    const int HoWo = a.Ho * a.Wo;
+    const int HoWo = (MODE == 2) ? a.Hj * a.Wj : a.Ho * a.Wo;
+    const int rowW = (MODE == 2) ? a.Wj : a.Wo;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         const int m = m0 + lrow + 32 * p;
         if (m < a.M) {
             const int n = m / HoWo;
             const int rem = m - n * HoWo;
-            const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
+            const int oy = rem / rowW, ox = rem - oy * rowW;
             if constexpr (MODE == 0) {
                 aIy[p] = oy * STRIDE - PAD;
                 aIx[p] = ox * STRIDE - PAD;
                 aOff[p] = (unsigned)(((n * a.Hi + aIy[p]) * a.Wi + aIx[p]) * a.ldIn + 4 * kq) * 4u;
-            } else {
+            } else if constexpr (MODE == 1) {
                 aIy[p] = oy + PAD;                   // numerators of the source row / column
                 aIx[p] = ox + PAD;
+                aOff[p] = (unsigned)(n * a.Hi * a.Wi * a.ldIn + 4 * kq) * 4u;
+            } else {
+                aIy[p] = 2 * oy + a.py + PAD;
+                aIx[p] = 2 * ox + a.px + PAD;
                 aOff[p] = (unsigned)(n * a.Hi * a.Wi * a.ldIn + 4 * kq) * 4u;
             }
         } else {
@@ -176,9 +185,16 @@ void igemm_conv_kernel(ConvArgs a)
     auto load_global = [&](int kk) {
         // K order is (channel chunk of 32, tap, channel-in-chunk): the 9 taps of one chunk run back to back, so
         // the shifted re-reads of the same input pixels hit L1/L2 instead of going back to HBM 9 times
-        const int kbase = kk * kBK;
-        const int chunk = kk / (KS * KS);
-        const int tap = kk - chunk * (KS * KS);
+        int kbase = kk * kBK;
+        int chunk, tap;
+        if constexpr (MODE == 2) {
+            chunk = kk / a.ntaps;
+            tap = (int)((a.tapList >> (4 * (kk - chunk * a.ntaps))) & 15u);
+            kbase = (chunk * (KS * KS) + tap) * kBK;             // position of this (chunk, tap) in the packed weights
+        } else {
+            chunk = kk / (KS * KS);
+            tap = kk - chunk * (KS * KS);
+        }
         const int c0 = chunk * kBK;
         const int ky = tap / KS, kx = tap - ky * KS;
         const unsigned tapOff = (unsigned)((ky * a.Wi + kx) * a.ldIn + c0) * 4u;
@@ -214,7 +230,7 @@ void igemm_conv_kernel(ConvArgs a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nk = a.K / kBK;
+    const int nk = (MODE == 2) ? a.ntaps * (a.Cin / kBK) : a.K / kBK;
     load_global(0);
     store_lds(0);
     __syncthreads();
@@ -286,7 +302,14 @@ void igemm_conv_kernel(ConvArgs a)
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + rhalf;
                 if (m < a.M) {
-                    float *o = a.out + (long long)m * a.ldOut + n;
+                    long long pix = m;
+                    if constexpr (MODE == 2) {
+                        const int nn = m / HoWo;
+                        const int rem = m - nn * HoWo;
+                        const int jy = rem / a.Wj, jx = rem - jy * a.Wj;
+                        pix = ((long long)nn * a.Ho + 2 * jy + a.py) * a.Wo + 2 * jx + a.px;
+                    }
+                    float *o = a.out + pix * a.ldOut + n;
                     const float v = acc[i][j][r] + bv;
                     *o = a.accumulate ? *o + v : v;
                 }
@@ -482,13 +505,23 @@ int g_profCap = 0, g_profCount = 0;
 bool g_profOn = false;
 
 template <int KS, int STRIDE, int BN, int CIN, int MODE = 0>
-int launch_igemm(const xl_op &op, hipStream_t st)
+int launch_igemm(const xl_op &op, hipStream_t st, int py = 0, int px = 0)
 {
     ConvArgs a;
     a.in = (const float *)op.in; a.w = (const float *)op.w; a.bias = (const float *)op.bias; a.out = (float *)op.out;
     a.B = op.B; a.Hi = op.Hi; a.Wi = op.Wi; a.Cin = op.Cin; a.Ho = op.Ho; a.Wo = op.Wo; a.Cout = op.Cout;
     a.ldIn = op.ld_in; a.ldOut = op.ld_out;
     a.M = op.B * op.Ho * op.Wo; a.K = op.ksize * op.ksize * op.Cin;
+    a.py = py; a.px = px; a.Hj = 0; a.Wj = 0; a.ntaps = 0; a.tapList = 0;
+    if (MODE == 2) {
+        // result pixel (iy,ix) = (2jy+py, 2jx+px); source row (iy+1-ky)/2 needs ky of parity (py+1)&1
+        a.Hj = (op.Ho - py + 1) / 2; a.Wj = (op.Wo - px + 1) / 2;
+        a.M = op.B * a.Hj * a.Wj;
+        for (int ky = 0; ky < 3; ++ky)
+            for (int kx = 0; kx < 3; ++kx)
+                if (((py + 1 - ky) & 1) == 0 && ((px + 1 - kx) & 1) == 0) { a.tapList |= (unsigned)(ky * 3 + kx) << (4 * a.ntaps); ++a.ntaps; }
+        if (a.M == 0) return XL_OK;
+    }
     a.nbm = (a.M + kBM - 1) / kBM; a.nbn = (op.Cout + BN - 1) / BN;   // weight rows past Cout read as zero (bounds check)
     const long long inBytes = (((long long)op.B * op.Hi * op.Wi - 1) * op.ld_in + op.Cin) * 4;
     const long long wBytes = (long long)op.Cout * a.K * 4;
@@ -519,7 +552,15 @@ int run_conv(const xl_op &op, hipStream_t st)
     const bool wide = (op.Cout % 128 == 0);
     if (op.flags & XL_CONV_DGRAD) {
         if (op.ksize == 3 && op.stride == 1) return wide ? launch_igemm<3, 1, 128, 0, 1>(op, st) : launch_igemm<3, 1, 64, 0, 1>(op, st);
-        if (op.ksize == 3 && op.stride == 2) return wide ? launch_igemm<3, 2, 128, 0, 1>(op, st) : launch_igemm<3, 2, 64, 0, 1>(op, st);
+        if (op.ksize == 3 && op.stride == 2) {
+            // four parity classes of result pixels, each with only the taps that reach it
+            for (int py = 0; py < 2; ++py)
+                for (int px = 0; px < 2; ++px) {
+                    const int rc = wide ? launch_igemm<3, 2, 128, 0, 2>(op, st, py, px) : launch_igemm<3, 2, 64, 0, 2>(op, st, py, px);
+                    if (rc != XL_OK) return rc;
+                }
+            return XL_OK;
+        }
         if (op.ksize == 1 && op.stride == 1) return wide ? launch_igemm<1, 1, 128, 0, 1>(op, st) : launch_igemm<1, 1, 64, 0, 1>(op, st);
         return XL_ERR_UNSUPPORTED;
     }

@@ -125,19 +125,34 @@ void wgrad_kernel(WgradArgs a)
         if (kk + 1 < nk) load_global(mBeg + (kk + 1) * KB);
         const float *Ab = &sA[buf][wo * (BO / WO) + fr];
         const float *Bb = &sB[buf][wc * (BC / WC) + fr];
+        // operand fragments ping-pong between two register sets (next k-pair's LDS reads under this pair's MFMAs)
+        float fa[2][TI], fb[2][TJ];
+#pragma unroll
+        for (int i = 0; i < TI; ++i) fa[0][i] = Ab[fk * BO + i * 32];
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) fb[0][j] = Bb[fk * BC + j * 32];
 #pragma unroll
         for (int kp = 0; kp < KB / 2; ++kp) {
-            float fa[TI], fb[TJ];
+            const int cur = kp & 1, nxt = cur ^ 1;
+            if (kp + 1 < KB / 2) {
 #pragma unroll
-            for (int i = 0; i < TI; ++i) fa[i] = Ab[(2 * kp + fk) * BO + i * 32];
+                for (int i = 0; i < TI; ++i) fa[nxt][i] = Ab[(2 * (kp + 1) + fk) * BO + i * 32];
 #pragma unroll
-            for (int j = 0; j < TJ; ++j) fb[j] = Bb[(2 * kp + fk) * BC + j * 32];
+                for (int j = 0; j < TJ; ++j) fb[nxt][j] = Bb[(2 * (kp + 1) + fk) * BC + j * 32];
+            }
 #pragma unroll
             for (int i = 0; i < TI; ++i)
 #pragma unroll
                 for (int j = 0; j < TJ; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i], fb[cur][j], acc[i][j], 0, 0, 0);
         }
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 * (TI + TJ), 0);
+#pragma unroll
+        for (int kp = 0; kp < KB / 2 - 2; ++kp) {
+            __builtin_amdgcn_sched_group_barrier(0x008, TI * TJ, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, TI + TJ, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 2 * TI * TJ, 0);
         if (kk + 1 < nk) store_lds(buf ^ 1);
         __syncthreads();
     }
@@ -201,7 +216,7 @@ int launch_wgrad(const xl_op &op, hipStream_t st)
 // per-channel forward coefficients of image n from the forward fp64 partial sums
 __device__ __forceinline__ void gn_coeffs(const double *fstats, int n, int nchunks, int G, int c, int cpg, int HW,
                                           float eps, const float *gamma, const float *beta,
-                                          float &mean, float &rstd, float &sc, float &sh)
+                                          float &mean, float &rstd, float &sc, float &sh, double *rstd64 = nullptr)
 {
     const int g = c / cpg;
     double s = 0.0, ss = 0.0;
@@ -214,6 +229,7 @@ __device__ __forceinline__ void gn_coeffs(const double *fstats, int n, int nchun
     const double r = 1.0 / sqrt(var + (double)eps);
     const double scd = (double)gamma[c] * r;
     mean = (float)mu; rstd = (float)r; sc = (float)scd; sh = (float)((double)beta[c] - mu * scd);
+    if (rstd64) *rstd64 = r;
 }
 
 struct GnbArgs {
@@ -221,7 +237,7 @@ struct GnbArgs {
     const double *fstats;
     double *bstats;          // [B][nchunks2][C][3]  (sum dv, sum dv*xhat, sum xhat)
     float *dx, *daux;
-    double *ncsums;          // [B][C][5]: A, Bc, Xh, S1, S2 (written by apply block 0 of each image)
+    double *ncsums;          // [B][C][6]: A, Bc, Xh, S1, S2, rstd (written by apply block 0 of each image)
     int HW, C, ldX, ldD, ldO, ldDx, ldAux, G, nchunks, nchunks2, flags;
     float eps;
 };
@@ -292,9 +308,12 @@ void gnb_apply_kernel(GnbArgs a)
     const int tid = threadIdx.x, n = blockIdx.y;
     const int C = a.C, cpg = C / a.G;
     double *dA = reinterpret_cast<double *>(sK + 7 * C);            // A, Bc, Xh totals per channel (fp64)
+    double *dR = dA + 3 * C;                                        // rstd in fp64 per channel
     for (int c = tid; c < C; c += 256) {
         float mu, rs, sc, sh;
-        gn_coeffs(a.fstats, n, a.nchunks, a.G, c, cpg, a.HW, a.eps, a.gamma, a.beta, mu, rs, sc, sh);
+        double r64;
+        gn_coeffs(a.fstats, n, a.nchunks, a.G, c, cpg, a.HW, a.eps, a.gamma, a.beta, mu, rs, sc, sh, &r64);
+        dR[c] = r64;
         sK[c] = mu; sK[C + c] = rs; sK[2 * C + c] = sc; sK[3 * C + c] = sh;
         double A = 0.0, Bc = 0.0, X = 0.0;
         const double *bs = a.bstats + ((long long)n * a.nchunks2 * C + c) * 3;
@@ -316,8 +335,8 @@ void gnb_apply_kernel(GnbArgs a)
         sK[5 * C + c] = (float)(rs * sS[2 * g] / m);
         sK[6 * C + c] = (float)(rs * sS[2 * g + 1] / m);
         if (blockIdx.x == 0 && a.ncsums) {
-            double *o = a.ncsums + ((long long)n * C + c) * 5;
-            o[0] = dA[3 * c]; o[1] = dA[3 * c + 1]; o[2] = dA[3 * c + 2]; o[3] = sS[2 * g]; o[4] = sS[2 * g + 1];
+            double *o = a.ncsums + ((long long)n * C + c) * 6;
+            o[0] = dA[3 * c]; o[1] = dA[3 * c + 1]; o[2] = dA[3 * c + 2]; o[3] = sS[2 * g]; o[4] = sS[2 * g + 1]; o[5] = dR[c];
         }
     }
     __syncthreads();
@@ -360,28 +379,19 @@ void gnb_apply_kernel(GnbArgs a)
 }
 
 // d gamma, d beta, d conv-bias from the per-(image, channel) sums; one thread per channel
-__global__ void gnb_params_kernel(const double *ncsums, const double *fstats, const float *gamma, int B, int C, int G,
-                                  int HW, int nchunks, float eps, float *dgamma, float *dbeta, float *dbias)
+__global__ void gnb_params_kernel(const double *ncsums, const float *gamma, int B, int C, int G, int HW,
+                                  float *dgamma, float *dbeta, float *dbias)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    const int cpg = C / G, g = c / cpg;
+    const int cpg = C / G;
     const double m = (double)cpg * (double)HW;
     double dg = 0.0, db = 0.0, dbi = 0.0;
     for (int n = 0; n < B; ++n) {
-        const double *o = ncsums + ((long long)n * C + c) * 5;
+        const double *o = ncsums + ((long long)n * C + c) * 6;
         dg += o[1]; db += o[0];
-        if (dbias) {
-            double s = 0.0, ss = 0.0;
-            const double *st = fstats + ((long long)n * nchunks * G + g) * 2;
-            for (int k = 0; k < nchunks; ++k) { s += st[(long long)k * G * 2]; ss += st[(long long)k * G * 2 + 1]; }
-            const double mu = s / m;
-            double var = ss / m - mu * mu;
-            if (var < 0.0) var = 0.0;
-            const double rs = 1.0 / sqrt(var + (double)eps);
-            // sum over pixels of dx = rstd*(gamma*A - (HW*S1 + S2*sum_xhat)/m)
-            dbi += rs * ((double)gamma[c] * o[0] - ((double)HW * o[3] + o[4] * o[2]) / m);
-        }
+        // sum over pixels of dx = rstd*(gamma*A - (HW*S1 + S2*sum_xhat)/m)
+        dbi += o[5] * ((double)gamma[c] * o[0] - ((double)HW * o[3] + o[4] * o[2]) / m);
     }
     dgamma[c] = (float)dg; dbeta[c] = (float)db;
     // one channel per group = instance norm: a per-channel bias cancels exactly, its gradient is identically 0
@@ -473,50 +483,69 @@ __global__ void partial_sum_kernel(const float *__restrict__ partial, float *__r
 // ---------------------------------------------------------------------------------------------- conv1 wgrad
 
 // dW[o][c][ky][kx] = sum dY[n,y,x,o] * img[n,c,y+ky-1,x+kx-1]; db[o] = sum dY.  Thread = (o, pixel lane j of 8).
-// partial [blocks][(9*Cin + 1)][Cout]
+// A block walks `rowsPerBlock` output rows of one image two at a time; the 4 image rows (with halo, channels padded
+// to a float4) they touch are staged in LDS, so the 27 taps of a pixel are 9 broadcast ds_read_b128.
+// partial [gridDim.y * gridDim.x][28][Cout]
 __global__ __launch_bounds__(256)
 void conv1_wgrad_kernel(const float *__restrict__ img, const float *__restrict__ dy, float *__restrict__ partial,
-                        int B, int Cin, int H, int W, int Cout, int ldY)
+                        int B, int Cin, int H, int W, int Cout, int ldY, int rowsPerBlock)
 {
-    __shared__ float sRed[8 * 32 * 28];
+    constexpr int R = 2;
+    extern __shared__ __attribute__((aligned(16))) float sDyn[];
+    f32x4 *sImg = reinterpret_cast<f32x4 *>(sDyn);                 // [(R+2)][W+2]
+    float *sRed = sDyn;                                            // [8][Cout][28], reuses the tile after the loop
     const int o = threadIdx.x % Cout, j = threadIdx.x / Cout, lanes = 256 / Cout;
-    const long long HW = (long long)H * W, total = (long long)B * HW;
-    const long long per = (total + gridDim.x - 1) / gridDim.x;
-    const long long pBeg = (long long)blockIdx.x * per;
-    long long pEnd = pBeg + per; if (pEnd > total) pEnd = total;
+    const int n = blockIdx.y;
+    const long long HW = (long long)H * W;
+    const int yBeg = blockIdx.x * rowsPerBlock;
+    int yEnd = yBeg + rowsPerBlock; if (yEnd > H) yEnd = H;
     float acc[28];
 #pragma unroll
     for (int k = 0; k < 28; ++k) acc[k] = 0.f;
-    for (long long p = pBeg + j; p < pEnd; p += lanes) {
-        const int n = (int)(p / HW);
-        const int rem = (int)(p - (long long)n * HW);
-        const int y = rem / W, x = rem - y * W;
-        const float g = dy[p * ldY + o];
-        acc[27] += g;
+    const int W2 = W + 2;
+    for (int y0 = yBeg; y0 < yEnd; y0 += R) {
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < (R + 2) * W2; idx += 256) {
+            const int r = idx / W2, xx = idx - r * W2 - 1;
+            const int iy = y0 - 1 + r;
+            f32x4 v = { 0.f, 0.f, 0.f, 0.f };
+            if ((unsigned)iy < (unsigned)H && (unsigned)xx < (unsigned)W) {
+                const float *q = img + (long long)n * Cin * HW + (long long)iy * W + xx;
+                v.x = q[0];
+                if (Cin > 1) { v.y = q[HW]; v.z = q[2 * HW]; }
+            }
+            sImg[idx] = v;
+        }
+        __syncthreads();
+        const int rows = (yEnd - y0 < R) ? (yEnd - y0) : R;
+        for (int p = j; p < rows * W; p += lanes) {
+            const int ry = p / W, x = p - ry * W;
+            const float g = dy[(((long long)n * H + (y0 + ry)) * W + x) * ldY + o];
+            acc[27] += g;
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
+            for (int ky = 0; ky < 3; ++ky) {
+                const f32x4 *row = sImg + (ry + ky) * W2 + x;
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const int iy = y + ky - 1, ix = x + kx - 1;
-                const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    if (c < Cin) {
-                        const float v = ok ? img[((long long)n * Cin + c) * HW + (long long)iy * W + ix] : 0.f;
-                        acc[(ky * 3 + kx) * 3 + c] = fmaf(g, v, acc[(ky * 3 + kx) * 3 + c]);
-                    }
+                for (int kx = 0; kx < 3; ++kx) {
+                    const f32x4 v = row[kx];
+                    acc[(ky * 3 + kx) * 3 + 0] = fmaf(g, v.x, acc[(ky * 3 + kx) * 3 + 0]);
+                    acc[(ky * 3 + kx) * 3 + 1] = fmaf(g, v.y, acc[(ky * 3 + kx) * 3 + 1]);
+                    acc[(ky * 3 + kx) * 3 + 2] = fmaf(g, v.z, acc[(ky * 3 + kx) * 3 + 2]);
                 }
             }
+        }
     }
     // reduce over the pixel lanes j in fixed order
+    __syncthreads();
 #pragma unroll
     for (int k = 0; k < 28; ++k) sRed[(j * Cout + o) * 28 + k] = acc[k];
     __syncthreads();
     if (j == 0) {
+        const long long blk = (long long)blockIdx.y * gridDim.x + blockIdx.x;
         for (int k = 0; k < 28; ++k) {
             float s = 0.f;
             for (int jj = 0; jj < lanes; ++jj) s += sRed[(jj * Cout + o) * 28 + k];
-            partial[((long long)blockIdx.x * 28 + k) * Cout + o] = s;
+            partial[(blk * 28 + k) * Cout + o] = s;
         }
     }
 }
@@ -575,7 +604,7 @@ int xl_run_bwd_op(const xl_op &op, hipStream_t st)
                 int achunks = (a.HW * (op.Cin / 4) + 256 * 16 - 1) / (256 * 16);
                 if (achunks < 1) achunks = 1;
                 if (achunks > 1024) achunks = 1024;
-                const size_t lds = sizeof(float) * 7 * op.Cin + sizeof(double) * 3 * op.Cin;
+                const size_t lds = sizeof(float) * 7 * op.Cin + sizeof(double) * 4 * op.Cin;
                 hipLaunchKernelGGL(gnb_apply_kernel, dim3(achunks, op.B), dim3(256), lds, st, a);
             }
             return XL_OK;
@@ -583,9 +612,8 @@ int xl_run_bwd_op(const xl_op &op, hipStream_t st)
         case XL_OP_GNB_PARAMS: {
             const double *nc = (const double *)op.stats2 + (long long)op.B * op.nchunks2 * op.Cin * 3;
             float *dbias = (op.flags & XL_GN_NO_CONV_BIAS) ? nullptr : (float *)op.aux2;
-            hipLaunchKernelGGL(gnb_params_kernel, dim3((op.Cin + 63) / 64), dim3(64), 0, st, nc, (const double *)op.stats,
-                               (const float *)op.w, op.B, op.Cin, op.groups, op.Hi * op.Wi, op.nchunks, op.eps,
-                               (float *)op.out, (float *)op.out2, dbias);
+            hipLaunchKernelGGL(gnb_params_kernel, dim3((op.Cin + 63) / 64), dim3(64), 0, st, nc, (const float *)op.w, op.B,
+                               op.Cin, op.groups, op.Hi * op.Wi, (float *)op.out, (float *)op.out2, dbias);
             return XL_OK;
         }
         case XL_OP_HEAD_BWD: {
@@ -607,9 +635,14 @@ int xl_run_bwd_op(const xl_op &op, hipStream_t st)
         }
         case XL_OP_CONV1_WGRAD: {
             if (op.Cout != 32 || op.Cin > 3) return XL_ERR_UNSUPPORTED;
-            const int blocks = 1024;
-            hipLaunchKernelGGL(conv1_wgrad_kernel, dim3(blocks), dim3(256), 0, st, (const float *)op.in, (const float *)op.aux,
-                               (float *)op.stats2, op.B, op.Cin, op.Hi, op.Wi, op.Cout, op.ld_aux);
+            const int rowsPerBlock = 16;
+            const int rb = (op.Hi + rowsPerBlock - 1) / rowsPerBlock;
+            const int blocks = rb * op.B;                                    // scratch: blocks*28*Cout floats
+            size_t lds = sizeof(float) * (size_t)4 * (op.Wi + 2) * 4;
+            if (lds < sizeof(float) * (size_t)8 * op.Cout * 28) lds = sizeof(float) * (size_t)8 * op.Cout * 28;
+            if (lds > 64 * 1024) return XL_ERR_UNSUPPORTED;
+            hipLaunchKernelGGL(conv1_wgrad_kernel, dim3(rb, op.B), dim3(256), lds, st, (const float *)op.in, (const float *)op.aux,
+                               (float *)op.stats2, op.B, op.Cin, op.Hi, op.Wi, op.Cout, op.ld_aux, rowsPerBlock);
             hipLaunchKernelGGL(conv1_wgrad_reduce_kernel, dim3((28 * op.Cout + 255) / 256), dim3(256), 0, st,
                                (const float *)op.stats2, (float *)op.out, (float *)op.out2, blocks, op.Cin, op.Cout);
             return XL_OK;

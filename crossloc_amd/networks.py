@@ -466,7 +466,7 @@ class _Plan:
                 prod = producers.get(self._key(e["raw"]))
                 G = e["norm"].num_groups
                 nch2 = max(1, min(128, (H * W + 255) // 256))
-                scratch_d = max(scratch_d, B * nch2 * C * 3 + B * C * 5)
+                scratch_d = max(scratch_d, B * nch2 * C * 3 + B * C * 6)
                 for typ in (XL_OP_GNB_STATS, XL_OP_GNB_APPLY, XL_OP_GNB_PARAMS):
                     op = XlOp()
                     op.type = typ
@@ -506,7 +506,18 @@ class _Plan:
                 bc = 128 if C % 128 == 0 else (64 if C % 64 == 0 else 32)
                 tiles = k * k * (Cout // bo) * (C // bc)
                 M = B * Ho * Wo
-                splits = max(1, min(64, -(-1536 // tiles), M // 256))
+                # split-K factor: fill whole waves of the 512 resident workgroups (2 per CU) — e.g. 144 tiles x 7
+                # = 1008 is 98 % full, x 11 = 1584 would leave the 4th wave 9 % full
+                best, splits = -1.0, 1
+                for cand in range(1, 65):
+                    if cand > max(1, M // 256):
+                        break
+                    n_wg = tiles * cand
+                    eff = n_wg / (-(-n_wg // 512) * 512)
+                    if n_wg >= 512:
+                        eff += 1.0                      # prefer any configuration that fills the chip at least once
+                    if eff > best + 1e-9:
+                        best, splits = eff, cand
                 op.nchunks2 = splits
                 op.in_, op.aux = t.data_ptr() + 4 * off, dy.data_ptr()
                 op.out = pgrad(conv.weight).data_ptr()
@@ -543,7 +554,7 @@ class _Plan:
                 # kernel also produces goes to a scratch vector
                 self.conv1_db_unused = torch.empty(Cout, dtype=torch.float32, device=dev)
                 op.out2 = self.conv1_db_unused.data_ptr()
-                scratch_f = max(scratch_f, 1024 * 28 * Cout)
+                scratch_f = max(scratch_f, B * ((H + 15) // 16) * 28 * Cout)
                 patch_f.append(len(bops))
                 self.conv1_wgrad_index = len(bops)
                 bops.append(op)

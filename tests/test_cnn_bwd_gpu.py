@@ -193,7 +193,7 @@ def test_groupnorm_backward_vs_autograd(B, H, W, C, flags):
     ap.flags, ap.eps = flags, 1e-5
     ap.in_, ap.w, ap.bias, ap.aux, ap.stats, ap.out = (xd.data_ptr(), gd.data_ptr(), bd.data_ptr(), ad.data_ptr(),
                                                        stats.data_ptr(), outf.data_ptr())
-    scratch = torch.zeros(B * nch * C * 3 + B * C * 5, dtype=torch.float64, device="cuda")
+    scratch = torch.zeros(B * nch * C * 3 + B * C * 6, dtype=torch.float64, device="cuda")
     dx = torch.full_like(xd, float("nan"))
     daux = torch.full_like(xd, float("nan"))
     dg, db, dbias = (torch.empty(C, device="cuda") for _ in range(3))
