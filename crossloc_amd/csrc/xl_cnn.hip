@@ -96,6 +96,8 @@ struct ConvArgs {
     unsigned inBytes, wBytes;       // extents for the buffer descriptors (hardware bounds check)
     int dbg;                        // diagnostics only (XL_CONV_DBG): 1 = skip global loads, 2 = skip LDS refill
     int accumulate;                 // epilogue: out += result (XL_CONV_ACCUMULATE)
+    // fused GroupNorm statistics of the OUTPUT (forward only): fp64 partial sums per (image, tile-within-image, group)
+    double *stats; int HW, G, cpg, nchunks;
     // MODE 2 (stride-2 data gradient, one parity class of result pixels per launch)
     int py, px, Hj, Wj, ntaps; unsigned tapList;
 };
@@ -291,6 +293,15 @@ void igemm_conv_kernel(ConvArgs a)
 
     // ---- epilogue: bias + store. C layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     const int col = lane & 31, rhalf = (lane >> 5) * 4;
+    // fused GroupNorm statistics: a 128-row tile touches at most two images (HW >= 128); `split` = first tile row
+    // of the second image.  Per lane: sums over its 32 rows per column and image slot, then half-wave, wave-pair
+    // and channel-group reductions in a fixed order; every (image, tile, group) entry has exactly one writer.
+    const bool doStats = (MODE == 0) && a.stats != nullptr;
+    const int nLo = doStats ? m0 / a.HW : 0;
+    const int split = doStats ? (nLo + 1) * a.HW - m0 : 0;
+    float ps[2][NJ], pss[2][NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) { ps[0][j] = ps[1][j] = 0.f; pss[0][j] = pss[1][j] = 0.f; }
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const int n = n0 + wn * (BN / 2) + j * 32 + col;
@@ -300,7 +311,8 @@ void igemm_conv_kernel(ConvArgs a)
         for (int i = 0; i < 2; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + rhalf;
+                const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + rhalf;
+                const int m = m0 + row;
                 if (m < a.M) {
                     long long pix = m;
                     if constexpr (MODE == 2) {
@@ -312,6 +324,46 @@ void igemm_conv_kernel(ConvArgs a)
                     float *o = a.out + pix * a.ldOut + n;
                     const float v = acc[i][j][r] + bv;
                     *o = a.accumulate ? *o + v : v;
+                    if (doStats) {
+                        const int sl = row >= split ? 1 : 0;
+                        ps[sl][j] += v; pss[sl][j] += v * v;
+                    }
+                }
+            }
+        }
+    }
+    if (doStats) {
+        double *sS = reinterpret_cast<double *>(smem);              // [wm][BN cols][slot][2]; tiles are dead now
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int sl = 0; sl < 2; ++sl) {
+                double s1 = (double)ps[sl][j], s2 = (double)pss[sl][j];
+                s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+                if (lane < 32) {
+                    const int c = wn * (BN / 2) + j * 32 + col;
+                    sS[((wm * BN + c) * 2 + sl) * 2] = s1;
+                    sS[((wm * BN + c) * 2 + sl) * 2 + 1] = s2;
+                }
+            }
+        __syncthreads();
+        const int groupsInTile = BN / a.cpg;
+        if (tid < groupsInTile * 2) {
+            const int gi = tid >> 1, sl = tid & 1;
+            const int n = nLo + sl;
+            const int firstRow = sl ? split : 0;
+            if (n < a.B && m0 + firstRow < a.M && (sl == 0 || split < kBM)) {
+                double s1 = 0.0, s2 = 0.0;
+                for (int w = 0; w < 2; ++w)
+                    for (int c = gi * a.cpg; c < (gi + 1) * a.cpg; ++c) {
+                        s1 += sS[((w * BN + c) * 2 + sl) * 2];
+                        s2 += sS[((w * BN + c) * 2 + sl) * 2 + 1];
+                    }
+                const int g = (n0 + gi * a.cpg) / a.cpg;
+                if (g < a.G) {
+                    const int k = mt - (int)(((long long)n * a.HW) / kBM);       // tile index within the image
+                    double *o = a.stats + (((long long)n * a.nchunks + k) * a.G + g) * 2;
+                    o[0] = s1; o[1] = s2;
                 }
             }
         }
@@ -356,20 +408,74 @@ __global__ void gn_stats_kernel(const float *__restrict__ x, double *__restrict_
     }
 }
 
+// per-(image, channel) scale/shift from the fp64 partial sums, fixed summation order.  grid (B), 256 threads.
+__global__ __launch_bounds__(256)
+void gn_final_kernel(const double *__restrict__ stats, const float *__restrict__ gamma, const float *__restrict__ beta,
+                     float *__restrict__ coeff, int HW, int C, int G, int nchunks, float eps, int statTile)
+{
+    __shared__ double sG[2 * 64];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const int cpg = C / G;
+    int valid = nchunks;
+    if (statTile > 0)          // statistics came from a conv epilogue: one entry per conv tile overlapping image n
+        valid = (int)((((long long)(n + 1) * HW - 1) / statTile) - (((long long)n * HW) / statTile)) + 1;
+    // 8 threads per group each sum a contiguous slice of the chunks, then the 8 slices are added in order
+    __shared__ double sP[256 * 2];
+    {
+        const int g = tid >> 3, part = tid & 7;
+        double a = 0.0, b = 0.0;
+        if (g < G) {
+            const int per = (valid + 7) / 8;
+            int k0 = part * per, k1 = k0 + per;
+            if (k1 > valid) k1 = valid;
+            const double *st = stats + ((long long)n * nchunks * G + g) * 2;
+            for (int k = k0; k < k1; ++k) { a += st[(long long)k * G * 2]; b += st[(long long)k * G * 2 + 1]; }
+        }
+        sP[2 * tid] = a; sP[2 * tid + 1] = b;
+    }
+    __syncthreads();
+    for (int g = tid; g < G; g += 256) {
+        double a = 0.0, b = 0.0;
+        for (int part = 0; part < 8; ++part) { a += sP[2 * (g * 8 + part)]; b += sP[2 * (g * 8 + part) + 1]; }
+        const double cnt = (double)HW * (double)cpg;
+        const double mean = a / cnt;
+        double var = b / cnt - mean * mean;
+        if (var < 0.0) var = 0.0;
+        sG[2 * g] = mean; sG[2 * g + 1] = 1.0 / sqrt(var + (double)eps);
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        const int g = c / cpg;
+        const double sc = (double)gamma[c] * sG[2 * g + 1];
+        coeff[((long long)n * C + c) * 2] = (float)sc;
+        coeff[((long long)n * C + c) * 2 + 1] = (float)((double)beta[c] - sG[2 * g] * sc);
+    }
+}
+
 // grid (achunks, B), 256 threads. v = x*scale + shift; flags as in crossloc_cnn.h
 __global__ __launch_bounds__(256)
 void gn_apply_kernel(const float *__restrict__ x, const double *__restrict__ stats, const float *__restrict__ gamma,
                      const float *__restrict__ beta, const float *__restrict__ aux, float *__restrict__ out,
-                     int HW, int C, int ldIn, int ldOut, int ldAux, int G, int nchunks, float eps, int flags)
+                     int HW, int C, int ldIn, int ldOut, int ldAux, int G, int nchunks, float eps, int flags, int statTile,
+                     const float *__restrict__ coeff)
 {
     extern __shared__ __attribute__((aligned(16))) float sSS[];        // scale[C], shift[C]
     const int tid = threadIdx.x, n = blockIdx.y;
     const int cpg = C / G;
+    if (coeff) {
+        for (int c = tid; c < C; c += 256) {
+            sSS[c] = coeff[((long long)n * C + c) * 2];
+            sSS[C + c] = coeff[((long long)n * C + c) * 2 + 1];
+        }
+    } else {
     for (int c = tid; c < C; c += 256) {
         const int g = c / cpg;
         double a = 0.0, b = 0.0;
         const double *st = stats + ((long long)n * nchunks * G + g) * 2;
-        for (int k = 0; k < nchunks; ++k) { a += st[(long long)k * G * 2]; b += st[(long long)k * G * 2 + 1]; }
+        int valid = nchunks;
+        if (statTile > 0)      // statistics came from the conv epilogue: one entry per conv tile overlapping image n
+            valid = (int)((((long long)(n + 1) * HW - 1) / statTile) - (((long long)n * HW) / statTile)) + 1;
+        for (int k = 0; k < valid; ++k) { a += st[(long long)k * G * 2]; b += st[(long long)k * G * 2 + 1]; }
         const double cnt = (double)HW * (double)cpg;
         const double mean = a / cnt;
         double var = b / cnt - mean * mean;
@@ -378,6 +484,7 @@ void gn_apply_kernel(const float *__restrict__ x, const double *__restrict__ sta
         const double sc = (double)gamma[c] * rstd;
         sSS[c] = (float)sc;
         sSS[C + c] = (float)((double)beta[c] - mean * sc);
+    }
     }
     __syncthreads();
     const int C4 = C >> 2;
@@ -513,6 +620,12 @@ int launch_igemm(const xl_op &op, hipStream_t st, int py = 0, int px = 0)
     a.ldIn = op.ld_in; a.ldOut = op.ld_out;
     a.M = op.B * op.Ho * op.Wo; a.K = op.ksize * op.ksize * op.Cin;
     a.py = py; a.px = px; a.Hj = 0; a.Wj = 0; a.ntaps = 0; a.tapList = 0;
+    a.stats = nullptr; a.HW = op.Ho * op.Wo; a.G = 0; a.cpg = 1; a.nchunks = 0;
+    if (MODE == 0 && op.stats && op.groups > 0) {
+        a.G = op.groups; a.cpg = op.Cout / op.groups; a.nchunks = op.nchunks;
+        if (a.HW < kBM || op.Cout % op.groups != 0 || BN % a.cpg != 0 || a.nchunks < (a.HW + kBM - 1) / kBM + 1) return XL_ERR_ARG;
+        a.stats = (double *)op.stats;
+    }
     if (MODE == 2) {
         // result pixel (iy,ix) = (2jy+py, 2jx+px); source row (iy+1-ky)/2 needs ky of parity (py+1)&1
         a.Hj = (op.Ho - py + 1) / 2; a.Wj = (op.Wo - px + 1) / 2;
@@ -613,7 +726,14 @@ int run_op(const xl_op &op, hipStream_t st)
             hipLaunchKernelGGL(gn_apply_kernel, dim3(achunks, op.B), dim3(256), sizeof(float) * 2 * op.Cin, st,
                                (const float *)op.in, (const double *)op.stats, (const float *)op.w,
                                (const float *)op.bias, (const float *)op.aux, (float *)op.out, HW, op.Cin, op.ld_in,
-                               op.ld_out, op.ld_aux, op.groups, op.nchunks, op.eps, op.flags);
+                               op.ld_out, op.ld_aux, op.groups, op.nchunks, op.eps, op.flags, op.reserved_i, (const float *)op.aux2);
+            return XL_OK;
+        }
+        case XL_OP_GN_FINAL: {
+            if (op.groups > 32 || op.Cin % op.groups != 0) return XL_ERR_ARG;
+            hipLaunchKernelGGL(gn_final_kernel, dim3(op.B), dim3(256), 0, st, (const double *)op.stats, (const float *)op.w,
+                               (const float *)op.bias, (float *)op.out, op.Hi * op.Wi, op.Cin, op.groups, op.nchunks, op.eps,
+                               op.reserved_i);
             return XL_OK;
         }
         case XL_OP_HEAD: {

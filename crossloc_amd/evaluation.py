@@ -143,3 +143,42 @@ def localize_batch(network, images, n_hyp, focal, image_h, image_w, image0=0, im
                                inlier_alpha, max_pixel_error, network.OUTPUT_SUBSAMPLE,
                                image0=image0, image_stride=image_stride)
     return poses, pred
+
+
+class PipelinedLocalizer:
+    """Two-stream software pipeline over batches: the CNN of batch s+1 runs on the caller's stream while the
+    DSAC* solver of batch s (24 workgroups, latency-bound: it cannot fill 256 CUs on its own) runs on a side
+    stream; an event orders solver(s) after CNN(s).  The reference serialises the two stages per image
+    (GPU forward, .cpu(), CPU solver: test_single_task.py:347-363)."""
+
+    def __init__(self, network, n_hyp, focal, image_h, image_w, threshold=10.0, inlier_alpha=100.0,
+                 max_pixel_error=100.0):
+        self.net, self.n_hyp, self.focal = network, n_hyp, focal
+        self.h, self.w = image_h, image_w
+        self.thr, self.alpha, self.maxerr = threshold, inlier_alpha, max_pixel_error
+        self.side = torch.cuda.Stream()
+        self.pending = []
+
+    def submit(self, images, image0=0, image_stride=1, scene_coords=None):
+        """Enqueue one batch; returns (poses [B,4,4], predictions).  `poses` is valid after finish() (or after
+        synchronising the side stream)."""
+        import dsacstar
+        main = torch.cuda.current_stream()
+        with torch.no_grad():
+            pred = self.net(images)
+        coords = pred[:, :self.net.num_task_channel] if scene_coords is None else scene_coords
+        done = torch.cuda.Event()
+        done.record(main)
+        poses = torch.zeros((coords.shape[0], 4, 4), dtype=torch.float32, device=coords.device)
+        self.side.wait_event(done)
+        with torch.cuda.stream(self.side):
+            dsacstar.forward_rgb_batch(coords, poses, self.n_hyp, self.thr, self.focal, float(self.w / 2),
+                                       float(self.h / 2), self.alpha, self.maxerr, self.net.OUTPUT_SUBSAMPLE,
+                                       image0=image0, image_stride=image_stride)
+        pred.record_stream(self.side)
+        poses.record_stream(self.side)
+        return poses, pred
+
+    def finish(self):
+        """Make the caller's stream wait for every enqueued solver launch."""
+        torch.cuda.current_stream().wait_stream(self.side)

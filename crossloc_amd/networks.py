@@ -13,6 +13,7 @@ raises.  The backward pass covers the single-task network (3-encoder MLR backwar
 """
 import ctypes
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -22,6 +23,7 @@ from . import _lib
 XL_OP_CONV1, XL_OP_CONV, XL_OP_GN_STATS, XL_OP_GN_APPLY, XL_OP_HEAD = 0, 1, 2, 3, 4
 GN_RELU_IN, GN_ADD, GN_RELU_OUT, GN_ACC_AUX, GN_NO_CONV_BIAS = 1, 2, 4, 8, 16
 XL_OP_WGRAD, XL_OP_GNB_STATS, XL_OP_GNB_APPLY, XL_OP_GNB_PARAMS, XL_OP_HEAD_BWD, XL_OP_CONV1_WGRAD = 5, 6, 7, 8, 9, 10
+XL_OP_GN_FINAL = 11
 CONV_DGRAD, CONV_ACCUMULATE = 1, 2
 
 
@@ -179,6 +181,15 @@ class _Plan:
         self.stats = torch.zeros(max(self.max_stats, 1), dtype=torch.float64, device=device)
         for i in self.stats_ops:
             self.op_array[i].stats = self.stats.data_ptr()
+        self.coeff = torch.zeros(max(getattr(self, "max_coeff", 0), 1), dtype=torch.float32, device=device)
+        for i, op in enumerate(self.ops):
+            if op.type == XL_OP_GN_FINAL:
+                self.op_array[i].out = self.coeff.data_ptr()
+                # the GN_APPLY that consumes it is the next GN_APPLY in program order
+                j = i + 1
+                while self.ops[j].type != XL_OP_GN_APPLY:
+                    j += 1
+                self.op_array[j].aux2 = self.coeff.data_ptr()
         if train:
             self._lower_backward()
 
@@ -273,6 +284,8 @@ class _Plan:
             self.max_stats = max(self.max_stats, self.B * nchunks * G * 2)
             self.stats_ops += [len(self.ops), len(self.ops) + 1]
         self.ops.append(st)
+        if not self.train:
+            self._emit_final(ap, gamma, beta, 0)
         if aux is not None:
             ap.aux = aux[0].data_ptr() + 4 * aux[5]
             ap.ld_aux = aux[4]
@@ -292,10 +305,56 @@ class _Plan:
 
     def cgr(self, act, conv, norm, flags=GN_RELU_IN, aux=None):
         y = self.conv(act, conv)
+        if not self.train and y[1] * y[2] >= 128 and not os.environ.get("XL_NO_FUSED_STATS"):
+            # inference: the conv epilogue produces the GroupNorm statistics, the separate stats pass is dropped
+            return self.gn_fused(y, norm, flags, aux, len(self.ops) - 1)
         r = self.gn(y, norm, flags, aux)
         if r[0] is not y[0]:
             self.release(y[0])
         return r
+
+    def gn_fused(self, act, norm, flags, aux, conv_index, out=None):
+        """GroupNorm apply (in place) consuming statistics emitted by the epilogue of the conv op `conv_index`."""
+        t, H, W, C, ld, off = act
+        G, HW = norm.num_groups, H * W
+        nchunks = (HW + 127) // 128 + 1
+        self.max_stats = max(self.max_stats, self.B * nchunks * G * 2)
+        cop = self.ops[conv_index]
+        cop.groups, cop.nchunks = G, nchunks
+        ap = XlOp()
+        ap.type = XL_OP_GN_APPLY
+        ap.B, ap.Hi, ap.Wi, ap.Cin, ap.groups, ap.nchunks, ap.ld_in = self.B, H, W, C, G, nchunks, ld
+        ap.flags, ap.eps, ap.reserved_i = flags, norm.eps, 128
+        ap.in_ = t.data_ptr() + 4 * off
+        gamma, beta = self.dev(norm.weight), self.dev(norm.bias)
+        ap.w, ap.bias = gamma.data_ptr(), beta.data_ptr()
+        self.stats_ops.append(conv_index)
+        self._emit_final(ap, gamma, beta, 128)
+        if aux is not None:
+            ap.aux = aux[0].data_ptr() + 4 * aux[5]
+            ap.ld_aux = aux[4]
+        if out is None:
+            ap.out, ap.ld_out = ap.in_, ld
+            res = act
+        else:
+            ot, old, ooff = out
+            ap.out, ap.ld_out = ot.data_ptr() + 4 * ooff, old
+            res = (ot, H, W, C, old, ooff)
+        self.stats_ops.append(len(self.ops))
+        self.ops.append(ap)
+        return res
+
+    def _emit_final(self, ap, gamma, beta, stat_tile):
+        """GN_FINAL op: one tiny launch turns the partial sums into per-(image, channel) scale/shift so the
+        streaming apply kernel does no redundant reduction per workgroup."""
+        self.max_coeff = max(getattr(self, "max_coeff", 0), self.B * ap.Cin * 2)
+        fin = XlOp()
+        fin.type = XL_OP_GN_FINAL
+        fin.B, fin.Hi, fin.Wi, fin.Cin, fin.groups, fin.nchunks = ap.B, ap.Hi, ap.Wi, ap.Cin, ap.groups, ap.nchunks
+        fin.eps, fin.reserved_i = ap.eps, stat_tile
+        fin.w, fin.bias = gamma.data_ptr(), beta.data_ptr()
+        self.stats_ops.append(len(self.ops))
+        self.ops.append(fin)
 
     def res_block(self, res, block):
         """relu(res + block(res)), networks.py:252-254 / :332-334"""

@@ -23,7 +23,11 @@ extern "C" {
 
 enum {
     XL_OP_CONV1 = 0,     /* 3x3 s1 p1 conv, Cin in {1,3} NCHW input -> NHWC, + bias (networks.py:186-189) */
-    XL_OP_CONV = 1,      /* 3x3 (pad 1) or 1x1 conv, stride 1 or 2, NHWC, implicit GEMM on fp32 MFMA, + bias */
+    XL_OP_CONV = 1,      /* 3x3 (pad 1) or 1x1 conv, stride 1 or 2, NHWC, implicit GEMM on fp32 MFMA, + bias.
+                            With stats != NULL and groups > 0 the epilogue also emits the GroupNorm partial sums of
+                            its output ([B][nchunks][groups][2], one entry per 128-row tile overlapping an image;
+                            needs Ho*Wo >= 128 and nchunks >= ceil(Ho*Wo/128)+1); the consuming GN_APPLY sets
+                            reserved_i = 128 and no GN_STATS pass is needed. */
     XL_OP_GN_STATS = 2,  /* per-(image, chunk, group) partial sums of x and x^2 (fp64) */
     XL_OP_GN_APPLY = 3,  /* GroupNorm affine from the partial sums, fused ReLU / residual add / ReLU */
     XL_OP_HEAD = 4,      /* fc3 1x1 conv to (n_task + n_pos) channels + mean offset + exp(hardtanh), NCHW out */
@@ -33,7 +37,9 @@ enum {
     XL_OP_GNB_APPLY = 7, /* pass 2: dx, optional d(residual), per-(image, channel) sums for the parameter grads */
     XL_OP_GNB_PARAMS = 8,/* d gamma, d beta and the bias gradient of the preceding conv */
     XL_OP_HEAD_BWD = 9,  /* backward of XL_OP_HEAD: d(input) NHWC, d(fc3 weight), d(fc3 bias) */
-    XL_OP_CONV1_WGRAD = 10 /* weight + bias gradient of the NCHW-input first conv */
+    XL_OP_CONV1_WGRAD = 10, /* weight + bias gradient of the NCHW-input first conv */
+    XL_OP_GN_FINAL = 11  /* per-(image, channel) GroupNorm scale/shift [B][C][2] from the partial sums (out);
+                            GN_APPLY with aux2 = that buffer skips its own finalisation */
 };
 
 /* xl_op.flags for XL_OP_CONV */
@@ -58,7 +64,8 @@ typedef struct xl_op {
     int32_t flags;
     int32_t ld_in, ld_out, ld_aux; /* pixel strides in floats of in / out / aux (NHWC tensors) */
     int32_t n_task, n_pos;         /* XL_OP_HEAD: task channels (mean added) and positive channels */
-    int32_t nchunks2, reserved_i;  /* backward: pixel chunks of the GNB stats pass / split-K factor of WGRAD */
+    int32_t nchunks2, reserved_i;  /* backward: pixel chunks of the GNB stats pass / split-K factor of WGRAD;
+                                      GN_APPLY: reserved_i = conv tile rows when the stats came from a conv epilogue */
     float eps;                     /* GroupNorm epsilon (1e-5) */
     float clamp_lo, clamp_hi;      /* XL_OP_HEAD hardtanh bounds (-16.10, 13.82), networks.py:355-356 */
     float reserved;
