@@ -214,21 +214,30 @@ class _Plan:
         w = conv.weight
         key = (id(w), dgrad)
         if key not in self.packed:
-            L = _bind()
-            src = w.detach().to(device=self.device, dtype=torch.float32).contiguous()
+            src = w.detach().to(device=self.device, dtype=torch.float32).contiguous()     # aliases the live parameter
             cout, cin, k, _ = src.shape
-            stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-            if cin in (1, 3) and k == 3:        # conv1: [(ky*3+kx)*Cin + c][Cout]
-                dst = src.permute(2, 3, 1, 0).contiguous()
-            elif dgrad:
-                dst = torch.empty_like(src)
-                _check(L.xl_cnn_pack_conv_weight_dgrad(src.data_ptr(), dst.data_ptr(), cout, cin, k, stream))
-            else:
-                dst = torch.empty_like(src)
-                _check(L.xl_cnn_pack_conv_weight(src.data_ptr(), dst.data_ptr(), cout, cin, k, stream))
-            self.packed[key] = dst
-            self.keep.append(src)
-        return self.packed[key]
+            kind = "conv1" if (cin in (1, 3) and k == 3) else ("dgrad" if dgrad else "fwd")
+            dst = torch.empty(src.numel(), dtype=torch.float32, device=self.device)
+            self.packed[key] = (dst, src, kind)
+            self._pack(dst, src, kind)
+        return self.packed[key][0]
+
+    def _pack(self, dst, src, kind):
+        L = _bind()
+        cout, cin, k, _ = src.shape
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        if kind == "conv1":                     # [(ky*3+kx)*Cin + c][Cout]
+            dst.view(k, k, cin, cout).copy_(src.permute(2, 3, 1, 0))
+        elif kind == "dgrad":
+            _check(L.xl_cnn_pack_conv_weight_dgrad(src.data_ptr(), dst.data_ptr(), cout, cin, k, stream))
+        else:
+            _check(L.xl_cnn_pack_conv_weight(src.data_ptr(), dst.data_ptr(), cout, cin, k, stream))
+
+    def refresh_weights(self):
+        """Parameters changed in place (optimizer step, load_state_dict): re-pack the conv operands.  Biases,
+        GroupNorm affine parameters and fc3 are read through pointers to the live parameters."""
+        for dst, src, kind in self.packed.values():
+            self._pack(dst, src, kind)
 
     def dev(self, p):
         t = p.detach().to(device=self.device, dtype=torch.float32).contiguous()
@@ -740,7 +749,8 @@ class TransPoseNet(nn.Module):
             raise RuntimeError("expected %d input channels, got %d" % (1 if self.grayscale else 3, C))
         ver = self._version()
         if ver != self._plan_version:
-            self._plans = {}
+            for plan in self._plans.values():
+                plan.refresh_weights()
             self._plan_version = ver
         params = [p for p in self.parameters()]
         train = torch.is_grad_enabled() and any(p.requires_grad for p in params)

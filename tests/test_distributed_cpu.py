@@ -87,3 +87,27 @@ def test_get_pose_err_rotation_identities():
     assert evaluation.get_pose_err(T, np.eye(4))[0] == pytest.approx(13.0)
     te, re = evaluation.pose_errors(torch.tensor(np.stack([rot_z(30.0), T])), torch.eye(4).repeat(2, 1, 1))
     assert re[0].item() == pytest.approx(30.0, abs=1e-9) and te[1].item() == pytest.approx(13.0)
+
+
+def _grad_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from crossloc_amd import optim
+    torch.manual_seed(0)
+    params = [torch.nn.Parameter(torch.zeros(5, 3)), torch.nn.Parameter(torch.zeros(7)), torch.nn.Parameter(torch.zeros(2))]
+    params[0].grad = torch.full((5, 3), float(rank + 1))
+    params[1].grad = torch.arange(7, dtype=torch.float32) * (rank + 1)
+    # params[2] has no gradient on any rank (frozen): must be skipped consistently
+    optim.allreduce_gradients(params, world)
+    np.save(os.path.join(out_dir, "g%d.npy" % rank), np.concatenate([params[0].grad.ravel().numpy(), params[1].grad.numpy()]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_allreduce_averages_over_ranks(tmp_path):
+    """Data-parallel training step: one flat all-reduce, mean over ranks, every rank identical."""
+    mp.spawn(_grad_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    g0, g1 = np.load(tmp_path / "g0.npy"), np.load(tmp_path / "g1.npy")
+    assert np.array_equal(g0, g1)
+    assert np.allclose(g0[:15], 1.5) and np.allclose(g0[15:], np.arange(7) * 1.5)

@@ -1,0 +1,73 @@
+"""GPU: fused Adam against torch.optim.Adam, and the whole training step (forward + fused coord loss + backward +
+Adam, train_single_task.py:245-301) on the HIP path: the loss must go down and match a PyTorch-CPU replica."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+from crossloc_amd import loss as xl_loss, networks, optim, synth     # noqa: E402
+from crossloc_amd.weights import seeded_state_dict                   # noqa: E402
+from oracle import cnn_oracle, loss_oracle                           # noqa: E402
+
+pytestmark = pytest.mark.gpu
+MEAN = torch.tensor(synth.SCENE_MEAN, dtype=torch.float32)
+
+
+def test_fused_adam_matches_torch_adam():
+    g = torch.Generator().manual_seed(0)
+    shapes = [(512, 512, 3, 3), (512,), (70001,), (4, 512, 1, 1), (1,)]
+    ours = [torch.randn(s, generator=g).cuda().requires_grad_(True) for s in shapes]
+    ref = [p.detach().clone().requires_grad_(True) for p in ours]
+    oa = optim.Adam(ours, lr=1e-3)
+    ob = torch.optim.Adam(ref, lr=1e-3)
+    sched_a = torch.optim.lr_scheduler.MultiStepLR(oa, [2], gamma=0.5)          # utils/learning.py:392-396
+    sched_b = torch.optim.lr_scheduler.MultiStepLR(ob, [2], gamma=0.5)
+    for step in range(4):
+        for a, b in zip(ours, ref):
+            gr = torch.randn(a.shape, generator=g).cuda() * (10.0 ** (step - 2))
+            a.grad, b.grad = gr.clone(), gr.clone()
+        v0 = ours[0]._version
+        oa.step(); ob.step(); sched_a.step(); sched_b.step()
+        assert ours[0]._version > v0
+        for a, b in zip(ours, ref):
+            assert torch.allclose(a, b, rtol=2e-6, atol=1e-7)
+    st = oa.state[ours[0]]
+    assert st["step"] == 4 and torch.allclose(st["exp_avg"], ob.state[ref[0]]["exp_avg"], rtol=1e-5, atol=1e-6)
+
+
+def test_training_steps_reduce_loss_and_track_cpu_replica():
+    B, H, W = 2, 64, 96
+    net = networks.TransPoseNet(MEAN, False, False, 1, 1, 3, 1)
+    sd0 = seeded_state_dict(net, seed=5)
+    net.load_state_dict(sd0)
+    coords, gt, poses = synth.make_batch(10, B, noise=0.0, outlier_ratio=0.0, Ho=H // 8, Wo=W // 8, focal=60.0)
+    images = torch.rand(B, 3, H, W, generator=torch.Generator().manual_seed(2))
+    gt_t, poses_t = torch.from_numpy(gt), torch.from_numpy(poses.astype(np.float32))
+
+    # PyTorch-CPU replica of the same three steps (reference graph + reference loss + torch Adam)
+    sd = {k: v.clone().requires_grad_(v.dtype.is_floating_point and not k.endswith("mean")) for k, v in sd0.items()}
+    leaves = [v for v in sd.values() if v.requires_grad]
+    oref = torch.optim.Adam(leaves, lr=1e-4)
+    ref_losses = []
+    for _ in range(3):
+        oref.zero_grad()
+        pred = cnn_oracle.decoder_forward(sd, cnn_oracle.encoder_forward(sd, images, "encoder", 1, 32), 1, 3, 1, 32)
+        l, _ = loss_oracle.coord_loss(pred[:, :3], pred[:, 3:], poses_t, gt_t, 60.0, W / 2, H / 2, 8.0)
+        l.backward()
+        oref.step()
+        ref_losses.append(l.item())
+
+    net = net.cuda().train()
+    opt = optim.Adam(net.parameters(), lr=1e-4)                                   # lr of the finetune scripts
+    grid, cam = xl_loss.get_pixel_grid(8), xl_loss.get_cam_mat(W, H, 60.0)
+    losses = []
+    for _ in range(3):
+        l, rate = optim.train_step(net, opt, images.cuda(), poses_t.cuda(), gt_t.cuda(), grid, cam)
+        losses.append(l.item())
+    assert losses[2] < losses[0]
+    assert np.allclose(losses, ref_losses, rtol=2e-3), (losses, ref_losses)
+    # after the steps the in-place updated weights are the ones the next forward uses
+    with torch.no_grad():
+        y = net(images.cuda()).cpu()
+    yref = cnn_oracle.transposenet_forward({k: v.detach() for k, v in net.state_dict().items()}, images, 0, 1, 1)
+    assert (y[:, :3] - yref[:, :3]).abs().max().item() < 1e-2
