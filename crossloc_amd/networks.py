@@ -754,6 +754,14 @@ class TransPoseNet(nn.Module):
             self._plan_version = ver
         params = [p for p in self.parameters()]
         train = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        # the kernels address each tensor with 32-bit byte offsets: the largest one (conv1 output, 32 channels at
+        # full resolution) must stay below 2 GiB -> at most 48 frames of 480x720 per launch; larger inference
+        # batches are split transparently
+        max_b = max(1, (2 ** 31 - 1) // (H * W * self.num_gn_channel * 4) - 1)
+        if B > max_b:
+            if train:
+                raise RuntimeError("batch of %d frames exceeds the per-launch limit of %d at %dx%d" % (B, max_b, H, W))
+            return torch.cat([self.forward(x[i:i + max_b]) for i in range(0, B, max_b)], dim=0)
         key = (B, H, W, x.device.index, train)
         with torch.cuda.device(x.device):
             plan = self._plans.get(key)

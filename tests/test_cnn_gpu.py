@@ -217,3 +217,33 @@ def test_weight_update_invalidates_packed_weights():
     ref = cnn_oracle.transposenet_forward(net.state_dict(), x, 0, 0, 0)
     assert not torch.equal(y0, y1)
     _close(y1.cpu()[:, :3] - MEAN[None, :, None, None], ref[:, :3] - MEAN[None, :, None, None], 1e-3)
+
+
+@pytest.mark.parametrize("n_task,n_pos,mean", [(1, 1, [241.47]), (2, 1, [0.0, 0.0]), (3, 0, [-455.934, 417.50, 520.31])])
+def test_depth_normal_and_plain_heads(n_task, n_pos, mean):
+    """The depth (1+1 channels, label mean utils/learning.py:116) and normal (2+1) encoders of CrossLoc and the
+    uncertainty-free coord net share the graph; only the head width changes."""
+    m = torch.tensor(mean)
+    net = networks.TransPoseNet(m, False, False, 1, 1, n_task, n_pos)
+    net.load_state_dict(seeded_state_dict(net, seed=17))
+    x = torch.rand(2, 3, 64, 96, generator=torch.Generator().manual_seed(4))
+    ref = cnn_oracle.transposenet_forward(net.state_dict(), x, 0, 1, 1, n_task, n_pos)
+    y = net.cuda()(x.cuda()).cpu()
+    assert y.shape == (2, n_task + n_pos, 8, 12)
+    _close(y[:, :n_task] - m[None, :, None, None], ref[:, :n_task] - m[None, :, None, None], 1e-3)
+    if n_pos:
+        assert torch.allclose(y[:, n_task:], ref[:, n_task:], rtol=2e-3)
+
+
+def test_large_batches_are_split_transparently():
+    net = networks.TransPoseNet(MEAN, False, False, 0, 0).cuda()
+    x = torch.rand(5, 3, 64, 96, device="cuda")
+    old = net.num_gn_channel
+    with torch.no_grad():
+        full = net(x)
+        try:
+            net.num_gn_channel = 2 ** 31 // (64 * 96 * 4) // 2    # pretend conv1's output is huge: limit becomes 1-2 frames
+            parts = net(x)
+        finally:
+            net.num_gn_channel = old
+    assert torch.equal(full, parts)
