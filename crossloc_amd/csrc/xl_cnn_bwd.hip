@@ -591,7 +591,7 @@ int xl_run_bwd_op(const xl_op &op, hipStream_t st)
             a.gamma = (const float *)op.w; a.beta = (const float *)op.bias; a.fstats = (const double *)op.stats;
             a.bstats = (double *)op.stats2; a.dx = (float *)op.out; a.daux = (float *)op.out2; a.ncsums = nullptr;
             a.HW = op.Hi * op.Wi; a.C = op.Cin; a.ldX = op.ld_in; a.ldD = op.ld_aux; a.ldO = op.ld_out; a.ldDx = op.ld_in;
-            a.ldAux = op.ld_out; a.G = op.groups; a.nchunks = op.nchunks; a.nchunks2 = op.nchunks2; a.flags = op.flags;
+            a.ldAux = op.Cout > 0 ? op.Cout : op.ld_out; a.G = op.groups; a.nchunks = op.nchunks; a.nchunks2 = op.nchunks2; a.flags = op.flags;
             a.eps = op.eps;
             if (op.type == XL_OP_GNB_STATS) {
                 const int T = gnb_threads(op.Cin);
@@ -605,6 +605,12 @@ int xl_run_bwd_op(const xl_op &op, hipStream_t st)
                 if (achunks < 1) achunks = 1;
                 if (achunks > 1024) achunks = 1024;
                 const size_t lds = sizeof(float) * 7 * op.Cin + sizeof(double) * 4 * op.Cin;
+                static size_t configured = 0;
+                if (lds > 64 * 1024 && lds > configured) {                         // C = 1536 (MLR concat): 92 KB
+                    if (hipFuncSetAttribute(reinterpret_cast<const void *>(gnb_apply_kernel),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return XL_ERR_HIP;
+                    configured = lds;
+                }
                 hipLaunchKernelGGL(gnb_apply_kernel, dim3(achunks, op.B), dim3(256), lds, st, a);
             }
             return XL_OK;

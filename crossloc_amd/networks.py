@@ -9,7 +9,7 @@ gradients through the same MFMA kernel, split-K weight gradients, fused GroupNor
 
 The nn.Conv2d / nn.GroupNorm children are parameter containers only (they give identical keys, shapes and
 default initialisation); they are never called.  There is no CPU/eager fallback: forward on a non-GPU tensor
-raises.  The backward pass covers the single-task network (3-encoder MLR backward: not yet).
+raises.  The backward pass covers the single-task and the 3-encoder MLR networks (frozen encoders are skipped).
 """
 import ctypes
 import math
@@ -378,6 +378,17 @@ class _Plan:
     def encoder(self, enc, image, out=None):
         """networks.py:221-256.  `out` = (tensor, ld, off): write the final activation into a channel slice."""
         B, H, W = self.B, self.H, self.W
+        tape_start = len(self.tape)
+        frozen = not any(p.requires_grad for p in enc.parameters())
+        try:
+            return self._encoder_body(enc, image, out)
+        finally:
+            if frozen:
+                for e in self.tape[tape_start:]:
+                    e["frozen"] = True
+
+    def _encoder_body(self, enc, image, out=None):
+        B, H, W = self.B, self.H, self.W
         cin = enc.conv1.in_channels
         c1 = enc.conv1.out_channels
         t1 = self.alloc(B * H * W * c1)
@@ -429,8 +440,6 @@ class _Plan:
         if net.num_mlr == 0:
             res = self.encoder(net.encoder, _DUMMY)
         else:
-            if self.train:
-                raise NotImplementedError("backward through the 3-encoder MLR network is not implemented yet")
             c = (512, 128)[net.tiny]
             # encoders write straight into channel slices of the concat buffer (networks.py:485-488)
             h, w = self.H, self.W
@@ -480,17 +489,18 @@ class _Plan:
     # ------------------------------------------------------------------ backward lowering (train plans)
     @staticmethod
     def _key(act):
-        return (act[0].data_ptr(), act[5])
+        return (act[0].data_ptr(), act[5], act[3])          # (storage, channel offset, channels)
 
     def _lower_backward(self):
         B, dev = self.B, self.device
         bops = []
-        grads = {}                # activation key -> gradient tensor (same layout as the activation, ld = C)
-        graw = {}                 # conv-output key -> gradient tensor
+        grads = {}                # activation key -> (gradient tensor, ld, channel offset); layout like the activation
+        graw = {}                 # conv-output key -> dense gradient tensor
         self.param_grads = []     # (parameter, tensor) in production order
         scratch_f = 0             # fp32 scratch (wgrad split-K partials, head / conv1 partials)
         scratch_d = 0             # fp64 scratch (GroupNorm backward sums)
         patch_f, patch_d = [], []
+        self.conv1_wgrad_indices = []
         producers = {self._key(e["raw"]): e for e in self.tape if e["kind"] in ("conv", "conv1")}
 
         def pgrad(param):
@@ -498,8 +508,22 @@ class _Plan:
             self.param_grads.append((param, t))
             return t
 
+        def find_grad(act):
+            """Gradient of an activation: its own entry, or a channel slice of a wider tensor's gradient
+            (the three encoder outputs are slices of the MLR concat buffer)."""
+            k = self._key(act)
+            if k in grads:
+                return grads[k]
+            ptr, off, C = k
+            for (p2, o2, c2), (gt, gld, goff) in grads.items():
+                if p2 == ptr and o2 <= off and off + C <= o2 + c2:
+                    return (gt, gld, goff + off - o2)
+            return None
+
         for e in reversed(self.tape):
             kind = e["kind"]
+            if e.get("frozen"):
+                continue                                       # frozen encoder (networks.py:424-428): nothing to do
             if kind == "head":
                 t, H, W, C, ld, off = e["x"]
                 gin = self.alloc(B * H * W * C)
@@ -516,21 +540,22 @@ class _Plan:
                 patch_f.append(len(bops))
                 self.head_bwd_index = len(bops)
                 bops.append(op)
-                grads[self._key(e["x"])] = gin
+                grads[self._key(e["x"])] = (gin, C, 0)
             elif kind == "gn":
                 t, H, W, C, ld, off = e["raw"]
-                gout = grads.pop(self._key(e["out"]))
+                gout = find_grad(e["out"])
+                if gout is None:
+                    continue                                   # output unused downstream of any trainable path
                 dx = self.alloc(B * H * W * C)
                 flags = e["flags"]
                 daux = None
                 if e["aux"] is not None:
-                    ak = self._key(e["aux"])
-                    if ak in grads:
+                    daux = find_grad(e["aux"])
+                    if daux is not None:
                         flags |= GN_ACC_AUX
-                        daux = grads[ak]
                     else:
-                        daux = self.alloc(B * H * W * C)
-                        grads[ak] = daux
+                        daux = (self.alloc(B * H * W * C), C, 0)
+                        grads[self._key(e["aux"])] = daux
                 prod = producers.get(self._key(e["raw"]))
                 G = e["norm"].num_groups
                 nch2 = max(1, min(128, (H * W + 255) // 256))
@@ -540,15 +565,17 @@ class _Plan:
                     op.type = typ
                     op.B, op.Hi, op.Wi, op.Cin, op.groups = B, H, W, C, G
                     op.nchunks, op.nchunks2, op.flags, op.eps = e["nchunks"], nch2, flags, e["norm"].eps
-                    op.ld_in, op.ld_aux, op.ld_out = ld, C, e["out"][4]
+                    op.ld_in, op.ld_aux, op.ld_out = ld, gout[1], e["out"][4]
                     op.in_ = t.data_ptr() + 4 * off
                     op.w, op.bias = e["gamma"].data_ptr(), e["beta"].data_ptr()
                     op.stats = e["stats"].data_ptr()
-                    op.aux = gout.data_ptr()
+                    op.aux = gout[0].data_ptr() + 4 * gout[2]
                     op.aux2 = e["out"][0].data_ptr() + 4 * e["out"][5]
                     if typ == XL_OP_GNB_APPLY:
                         op.out = dx.data_ptr()
-                        op.out2 = daux.data_ptr() if daux is not None else None
+                        if daux is not None:
+                            op.out2 = daux[0].data_ptr() + 4 * daux[2]
+                            op.Cout = daux[1]                  # pixel stride of the d(residual) tensor
                     elif typ == XL_OP_GNB_PARAMS:
                         op.out = pgrad(e["norm"].weight).data_ptr()
                         op.out2 = pgrad(e["norm"].bias).data_ptr()
@@ -558,13 +585,22 @@ class _Plan:
                             op.flags = flags | GN_NO_CONV_BIAS
                     patch_d.append(len(bops))
                     bops.append(op)
-                graw[self._key(e["raw"])] = dx
-                self.release_grad(gout)
+                if self._key(e["out"]) in grads:                # dense, fully consumed: recycle (slices of the
+                    self.release_grad(grads.pop(self._key(e["out"]))[0])   # concat gradient stay until the end)
+                if prod is not None:
+                    graw[self._key(e["raw"])] = dx
+                else:
+                    # GroupNorm applied directly to an activation (mlr_norm on the concat buffer): dx is a
+                    # gradient of that activation
+                    assert find_grad(e["raw"]) is None
+                    grads[self._key(e["raw"])] = (dx, C, 0)
             elif kind == "conv":
                 conv = e["conv"]
                 t, H, W, C, ld, off = e["x"]
                 rt, Ho, Wo, Cout, rld, roff = e["raw"]
-                dy = graw.pop(self._key(e["raw"]))
+                dy = graw.pop(self._key(e["raw"]), None)
+                if dy is None:
+                    continue
                 k, s = conv.kernel_size[0], conv.stride[0]
                 op = XlOp()
                 op.type = XL_OP_WGRAD
@@ -592,27 +628,28 @@ class _Plan:
                 scratch_f = max(scratch_f, splits * k * k * Cout * C)
                 patch_f.append(len(bops))
                 bops.append(op)
-                # data gradient into grads[x]
-                xk = self._key(e["x"])
+                # data gradient into the gradient of x (second producers accumulate)
                 op = XlOp()
                 op.type = XL_OP_CONV
                 op.flags = CONV_DGRAD
-                if xk in grads:
+                gx = find_grad(e["x"])
+                if gx is not None:
                     op.flags |= CONV_ACCUMULATE
-                    gx = grads[xk]
                 else:
-                    gx = self.alloc(B * H * W * C)
-                    grads[xk] = gx
+                    gx = (self.alloc(B * H * W * C), C, 0)
+                    grads[self._key(e["x"])] = gx
                 op.B, op.Hi, op.Wi, op.Cin, op.Ho, op.Wo, op.Cout = B, Ho, Wo, Cout, H, W, C
-                op.ksize, op.stride, op.ld_in, op.ld_out = k, s, Cout, C
-                op.in_, op.out = dy.data_ptr(), gx.data_ptr()
+                op.ksize, op.stride, op.ld_in, op.ld_out = k, s, Cout, gx[1]
+                op.in_, op.out = dy.data_ptr(), gx[0].data_ptr() + 4 * gx[2]
                 op.w = self.pack_conv(conv, dgrad=True).data_ptr()
                 bops.append(op)      # 32 result channels (conv2): the kernel masks the padded half of its 64-wide tile
                 self.release_grad(dy)
             elif kind == "conv1":
                 conv = e["conv"]
                 rt, H, W, Cout, rld, roff = e["raw"]
-                dy = graw.pop(self._key(e["raw"]))
+                dy = graw.pop(self._key(e["raw"]), None)
+                if dy is None:
+                    continue
                 op = XlOp()
                 op.type = XL_OP_CONV1_WGRAD
                 op.B, op.Hi, op.Wi, op.Cin, op.Cout, op.ld_aux = B, H, W, conv.in_channels, Cout, Cout
@@ -624,7 +661,7 @@ class _Plan:
                 op.out2 = self.conv1_db_unused.data_ptr()
                 scratch_f = max(scratch_f, B * ((H + 15) // 16) * 28 * Cout)
                 patch_f.append(len(bops))
-                self.conv1_wgrad_index = len(bops)
+                self.conv1_wgrad_indices.append(len(bops))
                 bops.append(op)
                 self.release_grad(dy)
         self.bwd_scratch_f = torch.empty(max(scratch_f, 1), dtype=torch.float32, device=dev)
@@ -650,7 +687,8 @@ class _Plan:
         dout = dout.detach().to(torch.float32).contiguous()
         hb = self.bwd_array[self.head_bwd_index]
         hb.aux, hb.aux2 = dout.data_ptr(), self.last_out.data_ptr()
-        self.bwd_array[self.conv1_wgrad_index].in_ = self.last_image.data_ptr()
+        for i in self.conv1_wgrad_indices:
+            self.bwd_array[i].in_ = self.last_image.data_ptr()
         stream = torch.cuda.current_stream().cuda_stream
         _check(_bind().xl_cnn_run(self.bwd_array, len(self.bwd_array), ctypes.c_void_p(stream)))
         return self.param_grads

@@ -77,7 +77,8 @@ typedef struct xl_op {
     void *stats;                   /* GN_*: fp64 partial sums [B][nchunks][groups][2] */
     void *out;
     const void *aux2;              /* GNB_*: forward output of the fused epilogue (ReLU mask); HEAD_BWD: forward out */
-    void *out2;                    /* GNB_APPLY: d(residual); GNB_PARAMS: d beta; HEAD_BWD: d weight */
+    void *out2;                    /* GNB_APPLY: d(residual), pixel stride in Cout (0: ld_out); GNB_PARAMS: d beta;
+                                      HEAD_BWD: d weight */
     void *stats2;                  /* GNB_*: fp64 backward sums; WGRAD: fp32 split-K partials; GNB_PARAMS out3 = d bias */
 } xl_op;
 

@@ -1,14 +1,18 @@
 """GPU parity of the CNN backward pass (loss.backward() through crossloc_amd.TransPoseNet) against PyTorch
-autograd on the fp32 CPU restatement of the reference graph (oracle/cnn_oracle.py, itself pinned to reference
-goldens).  Every parameter gradient (116 tensors) is compared; tolerance 2e-4 * max|ref| per tensor (observed:
-<1e-5; fp32, different summation orders through 29 convs + 28 GroupNorms, forward and backward).
+autograd in float64 on the CPU restatement of the reference graph (oracle/cnn_oracle.py, itself pinned to
+reference goldens).  Every parameter gradient (116 tensors single-task, the trainable subset for the 3-encoder
+net) is compared.
 
-ReLU'(0) caveat: a pre-activation that lies within fp32 rounding of zero can get a different ReLU mask on the
-GPU than on the CPU (different conv summation order).  One such flip changes one channel of one d beta by
-O(1 %) and its GroupNorm group accordingly — seen once while choosing these seeds ((1,96,128) input: exactly
-1 of 512 channels of one layer differed, everything else agreed to 1e-6).  The kernels are deterministic, so
-the configurations below, which contain no such element, are stable; the per-op backward tests cover the
-arithmetic of every kernel independently of this effect."""
+Two levels, because ReLU'(0) makes whole-network gradients discontinuous: a pre-activation within fp32 rounding
+of zero gets a different ReLU mask under a different summation order.  One such element changes one channel of one
+d beta by O(1 %) and everything upstream by O(0.1 %); it happens on the GPU *and* in PyTorch's own fp32 CPU run
+relative to float64 (observed: one flipped element, 1 of 512 channels of one layer, everything else 1e-6).
+  * per-op tests (data gradient, weight gradient, GroupNorm/ReLU/residual backward) on random data pin the
+    arithmetic of every kernel at <= 2e-5 / 5e-6 — flips are measure-zero there and masks are compared exactly;
+  * network tests pin the wiring (tape, accumulation order, slices of the MLR concat, frozen encoders): every
+    tensor within 5e-2 of its max (a wiring error — a missing accumulation, a wrong slice — is O(1); a single
+    flipped element on a 12x16 map was measured at 5e-2 on one d beta), typically 3e-6.
+"""
 import numpy as np
 import pytest
 
@@ -23,8 +27,11 @@ MEAN = torch.tensor([-455.934, 417.50, 520.31])
 
 
 def _reference_grads(sd, x, wgt, enc_add, dec_add):
-    sd = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and not k.endswith("mean") else v)
-          for k, v in sd.items()}
+    """Autograd in float64 on the CPU: the reference must not have ReLU-mask flips of its own (an fp32 CPU run
+    does, now and then, relative to fp64 — see the module docstring)."""
+    sd = {k: (v.double().clone().requires_grad_(True) if v.dtype.is_floating_point and not k.endswith("mean")
+              else (v.double() if v.dtype.is_floating_point else v)) for k, v in sd.items()}
+    x, wgt = x.double(), wgt.double()
 
     class _Id(dict):
         pass
@@ -34,10 +41,10 @@ def _reference_grads(sd, x, wgt, enc_add, dec_add):
     res = cnn_oracle.encoder_forward(sd, x, "encoder", enc_add, 32)
     y = cnn_oracle.decoder_forward(sd, res, dec_add, 3, 1, 32)
     (y * wgt).sum().backward()
-    return y.detach(), {k: v.grad for k, v in leaves.items()}
+    return y.detach().float(), {k: v.grad.float() for k, v in leaves.items()}
 
 
-@pytest.mark.parametrize("B,H,W,enc_add,dec_add", [(2, 64, 96, 1, 1), (1, 64, 128, 2, 2), (3, 40, 56, 0, 0)])
+@pytest.mark.parametrize("B,H,W,enc_add,dec_add", [(2, 64, 96, 1, 1), (1, 96, 128, 2, 2), (3, 40, 56, 0, 0)])
 def test_parameter_gradients_vs_autograd(B, H, W, enc_add, dec_add):
     net = networks.TransPoseNet(MEAN, False, False, enc_add, dec_add, 3, 1)
     net.load_state_dict(seeded_state_dict(net, seed=11))
@@ -67,7 +74,8 @@ def test_parameter_gradients_vs_autograd(B, H, W, enc_add, dec_add):
         worst.append((err / sc, name))
     worst.sort(reverse=True)
     worst = [w for w in worst if w[1] != "encoder.conv1.bias"]   # exactly 0 here; the reference holds noise
-    assert worst[0][0] <= 2e-4, worst[:5]
+    assert worst[0][0] <= 5e-2, worst[:5]
+    print("worst relative gradient error %.2e (%s), median %.2e" % (worst[0][0], worst[0][1], worst[len(worst) // 2][0]))
     assert net.encoder.conv1.bias.grad.abs().max().item() == 0.0
 
 
@@ -224,3 +232,45 @@ def test_groupnorm_backward_vs_autograd(B, H, W, C, flags):
         assert rel(dbias.cpu(), x.grad.sum((0, 2, 3))) < 2e-5        # closed-form conv-bias gradient
     else:
         assert dbias.abs().max().item() == 0.0                        # instance norm: exactly zero
+
+
+def test_mlr_network_backward_with_frozen_encoders():
+    """finetune_decoder_single_task.py configuration: TransPoseNet(num_mlr=3, num_unfrozen_encoder=1)
+    (utils/learning.py:294-305) — gradients flow through the fusion block into encoder 1 only."""
+    B, H, W = 1, 64, 96
+    net = networks.TransPoseNet(MEAN, False, False, 1, 1, 3, 1, 32, 3, 1, False)
+    net.load_state_dict(seeded_state_dict(net, seed=23))
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(B, 3, H, W, generator=g)
+    wgt = torch.randn(B, 4, H // 8, W // 8, generator=g)
+    wgt[:, 3] *= 0.1
+    trainable = {n for n, p in net.named_parameters() if p.requires_grad}
+    assert not any(n.startswith("mlr_encoder_2") or n.startswith("mlr_encoder_3") for n in trainable)
+    sd = {k: (v.double().clone().requires_grad_(True) if k in trainable else (v.double() if v.dtype.is_floating_point else v.clone()))
+          for k, v in net.state_dict().items()}
+    import torch.nn.functional as F
+    xd = x.double()
+    mlr = torch.cat([cnn_oracle.encoder_forward(sd, xd, "mlr_encoder_%d" % (i + 1), 1, 32) for i in range(3)], dim=1)
+    res = cnn_oracle._cgr(sd, mlr, "mlr_skip.0", "mlr_skip.1", groups=32, relu=False)
+    m2 = F.group_norm(mlr, 32, sd["mlr_norm.weight"], sd["mlr_norm.bias"], eps=1e-5)
+    res = F.relu(res + cnn_oracle._res_block(sd, "mlr_forward", m2, 32))
+    yref = cnn_oracle.decoder_forward(sd, res, 1, 3, 1, 32)
+    (yref * wgt.double()).sum().backward()
+    yref = yref.detach().float()
+
+    net = net.cuda().train()
+    y = net(x.cuda())
+    (y * wgt.cuda()).sum().backward()
+    torch.cuda.synchronize()
+    assert (y.detach().cpu()[:, :3] - yref[:, :3]).abs().max().item() < 1e-3 * max(1.0, (yref[:, :3] - MEAN[None, :, None, None]).abs().max().item())
+    gmax = max(sd[n].grad.abs().max().item() for n in trainable)
+    worst = []
+    for name, p in net.named_parameters():
+        if name not in trainable:
+            assert p.grad is None, name
+            continue
+        ref = sd[name].grad.float()
+        sc = max(ref.abs().max().item(), 1e-4 * gmax)
+        worst.append(((p.grad.cpu() - ref).abs().max().item() / sc, name))
+    worst = sorted(w for w in worst if w[1] != "mlr_encoder_1.conv1.bias")
+    assert worst[-1][0] <= 5e-2, [(round(a, 5), b) for a, b in worst if a > 5e-2]
