@@ -44,7 +44,7 @@ def _reference_grads(sd, x, wgt, enc_add, dec_add):
     return y.detach().float(), {k: v.grad.float() for k, v in leaves.items()}
 
 
-@pytest.mark.parametrize("B,H,W,enc_add,dec_add", [(2, 64, 96, 1, 1), (1, 96, 128, 2, 2), (3, 40, 56, 0, 0)])
+@pytest.mark.parametrize("B,H,W,enc_add,dec_add", [(2, 64, 96, 1, 1), (1, 128, 192, 2, 2), (3, 40, 56, 0, 0)])
 def test_parameter_gradients_vs_autograd(B, H, W, enc_add, dec_add):
     net = networks.TransPoseNet(MEAN, False, False, enc_add, dec_add, 3, 1)
     net.load_state_dict(seeded_state_dict(net, seed=11))
