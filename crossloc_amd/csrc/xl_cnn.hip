@@ -126,17 +126,20 @@ __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t rsrc, unsigned
 // for the taps whose offset is divisible by the forward stride S (others are zero-filled by the bounds check).
 // MODE 2: the stride-2 data gradient split by result-pixel parity (py,px): only the 1/2/2/4 taps that can reach a
 // pixel of that class are multiplied (9 tap-GEMMs in total over the four launches instead of 36).
-template <int KS, int STRIDE, int BN, int CIN, int MODE = 0>     // CIN = compile-time Cin tag (0: runtime)
+template <int KS, int STRIDE, int BN, int CIN, int MODE = 0, int BM = 128>   // CIN = compile-time Cin tag (0: runtime);
+                                                                             // BM = 64 for launches that would not fill the chip
 __global__ __launch_bounds__(256, 2)
 void igemm_conv_kernel(ConvArgs a)
 {
     constexpr int PAD = (KS == 3) ? 1 : 0;
     constexpr int NJ = BN / 64;                 // 32-wide MFMA tiles per wave along N
     constexpr int BROWS = BN / 32;              // B-tile rows loaded per thread
+    constexpr int AROWS = BM / 32;              // A-tile rows loaded per thread
+    constexpr int TI = BM / 64;                 // 32-high MFMA tiles per wave along M
     constexpr unsigned OOB = 0x80000000u;       // > any legal extent: forces the zero-fill path
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *As = smem;                           // [2][kBM][kPitch]
-    float *Bs = smem + 2 * kBM * kPitch;        // [2][BN][kPitch]
+    float *As = smem;                           // [2][BM][kPitch]
+    float *Bs = smem + 2 * BM * kPitch;         // [2][BN][kPitch]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -144,19 +147,19 @@ void igemm_conv_kernel(ConvArgs a)
 
     const int tile = xcd_remap(blockIdx.x, a.nbm * a.nbn);
     const int mt = tile / a.nbn, nt = tile - mt * a.nbn;
-    const int m0 = mt * kBM, n0 = nt * BN;
+    const int m0 = mt * BM, n0 = nt * BN;
 
     const __amdgpu_buffer_rsrc_t srdA = __builtin_amdgcn_make_buffer_rsrc((void *)a.in, 0, (int)a.inBytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t srdB = __builtin_amdgcn_make_buffer_rsrc((void *)a.w, 0, (int)a.wBytes, 0x00020000);
 
     // ---- per-thread load coordinates: 4 A rows (and BROWS B rows) at float4 column kq
     const int lrow = tid >> 3, kq = tid & 7;
-    unsigned aOff[4];                           // byte offset of (n, iy0, ix0, 4*kq); wraps for padding rows
-    int aIy[4], aIx[4];
+    unsigned aOff[AROWS];                           // byte offset of (n, iy0, ix0, 4*kq); wraps for padding rows
+    int aIy[AROWS], aIx[AROWS];
     const int HoWo = (MODE == 2) ? a.Hj * a.Wj : a.Ho * a.Wo;
     const int rowW = (MODE == 2) ? a.Wj : a.Wo;
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
+    for (int p = 0; p < AROWS; ++p) {
         const int m = m0 + lrow + 32 * p;
         if (m < a.M) {
             const int n = m / HoWo;
@@ -183,7 +186,7 @@ void igemm_conv_kernel(ConvArgs a)
 #pragma unroll
     for (int p = 0; p < BROWS; ++p) bOff[p] = (unsigned)((n0 + lrow + 32 * p) * a.K + 4 * kq) * 4u;
 
-    f32x4 ra[4], rb[BROWS];
+    f32x4 ra[AROWS], rb[BROWS];
     auto load_global = [&](int kk) {
         // K order is (channel chunk of 32, tap, channel-in-chunk): the 9 taps of one chunk run back to back, so
         // the shifted re-reads of the same input pixels hit L1/L2 instead of going back to HBM 9 times
@@ -201,7 +204,7 @@ void igemm_conv_kernel(ConvArgs a)
         const int ky = tap / KS, kx = tap - ky * KS;
         const unsigned tapOff = (unsigned)((ky * a.Wi + kx) * a.ldIn + c0) * 4u;
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
+        for (int p = 0; p < AROWS; ++p) {
             if constexpr (MODE == 0) {
                 const bool ok = (unsigned)(aIy[p] + ky) < (unsigned)a.Hi && (unsigned)(aIx[p] + kx) < (unsigned)a.Wi;
                 ra[p] = buf_load4(srdA, ok ? aOff[p] + tapOff : OOB, 0);
@@ -216,17 +219,17 @@ void igemm_conv_kernel(ConvArgs a)
         for (int p = 0; p < BROWS; ++p) rb[p] = buf_load4(srdB, bOff[p], (unsigned)kbase * 4u);
     };
     auto store_lds = [&](int buf) {
-        float *Ad = As + buf * kBM * kPitch + lrow * kPitch + 4 * kq;
+        float *Ad = As + buf * BM * kPitch + lrow * kPitch + 4 * kq;
 #pragma unroll
-        for (int p = 0; p < 4; ++p) *reinterpret_cast<f32x4 *>(Ad + 32 * p * kPitch) = ra[p];
+        for (int p = 0; p < AROWS; ++p) *reinterpret_cast<f32x4 *>(Ad + 32 * p * kPitch) = ra[p];
         float *Bd = Bs + buf * BN * kPitch + lrow * kPitch + 4 * kq;
 #pragma unroll
         for (int p = 0; p < BROWS; ++p) *reinterpret_cast<f32x4 *>(Bd + 32 * p * kPitch) = rb[p];
     };
 
-    f32x16 acc[2][NJ];
+    f32x16 acc[TI][NJ];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TI; ++i)
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
@@ -238,19 +241,19 @@ void igemm_conv_kernel(ConvArgs a)
     __syncthreads();
 
     const int fragRow = lane & 31, fragK = (lane >> 5) * 4;
-    const float *Afrag = As + (wm * 64 + fragRow) * kPitch + fragK;
+    const float *Afrag = As + (wm * (BM / 2) + fragRow) * kPitch + fragK;
     const float *Bfrag = Bs + (wn * (BN / 2) + fragRow) * kPitch + fragK;
     for (int kk = 0; kk < nk; ++kk) {
         const int buf = kk & 1;
         if (kk + 1 < nk && !(a.dbg & 1)) load_global(kk + 1);
-        const float *Ab = Afrag + buf * kBM * kPitch;
+        const float *Ab = Afrag + buf * BM * kPitch;
         const float *Bb = Bfrag + buf * BN * kPitch;
         // fragments ping-pong between two register sets: chunk c+1 is read from LDS while chunk c multiplies.
         // The sched_group_barrier sequence pins that order (hipcc otherwise re-merges the two sets and exposes
         // the LDS latency once per chunk).
-        f32x4 fa[2][2], fb[2][NJ];
+        f32x4 fa[2][TI], fb[2][NJ];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) fa[0][i] = *reinterpret_cast<const f32x4 *>(Ab + i * 32 * kPitch);
+        for (int i = 0; i < TI; ++i) fa[0][i] = *reinterpret_cast<const f32x4 *>(Ab + i * 32 * kPitch);
 #pragma unroll
         for (int j = 0; j < NJ; ++j) fb[0][j] = *reinterpret_cast<const f32x4 *>(Bb + j * 32 * kPitch);
         auto chunk = [&](auto cc) {
@@ -259,12 +262,12 @@ void igemm_conv_kernel(ConvArgs a)
             if constexpr (c < 3) {
                 if (!(a.dbg & 8)) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i) fa[nxt][i] = *reinterpret_cast<const f32x4 *>(Ab + i * 32 * kPitch + (c + 1) * 8);
+                for (int i = 0; i < TI; ++i) fa[nxt][i] = *reinterpret_cast<const f32x4 *>(Ab + i * 32 * kPitch + (c + 1) * 8);
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) fb[nxt][j] = *reinterpret_cast<const f32x4 *>(Bb + j * 32 * kPitch + (c + 1) * 8);
                 } else {
 #pragma unroll
-                for (int i = 0; i < 2; ++i) fa[nxt][i] = fa[cur][i];
+                for (int i = 0; i < TI; ++i) fa[nxt][i] = fa[cur][i];
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) fb[nxt][j] = fb[cur][j];
                 }
@@ -272,7 +275,7 @@ void igemm_conv_kernel(ConvArgs a)
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < TI; ++i)
 #pragma unroll
                     for (int j = 0; j < NJ; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i][e], fb[cur][j][e], acc[i][j], 0, 0, 0);
@@ -281,19 +284,19 @@ void igemm_conv_kernel(ConvArgs a)
         chunk(std::integral_constant<int, 1>{});
         chunk(std::integral_constant<int, 2>{});
         chunk(std::integral_constant<int, 3>{});
-        __builtin_amdgcn_sched_group_barrier(0x100, 2 * (2 + NJ), 0);     // chunk 0 + chunk 1 fragments
-        __builtin_amdgcn_sched_group_barrier(0x008, 8 * NJ, 0);           // chunk 0 MFMAs
-        __builtin_amdgcn_sched_group_barrier(0x100, 2 + NJ, 0);           // chunk 2 fragments
-        __builtin_amdgcn_sched_group_barrier(0x008, 8 * NJ, 0);           // chunk 1 MFMAs
-        __builtin_amdgcn_sched_group_barrier(0x100, 2 + NJ, 0);           // chunk 3 fragments
-        __builtin_amdgcn_sched_group_barrier(0x008, 16 * NJ, 0);          // chunk 2 + 3 MFMAs
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 * (TI + NJ), 0);    // chunk 0 + chunk 1 fragments
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * TI * NJ, 0);      // chunk 0 MFMAs
+        __builtin_amdgcn_sched_group_barrier(0x100, TI + NJ, 0);          // chunk 2 fragments
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * TI * NJ, 0);      // chunk 1 MFMAs
+        __builtin_amdgcn_sched_group_barrier(0x100, TI + NJ, 0);          // chunk 3 fragments
+        __builtin_amdgcn_sched_group_barrier(0x008, 8 * TI * NJ, 0);      // chunk 2 + 3 MFMAs
         if (kk + 1 < nk && !(a.dbg & 2)) store_lds(buf ^ 1);
         if (!(a.dbg & 4)) __syncthreads();
     }
 
     // ---- epilogue: bias + store. C layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     const int col = lane & 31, rhalf = (lane >> 5) * 4;
-    // fused GroupNorm statistics: a 128-row tile touches at most two images (HW >= 128); `split` = first tile row
+    // fused GroupNorm statistics: a BM-row tile touches at most two images (HW >= BM); `split` = first tile row
     // of the second image.  Per lane: sums over its 32 rows per column and image slot, then half-wave, wave-pair
     // and channel-group reductions in a fixed order; every (image, tile, group) entry has exactly one writer.
     const bool doStats = (MODE == 0) && a.stats != nullptr;
@@ -308,10 +311,10 @@ void igemm_conv_kernel(ConvArgs a)
         if (n >= a.Cout) continue;                      // narrow outputs (Cout < BN): columns beyond Cout are padding
         const float bv = a.bias ? a.bias[n] : 0.f;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < TI; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + rhalf;
+                const int row = wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + rhalf;
                 const int m = m0 + row;
                 if (m < a.M) {
                     long long pix = m;
@@ -352,7 +355,7 @@ void igemm_conv_kernel(ConvArgs a)
             const int gi = tid >> 1, sl = tid & 1;
             const int n = nLo + sl;
             const int firstRow = sl ? split : 0;
-            if (n < a.B && m0 + firstRow < a.M && (sl == 0 || split < kBM)) {
+            if (n < a.B && m0 + firstRow < a.M && (sl == 0 || split < BM)) {
                 double s1 = 0.0, s2 = 0.0;
                 for (int w = 0; w < 2; ++w)
                     for (int c = gi * a.cpg; c < (gi + 1) * a.cpg; ++c) {
@@ -361,7 +364,7 @@ void igemm_conv_kernel(ConvArgs a)
                     }
                 const int g = (n0 + gi * a.cpg) / a.cpg;
                 if (g < a.G) {
-                    const int k = mt - (int)(((long long)n * a.HW) / kBM);       // tile index within the image
+                    const int k = mt - (int)(((long long)n * a.HW) / BM);       // tile index within the image
                     double *o = a.stats + (((long long)n * a.nchunks + k) * a.G + g) * 2;
                     o[0] = s1; o[1] = s2;
                 }
@@ -611,7 +614,7 @@ ProfRec *g_prof = nullptr;
 int g_profCap = 0, g_profCount = 0;
 bool g_profOn = false;
 
-template <int KS, int STRIDE, int BN, int CIN, int MODE = 0>
+template <int KS, int STRIDE, int BN, int CIN, int MODE = 0, int BM = 128>
 int launch_igemm(const xl_op &op, hipStream_t st, int py = 0, int px = 0)
 {
     ConvArgs a;
@@ -623,7 +626,7 @@ int launch_igemm(const xl_op &op, hipStream_t st, int py = 0, int px = 0)
     a.stats = nullptr; a.HW = op.Ho * op.Wo; a.G = 0; a.cpg = 1; a.nchunks = 0;
     if (MODE == 0 && op.stats && op.groups > 0) {
         a.G = op.groups; a.cpg = op.Cout / op.groups; a.nchunks = op.nchunks;
-        if (a.HW < kBM || op.Cout % op.groups != 0 || BN % a.cpg != 0 || a.nchunks < (a.HW + kBM - 1) / kBM + 1) return XL_ERR_ARG;
+        if (a.HW < BM || op.Cout % op.groups != 0 || BN % a.cpg != 0 || a.nchunks < (a.HW + BM - 1) / BM + 1) return XL_ERR_ARG;
         a.stats = (double *)op.stats;
     }
     if (MODE == 2) {
@@ -635,7 +638,7 @@ int launch_igemm(const xl_op &op, hipStream_t st, int py = 0, int px = 0)
                 if (((py + 1 - ky) & 1) == 0 && ((px + 1 - kx) & 1) == 0) { a.tapList |= (unsigned)(ky * 3 + kx) << (4 * a.ntaps); ++a.ntaps; }
         if (a.M == 0) return XL_OK;
     }
-    a.nbm = (a.M + kBM - 1) / kBM; a.nbn = (op.Cout + BN - 1) / BN;   // weight rows past Cout read as zero (bounds check)
+    a.nbm = (a.M + BM - 1) / BM; a.nbn = (op.Cout + BN - 1) / BN;   // weight rows past Cout read as zero (bounds check)
     const long long inBytes = (((long long)op.B * op.Hi * op.Wi - 1) * op.ld_in + op.Cin) * 4;
     const long long wBytes = (long long)op.Cout * a.K * 4;
     if (inBytes >= 0x7fffffffLL || wBytes >= 0x7fffffffLL) {
@@ -647,15 +650,15 @@ int launch_igemm(const xl_op &op, hipStream_t st, int py = 0, int px = 0)
     static const int ldsPad = getenv("XL_CONV_LDS_PAD") ? atoi(getenv("XL_CONV_LDS_PAD")) : 0;
     a.dbg = dbgFlags;
     a.accumulate = (op.flags & XL_CONV_ACCUMULATE) ? 1 : 0;
-    const size_t lds = sizeof(float) * 2 * (kBM + BN) * kPitch + (size_t)ldsPad;
+    const size_t lds = sizeof(float) * 2 * (BM + BN) * kPitch + (size_t)ldsPad;
     static bool configured = false;
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(igemm_conv_kernel<KS, STRIDE, BN, CIN, MODE>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(igemm_conv_kernel<KS, STRIDE, BN, CIN, MODE, BM>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { snprintf(g_err, sizeof(g_err), "hipFuncSetAttribute: %s", hipGetErrorString(e)); return XL_ERR_HIP; }
         configured = true;
     }
-    hipLaunchKernelGGL((igemm_conv_kernel<KS, STRIDE, BN, CIN, MODE>), dim3(a.nbm * a.nbn), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((igemm_conv_kernel<KS, STRIDE, BN, CIN, MODE, BM>), dim3(a.nbm * a.nbn), dim3(256), lds, st, a);
     return XL_OK;
 }
 
@@ -677,12 +680,25 @@ int run_conv(const xl_op &op, hipStream_t st)
         if (op.ksize == 1 && op.stride == 1) return wide ? launch_igemm<1, 1, 128, 0, 1>(op, st) : launch_igemm<1, 1, 64, 0, 1>(op, st);
         return XL_ERR_UNSUPPORTED;
     }
+    const bool small = (op.reserved_i == 64);          // 64-row tiles: the host asks for them when 128-row tiles
+                                                        // would leave most of the 256 CUs idle (small batches)
     if (op.ksize == 3 && op.stride == 1) {
+        if (small) {
+            if (wide && op.Cin == 512) return launch_igemm<3, 1, 128, 512, 0, 64>(op, st);
+            return wide ? launch_igemm<3, 1, 128, 0, 0, 64>(op, st) : launch_igemm<3, 1, 64, 0, 0, 64>(op, st);
+        }
         if (wide && op.Cin == 512) return launch_igemm<3, 1, 128, 512>(op, st);      // 78 % of the forward FLOPs
         return wide ? launch_igemm<3, 1, 128, 0>(op, st) : launch_igemm<3, 1, 64, 0>(op, st);
     }
-    if (op.ksize == 3 && op.stride == 2) return wide ? launch_igemm<3, 2, 128, 0>(op, st) : launch_igemm<3, 2, 64, 0>(op, st);
+    if (op.ksize == 3 && op.stride == 2) {
+        if (small) return wide ? launch_igemm<3, 2, 128, 0, 0, 64>(op, st) : launch_igemm<3, 2, 64, 0, 0, 64>(op, st);
+        return wide ? launch_igemm<3, 2, 128, 0>(op, st) : launch_igemm<3, 2, 64, 0>(op, st);
+    }
     if (op.ksize == 1 && op.stride == 1) {
+        if (small) {
+            if (wide && op.Cin == 512) return launch_igemm<1, 1, 128, 512, 0, 64>(op, st);
+            return wide ? launch_igemm<1, 1, 128, 0, 0, 64>(op, st) : launch_igemm<1, 1, 64, 0, 0, 64>(op, st);
+        }
         if (wide && op.Cin == 512) return launch_igemm<1, 1, 128, 512>(op, st);
         return wide ? launch_igemm<1, 1, 128, 0>(op, st) : launch_igemm<1, 1, 64, 0>(op, st);
     }

@@ -262,6 +262,10 @@ class _Plan:
         op.w = self.pack_conv(conv).data_ptr()
         op.bias = self.dev(conv.bias).data_ptr()
         op.out = out.data_ptr() + 4 * out_off
+        # 64-row tiles when 128-row tiles would not even fill one wave of workgroups over the 256 CUs
+        bn = 128 if cout % 128 == 0 else 64
+        if -(-self.B * Ho * Wo // 128) * -(-cout // bn) <= 256:
+            op.reserved_i = 64
         self.ops.append(op)
         res = (out, Ho, Wo, cout, out_ld, out_off)
         self.tape.append(dict(kind="conv", conv=conv, x=act, raw=res))
@@ -326,19 +330,20 @@ class _Plan:
         """GroupNorm apply (in place) consuming statistics emitted by the epilogue of the conv op `conv_index`."""
         t, H, W, C, ld, off = act
         G, HW = norm.num_groups, H * W
-        nchunks = (HW + 127) // 128 + 1
-        self.max_stats = max(self.max_stats, self.B * nchunks * G * 2)
         cop = self.ops[conv_index]
+        tile = 64 if cop.reserved_i == 64 else 128
+        nchunks = (HW + tile - 1) // tile + 1
+        self.max_stats = max(self.max_stats, self.B * nchunks * G * 2)
         cop.groups, cop.nchunks = G, nchunks
         ap = XlOp()
         ap.type = XL_OP_GN_APPLY
         ap.B, ap.Hi, ap.Wi, ap.Cin, ap.groups, ap.nchunks, ap.ld_in = self.B, H, W, C, G, nchunks, ld
-        ap.flags, ap.eps, ap.reserved_i = flags, norm.eps, 128
+        ap.flags, ap.eps, ap.reserved_i = flags, norm.eps, tile
         ap.in_ = t.data_ptr() + 4 * off
         gamma, beta = self.dev(norm.weight), self.dev(norm.bias)
         ap.w, ap.bias = gamma.data_ptr(), beta.data_ptr()
         self.stats_ops.append(conv_index)
-        self._emit_final(ap, gamma, beta, 128)
+        self._emit_final(ap, gamma, beta, tile)
         if aux is not None:
             ap.aux = aux[0].data_ptr() + 4 * aux[5]
             ap.ld_aux = aux[4]
