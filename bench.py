@@ -184,6 +184,10 @@ def main():
                                        "random weights on random images (no trained weights offline)",
                        "cnn_ms_per_batch": round(cnn_ms, 3), "dsac_ms_per_batch": round(dsac_ms, 3),
                        "pipeline": "solver(s) on a side stream under CNN(s+1), ordered by an event",
+                       # north_star asks for the RANSAC stage against the HBM roofline as well: algorithmic bytes =
+                       # nHyp*N*12 B + 64 B per image; the stage is LDS-resident and fp64/latency-bound
+                       "dsac_algorithmic_GBps": round(B * (NH * 5400 * 12 + 64) / (dsac_ms * 1e-3) / 1e9, 1),
+                       "dsac_hbm_roofline_frac": round(B * (NH * 5400 * 12 + 64) / (dsac_ms * 1e-3) / 8e12, 5),
                        "cnn_fwd_tflops": round(FWD_GFLOP_PER_IMAGE * B / cnn_ms, 2),
                        "median_err_cm": round(med_t_cm, 3), "median_err_deg": round(med_r_deg, 5)},
             "roofline": {"bound": "mfma", "kernel": "igemm_conv_kernel<3,1,128,512> (3x3 512->512 @60x90 x%d images)" % B,

@@ -43,7 +43,11 @@ def _parse():
     p.add_argument('--batch', type=int, default=16)
     p.add_argument('--noise', type=float, default=0.5)
     p.add_argument('--outliers', type=float, default=0.3)
-    p.add_argument('--solver_input', choices=['synthetic', 'network'], default='synthetic')
+    p.add_argument('--solver_input', choices=['synthetic', 'network', 'labels'], default='synthetic',
+                   help="what the solver consumes: synthetic scene maps, the network output, or the ground-truth labels "
+                        "(the `predictions = gt_label  # debug only!` switch of test_single_task.py:361)")
+    p.add_argument('--scene_dir', type=str, default=None,
+                   help='CrossLoc on-disk scene section (rgb/ poses/ calibration/ init/), read by crossloc_amd.dataset')
     p.add_argument('--num_mlr', type=int, default=0, help='3 = CrossLoc three-encoder network')
     p.add_argument('--testing_log', type=str, default=None)
     return p.parse_args()
@@ -69,7 +73,13 @@ def main():
         net.load_state_dict(seeded_state_dict(net, seed=2021))
     net = net.to(dev).eval()
 
-    K = opt.synthetic
+    ds = None
+    if opt.scene_dir:
+        from .dataset import CamLocDataset
+        ds = CamLocDataset(opt.scene_dir, mode=1, sparse=True, coord=True, raw_image=True)      # evaluation.py:33-44
+        if opt.solver_input == 'synthetic':
+            opt.solver_input = 'network'
+    K = len(ds) if ds is not None else opt.synthetic
     mine = evaluation.shard_indices(K, rank, world)
     H, W = synth.IMAGE_H, synth.IMAGE_W
     g = torch.Generator().manual_seed(2021)
@@ -77,19 +87,29 @@ def main():
     t0 = time.time()
     for s in range(0, len(mine), opt.batch):
         idx = mine[s:s + opt.batch]
-        scenes = [synth.make_scene(2021 + i, noise=opt.noise, outlier_ratio=opt.outliers) for i in idx]
-        images = torch.rand((len(idx), 3, H, W), generator=g).to(dev)           # raw_image=True: un-normalised [0,1]
-        coords = torch.from_numpy(np.stack([sc["coords"] for sc in scenes])).to(dev)
-        gt_pose = torch.from_numpy(np.stack([sc["pose"] for sc in scenes])).to(dev)
-        gt_coords = torch.from_numpy(np.stack([sc["gt_coords"] for sc in scenes])).to(dev)
+        if ds is not None:
+            items = [ds[i] for i in idx]
+            images = torch.stack([it[0] for it in items]).to(dev)
+            gt_pose = torch.stack([it[1] for it in items]).to(dev)
+            gt_coords = torch.stack([it[2] for it in items]).to(dev)
+            focal = float(items[0][3])                                          # one camera per section
+            coords = gt_coords
+            H, W = images.shape[2], images.shape[3]
+        else:
+            scenes = [synth.make_scene(2021 + i, noise=opt.noise, outlier_ratio=opt.outliers) for i in idx]
+            images = torch.rand((len(idx), 3, H, W), generator=g).to(dev)       # raw_image=True: un-normalised [0,1]
+            coords = torch.from_numpy(np.stack([sc["coords"] for sc in scenes])).to(dev)
+            gt_pose = torch.from_numpy(np.stack([sc["pose"] for sc in scenes])).to(dev)
+            gt_coords = torch.from_numpy(np.stack([sc["gt_coords"] for sc in scenes])).to(dev)
+            focal = synth.FOCAL
         # image0/stride reproduce the i % R sharding in the sampler key
-        poses, pred = evaluation.localize_batch(net, images, opt.hypotheses, synth.FOCAL, H, W, image0=idx[0],
+        poses, pred = evaluation.localize_batch(net, images, opt.hypotheses, focal, H, W, image0=idx[0],
                                                 image_stride=world, threshold=opt.threshold,
                                                 inlier_alpha=opt.inlieralpha, max_pixel_error=opt.maxpixelerror,
-                                                scene_coords=coords if opt.solver_input == 'synthetic' else None)
+                                                scene_coords=None if opt.solver_input == 'network' else coords)
         t_err, r_err = evaluation.pose_errors(gt_pose, poses)
         rows.append(torch.stack([t_err, r_err], 1))
-        used = coords if opt.solver_input == 'synthetic' else pred[:, :3]
+        used = pred[:, :3] if opt.solver_input == 'network' else coords
         mask = evaluation.pick_valid_points(gt_coords.flatten(2), synth.NODATA)
         coord_errs.append(torch.norm(gt_coords.flatten(2) - used.flatten(2), dim=1)[mask].cpu())
     torch.cuda.synchronize()

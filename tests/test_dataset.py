@@ -1,0 +1,43 @@
+"""CPU: the CrossLoc on-disk format reader (crossloc_amd/dataset.py) on a scene written by its own writer:
+tensor contract of dataloader/dataloader.py (shapes, nodata = -1, un-normalised [0,1] input with raw_image=True,
+focal rescaling, file ordering)."""
+import numpy as np
+import pytest
+import torch
+
+from crossloc_amd import dataset, synth
+
+
+def test_round_trip_scene(tmp_path):
+    root = dataset.write_synthetic_scene(str(tmp_path / "scene"), 3, seed=77)
+    ds = dataset.CamLocDataset(root, mode=1, sparse=True, coord=True, raw_image=True)
+    assert len(ds) == 3
+    image, pose, gt, focal, name = ds[1]
+    assert image.shape == (3, 480, 720) and image.dtype == torch.float32
+    assert 0.0 <= image.min() and image.max() <= 1.0 and image.max() > 0.9          # raw [0,1] RGB
+    sc = synth.make_scene(78, noise=0.5, outlier_ratio=0.0)
+    assert torch.allclose(pose, torch.from_numpy(sc["pose"]).float(), atol=1e-4)
+    assert torch.equal(gt, torch.from_numpy(sc["gt_coords"])) and gt.shape == (3, 60, 90)
+    assert focal == pytest.approx(480.0) and name.endswith("frame_00001.png")
+    norm = dataset.CamLocDataset(root, raw_image=False)[1][0]
+    assert torch.allclose(norm[0], (image[0] - 0.4245) / 0.1823, atol=1e-6)
+
+
+def test_resize_scales_focal_length(tmp_path):
+    from PIL import Image
+    root = dataset.write_synthetic_scene(str(tmp_path / "scene"), 1, seed=5)
+    p = ds_path = root + "/rgb/frame_00000.png"
+    Image.open(p).resize((1440, 960)).save(ds_path)                                   # stored at twice the size
+    np.savetxt(root + "/calibration/frame_00000.txt", [960.0])
+    image, _, _, focal, _ = dataset.CamLocDataset(root, raw_image=True)[0]
+    assert image.shape == (3, 480, 720) and focal == pytest.approx(480.0)
+
+
+def test_unsupported_modes_raise(tmp_path):
+    root = dataset.write_synthetic_scene(str(tmp_path / "scene"), 1)
+    with pytest.raises(NotImplementedError):
+        dataset.CamLocDataset(root, augment=True)
+    with pytest.raises(NotImplementedError):
+        dataset.CamLocDataset(root, mode=2)
+    with pytest.raises(Exception):
+        dataset.CamLocDataset(root, coord=False)
