@@ -1,7 +1,9 @@
 // xl_dsac.hip — MI355X (gfx950) kernel bundle for CrossLoc's DSAC* pose solver.
 //
 // Replaces dsacstar_rgb_forward (/root/reference/dsacstar/dsacstar.cpp:63-178) behind the C ABI of
-// include/crossloc_dsac.h.  One 256-thread workgroup (4 wavefronts) per image, everything in one launch:
+// include/crossloc_dsac.h.  One 256-thread workgroup (4 wavefronts) per image, everything in one launch (large
+// batches), or — when the batch alone cannot fill 256 CUs — the sample/score phase spread over S workgroups per
+// image followed by a select/refine launch (xl_dsac_forward_kernel<1>, <2>); both forms give identical bits:
 //
 //   stage      scene coordinates -> LDS as SoA planes (64.8 KB for 60x90), read by every later phase
 //   sample     wavefront w owns hypotheses w, w+4, ...; the 64 lanes evaluate 64 consecutive tries of
@@ -600,6 +602,8 @@ struct Params {
     uint64_t seed, image0, imageStride;
     uint32_t maxTries;
     int nHyp, Ho, Wo, sub, Npad;
+    double *part;                 // split launch: [B][S*4][16] per-wave bests + [B][12] pose of hypothesis 0
+    int S;                        // sub-blocks per image in the split launch
     float thr, focal, ppx, ppy, alpha, maxReproj;
 };
 
@@ -615,6 +619,12 @@ struct Smem {
     int pad[4];
 };
 
+// PHASE 0: whole pipeline, one workgroup per image (enough images to fill the chip).
+// PHASE 1: sample + score only, S workgroups per image (grid S x B); per-wave bests go to P.part.
+// PHASE 2: select over the S*4 per-wave bests + refine + write, one workgroup per image.
+// The split (1 then 2) exists for small batches: with B < ~100 images the fused kernel leaves most CUs idle and
+// its latency is the 64 hypotheses each wavefront walks through.  Results are identical in both forms.
+template <int PHASE>
 __global__ __launch_bounds__(kThreads)
 void xl_dsac_forward_kernel(Params P)
 {
@@ -624,7 +634,9 @@ void xl_dsac_forward_kernel(Params P)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = blockIdx.x;
+    const int b = (PHASE == 1) ? blockIdx.y : blockIdx.x;
+    const int sub = (PHASE == 1) ? blockIdx.x : 0;
+    const int nSub = (PHASE == 1) ? P.S : 1;
     const int N = P.Ho * P.Wo;
 
     Cam cam;
@@ -657,7 +669,8 @@ void xl_dsac_forward_kernel(Params P)
     const float beta = 5.0f / cam.thr;
     const float fac = cam.alpha / (float)cam.Wo / (float)cam.Ho;
 
-    for (int h = wave; h < P.nHyp; h += kWaves) {
+    if (PHASE != 2)
+    for (int h = sub * kWaves + wave; h < P.nHyp; h += kWaves * nSub) {
         Pose pose;
         int c4[4] = { 0, 0, 0, 0 };
         int triesUsed = 0;
@@ -716,26 +729,45 @@ void xl_dsac_forward_kernel(Params P)
             }
         }
     }
-    if (lane == 0) { S.bestScore[wave] = bestScore; S.bestIdx[wave] = bestIdx; S.anyNan[wave] = anyNan; }
-    __syncthreads();
+    if (PHASE == 1) {
+        // publish this wave's best to global memory for the PHASE 2 launch (stream order makes it visible)
+        __syncthreads();                                            // S.bestPose / S.pose0 written by lane 0s
+        if (lane == 0) {
+            double *o = P.part + ((int64_t)b * (P.S * kWaves) + sub * kWaves + wave) * 16;
+            o[0] = bestScore; o[1] = (double)bestIdx; o[2] = (double)anyNan;
+            for (int i = 0; i < 12; ++i) o[3 + i] = S.bestPose[wave][i];
+            if (sub == 0 && wave == 0) {
+                double *q = P.part + (int64_t)gridDim.y * (P.S * kWaves) * 16 + (int64_t)b * 12;
+                for (int i = 0; i < 12; ++i) q[i] = S.pose0[i];
+            }
+        }
+        return;
+    }
+    if (PHASE == 0) {
+        if (lane == 0) { S.bestScore[wave] = bestScore; S.bestIdx[wave] = bestIdx; S.anyNan[wave] = anyNan; }
+        __syncthreads();
+    }
 
     // ---- select: first maximum wins (draw(probs,false), dsacstar_util.h:727-752)
     int win = -1, winWave = 0, nanAny = 0;
+    const int nPart = (PHASE == 2) ? P.S * kWaves : kWaves;
+    const double *gPart = (PHASE == 2) ? P.part + (int64_t)b * nPart * 16 : nullptr;
     {
         double ws = 0.0;
-#pragma unroll
-        for (int w = 0; w < kWaves; ++w) {
-            nanAny |= S.anyNan[w];
-            int idx = S.bestIdx[w];
+        for (int w = 0; w < nPart; ++w) {
+            const double sc = (PHASE == 2) ? gPart[w * 16] : S.bestScore[w];
+            const int idx = (PHASE == 2) ? (int)gPart[w * 16 + 1] : S.bestIdx[w];
+            nanAny |= (PHASE == 2) ? (int)gPart[w * 16 + 2] : S.anyNan[w];
             if (idx < 0) continue;
-            double s = S.bestScore[w];
-            if (win < 0 || s > ws || (s == ws && idx < win)) { win = idx; ws = s; winWave = w; }
+            if (win < 0 || sc > ws || (sc == ws && idx < win)) { win = idx; ws = sc; winWave = w; }
         }
         if (nanAny) win = 0;        // any NaN score makes every softmax prob NaN -> draw() returns 0
     }
     Pose pose;
     {
-        const double *src = nanAny ? S.pose0 : S.bestPose[winWave];
+        const double *src;
+        if (PHASE == 2) src = nanAny ? P.part + (int64_t)gridDim.x * nPart * 16 + (int64_t)b * 12 : gPart + winWave * 16 + 3;
+        else src = nanAny ? S.pose0 : S.bestPose[winWave];
 #pragma unroll
         for (int i = 0; i < 9; ++i) pose.R[i] = src[i];
 #pragma unroll
@@ -874,11 +906,30 @@ int xl_dsac_forward_rgb_batch(const float *coords_dev, int64_t sb, int64_t sc, i
     if (lds > 160 * 1024) return XL_ERR_GRID;
     static size_t configured = 0;
     if (lds > configured) {
-        XL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(xl_dsac_forward_kernel),
+        XL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(xl_dsac_forward_kernel<0>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        XL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(xl_dsac_forward_kernel<1>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        XL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(xl_dsac_forward_kernel<2>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         configured = lds;
     }
-    hipLaunchKernelGGL(xl_dsac_forward_kernel, dim3(B), dim3(kThreads), lds, (hipStream_t)stream, P);
+    hipStream_t st = (hipStream_t)stream;
+    // sub-blocks per image: fill ~2 workgroups per CU, at least one hypothesis per wavefront
+    int S = 1;
+    while (S * 2 <= n_hyp / kWaves && (long long)B * S * 2 <= 512) S *= 2;
+    static const char *noSplit = getenv("XL_DSAC_NO_SPLIT");
+    if (noSplit) S = 1;
+    P.part = nullptr; P.S = S;
+    if (S == 1) {
+        hipLaunchKernelGGL(xl_dsac_forward_kernel<0>, dim3(B), dim3(kThreads), lds, st, P);
+    } else {
+        const size_t bytes = sizeof(double) * ((size_t)B * S * kWaves * 16 + (size_t)B * 12);
+        XL_HIP(hipMallocAsync((void **)&P.part, bytes, st));
+        hipLaunchKernelGGL(xl_dsac_forward_kernel<1>, dim3(S, B), dim3(kThreads), lds, st, P);
+        hipLaunchKernelGGL(xl_dsac_forward_kernel<2>, dim3(B), dim3(kThreads), lds, st, P);
+        XL_HIP(hipFreeAsync(P.part, st));
+    }
     XL_HIP(hipGetLastError());
     return XL_OK;
 }
