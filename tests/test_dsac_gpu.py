@@ -145,3 +145,36 @@ def test_full_size_batch_properties():
     assert (dg["dbg"][:, 1] >= 1).all() and (dg["dbg"][:, 1] <= 100).all()       # refinement rounds
     again, _ = _gpu_batch(coords, 256)
     assert np.array_equal(again, pose_g)                                          # deterministic
+
+
+def test_error_paths_and_limits():
+    """C-ABI status codes: oversized grids are refused before any launch, a single hypothesis works, the largest
+    supported grid (16384 cells) fits in LDS."""
+    import dsacstar
+    from crossloc_amd import _lib
+    big = torch.zeros((1, 3, 129, 128), dtype=torch.float32, device="cuda")          # 16512 cells > 16384
+    out = torch.zeros((1, 4, 4), dtype=torch.float32, device="cuda")
+    with pytest.raises(_lib.XlError, match="grid too large"):
+        dsacstar.forward_rgb_batch(big, out, 8, 10.0, 480.0, 512.0, 516.0, 100.0, 100.0, 8, max_tries=10)
+    sc = synth.make_scene(3, noise=0.0, outlier_ratio=0.0, Ho=120, Wo=116)            # 13920 cells, 167 KB of planes
+    co = torch.from_numpy(sc["coords"])[None].cuda()
+    with pytest.raises(_lib.XlError):                                                 # exceeds the 160 KB LDS
+        dsacstar.forward_rgb_batch(co, out, 8, 10.0, 480.0, sc["ppx"], sc["ppy"], 100.0, 100.0, 8)
+    sc = synth.make_scene(3, noise=0.0, outlier_ratio=0.0, Ho=100, Wo=128)            # 12800 cells fit
+    co = torch.from_numpy(sc["coords"])[None].cuda()
+    dsacstar.forward_rgb_batch(co, out, 1, 10.0, 480.0, sc["ppx"], sc["ppy"], 100.0, 100.0, 8)      # one hypothesis
+    torch.cuda.synchronize()
+    t, r = synth.pose_error(sc["pose"], out[0].cpu().numpy())
+    assert t < 1e-2 and r < 1e-2
+
+
+def test_split_and_fused_launch_forms_agree(oracle):
+    """Small batches use the split launch (S workgroups per image), large ones the fused kernel: same bits."""
+    coords, _, _ = synth.make_batch(4242, 3, noise=0.5, outlier_ratio=0.3)
+    small, dsmall = _gpu_batch(coords, 64, image0=7)                                   # 3 images -> split form
+    rep = np.concatenate([coords] * 100)[:260]                                         # 260 images -> fused form
+    # image keys differ per batch row; compare rows that carry the same (image index, data)
+    big, dbig = _gpu_batch(np.ascontiguousarray(rep), 64, image0=7)
+    for b in range(3):
+        assert np.array_equal(small[b], big[b]) and np.array_equal(dsmall["scores"][b], dbig["scores"][b])
+        _assert_same(oracle, coords[b], small, dsmall, b, 64, image=7 + b)
