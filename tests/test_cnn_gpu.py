@@ -247,3 +247,17 @@ def test_large_batches_are_split_transparently():
         finally:
             net.num_gn_channel = old
     assert torch.equal(full, parts)
+
+
+@pytest.mark.parametrize("H,W,gray", [(100, 140, False), (72, 88, True), (57, 91, False)])
+def test_odd_image_sizes_and_grayscale(H, W, gray):
+    """Sizes that are not multiples of 8 (three stride-2 convs: ceil division each time) and 1-channel input."""
+    net = networks.TransPoseNet(MEAN, False, gray, 1, 0, 3, 1)
+    net.load_state_dict(seeded_state_dict(net, seed=29))
+    x = torch.rand(2, 1 if gray else 3, H, W, generator=torch.Generator().manual_seed(H))
+    ref = cnn_oracle.transposenet_forward(net.state_dict(), x, 0, 1, 0)
+    with torch.no_grad():
+        y = net.cuda()(x.cuda()).cpu()
+    assert y.shape == ref.shape
+    _close(y[:, :3] - MEAN[None, :, None, None], ref[:, :3] - MEAN[None, :, None, None], 1e-3)
+    assert torch.allclose(y[:, 3], ref[:, 3], rtol=2e-3)
