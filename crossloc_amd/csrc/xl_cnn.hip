@@ -20,6 +20,8 @@
 // fp32 end to end: the MFMA used is bitwise an fmaf chain, so parity with the fp32 reference is at
 // summation-order level (tests compare against torch fp32 on CPU and the golden vectors).
 #include <hip/hip_runtime.h>
+#include <map>
+#include <vector>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -87,19 +89,20 @@ void conv1_direct_kernel(const float *__restrict__ in, const float *__restrict__
 
 // ---------------------------------------------------------------------------------------------- igemm conv
 
-constexpr int kBM = 128, kBK = 32, kPitch = 36;   // LDS row pitch in floats (32 + 4): conflict-free b128 reads
+constexpr int kWaitVm0 = 0x0F70;                   // s_waitcnt vmcnt(0) (expcnt / lgkmcnt fields left at their maxima)
+constexpr int kBK = 32;                            // K-step; one LDS tile row = 32 floats (128 B)
 
 struct ConvArgs {
     const float *in; const float *w; const float *bias; float *out;
     int B, Hi, Wi, Cin, Ho, Wo, Cout, ldIn, ldOut;
     int M, K, nbm, nbn;
-    unsigned inBytes, wBytes;       // extents for the buffer descriptors (hardware bounds check)
-    int dbg;                        // diagnostics only (XL_CONV_DBG): 1 = skip global loads, 2 = skip LDS refill
+    unsigned inBytes, wBytes, outBytes;   // extents for the buffer descriptors (hardware bounds check)
     int accumulate;                 // epilogue: out += result (XL_CONV_ACCUMULATE)
     // fused GroupNorm statistics of the OUTPUT (forward only): fp64 partial sums per (image, tile-within-image, group)
     double *stats; int HW, G, cpg, nchunks;
     // MODE 2 (stride-2 data gradient, one parity class of result pixels per launch)
     int py, px, Hj, Wj, ntaps; unsigned tapList;
+    long long *clk;                 // diagnostics (XL_CONV_CLK=1): per-workgroup shader-clock phase timings, else NULL
 };
 
 // bijective XCD remap: block b runs on XCD b%8; give each XCD a contiguous run of tiles
@@ -110,17 +113,11 @@ __device__ __forceinline__ int xcd_remap(int b, int nwg)
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
 }
 
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff)
-{
-    u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, (int)soff, 0);
-    return __builtin_bit_cast(f32x4, v);
-}
-
-// Global->register loads go through buffer descriptors: a padding tap gets an out-of-range offset and the
-// hardware returns zeros (no branch, no select on the data); destinations and offsets never alias, so the
-// eight loads of a K-step stay in flight together under the MFMAs of the previous one.
+// Tiles go global -> LDS directly (buffer_load ... lds through buffer descriptors): no register staging and no
+// ds_write phase.  A padding tap gets an out-of-range offset and the hardware writes zeros (no branch, no select on
+// the data).  LDS rows are unpadded (32 floats = 128 B = 8 lanes x 16 B, the lane-linear DMA destination); the 16-byte
+// slots of a row are XOR-swizzled by (row>>1)&7, applied to the SOURCE offset of the lane that fills a slot and again
+// to the fragment reads, which keeps ds_read_b128 conflict-free without padding.
 // MODE 0: forward convolution.  MODE 1: data gradient — `in` is dY [B,Hi,Wi,Cin] (the forward OUTPUT, Cin = forward
 // Cout), the result is dX [B,Ho,Wo,Cout] (forward input); output pixel (iy,ix) gathers dY[(iy+PAD-ky)/S][(ix+PAD-kx)/S]
 // for the taps whose offset is divisible by the forward stride S (others are zero-filled by the bounds check).
@@ -131,15 +128,16 @@ template <int KS, int STRIDE, int BN, int CIN, int MODE = 0, int BM = 128>   // 
 __global__ __launch_bounds__(256, 2)
 void igemm_conv_kernel(ConvArgs a)
 {
-    constexpr int PAD = (KS == 3) ? 1 : 0;
+    constexpr int PAD = KS / 2;
     constexpr int NJ = BN / 64;                 // 32-wide MFMA tiles per wave along N
     constexpr int BROWS = BN / 32;              // B-tile rows loaded per thread
     constexpr int AROWS = BM / 32;              // A-tile rows loaded per thread
     constexpr int TI = BM / 64;                 // 32-high MFMA tiles per wave along M
     constexpr unsigned OOB = 0x80000000u;       // > any legal extent: forces the zero-fill path
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *As = smem;                           // [2][BM][kPitch]
-    float *Bs = smem + 2 * BM * kPitch;         // [2][BN][kPitch]
+    float *As = smem;                           // [2][BM][32]
+    float *Bs = smem + 2 * BM * kBK;            // [2][BN][32]
+    if (CIN != 0) a.Cin = CIN, a.K = KS * KS * CIN;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -152,8 +150,10 @@ void igemm_conv_kernel(ConvArgs a)
     const __amdgpu_buffer_rsrc_t srdA = __builtin_amdgcn_make_buffer_rsrc((void *)a.in, 0, (int)a.inBytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t srdB = __builtin_amdgcn_make_buffer_rsrc((void *)a.w, 0, (int)a.wBytes, 0x00020000);
 
-    // ---- per-thread load coordinates: 4 A rows (and BROWS B rows) at float4 column kq
-    const int lrow = tid >> 3, kq = tid & 7;
+    // ---- per-thread load coordinates: AROWS A rows (and BROWS B rows); this lane fills physical slot tid&7 of its
+    // rows with the logical k-slot kq
+    const int lrow = tid >> 3;
+    const int kq = (tid & 7) ^ ((lrow >> 1) & 7);
     unsigned aOff[AROWS];                           // byte offset of (n, iy0, ix0, 4*kq); wraps for padding rows
     int aIy[AROWS], aIx[AROWS];
     const int HoWo = (MODE == 2) ? a.Hj * a.Wj : a.Ho * a.Wo;
@@ -186,8 +186,9 @@ void igemm_conv_kernel(ConvArgs a)
 #pragma unroll
     for (int p = 0; p < BROWS; ++p) bOff[p] = (unsigned)((n0 + lrow + 32 * p) * a.K + 4 * kq) * 4u;
 
-    f32x4 ra[AROWS], rb[BROWS];
-    auto load_global = [&](int kk) {
+    typedef __attribute__((address_space(3))) void lds_void;
+    // Source offsets of K-step kk: A rows (per lane, OOB for padding taps) and the weight K position (scalar)
+    auto tile_offsets = [&](int kk, unsigned (&voff)[AROWS], unsigned &kbytes) {
         // K order is (channel chunk of 32, tap, channel-in-chunk): the 9 taps of one chunk run back to back, so
         // the shifted re-reads of the same input pixels hit L1/L2 instead of going back to HBM 9 times
         int kbase = kk * kBK;
@@ -200,6 +201,7 @@ void igemm_conv_kernel(ConvArgs a)
             chunk = kk / (KS * KS);
             tap = kk - chunk * (KS * KS);
         }
+        kbytes = (unsigned)kbase * 4u;
         const int c0 = chunk * kBK;
         const int ky = tap / KS, kx = tap - ky * KS;
         const unsigned tapOff = (unsigned)((ky * a.Wi + kx) * a.ldIn + c0) * 4u;
@@ -207,24 +209,30 @@ void igemm_conv_kernel(ConvArgs a)
         for (int p = 0; p < AROWS; ++p) {
             if constexpr (MODE == 0) {
                 const bool ok = (unsigned)(aIy[p] + ky) < (unsigned)a.Hi && (unsigned)(aIx[p] + kx) < (unsigned)a.Wi;
-                ra[p] = buf_load4(srdA, ok ? aOff[p] + tapOff : OOB, 0);
+                voff[p] = ok ? aOff[p] + tapOff : OOB;
             } else {
                 const int ty = aIy[p] - ky, tx = aIx[p] - kx;
                 const int sy = ty / STRIDE, sx = tx / STRIDE;               // STRIDE is 1 or 2 (shift)
                 const bool ok = ty >= 0 && tx >= 0 && (STRIDE == 1 || (((ty | tx) & 1) == 0)) && sy < a.Hi && sx < a.Wi;
-                ra[p] = buf_load4(srdA, ok ? aOff[p] + (unsigned)((sy * a.Wi + sx) * a.ldIn + c0) * 4u : OOB, 0);
+                voff[p] = ok ? aOff[p] + (unsigned)((sy * a.Wi + sx) * a.ldIn + c0) * 4u : OOB;
             }
         }
-#pragma unroll
-        for (int p = 0; p < BROWS; ++p) rb[p] = buf_load4(srdB, bOff[p], (unsigned)kbase * 4u);
     };
-    auto store_lds = [&](int buf) {
-        float *Ad = As + buf * BM * kPitch + lrow * kPitch + 4 * kq;
+    // one wave instruction moves 8 rows x 128 B; destination = wave-uniform base (M0) + lane*16
+    auto issue_dma = [&](const unsigned (&voff)[AROWS], unsigned kbytes, int buf) {
 #pragma unroll
-        for (int p = 0; p < AROWS; ++p) *reinterpret_cast<f32x4 *>(Ad + 32 * p * kPitch) = ra[p];
-        float *Bd = Bs + buf * BN * kPitch + lrow * kPitch + 4 * kq;
+        for (int p = 0; p < AROWS; ++p)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srdA, (lds_void *)(As + (buf * BM + 32 * p + 8 * wave) * kBK), 16,
+                                                     (int)voff[p], 0, 0, 0);
 #pragma unroll
-        for (int p = 0; p < BROWS; ++p) *reinterpret_cast<f32x4 *>(Bd + 32 * p * kPitch) = rb[p];
+        for (int p = 0; p < BROWS; ++p)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srdB, (lds_void *)(Bs + (buf * BN + 32 * p + 8 * wave) * kBK), 16,
+                                                     (int)bOff[p], (int)kbytes, 0, 0);
+    };
+    auto load_dma = [&](int kk, int buf) {
+        unsigned voff[AROWS], kbytes;
+        tile_offsets(kk, voff, kbytes);
+        issue_dma(voff, kbytes, buf);
     };
 
     f32x16 acc[TI][NJ];
@@ -235,65 +243,108 @@ void igemm_conv_kernel(ConvArgs a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    long long tc0 = 0, tw0 = 0, tc1 = 0, tc2 = 0;
+    if (a.clk) { tc0 = clock64(); tw0 = wall_clock64(); }
     const int nk = (MODE == 2) ? a.ntaps * (a.Cin / kBK) : a.K / kBK;
-    load_global(0);
-    store_lds(0);
+    load_dma(0, 0);
+    load_dma(1, 1);                                   // (nk == 1: an unused tile, drained with the others below)
+    // An LDS-DMA is ordered for other waves' ds_reads only by the issuing wave's vmcnt wait followed by a barrier;
+    // the workgroup fence of __syncthreads() waits for LDS operations (lgkmcnt) only, so the vmcnt(0) is explicit.
+    __builtin_amdgcn_s_waitcnt(kWaitVm0);
     __syncthreads();
+    if (a.clk) tc1 = clock64();
 
-    const int fragRow = lane & 31, fragK = (lane >> 5) * 4;
-    const float *Afrag = As + (wm * (BM / 2) + fragRow) * kPitch + fragK;
-    const float *Bfrag = Bs + (wn * (BN / 2) + fragRow) * kPitch + fragK;
+    // MFMA 32x32x2: lane l multiplies row l&31 at k = l>>5.  One ds_read_b128 per 32-row fragment holds the four
+    // k-values 4*slot..4*slot+3 of logical slot 2c + (l>>5) of chunk c; the e-th element feeds the e-th MFMA.
+    const int fragRow = lane & 31, khalf = lane >> 5;
+    const int swz = (fragRow >> 1) & 7;
+    const float *Afrag = As + (wm * (BM / 2) + fragRow) * kBK;
+    const float *Bfrag = Bs + (wn * (BN / 2) + fragRow) * kBK;
+    int cOff[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) cOff[c] = ((2 * c + khalf) ^ swz) * 4;
+    // Fragments ping-pong between two register sets: chunk c+1 is read from LDS while chunk c multiplies, across
+    // K-steps too (the last chunk of a step prefetches the first fragments of the next one from the other buffer).
+    f32x4 fa[2][TI], fb[2][NJ];
+    auto read_frags = [&](int set, int buf, int c) {
+#pragma unroll
+        for (int i = 0; i < TI; ++i) fa[set][i] = *reinterpret_cast<const f32x4 *>(Afrag + (buf * BM + i * 32) * kBK + cOff[c]);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) fb[set][j] = *reinterpret_cast<const f32x4 *>(Bfrag + (buf * BN + j * 32) * kBK + cOff[c]);
+    };
+    auto multiply = [&](int set) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][i][e], fb[set][j][e], acc[i][j], 0, 0, 0);
+    };
+    read_frags(0, 0, 0);
+    // One barrier per K-step, placed before its LAST chunk: by then every wave has issued all its reads of the
+    // current buffer (so the DMA of step kk+2 may overwrite it) and, after the vmcnt(0) of the fence, the tile of
+    // step kk+1 has landed in the other buffer (so the cross-step prefetch may read it).  Each DMA has a full
+    // K-step (4096 MFMA cycles) to land.  Within a chunk the order is pinned to [first MFMA] [fragment reads of the
+    // next chunk] [remaining MFMAs]: the reads start early in the shadow of the MFMA stream and are the only LDS
+    // operations outstanding when the next chunk needs them.  The loop body is branch-free (a branch would split
+    // the scheduling region): the two DMAs past the last K-step fetch out-of-range / unused data into a buffer
+    // nobody reads, and are drained before the epilogue reuses the LDS.
+    constexpr int NM = 4 * TI * NJ, ND = TI + NJ, NV = AROWS + BROWS;
     for (int kk = 0; kk < nk; ++kk) {
         const int buf = kk & 1;
-        if (kk + 1 < nk && !(a.dbg & 1)) load_global(kk + 1);
-        const float *Ab = Afrag + buf * BM * kPitch;
-        const float *Bb = Bfrag + buf * BN * kPitch;
-        // fragments ping-pong between two register sets: chunk c+1 is read from LDS while chunk c multiplies.
-        // The sched_group_barrier sequence pins that order (hipcc otherwise re-merges the two sets and exposes
-        // the LDS latency once per chunk).
-        f32x4 fa[2][TI], fb[2][NJ];
-#pragma unroll
-        for (int i = 0; i < TI; ++i) fa[0][i] = *reinterpret_cast<const f32x4 *>(Ab + i * 32 * kPitch);
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) fb[0][j] = *reinterpret_cast<const f32x4 *>(Bb + j * 32 * kPitch);
-        auto chunk = [&](auto cc) {
-            constexpr int c = decltype(cc)::value;
-            constexpr int cur = c & 1, nxt = cur ^ 1;
-            if constexpr (c < 3) {
-                if (!(a.dbg & 8)) {
-#pragma unroll
-                for (int i = 0; i < TI; ++i) fa[nxt][i] = *reinterpret_cast<const f32x4 *>(Ab + i * 32 * kPitch + (c + 1) * 8);
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) fb[nxt][j] = *reinterpret_cast<const f32x4 *>(Bb + j * 32 * kPitch + (c + 1) * 8);
-                } else {
-#pragma unroll
-                for (int i = 0; i < TI; ++i) fa[nxt][i] = fa[cur][i];
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) fb[nxt][j] = fb[cur][j];
-                }
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int i = 0; i < TI; ++i)
-#pragma unroll
-                    for (int j = 0; j < NJ; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i][e], fb[cur][j][e], acc[i][j], 0, 0, 0);
-        };
-        chunk(std::integral_constant<int, 0>{});
-        chunk(std::integral_constant<int, 1>{});
-        chunk(std::integral_constant<int, 2>{});
-        chunk(std::integral_constant<int, 3>{});
-        __builtin_amdgcn_sched_group_barrier(0x100, 2 * (TI + NJ), 0);    // chunk 0 + chunk 1 fragments
-        __builtin_amdgcn_sched_group_barrier(0x008, 4 * TI * NJ, 0);      // chunk 0 MFMAs
-        __builtin_amdgcn_sched_group_barrier(0x100, TI + NJ, 0);          // chunk 2 fragments
-        __builtin_amdgcn_sched_group_barrier(0x008, 4 * TI * NJ, 0);      // chunk 1 MFMAs
-        __builtin_amdgcn_sched_group_barrier(0x100, TI + NJ, 0);          // chunk 3 fragments
-        __builtin_amdgcn_sched_group_barrier(0x008, 8 * TI * NJ, 0);      // chunk 2 + 3 MFMAs
-        if (kk + 1 < nk && !(a.dbg & 2)) store_lds(buf ^ 1);
-        if (!(a.dbg & 4)) __syncthreads();
+        unsigned voffN[AROWS], kbytesN;                // offsets of step kk+2, computed under the MFMAs of this one
+        tile_offsets(kk + 2, voffN, kbytesN);
+        read_frags(1, buf, 1);
+        multiply(0);
+        read_frags(0, buf, 2);
+        multiply(1);
+        read_frags(1, buf, 3);
+        multiply(0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, ND, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, ND, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, ND, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, NM - 1, 0);
+        __builtin_amdgcn_sched_barrier(0);            // nothing moves across: the MFMAs are not ordered by the fence
+        __builtin_amdgcn_s_waitcnt(kWaitVm0);         // tile kk+1 (issued one K-step ago) has landed
+        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+        issue_dma(voffN, kbytesN, buf);
+        read_frags(0, buf ^ 1, 0);
+        multiply(1);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, ND, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if constexpr (NV > 2) {
+            __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        }
+        if constexpr (NV > 4) {
+            __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        }
+        if constexpr (NV > 6) {
+            __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        }
     }
+    __builtin_amdgcn_s_waitcnt(kWaitVm0);             // drain the trailing DMAs before the epilogue reuses the LDS
+    __syncthreads();
 
+    if (a.clk) tc2 = clock64();
     // ---- epilogue: bias + store. C layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     const int col = lane & 31, rhalf = (lane >> 5) * 4;
     // fused GroupNorm statistics: a BM-row tile touches at most two images (HW >= BM); `split` = first tile row
@@ -305,36 +356,59 @@ void igemm_conv_kernel(ConvArgs a)
     float ps[2][NJ], pss[2][NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) { ps[0][j] = ps[1][j] = 0.f; pss[0][j] = pss[1][j] = 0.f; }
+    // The accumulate / statistics switches are hoisted out of the element loop as compile-time tags: a per-element
+    // "maybe load" makes the compiler wait for every store before the next element (64 serialized round trips).
+    // Branch-free: out-of-range rows / columns get an out-of-range buffer offset (stores dropped, loads return 0).
+    // With branches the compiler must assume a load pending at every block entry and emits vmcnt(0) before each
+    // store; loads and stores share that counter, so every store would wait for the one before it.
+    const __amdgpu_buffer_rsrc_t srdO = __builtin_amdgcn_make_buffer_rsrc((void *)a.out, 0, (int)a.outBytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srdBias = __builtin_amdgcn_make_buffer_rsrc((void *)a.bias, 0, a.bias ? a.Cout * 4 : 0, 0x00020000);
+    float bv[NJ];
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const int n = n0 + wn * (BN / 2) + j * 32 + col;
-        if (n >= a.Cout) continue;                      // narrow outputs (Cout < BN): columns beyond Cout are padding
-        const float bv = a.bias ? a.bias[n] : 0.f;
+    for (int j = 0; j < NJ; ++j)
+        bv[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srdBias, (n0 + wn * (BN / 2) + j * 32 + col) * 4, 0, 0));
+    auto store_tile = [&](auto accTag, auto statTag) {
+        constexpr bool ACC = decltype(accTag)::value, STATS = decltype(statTag)::value;
 #pragma unroll
-        for (int i = 0; i < TI; ++i) {
+        for (int j = 0; j < NJ; ++j) {
+            const int n = n0 + wn * (BN / 2) + j * 32 + col;
+            const bool colOk = n < a.Cout;              // narrow outputs (Cout < BN): columns beyond Cout are padding
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + rhalf;
-                const int m = m0 + row;
-                if (m < a.M) {
-                    long long pix = m;
+            for (int i = 0; i < TI; ++i) {
+                unsigned off[16];
+                float old[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + rhalf;
+                    const int m = m0 + row;
+                    int pix = m;
                     if constexpr (MODE == 2) {
                         const int nn = m / HoWo;
                         const int rem = m - nn * HoWo;
                         const int jy = rem / a.Wj, jx = rem - jy * a.Wj;
-                        pix = ((long long)nn * a.Ho + 2 * jy + a.py) * a.Wo + 2 * jx + a.px;
+                        pix = (nn * a.Ho + 2 * jy + a.py) * a.Wo + 2 * jx + a.px;
                     }
-                    float *o = a.out + pix * a.ldOut + n;
-                    const float v = acc[i][j][r] + bv;
-                    *o = a.accumulate ? *o + v : v;
-                    if (doStats) {
-                        const int sl = row >= split ? 1 : 0;
-                        ps[sl][j] += v; pss[sl][j] += v * v;
+                    off[r] = (colOk && m < a.M) ? (unsigned)(pix * a.ldOut + n) * 4u : OOB;
+                    if constexpr (ACC) old[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srdO, (int)off[r], 0, 0));
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[i][j][r] + bv[j];
+                    if constexpr (STATS) {
+                        const int row = wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + rhalf;
+                        const float vs = (off[r] != OOB) ? v : 0.f;
+                        if (row >= split) { ps[1][j] += vs; pss[1][j] += vs * vs; }
+                        else { ps[0][j] += vs; pss[0][j] += vs * vs; }
                     }
+                    if constexpr (ACC) v = old[r] + v;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), srdO, (int)off[r], 0, 0);
                 }
             }
         }
-    }
+    };
+    if (a.accumulate) store_tile(std::true_type{}, std::false_type{});       // gradients only: never with statistics
+    else if (doStats) store_tile(std::false_type{}, std::true_type{});
+    else store_tile(std::false_type{}, std::false_type{});
     if (doStats) {
         double *sS = reinterpret_cast<double *>(smem);              // [wm][BN cols][slot][2]; tiles are dead now
 #pragma unroll
@@ -370,6 +444,14 @@ void igemm_conv_kernel(ConvArgs a)
                 }
             }
         }
+    }
+    if (a.clk && tid == 0) {
+        long long *c = a.clk + (long long)blockIdx.x * 8;
+        unsigned hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        c[0] = tc0; c[1] = tw0; c[2] = tc1; c[3] = tc2; c[4] = clock64(); c[5] = wall_clock64(); c[6] = hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(hw));
+        c[7] = hw;
     }
 }
 
@@ -641,16 +723,15 @@ int launch_igemm(const xl_op &op, hipStream_t st, int py = 0, int px = 0)
     a.nbm = (a.M + BM - 1) / BM; a.nbn = (op.Cout + BN - 1) / BN;   // weight rows past Cout read as zero (bounds check)
     const long long inBytes = (((long long)op.B * op.Hi * op.Wi - 1) * op.ld_in + op.Cin) * 4;
     const long long wBytes = (long long)op.Cout * a.K * 4;
-    if (inBytes >= 0x7fffffffLL || wBytes >= 0x7fffffffLL) {
-        snprintf(g_err, sizeof(g_err), "conv input of %lld bytes exceeds 32-bit buffer addressing; split the batch", inBytes);
+    const long long outBytes = (((long long)op.B * op.Ho * op.Wo - 1) * op.ld_out + op.Cout) * 4;
+    if (inBytes >= 0x7fffffffLL || wBytes >= 0x7fffffffLL || outBytes >= 0x7fffffffLL) {
+        snprintf(g_err, sizeof(g_err), "conv tensors of %lld / %lld bytes exceed 32-bit buffer addressing; split the batch", inBytes, outBytes);
         return XL_ERR_ARG;
     }
-    a.inBytes = (unsigned)inBytes; a.wBytes = (unsigned)wBytes;
-    static const int dbgFlags = getenv("XL_CONV_DBG") ? atoi(getenv("XL_CONV_DBG")) : 0;
-    static const int ldsPad = getenv("XL_CONV_LDS_PAD") ? atoi(getenv("XL_CONV_LDS_PAD")) : 0;
-    a.dbg = dbgFlags;
+    a.inBytes = (unsigned)inBytes; a.wBytes = (unsigned)wBytes; a.outBytes = (unsigned)outBytes;
     a.accumulate = (op.flags & XL_CONV_ACCUMULATE) ? 1 : 0;
-    const size_t lds = sizeof(float) * 2 * (BM + BN) * kPitch + (size_t)ldsPad;
+    if (a.accumulate && a.stats) return XL_ERR_ARG;
+    const size_t lds = sizeof(float) * 2 * (BM + BN) * kBK;
     static bool configured = false;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(igemm_conv_kernel<KS, STRIDE, BN, CIN, MODE, BM>),
@@ -658,7 +739,33 @@ int launch_igemm(const xl_op &op, hipStream_t st, int py = 0, int px = 0)
         if (e != hipSuccess) { snprintf(g_err, sizeof(g_err), "hipFuncSetAttribute: %s", hipGetErrorString(e)); return XL_ERR_HIP; }
         configured = true;
     }
+    static const bool clkDbg = getenv("XL_CONV_CLK") != nullptr;
+    a.clk = nullptr;
+    const int nwg = a.nbm * a.nbn;
+    if (clkDbg) hipMalloc(&a.clk, sizeof(long long) * 8 * nwg);
     hipLaunchKernelGGL((igemm_conv_kernel<KS, STRIDE, BN, CIN, MODE, BM>), dim3(a.nbm * a.nbn), dim3(256), lds, st, a);
+    if (clkDbg) {
+        hipStreamSynchronize(st);
+        std::vector<long long> h(8 * (size_t)nwg);
+        hipMemcpy(h.data(), a.clk, sizeof(long long) * 8 * nwg, hipMemcpyDeviceToHost);
+        hipFree(a.clk);
+        double pro = 0, loop = 0, epi = 0, tot = 0, wall = 0;
+        long long wmin = h[1], wmax = h[5];
+        std::map<long long, int> perCu;
+        for (int i = 0; i < nwg; ++i) {
+            const long long *c = &h[8 * (size_t)i];
+            pro += c[2] - c[0]; loop += c[3] - c[2]; epi += c[4] - c[3]; tot += c[4] - c[0]; wall += c[5] - c[1];
+            if (c[1] < wmin) wmin = c[1];
+            if (c[5] > wmax) wmax = c[5];
+            // HW_ID: cu_id bits 8-11, sh 12, se 13-15 ; XCC id low bits
+            perCu[((c[7] & 15) << 16) | ((c[6] >> 8) & 0xff)]++;
+        }
+        int cmin = 1 << 30, cmax = 0;
+        for (auto &kv : perCu) { if (kv.second < cmin) cmin = kv.second; if (kv.second > cmax) cmax = kv.second; }
+        fprintf(stderr, "[clk] wgs %d nk %d: prologue %.0f loop %.0f (%.1f/step) epilogue %.0f total %.0f ticks; clock %.1f MHz; kernel span %.3f ms; CUs seen %zu, tiles per CU %d..%d\n",
+                nwg, a.K / kBK, pro / nwg, loop / nwg, loop / nwg / (a.K / kBK), epi / nwg, tot / nwg, tot / wall * 100.0,
+                (wmax - wmin) / 1e5, perCu.size(), cmin, cmax);
+    }
     return XL_OK;
 }
 
@@ -682,26 +789,28 @@ int run_conv(const xl_op &op, hipStream_t st)
     }
     const bool small = (op.reserved_i == 64);          // 64-row tiles: the host asks for them when 128-row tiles
                                                         // would leave most of the 256 CUs idle (small batches)
+#define XL_FWD(KS, S, BN, CIN, BM) launch_igemm<KS, S, BN, CIN, 0, BM>(op, st)
     if (op.ksize == 3 && op.stride == 1) {
         if (small) {
-            if (wide && op.Cin == 512) return launch_igemm<3, 1, 128, 512, 0, 64>(op, st);
-            return wide ? launch_igemm<3, 1, 128, 0, 0, 64>(op, st) : launch_igemm<3, 1, 64, 0, 0, 64>(op, st);
+            if (wide && op.Cin == 512) return XL_FWD(3, 1, 128, 512, 64);
+            return wide ? XL_FWD(3, 1, 128, 0, 64) : XL_FWD(3, 1, 64, 0, 64);
         }
-        if (wide && op.Cin == 512) return launch_igemm<3, 1, 128, 512>(op, st);      // 78 % of the forward FLOPs
-        return wide ? launch_igemm<3, 1, 128, 0>(op, st) : launch_igemm<3, 1, 64, 0>(op, st);
+        if (wide && op.Cin == 512) return XL_FWD(3, 1, 128, 512, 128);      // 78 % of the forward FLOPs
+        return wide ? XL_FWD(3, 1, 128, 0, 128) : XL_FWD(3, 1, 64, 0, 128);
     }
     if (op.ksize == 3 && op.stride == 2) {
-        if (small) return wide ? launch_igemm<3, 2, 128, 0, 0, 64>(op, st) : launch_igemm<3, 2, 64, 0, 0, 64>(op, st);
-        return wide ? launch_igemm<3, 2, 128, 0>(op, st) : launch_igemm<3, 2, 64, 0>(op, st);
+        if (small) return wide ? XL_FWD(3, 2, 128, 0, 64) : XL_FWD(3, 2, 64, 0, 64);
+        return wide ? XL_FWD(3, 2, 128, 0, 128) : XL_FWD(3, 2, 64, 0, 128);
     }
     if (op.ksize == 1 && op.stride == 1) {
         if (small) {
-            if (wide && op.Cin == 512) return launch_igemm<1, 1, 128, 512, 0, 64>(op, st);
-            return wide ? launch_igemm<1, 1, 128, 0, 0, 64>(op, st) : launch_igemm<1, 1, 64, 0, 0, 64>(op, st);
+            if (wide && op.Cin == 512) return XL_FWD(1, 1, 128, 512, 64);
+            return wide ? XL_FWD(1, 1, 128, 0, 64) : XL_FWD(1, 1, 64, 0, 64);
         }
-        if (wide && op.Cin == 512) return launch_igemm<1, 1, 128, 512>(op, st);
-        return wide ? launch_igemm<1, 1, 128, 0>(op, st) : launch_igemm<1, 1, 64, 0>(op, st);
+        if (wide && op.Cin == 512) return XL_FWD(1, 1, 128, 512, 128);
+        return wide ? XL_FWD(1, 1, 128, 0, 128) : XL_FWD(1, 1, 64, 0, 128);
     }
+#undef XL_FWD
     return XL_ERR_UNSUPPORTED;
 }
 
