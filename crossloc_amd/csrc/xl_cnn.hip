@@ -219,11 +219,13 @@ void igemm_conv_kernel(ConvArgs a)
         }
     };
     // one wave instruction moves 8 rows x 128 B; destination = wave-uniform base (M0) + lane*16
-    auto issue_dma = [&](const unsigned (&voff)[AROWS], unsigned kbytes, int buf) {
+    auto issue_dma_a = [&](const unsigned (&voff)[AROWS], int buf) {
 #pragma unroll
         for (int p = 0; p < AROWS; ++p)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(srdA, (lds_void *)(As + (buf * BM + 32 * p + 8 * wave) * kBK), 16,
                                                      (int)voff[p], 0, 0, 0);
+    };
+    auto issue_dma_b = [&](unsigned kbytes, int buf) {
 #pragma unroll
         for (int p = 0; p < BROWS; ++p)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(srdB, (lds_void *)(Bs + (buf * BN + 32 * p + 8 * wave) * kBK), 16,
@@ -232,7 +234,8 @@ void igemm_conv_kernel(ConvArgs a)
     auto load_dma = [&](int kk, int buf) {
         unsigned voff[AROWS], kbytes;
         tile_offsets(kk, voff, kbytes);
-        issue_dma(voff, kbytes, buf);
+        issue_dma_a(voff, buf);
+        issue_dma_b(kbytes, buf);
     };
 
     f32x16 acc[TI][NJ];
@@ -272,14 +275,16 @@ void igemm_conv_kernel(ConvArgs a)
 #pragma unroll
         for (int j = 0; j < NJ; ++j) fb[set][j] = *reinterpret_cast<const f32x4 *>(Bfrag + (buf * BN + j * 32) * kBK + cOff[c]);
     };
+    auto multiply_e = [&](int set, int e) {
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][i][e], fb[set][j][e], acc[i][j], 0, 0, 0);
+    };
     auto multiply = [&](int set) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int i = 0; i < TI; ++i)
-#pragma unroll
-                for (int j = 0; j < NJ; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][i][e], fb[set][j][e], acc[i][j], 0, 0, 0);
+        for (int e = 0; e < 4; ++e) multiply_e(set, e);
     };
     read_frags(0, 0, 0);
     // One barrier per K-step, placed before its LAST chunk: by then every wave has issued all its reads of the
@@ -312,34 +317,19 @@ void igemm_conv_kernel(ConvArgs a)
         __builtin_amdgcn_s_waitcnt(kWaitVm0);         // tile kk+1 (issued one K-step ago) has landed
         __syncthreads();
         __builtin_amdgcn_sched_barrier(0);
-        issue_dma(voffN, kbytesN, buf);
+        // last chunk: MFMAs first, then the DMA issue and the cross-step fragment prefetch in their shadow
+        // (ALU may move across the fences, MFMA / LDS / VMEM instructions may not)
+        multiply_e(1, 0);
+        __builtin_amdgcn_sched_barrier(0x6);
+        issue_dma_a(voffN, buf);
+        __builtin_amdgcn_sched_barrier(0x6);
+        multiply_e(1, 1);
+        __builtin_amdgcn_sched_barrier(0x6);
+        issue_dma_b(kbytesN, buf);
         read_frags(0, buf ^ 1, 0);
-        multiply(1);
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, ND, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        if constexpr (NV > 2) {
-            __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        }
-        if constexpr (NV > 4) {
-            __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        }
-        if constexpr (NV > 6) {
-            __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        }
+        __builtin_amdgcn_sched_barrier(0x6);
+        multiply_e(1, 2);
+        multiply_e(1, 3);
     }
     __builtin_amdgcn_s_waitcnt(kWaitVm0);             // drain the trailing DMAs before the epilogue reuses the LDS
     __syncthreads();
