@@ -33,7 +33,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md: fp
 # HBM-side bytes per launch of the dominant kernel from rocprofv3 PMC passes (profiles/r1_conv512_pmc.csv):
 # FETCH_SIZE (KB, doubled per the gfx950 note of MI355X_MICROARCH.md §HBM) + WRITE_SIZE (KB), batch 24.
 # PMC counters cannot be read from inside the process, so the profiled value is recorded per batch size.
-CONV512_TRAFFIC_BYTES = {24: (692294 * 2 + 259200) * 1024}
+CONV512_TRAFFIC_BYTES = {24: (755733 * 2 + 259200) * 1024}
 FWD_GFLOP_PER_IMAGE = 295.41        # SURVEY.md §8(d), single-task net, 480x720
 
 
