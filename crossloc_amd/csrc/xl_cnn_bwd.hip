@@ -32,6 +32,14 @@ __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t rsrc, unsigned
 
 // ---------------------------------------------------------------------------------------------- wgrad
 
+// bijective XCD remap: block b runs on XCD b%8; give each XCD a contiguous run of work items
+__device__ __forceinline__ int xcd_remap(int b, int nwg)
+{
+    const int q = nwg >> 3, r = nwg & 7;
+    const int xcd = b & 7, local = b >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+}
+
 struct WgradArgs {
     const float *x; const float *dy; float *partial;
     int B, Hi, Wi, Cin, Ho, Wo, Cout, ldX, ldY, ksize, stride;
@@ -41,27 +49,52 @@ struct WgradArgs {
 
 // tile BO (output channels) x BC (input channels) of ONE tap; K = output pixels of this split.
 // waves WO x WC, wave tile (BO/WO) x (BC/WC) = TI x TJ MFMA tiles of 32x32.
+// Both operand tiles are [pixel][channel] slices of dY / X, i.e. already K-major with the channel contiguous: they go
+// global -> LDS by DMA (buffer_load ... lds, lane-linear = the natural row-major tile; out-of-range pixels and padding
+// taps are zero-filled by the bounds check).  MFMA 32x32x2 takes ONE k per lane, so a lane cannot vectorise its
+// fragment along k; it reads TI (TJ) CONSECUTIVE channels instead and feeds them to TI (TJ) different MFMAs: MFMA
+// tile i of the wave holds the interleaved rows {TI*r + i} (columns {TJ*c + j}) — one ds_read_b64 per operand and
+// k-pair instead of two ds_read_b32, and float2 stores in the epilogue.  The K-loop has the same shape as the
+// forward kernel's: double-buffered, one barrier per K-step placed before its last chunk, the first fragments of
+// the next step prefetched across the step boundary, DMA issue in the shadow of the last chunk's MFMAs.
+template <int N> struct FragT { typedef float type; };
+template <> struct FragT<2> { typedef float type __attribute__((ext_vector_type(2))); };
+template <int N> __device__ __forceinline__ float frag_elem(const typename FragT<N>::type &v, int i);
+template <> __device__ __forceinline__ float frag_elem<1>(const float &v, int) { return v; }
+template <> __device__ __forceinline__ float frag_elem<2>(const FragT<2>::type &v, int i) { return v[i]; }
+
 template <int BO, int BC, int WO, int WC>
 __global__ __launch_bounds__(64 * WO * WC)
 void wgrad_kernel(WgradArgs a)
 {
-    constexpr int NT = 64 * WO * WC;
+    constexpr int NW = WO * WC, NT = 64 * NW;
     constexpr int TI = BO / WO / 32, TJ = BC / WC / 32;
+    static_assert(TI <= 2 && TJ <= 2, "fragment width");
     constexpr int KB = 32;                                  // pixels per K-step
-    constexpr int LA = (KB * BO / 4) / NT, LB = (KB * BC / 4) / NT;   // float4 loads per thread
-    __shared__ __attribute__((aligned(16))) float sA[2][KB * BO];     // dY tile  [pixel][o]
-    __shared__ __attribute__((aligned(16))) float sB[2][KB * BC];     // X tile   [pixel][c]
+    constexpr int LA = (KB * BO / 4) / NT, LB = (KB * BC / 4) / NT;   // DMA instructions per wave and K-step
+    constexpr int kWaitVm0 = 0x0F70;                        // s_waitcnt vmcnt(0)
+    // ONE LDS object: with a second one hipcc waits vmcnt(0) before every ds_read that follows an LDS-DMA
+    __shared__ __attribute__((aligned(16))) float smem[2 * KB * (BO + BC)];
+    float (*sA)[KB * BO] = reinterpret_cast<float (*)[KB * BO]>(smem);                  // dY tile  [pixel][o]
+    float (*sB)[KB * BC] = reinterpret_cast<float (*)[KB * BC]>(smem + 2 * KB * BO);    // X tile   [pixel][c]
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef typename FragT<TI>::type fragA_t;
+    typedef typename FragT<TJ>::type fragB_t;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wo = wave / WC, wc = wave - wo * WC;
     const int PAD = (a.ksize == 3) ? 1 : 0;
 
-    int t = blockIdx.x;
-    const int split = t % a.splits; t /= a.splits;
+    // Workgroup b runs on XCD b%8 (own L2).  Each XCD gets a contiguous run of the (split, tap, ob, cb) order, so
+    // the ~64 workgroups resident on an XCD stream the SAME pixel range (one split) through its L2 — the dY / X rows
+    // are fetched once per XCD and tap group instead of once per workgroup.
+    const int taps = a.ksize * a.ksize;
+    int t = xcd_remap(blockIdx.x, a.splits * taps * a.nbo * a.nbc);
     const int cb = t % a.nbc; t /= a.nbc;
     const int ob = t % a.nbo; t /= a.nbo;
-    const int tap = t;
+    const int tap = t % taps;
+    const int split = t / taps;
     const int ky = tap / a.ksize, kx = tap - ky * a.ksize;
     const int o0 = ob * BO, c0 = cb * BC;
     const int mBeg = split * a.mPerSplit;
@@ -72,37 +105,57 @@ void wgrad_kernel(WgradArgs a)
     constexpr unsigned OOB = 0x80000000u;
     const int HoWo = a.Ho * a.Wo;
 
-    f32x4 ra[LA], rb[LB];
-    auto load_global = [&](int m0) {
+    // DMA slot q of this wave covers float4s (q*NW + wave)*64 .. +63 of the [KB][B?/4] tile
+    int rowA[LA], colA[LA], rowB[LB], colB[LB];
+#pragma unroll
+    for (int q = 0; q < LA; ++q) { const int f = (q * NW + wave) * 64 + lane; rowA[q] = f / (BO / 4); colA[q] = (f - rowA[q] * (BO / 4)) * 4 + o0; }
+#pragma unroll
+    for (int q = 0; q < LB; ++q) { const int f = (q * NW + wave) * 64 + lane; rowB[q] = f / (BC / 4); colB[q] = (f - rowB[q] * (BC / 4)) * 4 + c0; }
+    // Pixel coordinates of the X rows this lane fetches, advanced by KB pixels per K-step WITHOUT divisions
+    // (straight-line selects only: the address arithmetic must stay in the MFMA basic block to overlap with it).
+    // Requires Ho*Wo >= KB (one image wrap per step at most); checked by the launcher.
+    int pn[LB], py[LB], px[LB];
+    const int dOy = KB / a.Wo, dOx = KB - dOy * a.Wo;
+#pragma unroll
+    for (int q = 0; q < LB; ++q) {
+        const int m = mBeg + rowB[q];
+        pn[q] = m / HoWo;
+        const int rem = m - pn[q] * HoWo;
+        py[q] = rem / a.Wo; px[q] = rem - py[q] * a.Wo;
+    }
+    int mCur = mBeg;
+    // offsets of the K-step starting at mCur, then advance to the next one
+    auto offsets = [&](unsigned (&va)[LA], unsigned (&vb)[LB]) {
 #pragma unroll
         for (int q = 0; q < LA; ++q) {
-            const int f = tid + q * NT;                     // float4 index in the [KB][BO/4] tile
-            const int row = f / (BO / 4), col = f - row * (BO / 4);
-            const int m = m0 + row;
-            ra[q] = buf_load4(srdY, m < mEnd ? (unsigned)(m * a.ldY + o0 + 4 * col) * 4u : OOB);
+            const int m = mCur + rowA[q];
+            va[q] = m < mEnd ? (unsigned)(m * a.ldY + colA[q]) * 4u : OOB;
         }
 #pragma unroll
         for (int q = 0; q < LB; ++q) {
-            const int f = tid + q * NT;
-            const int row = f / (BC / 4), col = f - row * (BC / 4);
-            const int m = m0 + row;
-            unsigned off = OOB;
-            if (m < mEnd) {
-                const int n = m / HoWo;
-                const int rem = m - n * HoWo;
-                const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
-                const int iy = oy * a.stride - PAD + ky, ix = ox * a.stride - PAD + kx;
-                if ((unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi)
-                    off = (unsigned)(((n * a.Hi + iy) * a.Wi + ix) * a.ldX + c0 + 4 * col) * 4u;
-            }
-            rb[q] = buf_load4(srdX, off);
+            const int m = mCur + rowB[q];
+            const int iy = py[q] * a.stride - PAD + ky, ix = px[q] * a.stride - PAD + kx;
+            const bool ok = m < mEnd && (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi;
+            // mask arithmetic, not a select: hipcc turns the select into an exec-masked branch around the multiplies
+            const unsigned msk = 0u - (unsigned)ok;
+            vb[q] = (((unsigned)(((pn[q] * a.Hi + iy) * a.Wi + ix) * a.ldX + colB[q]) * 4u) & msk) | (OOB & ~msk);
+            px[q] += dOx; py[q] += dOy;
+            const bool cx = px[q] >= a.Wo;
+            px[q] -= cx ? a.Wo : 0; py[q] += cx ? 1 : 0;
+            const bool cy = py[q] >= a.Ho;
+            py[q] -= cy ? a.Ho : 0; pn[q] += cy ? 1 : 0;
         }
+        mCur += KB;
     };
-    auto store_lds = [&](int buf) {
+    auto issue_a = [&](const unsigned (&va)[LA], int buf) {
 #pragma unroll
-        for (int q = 0; q < LA; ++q) *reinterpret_cast<f32x4 *>(&sA[buf][(tid + q * NT) * 4]) = ra[q];
+        for (int q = 0; q < LA; ++q)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srdY, (lds_void *)&sA[buf][(q * NW + wave) * 256], 16, (int)va[q], 0, 0, 0);
+    };
+    auto issue_b = [&](const unsigned (&vb)[LB], int buf) {
 #pragma unroll
-        for (int q = 0; q < LB; ++q) *reinterpret_cast<f32x4 *>(&sB[buf][(tid + q * NT) * 4]) = rb[q];
+        for (int q = 0; q < LB; ++q)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srdX, (lds_void *)&sB[buf][(q * NW + wave) * 256], 16, (int)vb[q], 0, 0, 0);
     };
 
     f32x16 acc[TI][TJ];
@@ -113,62 +166,97 @@ void wgrad_kernel(WgradArgs a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nk = (mEnd - mBeg + KB - 1) / KB;
-    if (nk > 0) {
-        load_global(mBeg);
-        store_lds(0);
+    int nk = (mEnd - mBeg + KB - 1) / KB;
+    if (nk < 0) nk = 0;
+    {
+        unsigned va[LA], vb[LB];
+        offsets(va, vb);
+        issue_a(va, 0); issue_b(vb, 0);
+        offsets(va, vb);
+        issue_a(va, 1); issue_b(vb, 1);
     }
+    __builtin_amdgcn_s_waitcnt(kWaitVm0);                   // the fence of __syncthreads() does not wait for LDS-DMA
     __syncthreads();
+
     const int fr = lane & 31, fk = lane >> 5;
+    const float *Afrag = &sA[0][fk * BO + wo * (BO / WO) + TI * fr];
+    const float *Bfrag = &sB[0][fk * BC + wc * (BC / WC) + TJ * fr];
+    // fragments of a chunk of 4 k-pairs, ping-ponging between two register sets
+    fragA_t fa[2][4];
+    fragB_t fb[2][4];
+    auto read_frags = [&](int set, int buf, int c) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            fa[set][u] = *reinterpret_cast<const fragA_t *>(Afrag + buf * (KB * BO) + 2 * (4 * c + u) * BO);
+            fb[set][u] = *reinterpret_cast<const fragB_t *>(Bfrag + buf * (KB * BC) + 2 * (4 * c + u) * BC);
+        }
+    };
+    auto multiply_u = [&](int set, int u) {
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(frag_elem<TI>(fa[set][u], i), frag_elem<TJ>(fb[set][u], j),
+                                                                 acc[i][j], 0, 0, 0);
+    };
+    auto multiply = [&](int set) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) multiply_u(set, u);
+    };
+    constexpr int NM = 4 * TI * TJ, ND = 8;
+    read_frags(0, 0, 0);
     for (int kk = 0; kk < nk; ++kk) {
         const int buf = kk & 1;
-        if (kk + 1 < nk) load_global(mBeg + (kk + 1) * KB);
-        const float *Ab = &sA[buf][wo * (BO / WO) + fr];
-        const float *Bb = &sB[buf][wc * (BC / WC) + fr];
-        // operand fragments ping-pong between two register sets (next k-pair's LDS reads under this pair's MFMAs)
-        float fa[2][TI], fb[2][TJ];
-#pragma unroll
-        for (int i = 0; i < TI; ++i) fa[0][i] = Ab[fk * BO + i * 32];
-#pragma unroll
-        for (int j = 0; j < TJ; ++j) fb[0][j] = Bb[fk * BC + j * 32];
-#pragma unroll
-        for (int kp = 0; kp < KB / 2; ++kp) {
-            const int cur = kp & 1, nxt = cur ^ 1;
-            if (kp + 1 < KB / 2) {
-#pragma unroll
-                for (int i = 0; i < TI; ++i) fa[nxt][i] = Ab[(2 * (kp + 1) + fk) * BO + i * 32];
-#pragma unroll
-                for (int j = 0; j < TJ; ++j) fb[nxt][j] = Bb[(2 * (kp + 1) + fk) * BC + j * 32];
-            }
-#pragma unroll
-            for (int i = 0; i < TI; ++i)
-#pragma unroll
-                for (int j = 0; j < TJ; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i], fb[cur][j], acc[i][j], 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x100, 2 * (TI + TJ), 0);
-#pragma unroll
-        for (int kp = 0; kp < KB / 2 - 2; ++kp) {
-            __builtin_amdgcn_sched_group_barrier(0x008, TI * TJ, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, TI + TJ, 0);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, 2 * TI * TJ, 0);
-        if (kk + 1 < nk) store_lds(buf ^ 1);
+        unsigned vaN[LA], vbN[LB];                          // offsets of step kk+2, computed under this step's MFMAs
+        offsets(vaN, vbN);
+        read_frags(1, buf, 1);
+        multiply(0);
+        read_frags(0, buf, 2);
+        multiply(1);
+        read_frags(1, buf, 3);
+        multiply(0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, ND, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, ND, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, ND, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, NM - 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(kWaitVm0);               // tile kk+1 has landed
         __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+        multiply_u(1, 0);
+        __builtin_amdgcn_sched_barrier(0x6);
+        issue_a(vaN, buf);
+        __builtin_amdgcn_sched_barrier(0x6);
+        multiply_u(1, 1);
+        __builtin_amdgcn_sched_barrier(0x6);
+        issue_b(vbN, buf);
+        read_frags(0, buf ^ 1, 0);
+        __builtin_amdgcn_sched_barrier(0x6);
+        multiply_u(1, 2);
+        multiply_u(1, 3);
     }
-    // partial[split][tap][o][c]
+    __builtin_amdgcn_s_waitcnt(kWaitVm0);                   // trailing DMAs must not outlive the workgroup's LDS
+
+    // partial[split][tap][o][c]; MFMA tile (i, j): rows TI*row + i, columns TJ*col + j
     const int col = lane & 31, rhalf = (lane >> 5) * 4;
     float *P = a.partial + ((long long)split * a.ksize * a.ksize + tap) * a.Cout * a.Cin;
 #pragma unroll
     for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int j = 0; j < TJ; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int o = o0 + wo * (BO / WO) + i * 32 + (r & 3) + 8 * (r >> 2) + rhalf;
-                const int c = c0 + wc * (BC / WC) + j * 32 + col;
-                P[(long long)o * a.Cin + c] = acc[i][j][r];
+        for (int r = 0; r < 16; ++r) {
+            const int o = o0 + wo * (BO / WO) + TI * ((r & 3) + 8 * (r >> 2) + rhalf) + i;
+            const int c = c0 + wc * (BC / WC) + TJ * col;
+            float *dst = P + (long long)o * a.Cin + c;
+            if constexpr (TJ == 2) {
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
+                *reinterpret_cast<f32x2 *>(dst) = f32x2{ acc[i][0][r], acc[i][1][r] };
+            } else {
+                *dst = acc[i][0][r];
             }
+        }
 }
 
 // dW[o][c][ky][kx] = sum over splits (fixed order) of partial[s][tap][o][c]
@@ -200,6 +288,7 @@ int launch_wgrad(const xl_op &op, hipStream_t st)
     const long long xb = (((long long)op.B * op.Hi * op.Wi - 1) * op.ld_in + op.Cin) * 4;
     const long long yb = (((long long)a.M - 1) * op.ld_aux + op.Cout) * 4;
     if (xb >= 0x7fffffffLL || yb >= 0x7fffffffLL) return XL_ERR_ARG;
+    if (op.Ho * op.Wo < 32) return XL_ERR_UNSUPPORTED;          // the kernel advances pixel coordinates by one K-step (32)
     a.xBytes = (unsigned)xb; a.dyBytes = (unsigned)yb;
     const int taps = op.ksize * op.ksize;
     hipLaunchKernelGGL((wgrad_kernel<BO, BC, WO, WC>), dim3(taps * a.nbo * a.nbc * a.splits), dim3(64 * WO * WC), 0, st, a);

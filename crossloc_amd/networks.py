@@ -615,18 +615,20 @@ class _Plan:
                 bc = 128 if C % 128 == 0 else (64 if C % 64 == 0 else 32)
                 tiles = k * k * (Cout // bo) * (C // bc)
                 M = B * Ho * Wo
-                # split-K factor: fill whole waves of the 512 resident workgroups (2 per CU) — e.g. 144 tiles x 7
-                # = 1008 is 98 % full, x 11 = 1584 would leave the 4th wave 9 % full
-                best, splits = -1.0, 1
+                # split-K factor from a cost model in units of one K-step (32 pixels) of a workgroup: rounds of the
+                # 512 resident workgroups (2 per CU) x (K-steps per split + ~8 steps of prologue / partial-tile
+                # store) + the fixed-order reduce pass over the partial tiles (~4 TB/s, one K-step ~ 1.8 us).
+                # E.g. 3x3 512->512 at batch 16: 144 tiles x 7 = 1008 workgroups = 1.97 rounds of 386 steps.
+                steps_total = -(-M // 32)
+                best, splits = None, 1
                 for cand in range(1, 65):
                     if cand > max(1, M // 256):
                         break
                     n_wg = tiles * cand
-                    eff = n_wg / (-(-n_wg // 512) * 512)
-                    if n_wg >= 512:
-                        eff += 1.0                      # prefer any configuration that fills the chip at least once
-                    if eff > best + 1e-9:
-                        best, splits = eff, cand
+                    rounds = -(-n_wg // 512)
+                    cost = rounds * (-(-steps_total // cand) + 8) + (cand + 1) * tiles * bo * bc * 4 / 4e12 / 1.8e-6
+                    if best is None or cost < best - 1e-9:
+                        best, splits = cost, cand
                 op.nchunks2 = splits
                 op.in_, op.aux = t.data_ptr() + 4 * off, dy.data_ptr()
                 op.out = pgrad(conv.weight).data_ptr()
