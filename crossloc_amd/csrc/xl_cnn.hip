@@ -213,8 +213,12 @@ void igemm_conv_kernel(ConvArgs a)
             } else {
                 const int ty = aIy[p] - ky, tx = aIx[p] - kx;
                 const int sy = ty / STRIDE, sx = tx / STRIDE;               // STRIDE is 1 or 2 (shift)
-                const bool ok = ty >= 0 && tx >= 0 && (STRIDE == 1 || (((ty | tx) & 1) == 0)) && sy < a.Hi && sx < a.Wi;
-                voff[p] = ok ? aOff[p] + (unsigned)((sy * a.Wi + sx) * a.ldIn + c0) * 4u : OOB;
+                // (bitwise &: a short-circuit chain becomes nested exec-masked branches)
+                const bool ok = ((ty | tx) >= 0) & (STRIDE == 1 || (((ty | tx) & 1) == 0)) & (sy < a.Hi) & (sx < a.Wi);
+                // mask arithmetic, not a select: hipcc turns the select into an exec-masked branch around the
+                // multiplies, which splits the K-loop into basic blocks that do not overlap with the MFMAs
+                const unsigned msk = 0u - (unsigned)ok;
+                voff[p] = ((aOff[p] + (unsigned)((sy * a.Wi + sx) * a.ldIn + c0) * 4u) & msk) | (OOB & ~msk);
             }
         }
     };
