@@ -818,3 +818,6 @@ int xo_num_threads(void)
     return 1;
 #endif
 }
+
+/* backward_rgb restatement (same translation unit: it uses the static helpers above) */
+#include "dsac_bwd_oracle.c"
