@@ -34,7 +34,12 @@ def lib():
         L.xl_dsac_forward_rgb_host.restype = c_i32
         L.xl_dsac_forward_rgb_host.argtypes = [c_vp, c_i64, c_i64, c_i64, c_i32, c_i32, c_vp, c_i32, c_f, c_f, c_f,
                                                c_f, c_f, c_f, c_i32, c_u64, c_u64, c_u32, c_vp, c_vp, c_vp, c_vp]
-        for name in ("xl_dsac_backward_rgb", "xl_dsac_forward_rgbd", "xl_dsac_backward_rgbd"):
+        L.xl_dsac_backward_rgb_batch.restype = c_i32
+        L.xl_dsac_backward_rgb_batch.argtypes = [c_vp, c_i64, c_i64, c_i64, c_i64, c_i32, c_i32, c_i32,
+                                                 c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_vp,
+                                                 c_i32, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i32,
+                                                 c_vp, c_u64, c_u64, c_u64, c_u32, c_vp, c_vp]
+        for name in ("xl_dsac_forward_rgbd", "xl_dsac_backward_rgbd"):
             getattr(L, name).restype = c_i32
         _lib = L
     return _lib

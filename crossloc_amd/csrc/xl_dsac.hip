@@ -599,6 +599,7 @@ struct Params {
     float *outPoses;
     const float *focals;
     int32_t *cells; int32_t *tries; double *scores; double *dbg;
+    double *hypPoses;             // optional [B][nHyp][12]: every hypothesis' pose (backward_rgb)
     uint64_t seed, image0, imageStride;
     uint32_t maxTries;
     int nHyp, Ho, Wo, sub, Npad;
@@ -618,6 +619,87 @@ struct Smem {
     unsigned cnt[2][kWaves];
     int pad[4];
 };
+
+// refineHyp (dsacstar_util.h:522-597), cooperative over the 256 threads of the workgroup: the pose is refined in
+// place; o.inlAcc is this thread's slice (bit j <-> cell tid + 256 j) of the inlier map of the last successful
+// re-fit, o.finalInl its size.  redSel / cntSel select the double-buffered LDS reduction scratch.
+struct RefineOut { unsigned long long inlAcc; unsigned finalInl; int rounds, evals; };
+
+__device__ __forceinline__ void refine_pose(const Coords &co, const Cam &cam, Smem &S, int tid, int wave, int lane,
+                                            Pose &pose, RefineOut &o, int &redSel, int &cntSel)
+{
+    const int N = cam.N;
+    unsigned long long inlAcc = 0ull;
+    unsigned best = 4;
+    int rounds = 0, evals = 0;
+    unsigned finalInl = 0;
+    for (int step = 0; step < XL_DSAC_MAX_REF_STEPS; ++step) {
+        unsigned long long inl = 0ull;
+        {
+            int j = 0;
+            for (int i = tid; i < N; i += kThreads, ++j) {
+                float e = cell_err(pose, co, i, cam);
+                if (e < cam.thr) inl |= (1ull << j);
+            }
+        }
+        unsigned cnt = (unsigned)__popcll(inl);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) cnt += (unsigned)__shfl_xor((int)cnt, off);
+        if (lane == 0) S.cnt[cntSel][wave] = cnt;
+        __syncthreads();
+        cnt = S.cnt[cntSel][0] + S.cnt[cntSel][1] + S.cnt[cntSel][2] + S.cnt[cntSel][3];
+        cntSel ^= 1;
+        if (cnt <= best) break;
+        best = cnt;
+
+        // Levenberg-Marquardt on the inliers (cv::solvePnP ITERATIVE + extrinsic guess)
+        Pose cur = pose, prev;
+        double ne[28], neNew[28];
+        int lg = -3, iters = 0;
+        bool failed = false;
+        normal_eq_thread(co, cam, cur, inl, tid, ne);
+        block_reduce28(ne, S.red[redSel], wave, lane); redSel ^= 1; ++evals;
+        for (;;) {
+            double d[6];
+            prev = cur;
+            if (!solve6(ne, lambda_of(lg), d)) { failed = true; break; }
+            apply_step(prev, d, cur);
+            double prevErr = ne[27];
+            normal_eq_thread(co, cam, cur, inl, tid, neNew);
+            block_reduce28(neNew, S.red[redSel], wave, lane); redSel ^= 1; ++evals;
+            while (neNew[27] > prevErr) {
+                if (++lg <= 16) {
+                    if (!solve6(ne, lambda_of(lg), d)) { failed = true; break; }
+                    apply_step(prev, d, cur);
+                    normal_eq_thread(co, cam, cur, inl, tid, neNew);
+                    block_reduce28(neNew, S.red[redSel], wave, lane); redSel ^= 1; ++evals;
+                } else break;
+            }
+            if (failed) break;
+            lg = (lg - 1 > -16) ? lg - 1 : -16;
+            double dn = d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3] + d[4] * d[4] + d[5] * d[5];
+            double pn = (3.0 - (prev.R[0] + prev.R[4] + prev.R[8]))
+                        + prev.t[0] * prev.t[0] + prev.t[1] * prev.t[1] + prev.t[2] * prev.t[2];
+            ++iters;
+            if (iters >= kLmMaxIter || dn < kFltEps * kFltEps * pn) break;
+#pragma unroll
+            for (int k = 0; k < 28; ++k) ne[k] = neNew[k];
+        }
+        if (!failed) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) if (!(cur.R[i] == cur.R[i])) failed = true;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) if (!(cur.t[i] == cur.t[i])) failed = true;
+        }
+        if (failed) break;
+        pose = cur;
+        finalInl = cnt;
+        inlAcc = inl;
+        ++rounds;
+    }
+
+    o.inlAcc = inlAcc; o.finalInl = finalInl; o.rounds = rounds; o.evals = evals;
+}
 
 // PHASE 0: whole pipeline, one workgroup per image (enough images to fill the chip).
 // PHASE 1: sample + score only, S workgroups per image (grid S x B); per-wave bests go to P.part.
@@ -710,6 +792,13 @@ void xl_dsac_forward_kernel(Params P)
             }
             if (P.tries) P.tries[(int64_t)b * P.nHyp + h] = triesUsed;
             if (P.scores) P.scores[(int64_t)b * P.nHyp + h] = score;
+            if (P.hypPoses) {
+                double *o = P.hypPoses + ((int64_t)b * P.nHyp + h) * 12;
+#pragma unroll
+                for (int i = 0; i < 9; ++i) o[i] = pose.R[i];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) o[9 + i] = pose.t[i];
+            }
         }
         if (score != score) anyNan = 1;
         bool better = (bestIdx < 0) || (score > bestScore);
@@ -781,73 +870,11 @@ void xl_dsac_forward_kernel(Params P)
     }
 
     // ---- refine (refineHyp, dsacstar_util.h:522-597)
-    unsigned best = 4;
-    int rounds = 0, evals = 0;
-    unsigned finalInl = 0;
+    RefineOut ro;
     int redSel = 0, cntSel = 0;
-    for (int step = 0; step < XL_DSAC_MAX_REF_STEPS; ++step) {
-        unsigned long long inl = 0ull;
-        {
-            int j = 0;
-            for (int i = tid; i < N; i += kThreads, ++j) {
-                float e = cell_err(pose, co, i, cam);
-                if (e < cam.thr) inl |= (1ull << j);
-            }
-        }
-        unsigned cnt = (unsigned)__popcll(inl);
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) cnt += (unsigned)__shfl_xor((int)cnt, off);
-        if (lane == 0) S.cnt[cntSel][wave] = cnt;
-        __syncthreads();
-        cnt = S.cnt[cntSel][0] + S.cnt[cntSel][1] + S.cnt[cntSel][2] + S.cnt[cntSel][3];
-        cntSel ^= 1;
-        if (cnt <= best) break;
-        best = cnt;
-
-        // Levenberg-Marquardt on the inliers (cv::solvePnP ITERATIVE + extrinsic guess)
-        Pose cur = pose, prev;
-        double ne[28], neNew[28];
-        int lg = -3, iters = 0;
-        bool failed = false;
-        normal_eq_thread(co, cam, cur, inl, tid, ne);
-        block_reduce28(ne, S.red[redSel], wave, lane); redSel ^= 1; ++evals;
-        for (;;) {
-            double d[6];
-            prev = cur;
-            if (!solve6(ne, lambda_of(lg), d)) { failed = true; break; }
-            apply_step(prev, d, cur);
-            double prevErr = ne[27];
-            normal_eq_thread(co, cam, cur, inl, tid, neNew);
-            block_reduce28(neNew, S.red[redSel], wave, lane); redSel ^= 1; ++evals;
-            while (neNew[27] > prevErr) {
-                if (++lg <= 16) {
-                    if (!solve6(ne, lambda_of(lg), d)) { failed = true; break; }
-                    apply_step(prev, d, cur);
-                    normal_eq_thread(co, cam, cur, inl, tid, neNew);
-                    block_reduce28(neNew, S.red[redSel], wave, lane); redSel ^= 1; ++evals;
-                } else break;
-            }
-            if (failed) break;
-            lg = (lg - 1 > -16) ? lg - 1 : -16;
-            double dn = d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3] + d[4] * d[4] + d[5] * d[5];
-            double pn = (3.0 - (prev.R[0] + prev.R[4] + prev.R[8]))
-                        + prev.t[0] * prev.t[0] + prev.t[1] * prev.t[1] + prev.t[2] * prev.t[2];
-            ++iters;
-            if (iters >= kLmMaxIter || dn < kFltEps * kFltEps * pn) break;
-#pragma unroll
-            for (int k = 0; k < 28; ++k) ne[k] = neNew[k];
-        }
-        if (!failed) {
-#pragma unroll
-            for (int i = 0; i < 9; ++i) if (!(cur.R[i] == cur.R[i])) failed = true;
-#pragma unroll
-            for (int i = 0; i < 3; ++i) if (!(cur.t[i] == cur.t[i])) failed = true;
-        }
-        if (failed) break;
-        pose = cur;
-        finalInl = cnt;
-        ++rounds;
-    }
+    refine_pose(co, cam, S, tid, wave, lane, pose, ro, redSel, cntSel);
+    const int rounds = ro.rounds, evals = ro.evals;
+    const unsigned finalInl = ro.finalInl;
 
     // ---- write (pose2trans): inverse rigid transform, float row-major
     if (tid == 0) {
@@ -866,6 +893,649 @@ void xl_dsac_forward_kernel(Params P)
             for (int i = 0; i < 3; ++i) q[25 + i] = pose.t[i];
         }
     }
+}
+
+// ============================================================================== backward_rgb
+// dsacstar_rgb_backward (dsacstar.cpp:200-483): expected pose loss over the soft-max distribution of the hypotheses
+// and its gradient w.r.t. the scene coordinates (path I through the refined poses, path II through the scores).
+// Every device function below mirrors oracle/dsac_bwd_oracle.c operation for operation (same order, no contraction),
+// so the two produce identical bits; reference line numbers are given there.
+
+constexpr double kProbThresh = 0.001;          // dsacstar_derivative.h:36
+constexpr double kEps = 0.00000001;            // dsacstar_util.h:45
+constexpr double kMaxLoss = 10000000.0;        // dsacstar_loss.h:35
+constexpr double kPiRef = 3.1415926;           // dsacstar_util.h:46
+constexpr double kCvPi = 3.1415926535897932384626433832795;
+constexpr double kDblEps = 2.2204460492503131e-16;
+
+__device__ double det_atan2(double y, double x)
+{
+    if (x == 0.0 && y == 0.0) return 0.0;
+    double n = sqrt(x * x + y * y);
+    double cn = x / n, sn = y / n;
+    double ax = fabs(x), ay = fabs(y);
+    double t;
+    if (ay <= ax) { double a = ay / ax; t = a / (1.0 + 0.28 * a * a); }
+    else { double a = ax / ay; t = 1.5707963267948966 - a / (1.0 + 0.28 * a * a); }
+    if (x < 0.0) t = 3.141592653589793 - t;
+    if (y < 0.0) t = -t;
+    for (int it = 0; it < 3; ++it) {
+        double s, c;
+        det_sincos(t, s, c);
+        double d = sn * c - cn * s;
+        double d2 = d * d;
+        t = t + d * (1.0 + d2 * (1.0 / 6.0 + d2 * (3.0 / 40.0)));
+    }
+    return t;
+}
+
+__device__ double det_acos(double v) { return det_atan2(sqrt((1.0 - v) * (1.0 + v)), v); }
+
+__device__ void log_so3(const double *R, double *r)
+{
+    double rx = R[7] - R[5], ry = R[2] - R[6], rz = R[3] - R[1];
+    double s = sqrt((rx * rx + ry * ry + rz * rz) * 0.25);
+    double c = (R[0] + R[4] + R[8] - 1.0) * 0.5;
+    c = c > 1.0 ? 1.0 : (c < -1.0 ? -1.0 : c);
+    double theta = det_atan2(s, c);
+    if (s < 1e-5) {
+        if (c > 0.0) { r[0] = 0.0; r[1] = 0.0; r[2] = 0.0; return; }
+        double t;
+        t = (R[0] + 1.0) * 0.5; rx = sqrt(t > 0.0 ? t : 0.0);
+        t = (R[4] + 1.0) * 0.5; ry = sqrt(t > 0.0 ? t : 0.0) * (R[1] < 0.0 ? -1.0 : 1.0);
+        t = (R[8] + 1.0) * 0.5; rz = sqrt(t > 0.0 ? t : 0.0) * (R[2] < 0.0 ? -1.0 : 1.0);
+        if (fabs(rx) < fabs(ry) && fabs(rx) < fabs(rz) && ((R[5] > 0.0) != (ry * rz > 0.0))) rz = -rz;
+        theta = theta / sqrt(rx * rx + ry * ry + rz * rz);
+        r[0] = rx * theta; r[1] = ry * theta; r[2] = rz * theta;
+        return;
+    }
+    double vth = (1.0 / (2.0 * s)) * theta;
+    r[0] = rx * vth; r[1] = ry * vth; r[2] = rz * vth;
+}
+
+__device__ void exp_so3(const double *r, double *R)
+{
+    double th = sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+    if (th < kDblEps) {
+        for (int i = 0; i < 9; ++i) R[i] = 0.0;
+        R[0] = 1.0; R[4] = 1.0; R[8] = 1.0;
+        return;
+    }
+    double s, c;
+    det_sincos(th, s, c);
+    double c1 = 1.0 - c, ith = 1.0 / th;
+    double kx = r[0] * ith, ky = r[1] * ith, kz = r[2] * ith;
+    R[0] = c + c1 * kx * kx;      R[1] = c1 * kx * ky - s * kz; R[2] = c1 * kx * kz + s * ky;
+    R[3] = c1 * kx * ky + s * kz; R[4] = c + c1 * ky * ky;      R[5] = c1 * ky * kz - s * kx;
+    R[6] = c1 * kx * kz - s * ky; R[7] = c1 * ky * kz + s * kx; R[8] = c + c1 * kz * kz;
+}
+
+// dR[(3a+b)*3 + c] = d R[a][b] / d r_c
+__device__ void rodrigues_jac(const double *r, double *dR)
+{
+    double th = sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+    for (int i = 0; i < 27; ++i) dR[i] = 0.0;
+    if (th < kDblEps) {
+        dR[5 * 3 + 0] = -1.0; dR[7 * 3 + 0] = 1.0;
+        dR[2 * 3 + 1] = 1.0;  dR[6 * 3 + 1] = -1.0;
+        dR[1 * 3 + 2] = -1.0; dR[3 * 3 + 2] = 1.0;
+        return;
+    }
+    double s, c;
+    det_sincos(th, s, c);
+    double c1 = 1.0 - c, ith = 1.0 / th;
+    double k[3] = { r[0] * ith, r[1] * ith, r[2] * ith };
+    for (int i = 0; i < 3; ++i) {
+        double dk[3];
+        for (int j = 0; j < 3; ++j) dk[j] = ((i == j ? 1.0 : 0.0) - k[i] * k[j]) * ith;
+        double ski = s * k[i], cki = c * k[i];
+        double K[9] = { 0.0, -k[2], k[1], k[2], 0.0, -k[0], -k[1], k[0], 0.0 };
+        double dK[9] = { 0.0, -dk[2], dk[1], dk[2], 0.0, -dk[0], -dk[1], dk[0], 0.0 };
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b) {
+                double v = ski * (k[a] * k[b]) + c1 * (dk[a] * k[b] + k[a] * dk[b]) + cki * K[3 * a + b] + s * dK[3 * a + b];
+                if (a == b) v -= ski;
+                dR[(3 * a + b) * 3 + i] = v;
+            }
+    }
+}
+
+// row of d max(|proj - pt|, EPS) / d (rvec, tvec), zero above maxReproj; returns the error
+__device__ double resid_row(const Pose &p, const double *dR, double X, double Y, double Z, float px, float py,
+                            const Cam &cam, double (&J6)[6])
+{
+    double qx = p.R[0] * X + p.R[1] * Y + p.R[2] * Z;
+    double qy = p.R[3] * X + p.R[4] * Y + p.R[5] * Z;
+    double qz = p.R[6] * X + p.R[7] * Y + p.R[8] * Z;
+    double xc = qx + p.t[0], yc = qy + p.t[1], zc = qz + p.t[2];
+    double z = (zc != 0.0) ? 1.0 / zc : 1.0;
+    double xn = xc * z, yn = yc * z;
+    float uf = (float)(xn * cam.f + cam.cx), vf = (float)(yn * cam.f + cam.cy);
+    float dxf = uf - px, dyf = vf - py;
+    double err = sqrt((double)dxf * (double)dxf + (double)dyf * (double)dyf);
+    if (err < kEps) err = kEps;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) J6[i] = 0.0;
+    if (err > (double)cam.maxReproj) return err;
+    double nx = 1.0 / err * (double)dxf, ny = 1.0 / err * (double)dyf;
+    double fa = cam.f * z;
+    double fc = -(fa * xn);
+    double fd = -(fa * yn);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        double dX = dR[0 * 3 + c] * X + dR[1 * 3 + c] * Y + dR[2 * 3 + c] * Z;
+        double dY = dR[3 * 3 + c] * X + dR[4 * 3 + c] * Y + dR[5 * 3 + c] * Z;
+        double dZ = dR[6 * 3 + c] * X + dR[7 * 3 + c] * Y + dR[8 * 3 + c] * Z;
+        double ju = fa * dX + fc * dZ, jv = fa * dY + fd * dZ;
+        J6[c] = nx * ju + ny * jv;
+    }
+    J6[3] = nx * fa;
+    J6[4] = ny * fa;
+    J6[5] = nx * fc + ny * fd;
+    return err;
+}
+
+// dProjectdObj, dsacstar_derivative.h:51-106
+__device__ void dproject_dobj(const Pose &p, double X, double Y, double Z, float ptx, float pty, const Cam &cam,
+                              double (&out)[3])
+{
+    out[0] = 0.0; out[1] = 0.0; out[2] = 0.0;
+    double ox = p.R[0] * X + p.R[1] * Y + p.R[2] * Z + p.t[0];
+    double oy = p.R[3] * X + p.R[4] * Y + p.R[5] * Z + p.t[1];
+    double oz = p.R[6] * X + p.R[7] * Y + p.R[8] * Z + p.t[2];
+    if (fabs(oz) < kEps) return;
+    double px = cam.f * ox / oz + cam.cx;
+    double py = cam.f * oy / oz + cam.cy;
+    double ex = (double)ptx - px, ey = (double)pty - py;
+    double err = sqrt(ex * ex + ey * ey);
+    if (err > (double)cam.maxReproj) return;
+    err += kEps;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        double pxd = cam.f * p.R[k] / oz - cam.f * ox / oz / oz * p.R[6 + k];
+        double pyd = cam.f * p.R[3 + k] / oz - cam.f * oy / oz / oz * p.R[6 + k];
+        out[k] = 0.5 / err * (2.0 * ex * -pxd + 2.0 * ey * -pyd);
+    }
+}
+
+// pseudo-inverse of a symmetric PSD 6x6: cyclic Jacobi, 12 sweeps, eigenvalues <= 2 eps sum|w| dropped
+__device__ void pinv6(const double *A_, double *Ainv)
+{
+    double A[6][6], V[6][6];
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < 6; ++j) { A[i][j] = A_[6 * i + j]; V[i][j] = (i == j) ? 1.0 : 0.0; }
+    for (int sweep = 0; sweep < 12; ++sweep)
+        for (int p = 0; p < 5; ++p)
+            for (int q = p + 1; q < 6; ++q) {
+                double apq = A[p][q];
+                if (apq == 0.0) continue;
+                double tau = (A[q][q] - A[p][p]) / (2.0 * apq);
+                double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+                double c = 1.0 / sqrt(1.0 + t * t), s = t * c;
+                for (int k = 0; k < 6; ++k) {
+                    double akp = A[k][p], akq = A[k][q];
+                    A[k][p] = c * akp - s * akq;
+                    A[k][q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < 6; ++k) {
+                    double apk = A[p][k], aqk = A[q][k];
+                    A[p][k] = c * apk - s * aqk;
+                    A[q][k] = s * apk + c * aqk;
+                }
+                for (int k = 0; k < 6; ++k) {
+                    double vkp = V[k][p], vkq = V[k][q];
+                    V[k][p] = c * vkp - s * vkq;
+                    V[k][q] = s * vkp + c * vkq;
+                }
+            }
+    double sum = 0.0;
+    for (int i = 0; i < 6; ++i) sum += fabs(A[i][i]);
+    double thr = sum * (2.0 * kDblEps);
+    double wi[6];
+    for (int i = 0; i < 6; ++i) wi[i] = (fabs(A[i][i]) > thr) ? 1.0 / A[i][i] : 0.0;
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < 6; ++j) {
+            double v = 0.0;
+            for (int k = 0; k < 6; ++k) v += V[i][k] * wi[k] * V[j][k];
+            Ainv[6 * i + j] = v;
+        }
+}
+
+struct Gt { double Rc2w[9]; double C[3]; double R2[9]; double t2[3]; };
+
+__device__ void gt_from_pose16(const float *gt16, Gt &g)
+{
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) g.Rc2w[3 * i + j] = (double)gt16[4 * i + j];
+        g.C[i] = (double)gt16[4 * i + 3];
+    }
+    double Rt[9], r2[3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) Rt[3 * i + j] = g.Rc2w[3 * j + i];
+    log_so3(Rt, r2);
+    exp_so3(r2, g.R2);
+    for (int i = 0; i < 3; ++i)
+        g.t2[i] = -(g.R2[3 * i] * g.C[0] + g.R2[3 * i + 1] * g.C[1] + g.R2[3 * i + 2] * g.C[2]);
+}
+
+__device__ double pose_loss(const Pose &est, const Gt &g, double wRot, double wTrans, double cut)
+{
+    double trace = 0.0;
+    for (int i = 0; i < 3; ++i)
+        for (int k = 0; k < 3; ++k) trace += g.Rc2w[3 * i + k] * est.R[3 * k + i];
+    trace = trace > 3.0 ? 3.0 : (trace < -1.0 ? -1.0 : trace);
+    double rotErr = 180.0 * det_acos((trace - 1.0) / 2.0) / kPiRef;
+    double d2 = 0.0;
+    for (int i = 0; i < 3; ++i) {
+        double c1 = -(est.R[i] * est.t[0] + est.R[3 + i] * est.t[1] + est.R[6 + i] * est.t[2]);
+        double d = c1 - g.C[i];
+        d2 += d * d;
+    }
+    double tErr = sqrt(d2);
+    double loss = wRot * rotErr + wTrans * tErr;
+    if (loss > cut) loss = sqrt(cut * loss);
+    return loss < kMaxLoss ? loss : kMaxLoss;
+}
+
+__device__ void dloss(const Pose &est, const double *dR, const Gt &g, double wRot, double wTrans, double cut,
+                      double (&jac)[6])
+{
+    for (int i = 0; i < 6; ++i) jac[i] = 0.0;
+    const double *R1 = est.R, *R2 = g.R2;
+    double trace = 0.0;
+    for (int a = 0; a < 3; ++a)
+        for (int k = 0; k < 3; ++k) trace += R1[3 * a + k] * R2[3 * a + k];
+    trace = trace > 3.0 ? 3.0 : (trace < -1.0 ? -1.0 : trace);
+    double rotErr = 180.0 * det_acos((trace - 1.0) / 2.0) / kCvPi;
+    double invT1[3], invT2[3], diff[3];
+    for (int i = 0; i < 3; ++i) {
+        invT1[i] = R1[i] * est.t[0] + R1[3 + i] * est.t[1] + R1[6 + i] * est.t[2];
+        invT2[i] = R2[i] * g.t2[0] + R2[3 + i] * g.t2[1] + R2[6 + i] * g.t2[2];
+        diff[i] = invT1[i] - invT2[i];
+    }
+    double tErr = sqrt(diff[0] * diff[0] + diff[1] * diff[1] + diff[2] * diff[2]);
+    double loss = wRot * rotErr + wTrans * tErr;
+    int cutLoss = 0;
+    if (loss > cut) { loss = sqrt(loss); cutLoss = 1; }
+    if (loss > kMaxLoss) return;
+    if ((tErr + rotErr) < kEps) return;
+    double dD[3];
+    for (int i = 0; i < 3; ++i) dD[i] = diff[i] / tErr;
+    for (int j = 0; j < 3; ++j)
+        jac[3 + j] += (dD[0] * R1[j * 3 + 0] + dD[1] * R1[j * 3 + 1] + dD[2] * R1[j * 3 + 2]) * wTrans;
+    for (int c = 0; c < 3; ++c) {
+        double v = 0.0;
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) v += dD[i] * est.t[j] * dR[(3 * j + i) * 3 + c];
+        jac[c] += v * wTrans;
+    }
+    double fac = 180.0 / kCvPi * -1.0 / sqrt(3.0 - trace * trace + 2.0 * trace);
+    for (int c = 0; c < 3; ++c) {
+        double v = 0.0;
+        for (int m = 0; m < 9; ++m) v += R2[m] * dR[m * 3 + c];
+        jac[c] += fac * v * wRot;
+    }
+    if (cutLoss)
+        for (int i = 0; i < 6; ++i) jac[i] *= 0.5 / loss;
+    for (int i = 0; i < 6; ++i)
+        if (!(jac[i] == jac[i]) || fabs(jac[i]) > 1.0e300) { for (int k = 0; k < 6; ++k) jac[k] = 0.0; return; }
+}
+
+// per-hypothesis record in global memory (doubles); the first 53 entries are the oracle's debug record
+constexpr int kRec = XL_DSAC_BWD_REC;
+constexpr int kRecDRinit = 64, kRecDRref = 91;             // 27 doubles each
+constexpr int kRecInit = 118;                              // unused tail up to kRec
+
+struct BwdParams {
+    const float *coords; int64_t sb, sc, sy, sx;
+    float *grad; int64_t gsb, gsc, gsy, gsx;
+    const float *gt; const float *focals;
+    const double *hypPoses; const double *scores; const int32_t *cells;
+    double *rec; unsigned long long *masks; double *outLoss;
+    int nHyp, Ho, Wo, sub, Npad;
+    float thr, focal, ppx, ppy, alpha, maxReproj, wRot, wTrans, softClamp;
+};
+
+__device__ __forceinline__ void bwd_cam(const BwdParams &P, int b, Cam &cam)
+{
+    cam.f = (double)(P.focals ? P.focals[b] : P.focal);
+    cam.cx = (double)P.ppx; cam.cy = (double)P.ppy;
+    cam.thr = P.thr; cam.alpha = P.alpha; cam.maxReproj = P.maxReproj;
+    cam.sub = P.sub; cam.Ho = P.Ho; cam.Wo = P.Wo; cam.N = P.Ho * P.Wo;
+}
+
+__device__ __forceinline__ void stage_coords(const BwdParams &P, int b, float *sCo, int tid)
+{
+    const int N = P.Ho * P.Wo;
+    const float *g = P.coords + (int64_t)b * P.sb;
+    for (int i = tid; i < N; i += kThreads) {
+        int y = i / P.Wo, x = i - y * P.Wo;
+        const float *q = g + (int64_t)y * P.sy + (int64_t)x * P.sx;
+        sCo[i] = q[0];
+        sCo[P.Npad + i] = q[P.sc];
+        sCo[2 * P.Npad + i] = q[2 * P.sc];
+    }
+}
+
+__device__ __forceinline__ void load_pose(const double *src, Pose &p)
+{
+#pragma unroll
+    for (int i = 0; i < 9; ++i) p.R[i] = src[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) p.t[i] = src[9 + i];
+}
+
+// K1 (grid nHyp x B): soft-max probability of the hypothesis, refinement if it matters, loss, path-I quantities
+__global__ __launch_bounds__(kThreads)
+void xl_dsac_bwd_hyp_kernel(BwdParams P)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    Smem &S = *reinterpret_cast<Smem *>(smem_raw);
+    float *sCo = reinterpret_cast<float *>(smem_raw + ((sizeof(Smem) + 15) & ~size_t(15)));
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = blockIdx.x, b = blockIdx.y;
+    Cam cam;
+    bwd_cam(P, b, cam);
+    const int N = cam.N;
+
+    // softMax (dsacstar_util.h:684-704), every thread in the same order
+    const double *sc = P.scores + (int64_t)b * P.nHyp;
+    double maxScore = 0.0, sum = 0.0;
+    for (int i = 0; i < P.nHyp; ++i) if (i == 0 || sc[i] > maxScore) maxScore = sc[i];
+    for (int i = 0; i < P.nHyp; ++i) sum += det_exp(sc[i] - maxScore);
+    const double prob = det_exp(sc[h] - maxScore) / sum;
+    const bool active = !(prob < kProbThresh);
+
+    Pose init, pose;
+    load_pose(P.hypPoses + ((int64_t)b * P.nHyp + h) * 12, init);
+    pose = init;
+    RefineOut ro;
+    ro.inlAcc = 0ull; ro.finalInl = 0; ro.rounds = 0; ro.evals = 0;
+    int redSel = 0, cntSel = 0;
+    Coords co{ sCo, sCo + P.Npad, sCo + 2 * P.Npad };
+    if (active) {
+        stage_coords(P, b, sCo, tid);
+        __syncthreads();
+        refine_pose(co, cam, S, tid, wave, lane, pose, ro, redSel, cntSel);
+    }
+    Gt gt;
+    gt_from_pose16(P.gt + (int64_t)b * 16, gt);
+    const double loss = pose_loss(pose, gt, (double)P.wRot, (double)P.wTrans, (double)P.softClamp);
+
+    double *rec = P.rec + ((int64_t)b * P.nHyp + h) * kRec;
+    double dLossH[6] = { 0.0, 0.0, 0.0, 0.0, 0.0, 0.0 }, wv[6] = { 0.0, 0.0, 0.0, 0.0, 0.0, 0.0 };
+    double maxJR = 0.0, rv[3] = { 0.0, 0.0, 0.0 };
+    int clampI = 0;
+    if (active) {
+        double r0[3], dRi[27], dRr[27];
+        log_so3(init.R, r0);
+        rodrigues_jac(r0, dRi);
+        log_so3(pose.R, rv);
+        rodrigues_jac(rv, dRr);
+        dloss(pose, dRr, gt, (double)P.wRot, (double)P.wTrans, (double)P.softClamp, dLossH);
+        if (tid == 0)
+            for (int i = 0; i < 27; ++i) { rec[kRecDRinit + i] = dRi[i]; rec[kRecDRref + i] = dRr[i]; }
+        if (ro.finalInl >= 4) {
+            double a[28];
+#pragma unroll
+            for (int k = 0; k < 28; ++k) a[k] = 0.0;
+            int j = 0;
+            for (int i = tid; i < N; i += kThreads, ++j) {
+                if (!((ro.inlAcc >> j) & 1ull)) continue;
+                int y = i / cam.Wo, x = i - y * cam.Wo;
+                double X, Y, Z, J6[6];
+                co.fetch(i, X, Y, Z);
+                resid_row(pose, dRr, X, Y, Z, (float)(x * cam.sub + cam.sub / 2), (float)(y * cam.sub + cam.sub / 2), cam, J6);
+                int k = 0;
+#pragma unroll
+                for (int r = 0; r < 6; ++r)
+#pragma unroll
+                    for (int c = r; c < 6; ++c) { a[k] += J6[r] * J6[c]; ++k; }
+            }
+            block_reduce28(a, S.red[redSel], wave, lane); redSel ^= 1;
+            double A[36], Ainv[36];
+            {
+                int k = 0;
+                for (int r = 0; r < 6; ++r)
+                    for (int c = r; c < 6; ++c) { A[6 * r + c] = a[k]; A[6 * c + r] = a[k]; ++k; }
+            }
+            pinv6(A, Ainv);
+            // max |jacobeanR| over this thread's inliers, then over the workgroup (order-free)
+            j = 0;
+            for (int i = tid; i < N; i += kThreads, ++j) {
+                if (!((ro.inlAcc >> j) & 1ull)) continue;
+                int y = i / cam.Wo, x = i - y * cam.Wo;
+                double X, Y, Z, J6[6];
+                co.fetch(i, X, Y, Z);
+                resid_row(pose, dRr, X, Y, Z, (float)(x * cam.sub + cam.sub / 2), (float)(y * cam.sub + cam.sub / 2), cam, J6);
+                for (int r = 0; r < 6; ++r) {
+                    double u = 0.0;
+                    for (int c = 0; c < 6; ++c) u += Ainv[6 * r + c] * J6[c];
+                    u = fabs(u);
+                    if (u > maxJR) maxJR = u;
+                }
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) { double o = __shfl_xor(maxJR, off); if (o > maxJR) maxJR = o; }
+            __syncthreads();                                    // S.bestScore is free: the reduction above has completed
+            if (lane == 0) S.bestScore[wave] = maxJR;
+            __syncthreads();
+            maxJR = S.bestScore[0];
+            for (int w = 1; w < kWaves; ++w) if (S.bestScore[w] > maxJR) maxJR = S.bestScore[w];
+            clampI = (maxJR > 10.0) ? 1 : 0;                    // dsacstar.cpp:411-412
+            for (int r = 0; r < 6; ++r) {
+                double v = 0.0;
+                for (int c = 0; c < 6; ++c) v += Ainv[6 * r + c] * dLossH[c];
+                wv[r] = v;
+            }
+        }
+    }
+    P.masks[((int64_t)b * P.nHyp + h) * kThreads + tid] = ro.inlAcc;
+    if (tid == 0) {
+        rec[0] = prob; rec[1] = loss; rec[2] = active ? 1.0 : 0.0; rec[3] = (double)ro.finalInl; rec[4] = (double)clampI;
+        rec[5] = 0.0;
+        for (int i = 0; i < 9; ++i) rec[6 + i] = pose.R[i];
+        for (int i = 0; i < 3; ++i) rec[15 + i] = pose.t[i];
+        for (int i = 0; i < 6; ++i) { rec[18 + i] = dLossH[i]; rec[24 + i] = wv[i]; }
+        for (int i = 0; i < 12; ++i) rec[30 + i] = 0.0;
+        rec[42] = maxJR; rec[43] = 0.0;
+        for (int i = 0; i < 6; ++i) rec[44 + i] = 0.0;
+        for (int i = 0; i < 3; ++i) rec[50 + i] = rv[i];
+    }
+}
+
+// K2 (grid B): expected loss and the gradient of the soft-max selection (dsacstar_derivative.h:345-356)
+__global__ __launch_bounds__(kThreads)
+void xl_dsac_bwd_expect_kernel(BwdParams P)
+{
+    const int b = blockIdx.x, tid = threadIdx.x;
+    double *rec = P.rec + (int64_t)b * P.nHyp * kRec;
+    if (tid == 0) {
+        double e = 0.0;
+        for (int h = 0; h < P.nHyp; ++h) e += rec[(int64_t)h * kRec] * rec[(int64_t)h * kRec + 1];
+        P.outLoss[b] = e;
+    }
+    for (int i = tid; i < P.nHyp; i += kThreads) {
+        const double pi = rec[(int64_t)i * kRec];
+        if (pi < kProbThresh) continue;
+        double g = pi * rec[(int64_t)i * kRec + 1];
+        for (int j = 0; j < P.nHyp; ++j) g -= pi * rec[(int64_t)j * kRec] * rec[(int64_t)j * kRec + 1];
+        rec[(int64_t)i * kRec + 5] = g;
+    }
+}
+
+// K3 (grid nHyp x B): path II per hypothesis — g6 = sum_c dRepro(c) J_init(c), dPNP by central differences,
+// support-point gradients (dsacstar_derivative.h:209-320)
+__global__ __launch_bounds__(kThreads)
+void xl_dsac_bwd_score_kernel(BwdParams P)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    Smem &S = *reinterpret_cast<Smem *>(smem_raw);
+    float *sCo = reinterpret_cast<float *>(smem_raw + ((sizeof(Smem) + 15) & ~size_t(15)));
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = blockIdx.x, b = blockIdx.y;
+    double *rec = P.rec + ((int64_t)b * P.nHyp + h) * kRec;
+    if (rec[0] < kProbThresh) return;
+    Cam cam;
+    bwd_cam(P, b, cam);
+    const int N = cam.N;
+    stage_coords(P, b, sCo, tid);
+    __syncthreads();
+    Coords co{ sCo, sCo + P.Npad, sCo + 2 * P.Npad };
+    Pose init;
+    load_pose(P.hypPoses + ((int64_t)b * P.nHyp + h) * 12, init);
+    double dRi[27];
+    for (int i = 0; i < 27; ++i) dRi[i] = rec[kRecDRinit + i];
+    const double sog = rec[5];
+    const float beta = 5.0f / cam.thr;
+    const float facf = cam.alpha / (float)cam.Wo / (float)cam.Ho;
+
+    double a[28];
+#pragma unroll
+    for (int k = 0; k < 28; ++k) a[k] = 0.0;
+    for (int i = tid; i < N; i += kThreads) {
+        int y = i / cam.Wo, x = i - y * cam.Wo;
+        double X, Y, Z, J6[6];
+        co.fetch(i, X, Y, Z);
+        float e = cell_err(init, co, i, cam);
+        float stf = beta * (e - cam.thr);
+        double st = 1.0 / (1.0 + det_exp(-(double)stf));
+        double dRep = -st * (1.0 - st) * (double)beta * sog;
+        dRep *= (double)facf;
+        resid_row(init, dRi, X, Y, Z, (float)(x * cam.sub + cam.sub / 2), (float)(y * cam.sub + cam.sub / 2), cam, J6);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) a[k] += dRep * J6[k];
+    }
+    block_reduce28(a, S.red[0], wave, lane);
+
+    // dPNP (dsacstar_derivative.h:131-190): lanes 0..17 each solve one perturbed P3P; the float += eps / -= 2 eps /
+    // += eps sequence of the earlier columns is replayed so every solve sees the points the serial code would
+    double *sol = S.red[1];                                  // [18][7]: rvec, tvec, ok
+    const int32_t *cells = P.cells + ((int64_t)b * P.nHyp + h) * 4;
+    if (tid < 18) {
+        const float eps = 0.001f;
+        float pts[4][3];
+        double uv[4][2];
+        for (int q = 0; q < 4; ++q) {
+            const int ci = cells[q];
+            const int y = ci / cam.Wo, x = ci - y * cam.Wo;
+            pts[q][0] = sCo[ci]; pts[q][1] = sCo[P.Npad + ci]; pts[q][2] = sCo[2 * P.Npad + ci];
+            uv[q][0] = (double)(float)(x * cam.sub + cam.sub / 2);
+            uv[q][1] = (double)(float)(y * cam.sub + cam.sub / 2);
+        }
+        const int col = tid >> 1, back = tid & 1;
+        for (int c = 0; c <= col; ++c) {
+            float &v = pts[c / 3][c % 3];
+            v += eps;
+            if (c < col || back) v -= 2 * eps;
+            if (c < col) v += eps;
+        }
+        Pose sp;
+        V3 Q[4];
+        for (int q = 0; q < 4; ++q) { Q[q].x = (double)pts[q][0]; Q[q].y = (double)pts[q][1]; Q[q].z = (double)pts[q][2]; }
+        const bool ok = p3p(Q[0], Q[1], Q[2], Q[3], uv, cam, sp);
+        double r[3] = { 0.0, 0.0, 0.0 };
+        if (ok) log_so3(sp.R, r);
+        double *o = sol + tid * 7;
+        o[0] = r[0]; o[1] = r[1]; o[2] = r[2];
+        o[3] = ok ? sp.t[0] : 0.0; o[4] = ok ? sp.t[1] : 0.0; o[5] = ok ? sp.t[2] : 0.0;
+        o[6] = ok ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double J[72];
+        for (int k = 0; k < 72; ++k) J[k] = 0.0;
+        const double den = (double)(2 * 0.001f);
+        bool fail = false;
+        for (int col = 0; col < 9 && !fail; ++col) {
+            const double *f = sol + (2 * col) * 7, *bk = sol + (2 * col + 1) * 7;
+            if (f[6] == 0.0 || bk[6] == 0.0) { fail = true; break; }
+            for (int k = 0; k < 3; ++k) {
+                double av = (f[k] - bk[k]) / den, bv = (f[3 + k] - bk[3 + k]) / den;
+                J[k * 12 + col] = av;
+                J[(3 + k) * 12 + col] = bv;
+                if (!(av == av) || !(bv == bv)) fail = true;
+            }
+        }
+        if (fail) for (int k = 0; k < 72; ++k) J[k] = 0.0;
+        double maxH = 0.0;
+        for (int k = 0; k < 72; ++k) { double v = fabs(J[k]); if (v > maxH) maxH = v; }
+        if (maxH > 10.0) for (int k = 0; k < 72; ++k) J[k] = 0.0;
+        for (int c = 0; c < 12; ++c) {
+            double v = 0.0;
+            for (int r = 0; r < 6; ++r) v += a[r] * J[r * 12 + c];
+            rec[30 + c] = v;
+        }
+        rec[43] = maxH;
+        for (int k = 0; k < 6; ++k) rec[44 + k] = a[k];
+    }
+}
+
+// K4 (grid ceil(N/256) x B): assemble the gradient per cell, hypotheses in ascending order, float accumulation
+// like the reference's tensor += (dsacstar.cpp:462-480)
+__global__ __launch_bounds__(kThreads)
+void xl_dsac_bwd_assemble_kernel(BwdParams P)
+{
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * kThreads + threadIdx.x;
+    Cam cam;
+    bwd_cam(P, b, cam);
+    if (i >= cam.N) return;
+    const int y = i / cam.Wo, x = i - y * cam.Wo;
+    const float *q = P.coords + (int64_t)b * P.sb + (int64_t)y * P.sy + (int64_t)x * P.sx;
+    const double X = (double)q[0], Y = (double)q[P.sc], Z = (double)q[2 * P.sc];
+    const float px = (float)(x * cam.sub + cam.sub / 2), py = (float)(y * cam.sub + cam.sub / 2);
+    float *g = P.grad + (int64_t)b * P.gsb + (int64_t)y * P.gsy + (int64_t)x * P.gsx;
+    float acc[3] = { g[0], g[P.gsc], g[2 * P.gsc] };
+    const float beta = 5.0f / cam.thr;
+    const float facf = cam.alpha / (float)cam.Wo / (float)cam.Ho;
+    const int mt = i % kThreads, mj = i / kThreads;
+    // one cell's coordinates as a 1-cell "plane" for cell_err()
+    const float cX = q[0], cY = q[P.sc], cZ = q[2 * P.sc];
+    for (int h = 0; h < P.nHyp; ++h) {
+        const double *rec = P.rec + ((int64_t)b * P.nHyp + h) * kRec;
+        const double prob = rec[0];
+        if (prob < kProbThresh) continue;
+        Pose init, ref;
+        load_pose(P.hypPoses + ((int64_t)b * P.nHyp + h) * 12, init);
+        load_pose(rec + 6, ref);
+        double gI[3] = { 0.0, 0.0, 0.0 };
+        const unsigned long long m = P.masks[((int64_t)b * P.nHyp + h) * kThreads + mt];
+        if (rec[3] >= 4.0 && rec[4] == 0.0 && ((m >> mj) & 1ull)) {
+            double J6[6], dNdO[3];
+            resid_row(ref, rec + kRecDRref, X, Y, Z, px, py, cam, J6);
+            double s = 0.0;
+            for (int k = 0; k < 6; ++k) s += J6[k] * rec[24 + k];
+            s = -s;
+            dproject_dobj(ref, X, Y, Z, px, py, cam, dNdO);
+            for (int k = 0; k < 3; ++k) gI[k] = s * dNdO[k];
+        }
+        // clamped float error of the cell under the unrefined hypothesis (same arithmetic as cell_err)
+        float e;
+        {
+            float u, v;
+            project(init, (double)cX, (double)cY, (double)cZ, cam, u, v);
+            float dx = px - u, dy = py - v;
+            double n = sqrt((double)dx * (double)dx + (double)dy * (double)dy);
+            float af = (float)n;
+            e = (cam.maxReproj < af) ? cam.maxReproj : af;
+        }
+        float stf = beta * (e - cam.thr);
+        double st = 1.0 / (1.0 + det_exp(-(double)stf));
+        double dRep = -st * (1.0 - st) * (double)beta * rec[5];
+        dRep *= (double)facf;
+        double dPdO[3];
+        dproject_dobj(init, X, Y, Z, px, py, cam, dPdO);
+        double jac[3] = { dPdO[0] * dRep, dPdO[1] * dRep, dPdO[2] * dRep };
+        const int32_t *cells = P.cells + ((int64_t)b * P.nHyp + h) * 4;
+        for (int j = 0; j < 4; ++j)
+            if (cells[j] == i)
+                for (int k = 0; k < 3; ++k) jac[k] += rec[30 + 3 * j + k];
+        for (int k = 0; k < 3; ++k) acc[k] = (float)((double)acc[k] + (prob * gI[k] + jac[k]));
+    }
+    g[0] = acc[0]; g[P.gsc] = acc[1]; g[2 * P.gsc] = acc[2];
 }
 
 thread_local char g_hipErr[256] = "";
@@ -897,7 +1567,7 @@ int xl_dsac_forward_rgb_batch(const float *coords_dev, int64_t sb, int64_t sc, i
     Params P;
     P.coords = coords_dev; P.sb = sb; P.sc = sc; P.sy = sy; P.sx = sx;
     P.outPoses = out_poses_dev; P.focals = focals_dev;
-    P.cells = cells_dev; P.tries = tries_dev; P.scores = scores_dev; P.dbg = dbg_dev;
+    P.cells = cells_dev; P.tries = tries_dev; P.scores = scores_dev; P.dbg = dbg_dev; P.hypPoses = nullptr;
     P.seed = seed; P.image0 = image0; P.imageStride = image_stride; P.maxTries = max_tries;
     P.nHyp = n_hyp; P.Ho = Ho; P.Wo = Wo; P.sub = sub; P.Npad = (N + 3) & ~3;
     P.thr = thr; P.focal = focal; P.ppx = ppx; P.ppy = ppy; P.alpha = alpha; P.maxReproj = max_reproj;
@@ -984,7 +1654,79 @@ done:
     return rc;
 }
 
-int xl_dsac_backward_rgb(void) { return XL_ERR_UNSUPPORTED; }
+int xl_dsac_backward_rgb_batch(const float *coords_dev, int64_t sb, int64_t sc, int64_t sy, int64_t sx,
+                               int B, int Ho, int Wo,
+                               float *grad_dev, int64_t gsb, int64_t gsc, int64_t gsy, int64_t gsx,
+                               const float *gt_poses_dev, double *out_loss_dev,
+                               int n_hyp, float thr, float focal, float ppx, float ppy,
+                               float w_rot, float w_trans, float soft_clamp, float alpha, float max_reproj, int sub,
+                               const float *focals_dev, uint64_t seed, uint64_t image0, uint64_t image_stride,
+                               uint32_t max_tries, void *stream, double *rec_dev)
+{
+    if (!coords_dev || !grad_dev || !gt_poses_dev || !out_loss_dev || B <= 0 || Ho <= 0 || Wo <= 0 || n_hyp <= 0 ||
+        sub <= 0 || max_tries == 0)
+        return XL_ERR_ARG;
+    const int N = Ho * Wo;
+    if (N > kMaxCells) return XL_ERR_GRID;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t nh = (size_t)B * n_hyp;
+
+    // workspace: every hypothesis' pose, score and sampled cells; per-hypothesis records and inlier masks
+    int S = 1;
+    while (S * 2 * kWaves <= n_hyp && (long long)B * S * 2 <= 1024) S *= 2;
+    const size_t bPoses = sizeof(double) * nh * 12, bScores = sizeof(double) * nh, bCells = sizeof(int32_t) * nh * 4;
+    const size_t bRec = rec_dev ? 0 : sizeof(double) * nh * kRec, bMasks = sizeof(unsigned long long) * nh * kThreads;
+    const size_t bPart = sizeof(double) * ((size_t)B * S * kWaves * 16 + (size_t)B * 12);
+    auto up = [](size_t v) { return (v + 255) & ~size_t(255); };
+    unsigned char *ws = nullptr;
+    XL_HIP(hipMallocAsync((void **)&ws, up(bPoses) + up(bScores) + up(bCells) + up(bRec) + up(bMasks) + up(bPart), st));
+    unsigned char *cur = ws;
+    double *hypPoses = (double *)cur; cur += up(bPoses);
+    double *scores = (double *)cur; cur += up(bScores);
+    int32_t *cells = (int32_t *)cur; cur += up(bCells);
+    double *rec = rec_dev ? rec_dev : (double *)cur; cur += up(bRec);
+    unsigned long long *masks = (unsigned long long *)cur; cur += up(bMasks);
+    double *part = (double *)cur;
+
+    Params P;
+    P.coords = coords_dev; P.sb = sb; P.sc = sc; P.sy = sy; P.sx = sx;
+    P.outPoses = nullptr; P.focals = focals_dev;
+    P.cells = cells; P.tries = nullptr; P.scores = scores; P.dbg = nullptr; P.hypPoses = hypPoses;
+    P.seed = seed; P.image0 = image0; P.imageStride = image_stride; P.maxTries = max_tries;
+    P.nHyp = n_hyp; P.Ho = Ho; P.Wo = Wo; P.sub = sub; P.Npad = (N + 3) & ~3;
+    P.thr = thr; P.focal = focal; P.ppx = ppx; P.ppy = ppy; P.alpha = alpha; P.maxReproj = max_reproj;
+    P.part = part; P.S = S;
+    BwdParams Q;
+    Q.coords = coords_dev; Q.sb = sb; Q.sc = sc; Q.sy = sy; Q.sx = sx;
+    Q.grad = grad_dev; Q.gsb = gsb; Q.gsc = gsc; Q.gsy = gsy; Q.gsx = gsx;
+    Q.gt = gt_poses_dev; Q.focals = focals_dev;
+    Q.hypPoses = hypPoses; Q.scores = scores; Q.cells = cells; Q.rec = rec; Q.masks = masks; Q.outLoss = out_loss_dev;
+    Q.nHyp = n_hyp; Q.Ho = Ho; Q.Wo = Wo; Q.sub = sub; Q.Npad = P.Npad;
+    Q.thr = thr; Q.focal = focal; Q.ppx = ppx; Q.ppy = ppy; Q.alpha = alpha; Q.maxReproj = max_reproj;
+    Q.wRot = w_rot; Q.wTrans = w_trans; Q.softClamp = soft_clamp;
+
+    size_t lds = ((sizeof(Smem) + 15) & ~size_t(15)) + (size_t)3 * P.Npad * sizeof(float);
+    if (lds > 160 * 1024) { (void)hipFreeAsync(ws, st); return XL_ERR_GRID; }
+    static size_t configured = 0;
+    if (lds > configured) {
+        XL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(xl_dsac_forward_kernel<1>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        XL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(xl_dsac_bwd_hyp_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        XL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(xl_dsac_bwd_score_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured = lds;
+    }
+    hipLaunchKernelGGL(xl_dsac_forward_kernel<1>, dim3(S, B), dim3(kThreads), lds, st, P);
+    hipLaunchKernelGGL(xl_dsac_bwd_hyp_kernel, dim3(n_hyp, B), dim3(kThreads), lds, st, Q);
+    hipLaunchKernelGGL(xl_dsac_bwd_expect_kernel, dim3(B), dim3(kThreads), 0, st, Q);
+    hipLaunchKernelGGL(xl_dsac_bwd_score_kernel, dim3(n_hyp, B), dim3(kThreads), lds, st, Q);
+    hipLaunchKernelGGL(xl_dsac_bwd_assemble_kernel, dim3((N + kThreads - 1) / kThreads, B), dim3(kThreads), 0, st, Q);
+    XL_HIP(hipFreeAsync(ws, st));
+    XL_HIP(hipGetLastError());
+    return XL_OK;
+}
+
 int xl_dsac_forward_rgbd(void) { return XL_ERR_UNSUPPORTED; }
 int xl_dsac_backward_rgbd(void) { return XL_ERR_UNSUPPORTED; }
 

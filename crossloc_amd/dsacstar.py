@@ -13,6 +13,8 @@ is the exact call utils/evaluation.py:162-172 makes.  Differences, all additive:
     (thread_rand.cpp:17); here every call consumes one "image index" from a module counter
     (reset with `set_image_index`), and results do not depend on thread or rank count.
   * `forward_rgb_batch` localises B images per launch (the reference is batch-1 only).
+  * `backward_rgb` (dsacstar.cpp:200-483, exported by the reference but never called by CrossLoc) and its batched
+    form `backward_rgb_batch` run on the GPU as well; the RGB-D pair stays unimplemented.
 There is no CPU fallback: without the HIP library the call raises.
 """
 import ctypes
@@ -125,10 +127,71 @@ def forward_rgb(sceneCoordinates, outPose, ransacHypotheses, inlierThreshold, fo
     return None
 
 
-def backward_rgb(*args, **kwargs):
-    """dsacstar_rgb_backward (dsacstar.cpp:200-483): exported by the reference but never called by
-    CrossLoc."""
-    raise NotImplementedError("dsacstar.backward_rgb is not on CrossLoc's path and is not implemented")
+BWD_REC = 128                            # XL_DSAC_BWD_REC: doubles per hypothesis in the debug record
+
+
+def backward_rgb_batch(sceneCoordinates, outSceneCoordinatesGrad, gtPoses, ransacHypotheses, inlierThreshold,
+                       focalLength, ppointX, ppointY, wLossRot, wLossTrans, softClamp, inlierAlpha, maxReproj,
+                       subSampling, randomSeed, image0=0, image_stride=1, focals=None, max_tries=None, debug=False):
+    """DSAC* expected pose loss of B images and its gradient w.r.t. their scene coordinates in one launch sequence.
+    sceneCoordinates [B,3,Ho,Wo] and outSceneCoordinatesGrad (same shape, any strides; ACCUMULATED like the
+    reference's `+=`) are float32 CUDA tensors, gtPoses [B,4,4] cam->world.  Returns the expected losses as a
+    float64 CUDA tensor [B] (asynchronous on the current stream); with debug=True also the per-hypothesis records
+    [B,nHyp,BWD_REC] (layout: include/crossloc_dsac.h)."""
+    _check_coords(sceneCoordinates, True)
+    g = outSceneCoordinatesGrad
+    if not sceneCoordinates.is_cuda or not isinstance(g, torch.Tensor) or not g.is_cuda:
+        raise RuntimeError("backward_rgb_batch needs CUDA(HIP) tensors; there is no CPU fallback")
+    if g.dtype != torch.float32 or tuple(g.shape) != tuple(sceneCoordinates.shape):
+        raise RuntimeError("outSceneCoordinatesGrad must be float32 with the shape of sceneCoordinates")
+    B, _, Ho, Wo = sceneCoordinates.shape
+    dev = sceneCoordinates.device
+    gt = gtPoses.to(device=dev, dtype=torch.float32).reshape(B, 16).contiguous()
+    if focals is not None:
+        focals = focals.to(device=dev, dtype=torch.float32).contiguous()
+        assert focals.numel() == B
+    loss = torch.zeros((B,), dtype=torch.float64, device=dev)
+    rec = torch.zeros((B, ransacHypotheses, BWD_REC), dtype=torch.float64, device=dev) if debug else None
+    sb, sc, sy, sx = sceneCoordinates.stride()
+    gb, gc, gy, gx = g.stride()
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream().cuda_stream
+        rc = _lib.lib().xl_dsac_backward_rgb_batch(
+            _ptr(sceneCoordinates), sb, sc, sy, sx, B, Ho, Wo, _ptr(g), gb, gc, gy, gx, _ptr(gt), _ptr(loss),
+            int(ransacHypotheses), float(inlierThreshold), float(focalLength), float(ppointX), float(ppointY),
+            float(wLossRot), float(wLossTrans), float(softClamp), float(inlierAlpha), float(maxReproj),
+            int(subSampling), _ptr(focals), int(randomSeed), int(image0), int(image_stride),
+            int(MAX_HYPOTHESES_TRIES if max_tries is None else max_tries), ctypes.c_void_p(stream), _ptr(rec))
+    _lib.check(rc)
+    return (loss, rec) if debug else loss
+
+
+def backward_rgb(sceneCoordinates, outSceneCoordinatesGrad, gtPose, ransacHypotheses, inlierThreshold, focalLength,
+                 ppointX, ppointY, wLossRot, wLossTrans, softClamp, inlierAlpha, maxReproj, subSampling, randomSeed):
+    """dsacstar_rgb_backward (dsacstar.cpp:200-215): pose estimation of ONE image plus the gradient of the expected
+    pose loss w.r.t. its scene coordinates, accumulated into outSceneCoordinatesGrad [1,3,H,W]; returns the DSAC
+    expectation of the pose loss as a Python float.  Tensors may live on the GPU or (like the reference) the CPU."""
+    _check_coords(sceneCoordinates, False)
+    g = outSceneCoordinatesGrad
+    if not isinstance(g, torch.Tensor) or g.dtype != torch.float32 or tuple(g.shape) != tuple(sceneCoordinates.shape):
+        raise RuntimeError("outSceneCoordinatesGrad must be float32 with the shape of sceneCoordinates")
+    if not isinstance(gtPose, torch.Tensor) or tuple(gtPose.shape) != (4, 4):
+        raise RuntimeError("gtPose must be a [4,4] tensor")
+    if sceneCoordinates.is_cuda and g.is_cuda:
+        loss = backward_rgb_batch(sceneCoordinates, g, gtPose.view(1, 4, 4), ransacHypotheses, inlierThreshold,
+                                  focalLength, ppointX, ppointY, wLossRot, wLossTrans, softClamp, inlierAlpha,
+                                  maxReproj, subSampling, randomSeed)
+        return float(loss.item())
+    if sceneCoordinates.is_cuda or g.is_cuda:
+        raise RuntimeError("sceneCoordinates and outSceneCoordinatesGrad must be on the same device")
+    dev = torch.device("cuda")                       # raises if there is no HIP device: no CPU fallback
+    co = sceneCoordinates.to(dev)
+    gd = torch.zeros(tuple(g.shape), dtype=torch.float32, device=dev)
+    gd.copy_(g)
+    loss = backward_rgb_batch(co, gd, gtPose.view(1, 4, 4), ransacHypotheses, inlierThreshold, focalLength, ppointX,
+                              ppointY, wLossRot, wLossTrans, softClamp, inlierAlpha, maxReproj, subSampling, randomSeed)
+    g.copy_(gd)
+    return float(loss.item())
 
 
 def forward_rgbd(*args, **kwargs):

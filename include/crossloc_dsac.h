@@ -73,9 +73,36 @@ int xl_dsac_forward_rgb_host(const float *coords_host, int64_t sc, int64_t sy, i
                              uint64_t seed, uint64_t image, uint32_t max_tries,
                              int32_t *cells_host, int32_t *tries_host, double *scores_host, double *dbg_host);
 
+/*
+ * Batched backward_rgb: replaces dsacstar_rgb_backward (dsacstar.cpp:200-215, 215-483) for B independent images.
+ * Computes the DSAC* expectation of the pose loss over the soft-max distribution of n_hyp hypotheses and ACCUMULATES
+ * (+=, like the reference) its gradient w.r.t. the scene coordinates.
+ *
+ *   coords_dev     [B,3,Ho,Wo] float32, strides (sb, sc, sy, sx) in elements
+ *   grad_dev       [B,3,Ho,Wo] float32 gradient, strides (gsb, gsc, gsy, gsx); accumulated in place
+ *   gt_poses_dev   [B,16] float32 ground-truth cam->world poses (gtPoseSrc)
+ *   out_loss_dev   [B] float64: the expected loss the reference returns
+ *   w_rot, w_trans, soft_clamp   wLossRot, wLossTrans, softClamp of dsacstar.cpp:210-212
+ *   seed           randomSeed of dsacstar.cpp:215 (keys the counter-based sampler together with the image index)
+ *   rec_dev        optional [B,n_hyp,XL_DSAC_BWD_REC] float64 per-hypothesis records for parity tests:
+ *                  [0] prob [1] loss [2] active (prob >= 1e-3) [3] accepted inliers [4] path I clamped [5] soft-max
+ *                  gradient [6..17] refined pose (R row-major, t) [18..23] dLoss/d(rvec,tvec) [24..29] pinv(JtJ) dLoss^T
+ *                  [30..41] support-point gradients [42] max|jacobeanR| [43] max|dPNP| [44..49] sum_c dRepro J
+ *                  [50..52] rvec of the refined pose; the rest is workspace
+ *   other arguments as in xl_dsac_forward_rgb_batch.  Asynchronous on `stream`.
+ */
+#define XL_DSAC_BWD_REC 128
+int xl_dsac_backward_rgb_batch(const float *coords_dev, int64_t sb, int64_t sc, int64_t sy, int64_t sx,
+                               int B, int Ho, int Wo,
+                               float *grad_dev, int64_t gsb, int64_t gsc, int64_t gsy, int64_t gsx,
+                               const float *gt_poses_dev, double *out_loss_dev,
+                               int n_hyp, float thr, float focal, float ppx, float ppy,
+                               float w_rot, float w_trans, float soft_clamp, float alpha, float max_reproj, int sub,
+                               const float *focals_dev, uint64_t seed, uint64_t image0, uint64_t image_stride,
+                               uint32_t max_tries, void *stream, double *rec_dev);
+
 /* Exported for symmetry with the reference module (dsacstar.cpp:889-891); not on CrossLoc's
  * path (no call site in the reference).  They return XL_ERR_UNSUPPORTED. */
-int xl_dsac_backward_rgb(void);
 int xl_dsac_forward_rgbd(void);
 int xl_dsac_backward_rgbd(void);
 

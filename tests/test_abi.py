@@ -37,8 +37,9 @@ def test_status_strings_and_stub_entry_points(hiplib):
     assert hiplib.xl_status_string(0) == b"ok"
     for code in (-1, -2, -3, -4):
         assert len(hiplib.xl_status_string(code)) > 0
-    for n in ("xl_dsac_backward_rgb", "xl_dsac_forward_rgbd", "xl_dsac_backward_rgbd"):
+    for n in ("xl_dsac_forward_rgbd", "xl_dsac_backward_rgbd"):
         assert getattr(hiplib, n)() == -4
+    assert hiplib.xl_dsac_backward_rgb_batch(None, 0, 0, 0, 0, 1, 60, 90, None) == -1
     # argument validation happens before any HIP call, so it is testable without a GPU
     assert hiplib.xl_dsac_forward_rgb_batch(None, 0, 0, 0, 0, 1, 60, 90, None, 64) == -1
 
@@ -49,6 +50,12 @@ def test_dsacstar_module_surface(hiplib):
         assert callable(getattr(dsacstar, n))
     with pytest.raises(NotImplementedError):
         dsacstar.forward_rgbd()
+    with pytest.raises(NotImplementedError):
+        dsacstar.backward_rgbd()
+    import torch as _t
+    with pytest.raises(RuntimeError):              # shape check before any device work (no GPU here)
+        dsacstar.backward_rgb(_t.zeros(1, 3, 60, 90), _t.zeros(1, 3, 60, 91), _t.eye(4), 64, 10.0, 480.0, 360.0, 240.0,
+                              1.0, 1.0, 100.0, 100.0, 100.0, 8, 1)
     import torch
     with pytest.raises(RuntimeError):
         dsacstar.forward_rgb(torch.zeros(3, 60, 90), torch.zeros(4, 4), 64, 10.0, 480.0, 360.0, 240.0, 100.0, 100.0, 8)

@@ -126,7 +126,7 @@ def test_reference_shaped_call_cpu_and_gpu_tensors(oracle):
     with pytest.raises(RuntimeError):
         dsacstar.forward_rgb(scene_coords.double(), out_pose, 64, 10.0, 480.0, 360.0, 240.0, 100.0, 100.0, 8)
     with pytest.raises(NotImplementedError):
-        dsacstar.backward_rgb()
+        dsacstar.backward_rgbd()
 
 
 def test_full_size_batch_properties():
