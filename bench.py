@@ -35,6 +35,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md: fp
 # PMC counters cannot be read from inside the process, so the profiled value is recorded per batch size.
 CONV512_TRAFFIC_BYTES = {24: (755733 * 2 + 259200) * 1024}
 FWD_GFLOP_PER_IMAGE = 295.41        # SURVEY.md §8(d), single-task net, 480x720
+FWD_GFLOP_PER_IMAGE_3ENC = 755.96   # SURVEY.md §8(d), CrossLoc 3-encoder net
 
 
 def main():
@@ -46,6 +47,9 @@ def main():
                     help="images per step per GPU (24 -> 4052 conv tiles = 7.9 full waves of 512 resident workgroups)")
     ap.add_argument("--hyps", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mlr", type=int, default=0, choices=[0, 3],
+                    help="3: BASELINE configs[4], the 3-encoder CrossLoc network (755.96 GFLOP per frame) instead of "
+                         "the single-task one the headline metric is quoted on")
     args = ap.parse_args()
 
     import torch
@@ -66,7 +70,7 @@ def main():
 
     B, K, W, H, IMW, NH = args.batch, args.steps, args.warmup, 480, 720, args.hyps
     mean = torch.tensor(synth.SCENE_MEAN, dtype=torch.float32)
-    net = networks.TransPoseNet(mean, False, False, 2, 2, 3, 1)          # utils/learning.py:302-305 sizes
+    net = networks.TransPoseNet(mean, False, False, 2, 2, 3, 1, num_mlr=args.mlr)   # utils/learning.py:302-305 sizes
     net.load_state_dict(seeded_state_dict(net, seed=2021))
     net = net.to(dev).eval()
 
@@ -168,7 +172,7 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(net, images, coords_np, NH)
+        cpu = cpu_baseline(net, images, coords_np, NH, args.mlr)
 
     if rank == 0:
         value = total_imgs / elapsed
@@ -176,8 +180,10 @@ def main():
             "metric": "images/sec localized (480x720, 256 hyps)", "value": round(value, 2), "unit": "images/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(elapsed / K * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[2]: single-task coord CNN forward (2+2 extra res blocks) + HIP "
-                                   "dsacstar.forward_rgb, 480x720 frames, 60x90 coordinate grid",
+            "config": {"workload": ("BASELINE configs[4]: CrossLoc 3-encoder (coord+depth+normal) fusion network forward"
+                                    if args.mlr else
+                                    "BASELINE configs[2]: single-task coord CNN forward (2+2 extra res blocks)")
+                                   + " + HIP dsacstar.forward_rgb, 480x720 frames, 60x90 coordinate grid",
                        "hypotheses": NH, "batch_per_gpu": B, "global_batch": B * world,
                        "parallelism": "images sharded over %d GPU(s), no data-path collective" % world,
                        "solver_input": "synthetic scene coordinates (0.5 m noise, 30% outliers); CNN runs seeded "
@@ -188,7 +194,7 @@ def main():
                        # nHyp*N*12 B + 64 B per image; the stage is LDS-resident and fp64/latency-bound
                        "dsac_algorithmic_GBps": round(B * (NH * 5400 * 12 + 64) / (dsac_ms * 1e-3) / 1e9, 1),
                        "dsac_hbm_roofline_frac": round(B * (NH * 5400 * 12 + 64) / (dsac_ms * 1e-3) / 8e12, 5),
-                       "cnn_fwd_tflops": round(FWD_GFLOP_PER_IMAGE * B / cnn_ms, 2),
+                       "cnn_fwd_tflops": round((FWD_GFLOP_PER_IMAGE_3ENC if args.mlr else FWD_GFLOP_PER_IMAGE) * B / cnn_ms, 2),
                        "median_err_cm": round(med_t_cm, 3), "median_err_deg": round(med_r_deg, 5)},
             "roofline": {"bound": "mfma", "kernel": "igemm_conv_kernel<3,1,128,512> (3x3 512->512 @60x90 x%d images)" % B,
                          "achieved": round(conv_tflops, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
@@ -204,7 +210,7 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(net, images, coords_np, n_hyp):
+def cpu_baseline(net, images, coords_np, n_hyp, num_mlr=0):
     """The restated reference CPU path on this box's host cores: PyTorch-CPU fp32 network + OpenMP C solver.
     Bounded sample (a few frames) so the default run stays within minutes."""
     import torch
@@ -217,11 +223,11 @@ def cpu_baseline(net, images, coords_np, n_hyp):
     dsac_oracle.set_num_threads(cores)
     sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
     x = images[:1].detach().cpu()
-    cnn_oracle.transposenet_forward(sd, x, 0, 2, 2)                      # warm-up
+    cnn_oracle.transposenet_forward(sd, x, num_mlr, 2, 2)                # warm-up
     n_cnn = 3
     t0 = time.perf_counter()
     for _ in range(n_cnn):
-        cnn_oracle.transposenet_forward(sd, x, 0, 2, 2)
+        cnn_oracle.transposenet_forward(sd, x, num_mlr, 2, 2)
     t_cnn = (time.perf_counter() - t0) / n_cnn
     n_dsac = min(16, coords_np.shape[0])
     dsac_oracle.forward_rgb(coords_np[0], n_hyp, 10.0, 480.0, 360.0, 240.0, 100.0, 100.0, 8)   # warm-up
