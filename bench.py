@@ -34,6 +34,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md: fp
 # FETCH_SIZE (KB, doubled per the gfx950 note of MI355X_MICROARCH.md §HBM) + WRITE_SIZE (KB), batch 24.
 # PMC counters cannot be read from inside the process, so the profiled value is recorded per batch size.
 CONV512_TRAFFIC_BYTES = {24: (755733 * 2 + 259200) * 1024}
+WINO512_TRAFFIC_BYTES = {}          # filled from profiles/r1_wino512_pmc.csv
 FWD_GFLOP_PER_IMAGE = 295.41        # SURVEY.md §8(d), single-task net, 480x720
 FWD_GFLOP_PER_IMAGE_3ENC = 755.96   # SURVEY.md §8(d), CrossLoc 3-encoder net
 
@@ -134,24 +135,30 @@ def main():
     typ = (ctypes.c_int32 * cap)()
     ms = (ctypes.c_float * cap)()
     nrec = L.xl_cnn_prof_end(idx, typ, ms, cap)
-    conv_ms, by_type = [], {}
+    conv_ms, by_type, wino = [], {}, False
     for i in range(max(nrec, 0)):
         op = plan.op_array[idx[i]]
         by_type[typ[i]] = by_type.get(typ[i], 0.0) + ms[i]
-        if typ[i] == networks.XL_OP_CONV and op.ksize == 3 and op.Cin == 512 and op.Cout == 512 and op.stride == 1:
+        if typ[i] == networks.XL_OP_CONV and op.Cin == 512 and op.Cout == 512 and op.stride == 1 and (
+                (op.ksize == 3 and op.nchunks2 <= 1) or (op.ksize == 1 and op.nchunks2 == 16)):
             conv_ms.append(ms[i])
+            wino = op.nchunks2 == 16
     if rank == 0 and os.environ.get("XL_BENCH_VERBOSE"):
         per_op = {}
         for i in range(max(nrec, 0)):
             per_op.setdefault(idx[i], []).append(ms[i])
-        names = {0: "conv1", 1: "conv", 2: "gn_stats", 3: "gn_apply", 4: "head", 11: "gn_final"}
+        names = {0: "conv1", 1: "conv", 2: "gn_stats", 3: "gn_apply", 4: "head", 11: "gn_final", 12: "wino_in",
+                 13: "wino_out"}
         for i in sorted(per_op):
             op = plan.op_array[i]
             sys.stderr.write("op %3d %-8s k%d s%d %4d->%4d %3dx%3d  %.4f ms\n" % (
                 i, names[op.type], op.ksize, op.stride, op.Cin, op.Cout, op.Hi, op.Wi, float(np.mean(per_op[i]))))
         sys.stderr.write("by type (ms/step): %s\n" % {names[k]: round(v / K, 3) for k, v in by_type.items()})
     conv_avg_ms = float(np.mean(conv_ms)) if conv_ms else float("nan")
-    conv_flop = 2.0 * (B * 60 * 90) * 512 * (9 * 512)
+    # dominant kernel: the 3x3 512->512 layers.  Direct form: one implicit GEMM of 2*M*512*4608 FLOP.  Winograd
+    # F(2x2,3x3) form (inference plans): one batched launch of 16 GEMMs [M/4 x 512] x [512 x 512]; the FLOPs counted
+    # are the ones that launch executes (2.25x fewer multiplies than the direct form for the same layer)
+    conv_flop = 16 * 2.0 * (B * 30 * 45) * 512 * 512 if wino else 2.0 * (B * 60 * 90) * 512 * (9 * 512)
     conv_tflops = conv_flop / (conv_avg_ms * 1e-3) / 1e12 if conv_ms else float("nan")
     cnn_ms = float(np.mean([ev[s][0].elapsed_time(ev[s][1]) for s in range(K)]))
     dsac_ms = float(np.mean([ev[s][2].elapsed_time(ev[s][3]) for s in range(K)]))
@@ -196,10 +203,15 @@ def main():
                        "dsac_hbm_roofline_frac": round(B * (NH * 5400 * 12 + 64) / (dsac_ms * 1e-3) / 8e12, 5),
                        "cnn_fwd_tflops": round((FWD_GFLOP_PER_IMAGE_3ENC if args.mlr else FWD_GFLOP_PER_IMAGE) * B / cnn_ms, 2),
                        "median_err_cm": round(med_t_cm, 3), "median_err_deg": round(med_r_deg, 5)},
-            "roofline": {"bound": "mfma", "kernel": "igemm_conv_kernel<3,1,128,512> (3x3 512->512 @60x90 x%d images)" % B,
+            "roofline": {"bound": "mfma",
+                         "kernel": ("igemm_conv_kernel<1,1,128,512> batched x16: the Winograd F(2x2,3x3) GEMMs of a 3x3 "
+                                    "512->512 layer @60x90 x%d images" if wino else
+                                    "igemm_conv_kernel<3,1,128,512> (3x3 512->512 @60x90 x%d images)") % B,
                          "achieved": round(conv_tflops, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(conv_tflops / PEAK_F32_MFMA_TFLOPS, 4), "traffic": CONV512_TRAFFIC_BYTES.get(B),
-                         "algorithmic_bytes_per_launch": 2 * B * 5400 * 512 * 4 + 512 * 4608 * 4,
+                         "frac": round(conv_tflops / PEAK_F32_MFMA_TFLOPS, 4),
+                         "traffic": (WINO512_TRAFFIC_BYTES if wino else CONV512_TRAFFIC_BYTES).get(B),
+                         "algorithmic_bytes_per_launch": (16 * (2 * B * 1350 * 512 + 512 * 512) * 4 if wino else
+                                                          2 * B * 5400 * 512 * 4 + 512 * 4608 * 4),
                          "avg_launch_ms": round(conv_avg_ms, 4), "launches_timed": len(conv_ms),
                          "algorithmic_gflop_per_launch": round(conv_flop / 1e9, 2)},
             "cpu_baseline": cpu,

@@ -102,6 +102,8 @@ struct ConvArgs {
     double *stats; int HW, G, cpg, nchunks;
     // MODE 2 (stride-2 data gradient, one parity class of result pixels per launch)
     int py, px, Hj, Wj, ntaps; unsigned tapList;
+    // batched launch (Winograd: 16 independent GEMMs): tile t of the grid belongs to GEMM z = t / (nbm*nbn)
+    int zCount; long long zIn, zW, zOut;   // element strides between consecutive GEMMs
     long long *clk;                 // diagnostics (XL_CONV_CLK=1): per-workgroup shader-clock phase timings, else NULL
 };
 
@@ -143,7 +145,13 @@ void igemm_conv_kernel(ConvArgs a)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
 
-    const int tile = xcd_remap(blockIdx.x, a.nbm * a.nbn);
+    // each XCD gets a contiguous run of (GEMM, m-tile, n-tile): the n-tiles of an m-tile share an L2
+    int tile = xcd_remap(blockIdx.x, a.nbm * a.nbn * a.zCount);
+    if (a.zCount > 1) {
+        const int z = tile / (a.nbm * a.nbn);
+        tile -= z * (a.nbm * a.nbn);
+        a.in += z * a.zIn; a.w += z * a.zW; a.out += z * a.zOut;
+    }
     const int mt = tile / a.nbn, nt = tile - mt * a.nbn;
     const int m0 = mt * BM, n0 = nt * BN;
 
@@ -449,6 +457,120 @@ void igemm_conv_kernel(ConvArgs a)
     }
 }
 
+// ---------------------------------------------------------------------------------------------- Winograd F(2x2, 3x3)
+
+// The stride-1 3x3 convolutions of inference plans run as Winograd F(2x2,3x3): 16 multiplies per 2x2 output tile and
+// (ci, co) pair instead of 36.  V[xi][t][c] = (B^T d B)[xi] for the 4x4 input patch d of output tile t (zero padded),
+// M[xi] = V[xi] U[xi]^T (16 GEMMs through igemm_conv_kernel, one batched launch), Y = A^T M A + bias.
+// HBM-bound elementwise passes, one tile x 4 channels per thread, coalesced along the channel.
+__global__ __launch_bounds__(256)
+void wino_in_kernel(const float *__restrict__ in, float *__restrict__ V, int B, int H, int W, int C, int ldIn, int Th, int Tw)
+{
+    const int C4 = C >> 2;
+    const long long T = (long long)B * Th * Tw;
+    const long long items = T * C4;
+    for (long long it = (long long)blockIdx.x * 256 + threadIdx.x; it < items; it += (long long)gridDim.x * 256) {
+        const int c4 = (int)(it % C4);
+        const long long t = it / C4;
+        const int tx = (int)(t % Tw);
+        const int ty = (int)((t / Tw) % Th);
+        const int n = (int)(t / ((long long)Tw * Th));
+        f32x4 d[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int y = 2 * ty - 1 + a;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int x = 2 * tx - 1 + b;
+                if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W)
+                    d[a][b] = *reinterpret_cast<const f32x4 *>(in + (((long long)n * H + y) * W + x) * ldIn + 4 * c4);
+                else
+                    d[a][b] = f32x4{ 0.f, 0.f, 0.f, 0.f };
+            }
+        }
+        f32x4 w[4][4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            w[0][b] = d[0][b] - d[2][b];
+            w[1][b] = d[1][b] + d[2][b];
+            w[2][b] = d[2][b] - d[1][b];
+            w[3][b] = d[1][b] - d[3][b];
+        }
+        float *o = V + t * C + 4 * c4;
+        const long long zs = T * C;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<f32x4 *>(o + (4 * i + 0) * zs) = w[i][0] - w[i][2];
+            *reinterpret_cast<f32x4 *>(o + (4 * i + 1) * zs) = w[i][1] + w[i][2];
+            *reinterpret_cast<f32x4 *>(o + (4 * i + 2) * zs) = w[i][2] - w[i][1];
+            *reinterpret_cast<f32x4 *>(o + (4 * i + 3) * zs) = w[i][1] - w[i][3];
+        }
+    }
+}
+
+// grid (nchunks, B): block k of image n transforms tiles [k*tpb, (k+1)*tpb) and writes the fp64 GroupNorm partial sums
+// of what it produced to stats[n][k][g] (fixed order: tiles per thread, then the S tile lanes, then the channels of
+// the group).  256 threads = S tile lanes x C/4 channel quads.
+__global__ __launch_bounds__(256)
+void wino_out_kernel(const float *__restrict__ M, const float *__restrict__ bias, float *__restrict__ out,
+                     double *__restrict__ stats, int B, int H, int W, int C, int ldOut, int Th, int Tw, int tpb,
+                     int G, int nchunks)
+{
+    __shared__ double sS[256 * 8];
+    const int tid = threadIdx.x;
+    const int C4 = C >> 2, S = 256 / C4;
+    const int c4 = tid % C4, sub = tid / C4;
+    const int n = blockIdx.y, k = blockIdx.x;
+    const int Timg = Th * Tw;
+    const long long T = (long long)B * Timg;
+    const long long zs = T * C;
+    int t1 = (k + 1) * tpb; if (t1 > Timg) t1 = Timg;
+    f32x4 bv = f32x4{ 0.f, 0.f, 0.f, 0.f };
+    if (bias) bv = *reinterpret_cast<const f32x4 *>(bias + 4 * c4);
+    f32x4 s1 = f32x4{ 0.f, 0.f, 0.f, 0.f }, s2 = f32x4{ 0.f, 0.f, 0.f, 0.f };
+    for (int tl = k * tpb + sub; tl < t1; tl += S) {
+        const int ty = tl / Tw, tx = tl - ty * Tw;
+        const float *m = M + ((long long)n * Timg + tl) * C + 4 * c4;
+        f32x4 r[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) r[i][j] = *reinterpret_cast<const f32x4 *>(m + (4 * i + j) * zs);
+        f32x4 q[2][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            q[0][j] = r[0][j] + r[1][j] + r[2][j];
+            q[1][j] = r[1][j] - r[2][j] - r[3][j];
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const f32x4 y0 = q[i][0] + q[i][1] + q[i][2] + bv;
+            const f32x4 y1 = q[i][1] - q[i][2] - q[i][3] + bv;
+            float *o = out + (((long long)n * H + 2 * ty + i) * W + 2 * tx) * ldOut + 4 * c4;
+            *reinterpret_cast<f32x4 *>(o) = y0;
+            *reinterpret_cast<f32x4 *>(o + ldOut) = y1;
+            s1 += y0; s1 += y1;
+            s2 += y0 * y0; s2 += y1 * y1;
+        }
+    }
+    if (!stats) return;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { sS[tid * 8 + e] = (double)s1[e]; sS[tid * 8 + 4 + e] = (double)s2[e]; }
+    __syncthreads();
+    if (tid < G) {
+        const int cpg = C / G;
+        double a = 0.0, b = 0.0;
+        for (int sb = 0; sb < S; ++sb)
+            for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) {
+                const int th = sb * C4 + (c >> 2);
+                a += sS[th * 8 + (c & 3)];
+                b += sS[th * 8 + 4 + (c & 3)];
+            }
+        double *o = stats + (((long long)n * nchunks + k) * G + tid) * 2;
+        o[0] = a; o[1] = b;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- GroupNorm
 
 // grid (nchunks, B); T threads with T % (C/4) == 0.  stats[((n*nchunks + chunk)*G + g)*2 + {0,1}] = sum, sumsq
@@ -700,6 +822,12 @@ int launch_igemm(const xl_op &op, hipStream_t st, int py = 0, int px = 0)
     a.M = op.B * op.Ho * op.Wo; a.K = op.ksize * op.ksize * op.Cin;
     a.py = py; a.px = px; a.Hj = 0; a.Wj = 0; a.ntaps = 0; a.tapList = 0;
     a.stats = nullptr; a.HW = op.Ho * op.Wo; a.G = 0; a.cpg = 1; a.nchunks = 0;
+    a.zCount = 1; a.zIn = 0; a.zW = 0; a.zOut = 0;
+    if (MODE == 0 && op.nchunks2 > 1) {             // batched GEMMs over consecutive blocks of in / w / out
+        if (op.stats) return XL_ERR_ARG;
+        a.zCount = op.nchunks2;
+        a.zIn = (long long)a.M * op.ld_in; a.zW = (long long)op.Cout * a.K; a.zOut = (long long)a.M * op.ld_out;
+    }
     if (MODE == 0 && op.stats && op.groups > 0) {
         a.G = op.groups; a.cpg = op.Cout / op.groups; a.nchunks = op.nchunks;
         if (a.HW < BM || op.Cout % op.groups != 0 || BN % a.cpg != 0 || a.nchunks < (a.HW + BM - 1) / BM + 1) return XL_ERR_ARG;
@@ -735,9 +863,9 @@ int launch_igemm(const xl_op &op, hipStream_t st, int py = 0, int px = 0)
     }
     static const bool clkDbg = getenv("XL_CONV_CLK") != nullptr;
     a.clk = nullptr;
-    const int nwg = a.nbm * a.nbn;
+    const int nwg = a.nbm * a.nbn * a.zCount;
     if (clkDbg) hipMalloc(&a.clk, sizeof(long long) * 8 * nwg);
-    hipLaunchKernelGGL((igemm_conv_kernel<KS, STRIDE, BN, CIN, MODE, BM>), dim3(a.nbm * a.nbn), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((igemm_conv_kernel<KS, STRIDE, BN, CIN, MODE, BM>), dim3(nwg), dim3(256), lds, st, a);
     if (clkDbg) {
         hipStreamSynchronize(st);
         std::vector<long long> h(8 * (size_t)nwg);
@@ -825,6 +953,27 @@ int run_op(const xl_op &op, hipStream_t st)
         }
         case XL_OP_CONV:
             return run_conv(op, st);
+        case XL_OP_WINO_IN: {
+            if (op.Cin % 4 != 0 || op.ld_in % 4 != 0 || op.Hi != 2 * op.Ho || op.Wi != 2 * op.Wo) return XL_ERR_ARG;
+            const long long items = (long long)op.B * op.Ho * op.Wo * (op.Cin / 4);
+            long long blocks = (items + 255) / 256;
+            if (blocks > 262144) blocks = 262144;
+            hipLaunchKernelGGL(wino_in_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float *)op.in, (float *)op.out,
+                               op.B, op.Hi, op.Wi, op.Cin, op.ld_in, op.Ho, op.Wo);
+            return XL_OK;
+        }
+        case XL_OP_WINO_OUT: {
+            // in: M [16][B*Th*Tw][C]; out [B,H,W,C] (Hi x Wi = output size); reserved_i = tiles per block
+            const int C4 = op.Cin / 4;
+            if (op.Cin % 4 != 0 || C4 > 256 || 256 % C4 != 0 || op.ld_out % 4 != 0 || op.reserved_i < 1) return XL_ERR_ARG;
+            const int Th = op.Hi / 2, Tw = op.Wi / 2;
+            if (op.Hi != 2 * Th || op.Wi != 2 * Tw || op.nchunks != (Th * Tw + op.reserved_i - 1) / op.reserved_i) return XL_ERR_ARG;
+            if (op.stats && (op.groups < 1 || op.groups > 256 || op.Cin % op.groups != 0)) return XL_ERR_ARG;
+            hipLaunchKernelGGL(wino_out_kernel, dim3(op.nchunks, op.B), dim3(256), 0, st, (const float *)op.in,
+                               (const float *)op.bias, (float *)op.out, (double *)op.stats, op.B, op.Hi, op.Wi, op.Cin,
+                               op.ld_out, Th, Tw, op.reserved_i, op.groups, op.nchunks);
+            return XL_OK;
+        }
         case XL_OP_GN_STATS: {
             const int C4 = op.Cin / 4;
             if (op.Cin % 4 != 0 || op.Cin % op.groups != 0 || op.ld_in % 4 != 0) return XL_ERR_ARG;

@@ -24,6 +24,7 @@ XL_OP_CONV1, XL_OP_CONV, XL_OP_GN_STATS, XL_OP_GN_APPLY, XL_OP_HEAD = 0, 1, 2, 3
 GN_RELU_IN, GN_ADD, GN_RELU_OUT, GN_ACC_AUX, GN_NO_CONV_BIAS = 1, 2, 4, 8, 16
 XL_OP_WGRAD, XL_OP_GNB_STATS, XL_OP_GNB_APPLY, XL_OP_GNB_PARAMS, XL_OP_HEAD_BWD, XL_OP_CONV1_WGRAD = 5, 6, 7, 8, 9, 10
 XL_OP_GN_FINAL = 11
+XL_OP_WINO_IN, XL_OP_WINO_OUT = 12, 13
 CONV_DGRAD, CONV_ACCUMULATE = 1, 2
 
 
@@ -210,6 +211,20 @@ class _Plan:
         self.free.setdefault(t.numel(), []).append(t)
 
     # -- weights
+    # Winograd F(2x2,3x3) weight transform U = G g G^T, G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]] (Lavin & Gray 2016)
+    _WINO_G = ((1.0, 0.0, 0.0), (0.5, 0.5, 0.5), (0.5, -0.5, 0.5), (0.0, 0.0, 1.0))
+
+    def pack_conv_wino(self, conv):
+        """[16][Cout][Cin] transformed weights of a 3x3 convolution (one plain [Cout][Cin] GEMM operand per frequency)."""
+        w = conv.weight
+        key = (id(w), "wino")
+        if key not in self.packed:
+            src = w.detach().to(device=self.device, dtype=torch.float32).contiguous()
+            dst = torch.empty(16 * src.shape[0] * src.shape[1], dtype=torch.float32, device=self.device)
+            self.packed[key] = (dst, src, "wino")
+            self._pack(dst, src, "wino")
+        return self.packed[key][0]
+
     def pack_conv(self, conv, dgrad=False):
         w = conv.weight
         key = (id(w), dgrad)
@@ -226,7 +241,11 @@ class _Plan:
         L = _bind()
         cout, cin, k, _ = src.shape
         stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-        if kind == "conv1":                     # [(ky*3+kx)*Cin + c][Cout]
+        if kind == "wino":
+            G = torch.tensor(self._WINO_G, dtype=torch.float64, device=self.device)
+            U = torch.einsum("ia,ocab,jb->ijoc", G, src.to(torch.float64), G)          # exact in fp64, rounded once
+            dst.view(4, 4, cout, cin).copy_(U)
+        elif kind == "conv1":                     # [(ky*3+kx)*Cin + c][Cout]
             dst.view(k, k, cin, cout).copy_(src.permute(2, 3, 1, 0))
         elif kind == "dgrad":
             _check(L.xl_cnn_pack_conv_weight_dgrad(src.data_ptr(), dst.data_ptr(), cout, cin, k, stream))
@@ -316,7 +335,70 @@ class _Plan:
                               nchunks=nchunks, gamma=gamma, beta=beta))
         return res
 
+    def wino_ok(self, act, conv):
+        """Inference plans run the stride-1 3x3 convolutions as Winograd F(2x2,3x3) (2.25x fewer multiplies)."""
+        t, H, W, C, ld, off = act
+        return (not self.train and conv.kernel_size[0] == 3 and conv.stride[0] == 1 and H % 2 == 0 and W % 2 == 0
+                and C % 32 == 0 and conv.out_channels % 128 == 0 and conv.out_channels <= 1024
+                and 256 % (conv.out_channels // 4) == 0 and H * W >= 64 and not os.environ.get("XL_NO_WINOGRAD"))
+
+    def conv_wino(self, act, conv, norm, flags, aux):
+        """conv3x3 + GroupNorm(+epilogue): input transform, 16 GEMMs in one batched launch, output transform that also
+        emits the GroupNorm partial sums, GN_FINAL, GN_APPLY (in place)."""
+        t, H, W, C, ld, off = act
+        B, cout = self.B, conv.out_channels
+        Th, Tw = H // 2, W // 2
+        T = B * Th * Tw
+        V = self.alloc(16 * T * C)
+        op = XlOp()
+        op.type = XL_OP_WINO_IN
+        op.B, op.Hi, op.Wi, op.Cin, op.Ho, op.Wo, op.ld_in = B, H, W, C, Th, Tw, ld
+        op.in_, op.out = t.data_ptr() + 4 * off, V.data_ptr()
+        self.ops.append(op)
+        Mb = self.alloc(16 * T * cout)
+        op = XlOp()
+        op.type = XL_OP_CONV
+        op.B, op.Hi, op.Wi, op.Cin, op.Ho, op.Wo, op.Cout = B, Th, Tw, C, Th, Tw, cout
+        op.ksize, op.stride, op.ld_in, op.ld_out, op.nchunks2 = 1, 1, C, cout, 16
+        op.in_, op.w, op.out = V.data_ptr(), self.pack_conv_wino(conv).data_ptr(), Mb.data_ptr()
+        if -(-T // 128) * (cout // 128) * 16 <= 256:
+            op.reserved_i = 64
+        self.ops.append(op)
+        self.wino_gemm_indices = getattr(self, "wino_gemm_indices", []) + [len(self.ops) - 1]
+        self.release(V)
+        out = self.alloc(B * H * W * cout)
+        G = norm.num_groups
+        tpb = 32
+        nchunks = -(-(Th * Tw) // tpb)
+        op = XlOp()
+        op.type = XL_OP_WINO_OUT
+        op.B, op.Hi, op.Wi, op.Cin, op.ld_out, op.groups, op.nchunks, op.reserved_i = B, H, W, cout, cout, G, nchunks, tpb
+        op.in_, op.out = Mb.data_ptr(), out.data_ptr()
+        op.bias = self.dev(conv.bias).data_ptr()
+        self.max_stats = max(self.max_stats, B * nchunks * G * 2)
+        self.stats_ops.append(len(self.ops))
+        self.ops.append(op)
+        self.release(Mb)
+        y = (out, H, W, cout, cout, 0)
+        ap = XlOp()
+        ap.type = XL_OP_GN_APPLY
+        ap.B, ap.Hi, ap.Wi, ap.Cin, ap.groups, ap.nchunks, ap.ld_in = B, H, W, cout, G, nchunks, cout
+        ap.flags, ap.eps = flags, norm.eps
+        ap.in_ = out.data_ptr()
+        gamma, beta = self.dev(norm.weight), self.dev(norm.bias)
+        ap.w, ap.bias = gamma.data_ptr(), beta.data_ptr()
+        self._emit_final(ap, gamma, beta, 0)
+        if aux is not None:
+            ap.aux = aux[0].data_ptr() + 4 * aux[5]
+            ap.ld_aux = aux[4]
+        ap.out, ap.ld_out = ap.in_, cout
+        self.stats_ops.append(len(self.ops))
+        self.ops.append(ap)
+        return y
+
     def cgr(self, act, conv, norm, flags=GN_RELU_IN, aux=None):
+        if self.wino_ok(act, conv):
+            return self.conv_wino(act, conv, norm, flags, aux)
         y = self.conv(act, conv)
         if not self.train and y[1] * y[2] >= 128 and not os.environ.get("XL_NO_FUSED_STATS"):
             # inference: the conv epilogue produces the GroupNorm statistics, the separate stats pass is dropped

@@ -38,6 +38,9 @@ enum {
     XL_OP_GNB_PARAMS = 8,/* d gamma, d beta and the bias gradient of the preceding conv */
     XL_OP_HEAD_BWD = 9,  /* backward of XL_OP_HEAD: d(input) NHWC, d(fc3 weight), d(fc3 bias) */
     XL_OP_CONV1_WGRAD = 10, /* weight + bias gradient of the NCHW-input first conv */
+    XL_OP_WINO_IN = 12,     /* Winograd F(2x2,3x3) input transform: in [B,Hi,Wi,Cin] -> out V [16][B*Ho*Wo][Cin], Ho = Hi/2 */
+    XL_OP_WINO_OUT = 13,    /* Winograd output transform + bias (+ GroupNorm partial sums): in M [16][B*Hi/2*Wi/2][Cin] ->
+                               out [B,Hi,Wi,Cin]; reserved_i = tiles per workgroup, nchunks = workgroups per image */
     XL_OP_GN_FINAL = 11  /* per-(image, channel) GroupNorm scale/shift [B][C][2] from the partial sums (out);
                             GN_APPLY with aux2 = that buffer skips its own finalisation */
 };
@@ -65,7 +68,9 @@ typedef struct xl_op {
     int32_t ld_in, ld_out, ld_aux; /* pixel strides in floats of in / out / aux (NHWC tensors) */
     int32_t n_task, n_pos;         /* XL_OP_HEAD: task channels (mean added) and positive channels */
     int32_t nchunks2, reserved_i;  /* backward: pixel chunks of the GNB stats pass / split-K factor of WGRAD;
-                                      GN_APPLY: reserved_i = conv tile rows when the stats came from a conv epilogue */
+                                      GN_APPLY: reserved_i = conv tile rows when the stats came from a conv epilogue;
+                                      forward CONV: nchunks2 > 1 = that many independent GEMMs over consecutive
+                                      blocks of in / w / out (Winograd), reserved_i = 64 selects 64-row tiles */
     float eps;                     /* GroupNorm epsilon (1e-5) */
     float clamp_lo, clamp_hi;      /* XL_OP_HEAD hardtanh bounds (-16.10, 13.82), networks.py:355-356 */
     float reserved;

@@ -21,20 +21,23 @@ def main():
     ap.add_argument("--H", type=int, default=60)
     ap.add_argument("--W", type=int, default=90)
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--z", type=int, default=1, help="batched GEMMs per launch (16 = the Winograd F(2x2,3x3) GEMMs)")
     a = ap.parse_args()
     L = networks._bind()
     torch.manual_seed(0)
     Ho = (a.H + 2 * (a.k // 2) - a.k) // a.s + 1
     Wo = (a.W + 2 * (a.k // 2) - a.k) // a.s + 1
-    x = torch.randn(a.B, a.H, a.W, a.cin, device="cuda")
-    w = torch.randn(a.cout, a.k, a.k, a.cin, device="cuda") * 0.02
+    x = torch.randn(a.z, a.B, a.H, a.W, a.cin, device="cuda")
+    w = torch.randn(a.z, a.cout, a.k, a.k, a.cin, device="cuda") * 0.02
     b = torch.randn(a.cout, device="cuda")
-    out = torch.empty(a.B, Ho, Wo, a.cout, device="cuda")
+    out = torch.empty(a.z, a.B, Ho, Wo, a.cout, device="cuda")
     op = networks.XlOp()
     op.type = networks.XL_OP_CONV
     op.B, op.Hi, op.Wi, op.Cin, op.Ho, op.Wo, op.Cout = a.B, a.H, a.W, a.cin, Ho, Wo, a.cout
     op.ksize, op.stride, op.ld_in, op.ld_out = a.k, a.s, a.cin, a.cout
     op.in_, op.w, op.bias, op.out = x.data_ptr(), w.data_ptr(), b.data_ptr(), out.data_ptr()
+    if a.z > 1:
+        op.nchunks2, op.bias = a.z, None
     arr = (networks.XlOp * 1)(op)
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     for _ in range(3):
@@ -49,7 +52,7 @@ def main():
     ms = e0.elapsed_time(e1) / a.iters
     od = out.double()
     print("checksum sum=%.9e abs=%.9e" % (od.sum().item(), od.abs().sum().item()))
-    flop = 2.0 * a.B * Ho * Wo * a.cout * a.k * a.k * a.cin
+    flop = 2.0 * a.z * a.B * Ho * Wo * a.cout * a.k * a.k * a.cin
     print("conv %dx%d s%d %d->%d B%d %dx%d: %.4f ms  %.1f TFLOP/s (%.1f%% of 157.3)" % (
         a.k, a.k, a.s, a.cin, a.cout, a.B, a.H, a.W, ms, flop / ms / 1e9, flop / ms / 1e9 / 157.3 * 100))
 
