@@ -34,7 +34,8 @@ PEAK_F32_MFMA_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md: fp
 # FETCH_SIZE (KB, doubled per the gfx950 note of MI355X_MICROARCH.md §HBM) + WRITE_SIZE (KB), batch 24.
 # PMC counters cannot be read from inside the process, so the profiled value is recorded per batch size.
 CONV512_TRAFFIC_BYTES = {24: (755733 * 2 + 259200) * 1024}
-WINO512_TRAFFIC_BYTES = {}          # filled from profiles/r1_wino512_pmc.csv
+# the batched Winograd GEMM launch of a 3x3 512->512 layer (profiles/r1_wino512_pmc.csv)
+WINO512_TRAFFIC_BYTES = {24: (762829 * 2 + 1036800) * 1024}
 FWD_GFLOP_PER_IMAGE = 295.41        # SURVEY.md §8(d), single-task net, 480x720
 FWD_GFLOP_PER_IMAGE_3ENC = 755.96   # SURVEY.md §8(d), CrossLoc 3-encoder net
 
@@ -201,7 +202,10 @@ def main():
                        # nHyp*N*12 B + 64 B per image; the stage is LDS-resident and fp64/latency-bound
                        "dsac_algorithmic_GBps": round(B * (NH * 5400 * 12 + 64) / (dsac_ms * 1e-3) / 1e9, 1),
                        "dsac_hbm_roofline_frac": round(B * (NH * 5400 * 12 + 64) / (dsac_ms * 1e-3) / 8e12, 5),
-                       "cnn_fwd_tflops": round((FWD_GFLOP_PER_IMAGE_3ENC if args.mlr else FWD_GFLOP_PER_IMAGE) * B / cnn_ms, 2),
+                       # direct-convolution FLOP count of the network over the CNN time; with the Winograd
+                       # layers fewer multiplies are executed, so this "algorithmic" rate may exceed the MFMA peak
+                       "cnn_fwd_algorithmic_tflops": round((FWD_GFLOP_PER_IMAGE_3ENC if args.mlr else FWD_GFLOP_PER_IMAGE) * B / cnn_ms, 2),
+                       "conv3x3_s1_algorithm": "winograd F(2x2,3x3)" if wino else "direct implicit GEMM",
                        "median_err_cm": round(med_t_cm, 3), "median_err_deg": round(med_r_deg, 5)},
             "roofline": {"bound": "mfma",
                          "kernel": ("igemm_conv_kernel<1,1,128,512> batched x16: the Winograd F(2x2,3x3) GEMMs of a 3x3 "

@@ -125,8 +125,8 @@ __device__ __forceinline__ int xcd_remap(int b, int nwg)
 // for the taps whose offset is divisible by the forward stride S (others are zero-filled by the bounds check).
 // MODE 2: the stride-2 data gradient split by result-pixel parity (py,px): only the 1/2/2/4 taps that can reach a
 // pixel of that class are multiplied (9 tap-GEMMs in total over the four launches instead of 36).
-template <int KS, int STRIDE, int BN, int CIN, int MODE = 0, int BM = 128>   // CIN = compile-time Cin tag (0: runtime);
-                                                                             // BM = 64 for launches that would not fill the chip
+template <int KS, int STRIDE, int BN, int CIN, int MODE = 0, int BM = 128, int ZB = 0>   // CIN = compile-time Cin tag (0: runtime);
+                                         // BM = 64 for launches that would not fill the chip; ZB 1 = batched GEMMs (Winograd)
 __global__ __launch_bounds__(256, 2)
 void igemm_conv_kernel(ConvArgs a)
 {
@@ -146,8 +146,8 @@ void igemm_conv_kernel(ConvArgs a)
     const int wm = wave >> 1, wn = wave & 1;
 
     // each XCD gets a contiguous run of (GEMM, m-tile, n-tile): the n-tiles of an m-tile share an L2
-    int tile = xcd_remap(blockIdx.x, a.nbm * a.nbn * a.zCount);
-    if (a.zCount > 1) {
+    int tile = xcd_remap(blockIdx.x, a.nbm * a.nbn * (ZB ? a.zCount : 1));
+    if constexpr (ZB) {
         const int z = tile / (a.nbm * a.nbn);
         tile -= z * (a.nbm * a.nbn);
         a.in += z * a.zIn; a.w += z * a.zW; a.out += z * a.zOut;
@@ -812,7 +812,7 @@ ProfRec *g_prof = nullptr;
 int g_profCap = 0, g_profCount = 0;
 bool g_profOn = false;
 
-template <int KS, int STRIDE, int BN, int CIN, int MODE = 0, int BM = 128>
+template <int KS, int STRIDE, int BN, int CIN, int MODE = 0, int BM = 128, int ZB = 0>
 int launch_igemm(const xl_op &op, hipStream_t st, int py = 0, int px = 0)
 {
     ConvArgs a;
@@ -823,8 +823,8 @@ int launch_igemm(const xl_op &op, hipStream_t st, int py = 0, int px = 0)
     a.py = py; a.px = px; a.Hj = 0; a.Wj = 0; a.ntaps = 0; a.tapList = 0;
     a.stats = nullptr; a.HW = op.Ho * op.Wo; a.G = 0; a.cpg = 1; a.nchunks = 0;
     a.zCount = 1; a.zIn = 0; a.zW = 0; a.zOut = 0;
-    if (MODE == 0 && op.nchunks2 > 1) {             // batched GEMMs over consecutive blocks of in / w / out
-        if (op.stats) return XL_ERR_ARG;
+    if (ZB) {                                        // batched GEMMs over consecutive blocks of in / w / out
+        if (op.stats || op.nchunks2 < 1) return XL_ERR_ARG;
         a.zCount = op.nchunks2;
         a.zIn = (long long)a.M * op.ld_in; a.zW = (long long)op.Cout * a.K; a.zOut = (long long)a.M * op.ld_out;
     }
@@ -856,7 +856,7 @@ int launch_igemm(const xl_op &op, hipStream_t st, int py = 0, int px = 0)
     const size_t lds = sizeof(float) * 2 * (BM + BN) * kBK;
     static bool configured = false;
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(igemm_conv_kernel<KS, STRIDE, BN, CIN, MODE, BM>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(igemm_conv_kernel<KS, STRIDE, BN, CIN, MODE, BM, ZB>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { snprintf(g_err, sizeof(g_err), "hipFuncSetAttribute: %s", hipGetErrorString(e)); return XL_ERR_HIP; }
         configured = true;
@@ -865,7 +865,7 @@ int launch_igemm(const xl_op &op, hipStream_t st, int py = 0, int px = 0)
     a.clk = nullptr;
     const int nwg = a.nbm * a.nbn * a.zCount;
     if (clkDbg) hipMalloc(&a.clk, sizeof(long long) * 8 * nwg);
-    hipLaunchKernelGGL((igemm_conv_kernel<KS, STRIDE, BN, CIN, MODE, BM>), dim3(nwg), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((igemm_conv_kernel<KS, STRIDE, BN, CIN, MODE, BM, ZB>), dim3(nwg), dim3(256), lds, st, a);
     if (clkDbg) {
         hipStreamSynchronize(st);
         std::vector<long long> h(8 * (size_t)nwg);
@@ -923,6 +923,11 @@ int run_conv(const xl_op &op, hipStream_t st)
     if (op.ksize == 3 && op.stride == 2) {
         if (small) return wide ? XL_FWD(3, 2, 128, 0, 64) : XL_FWD(3, 2, 64, 0, 64);
         return wide ? XL_FWD(3, 2, 128, 0, 128) : XL_FWD(3, 2, 64, 0, 128);
+    }
+    if (op.ksize == 1 && op.stride == 1 && op.nchunks2 > 1) {         // Winograd: nchunks2 GEMMs in one launch
+        if (!wide) return XL_ERR_UNSUPPORTED;
+        if (small) return op.Cin == 512 ? launch_igemm<1, 1, 128, 512, 0, 64, 1>(op, st) : launch_igemm<1, 1, 128, 0, 0, 64, 1>(op, st);
+        return op.Cin == 512 ? launch_igemm<1, 1, 128, 512, 0, 128, 1>(op, st) : launch_igemm<1, 1, 128, 0, 0, 128, 1>(op, st);
     }
     if (op.ksize == 1 && op.stride == 1) {
         if (small) {
