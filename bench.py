@@ -35,7 +35,8 @@ PEAK_F32_MFMA_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md: fp
 # PMC counters cannot be read from inside the process, so the profiled value is recorded per batch size.
 CONV512_TRAFFIC_BYTES = {24: (755733 * 2 + 259200) * 1024}
 # the batched Winograd GEMM launch of a 3x3 512->512 layer (profiles/r1_wino512_pmc.csv)
-WINO512_TRAFFIC_BYTES = {24: (762829 * 2 + 1036800) * 1024}
+WINO512_TRAFFIC_BYTES = {16: {24: (762829 * 2 + 1036800) * 1024}, 36: {}}   # by GEMMs per launch, then batch
+WINO_NAME = {16: "F(2x2,3x3)", 36: "F(4x4,3x3)"}
 FWD_GFLOP_PER_IMAGE = 295.41        # SURVEY.md §8(d), single-task net, 480x720
 FWD_GFLOP_PER_IMAGE_3ENC = 755.96   # SURVEY.md §8(d), CrossLoc 3-encoder net
 
@@ -136,14 +137,15 @@ def main():
     typ = (ctypes.c_int32 * cap)()
     ms = (ctypes.c_float * cap)()
     nrec = L.xl_cnn_prof_end(idx, typ, ms, cap)
-    conv_ms, by_type, wino = [], {}, False
+    conv_ms, by_type, wino, wino_tiles = [], {}, 0, 0
     for i in range(max(nrec, 0)):
         op = plan.op_array[idx[i]]
         by_type[typ[i]] = by_type.get(typ[i], 0.0) + ms[i]
         if typ[i] == networks.XL_OP_CONV and op.Cin == 512 and op.Cout == 512 and op.stride == 1 and (
-                (op.ksize == 3 and op.nchunks2 <= 1) or (op.ksize == 1 and op.nchunks2 == 16)):
+                (op.ksize == 3 and op.nchunks2 <= 1) or (op.ksize == 1 and op.nchunks2 > 1)):
             conv_ms.append(ms[i])
-            wino = op.nchunks2 == 16
+            wino = int(op.nchunks2) if op.nchunks2 > 1 else 0
+            wino_tiles = op.Hi * op.Wi
     if rank == 0 and os.environ.get("XL_BENCH_VERBOSE"):
         per_op = {}
         for i in range(max(nrec, 0)):
@@ -159,7 +161,7 @@ def main():
     # dominant kernel: the 3x3 512->512 layers.  Direct form: one implicit GEMM of 2*M*512*4608 FLOP.  Winograd
     # F(2x2,3x3) form (inference plans): one batched launch of 16 GEMMs [M/4 x 512] x [512 x 512]; the FLOPs counted
     # are the ones that launch executes (2.25x fewer multiplies than the direct form for the same layer)
-    conv_flop = 16 * 2.0 * (B * 30 * 45) * 512 * 512 if wino else 2.0 * (B * 60 * 90) * 512 * (9 * 512)
+    conv_flop = wino * 2.0 * (B * wino_tiles) * 512 * 512 if wino else 2.0 * (B * 60 * 90) * 512 * (9 * 512)
     conv_tflops = conv_flop / (conv_avg_ms * 1e-3) / 1e12 if conv_ms else float("nan")
     cnn_ms = float(np.mean([ev[s][0].elapsed_time(ev[s][1]) for s in range(K)]))
     dsac_ms = float(np.mean([ev[s][2].elapsed_time(ev[s][3]) for s in range(K)]))
@@ -205,16 +207,16 @@ def main():
                        # direct-convolution FLOP count of the network over the CNN time; with the Winograd
                        # layers fewer multiplies are executed, so this "algorithmic" rate may exceed the MFMA peak
                        "cnn_fwd_algorithmic_tflops": round((FWD_GFLOP_PER_IMAGE_3ENC if args.mlr else FWD_GFLOP_PER_IMAGE) * B / cnn_ms, 2),
-                       "conv3x3_s1_algorithm": "winograd F(2x2,3x3)" if wino else "direct implicit GEMM",
+                       "conv3x3_s1_algorithm": ("winograd " + WINO_NAME.get(wino, "?")) if wino else "direct implicit GEMM",
                        "median_err_cm": round(med_t_cm, 3), "median_err_deg": round(med_r_deg, 5)},
             "roofline": {"bound": "mfma",
-                         "kernel": ("igemm_conv_kernel<1,1,128,512> batched x16: the Winograd F(2x2,3x3) GEMMs of a 3x3 "
-                                    "512->512 layer @60x90 x%d images" if wino else
-                                    "igemm_conv_kernel<3,1,128,512> (3x3 512->512 @60x90 x%d images)") % B,
+                         "kernel": (("igemm_conv_kernel<1,1,128,512,0,128,1> batched x%d: the Winograd %s GEMMs of a 3x3 "
+                                     "512->512 layer @60x90" % (wino, WINO_NAME.get(wino, "?")) if wino else
+                                     "igemm_conv_kernel<3,1,128,512> (3x3 512->512 @60x90") + " x%d images)" % B),
                          "achieved": round(conv_tflops, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(conv_tflops / PEAK_F32_MFMA_TFLOPS, 4),
-                         "traffic": (WINO512_TRAFFIC_BYTES if wino else CONV512_TRAFFIC_BYTES).get(B),
-                         "algorithmic_bytes_per_launch": (16 * (2 * B * 1350 * 512 + 512 * 512) * 4 if wino else
+                         "traffic": (WINO512_TRAFFIC_BYTES.get(wino, {}) if wino else CONV512_TRAFFIC_BYTES).get(B),
+                         "algorithmic_bytes_per_launch": (wino * (2 * B * wino_tiles * 512 + 512 * 512) * 4 if wino else
                                                           2 * B * 5400 * 512 * 4 + 512 * 4608 * 4),
                          "avg_launch_ms": round(conv_avg_ms, 4), "launches_timed": len(conv_ms),
                          "algorithmic_gflop_per_launch": round(conv_flop / 1e9, 2)},

@@ -571,6 +571,144 @@ void wino_out_kernel(const float *__restrict__ M, const float *__restrict__ bias
     }
 }
 
+// F(4x4, 3x3): 36 multiplies per 4x4 output tile and (ci, co) pair instead of 144 (Lavin & Gray 2016, interpolation
+// points 0, +-1, +-2, inf).  6x6 input patches at stride 4; H and W need not be multiples of 4 (partial tiles read zeros
+// and their surplus outputs are neither stored nor counted).  Same launch structure as the F(2x2,3x3) pair.
+template <typename V>
+__device__ __forceinline__ void wino4_bt(const V (&d)[6], V (&o)[6])
+{
+    o[0] = 4.f * d[0] - 5.f * d[2] + d[4];
+    o[1] = -4.f * d[1] - 4.f * d[2] + d[3] + d[4];
+    o[2] = 4.f * d[1] - 4.f * d[2] - d[3] + d[4];
+    o[3] = -2.f * d[1] - d[2] + 2.f * d[3] + d[4];
+    o[4] = 2.f * d[1] - d[2] - 2.f * d[3] + d[4];
+    o[5] = 4.f * d[1] - 5.f * d[3] + d[5];
+}
+
+template <typename V>
+__device__ __forceinline__ void wino4_at(const V (&m)[6], V (&o)[4])
+{
+    o[0] = m[0] + m[1] + m[2] + m[3] + m[4];
+    o[1] = m[1] - m[2] + 2.f * m[3] - 2.f * m[4];
+    o[2] = m[1] + m[2] + 4.f * m[3] + 4.f * m[4];
+    o[3] = m[1] - m[2] + 8.f * m[3] - 8.f * m[4] + m[5];
+}
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// one tile x 2 channels per thread
+__global__ __launch_bounds__(256)
+void wino4_in_kernel(const float *__restrict__ in, float *__restrict__ V, int B, int H, int W, int C, int ldIn, int Th, int Tw)
+{
+    const int C2 = C >> 1;
+    const long long T = (long long)B * Th * Tw;
+    const long long items = T * C2;
+    const long long zs = T * C;
+    for (long long it = (long long)blockIdx.x * 256 + threadIdx.x; it < items; it += (long long)gridDim.x * 256) {
+        const int c2 = (int)(it % C2);
+        const long long t = it / C2;
+        const int tx = (int)(t % Tw);
+        const int ty = (int)((t / Tw) % Th);
+        const int n = (int)(t / ((long long)Tw * Th));
+        f32x2 w[6][6];                               // w[i][b] = (B^T d)[i][b]
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+            const int x = 4 * tx - 1 + b;
+            f32x2 col[6], o[6];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+                const int y = 4 * ty - 1 + a;
+                if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W)
+                    col[a] = *reinterpret_cast<const f32x2 *>(in + (((long long)n * H + y) * W + x) * ldIn + 2 * c2);
+                else
+                    col[a] = f32x2{ 0.f, 0.f };
+            }
+            wino4_bt(col, o);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) w[i][b] = o[i];
+        }
+        float *op = V + t * C + 2 * c2;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            f32x2 o[6];
+            wino4_bt(w[i], o);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) *reinterpret_cast<f32x2 *>(op + (6 * i + j) * zs) = o[j];
+        }
+    }
+}
+
+// grid (nchunks, B); 256 threads = S tile lanes x C/2 channel pairs... C/2 may exceed 256: a block covers CB = min(C, 512)
+// channels and blockIdx.z walks the channel blocks.  Statistics: one fp64 partial per (image, chunk, group).
+__global__ __launch_bounds__(256)
+void wino4_out_kernel(const float *__restrict__ M, const float *__restrict__ bias, float *__restrict__ out,
+                      double *__restrict__ stats, int B, int H, int W, int C, int ldOut, int Th, int Tw, int tpb,
+                      int G, int nchunks)
+{
+    __shared__ double sS[256 * 4];
+    const int tid = threadIdx.x;
+    const int CB = C < 512 ? C : 512;                 // channels per block
+    const int C2 = CB >> 1, S = 256 / C2;
+    const int cb0 = blockIdx.z * CB;
+    const int c2 = tid % C2, sub = tid / C2;
+    const int cch = cb0 + 2 * c2;                      // first of this thread's two channels
+    const int n = blockIdx.y, k = blockIdx.x;
+    const int Timg = Th * Tw;
+    const long long T = (long long)B * Timg;
+    const long long zs = T * C;
+    int t1 = (k + 1) * tpb; if (t1 > Timg) t1 = Timg;
+    f32x2 bv = f32x2{ 0.f, 0.f };
+    if (bias) bv = *reinterpret_cast<const f32x2 *>(bias + cch);
+    f32x2 s1 = f32x2{ 0.f, 0.f }, s2 = f32x2{ 0.f, 0.f };
+    for (int tl = k * tpb + sub; tl < t1; tl += S) {
+        const int ty = tl / Tw, tx = tl - ty * Tw;
+        const float *m = M + ((long long)n * Timg + tl) * C + cch;
+        f32x2 q[4][6];                               // q[p][j] = (A^T r)[p][j]
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            f32x2 col[6], o[4];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) col[i] = *reinterpret_cast<const f32x2 *>(m + (6 * i + j) * zs);
+            wino4_at(col, o);
+#pragma unroll
+            for (int pI = 0; pI < 4; ++pI) q[pI][j] = o[pI];
+        }
+#pragma unroll
+        for (int pI = 0; pI < 4; ++pI) {
+            f32x2 y[4];
+            wino4_at(q[pI], y);
+            const int oy = 4 * ty + pI;
+            if (oy >= H) continue;
+#pragma unroll
+            for (int qI = 0; qI < 4; ++qI) {
+                const int ox = 4 * tx + qI;
+                if (ox >= W) continue;
+                const f32x2 v = y[qI] + bv;
+                *reinterpret_cast<f32x2 *>(out + (((long long)n * H + oy) * W + ox) * ldOut + cch) = v;
+                s1 += v; s2 += v * v;
+            }
+        }
+    }
+    if (!stats) return;
+    sS[tid * 4 + 0] = (double)s1[0]; sS[tid * 4 + 1] = (double)s1[1];
+    sS[tid * 4 + 2] = (double)s2[0]; sS[tid * 4 + 3] = (double)s2[1];
+    __syncthreads();
+    const int cpg = C / G;
+    const int gPerBlock = CB / cpg;                    // groups whose channels all live in this block
+    if (tid < gPerBlock) {
+        double a = 0.0, b = 0.0;
+        for (int sb = 0; sb < S; ++sb)
+            for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) {
+                const int th = sb * C2 + (c >> 1);
+                a += sS[th * 4 + (c & 1)];
+                b += sS[th * 4 + 2 + (c & 1)];
+            }
+        const int g = cb0 / cpg + tid;
+        double *o = stats + (((long long)n * nchunks + k) * G + g) * 2;
+        o[0] = a; o[1] = b;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- GroupNorm
 
 // grid (nchunks, B); T threads with T % (C/4) == 0.  stats[((n*nchunks + chunk)*G + g)*2 + {0,1}] = sum, sumsq
@@ -959,6 +1097,15 @@ int run_op(const xl_op &op, hipStream_t st)
         case XL_OP_CONV:
             return run_conv(op, st);
         case XL_OP_WINO_IN: {
+            if (op.ksize == 4) {                    // F(4x4,3x3): Ho x Wo tiles of 4x4 outputs, partial tiles allowed
+                if (op.Cin % 4 != 0 || op.ld_in % 2 != 0 || op.Ho != (op.Hi + 3) / 4 || op.Wo != (op.Wi + 3) / 4) return XL_ERR_ARG;
+                const long long items4 = (long long)op.B * op.Ho * op.Wo * (op.Cin / 2);
+                long long blocks4 = (items4 + 255) / 256;
+                if (blocks4 > 262144) blocks4 = 262144;
+                hipLaunchKernelGGL(wino4_in_kernel, dim3((unsigned)blocks4), dim3(256), 0, st, (const float *)op.in,
+                                   (float *)op.out, op.B, op.Hi, op.Wi, op.Cin, op.ld_in, op.Ho, op.Wo);
+                return XL_OK;
+            }
             if (op.Cin % 4 != 0 || op.ld_in % 4 != 0 || op.Hi != 2 * op.Ho || op.Wi != 2 * op.Wo) return XL_ERR_ARG;
             const long long items = (long long)op.B * op.Ho * op.Wo * (op.Cin / 4);
             long long blocks = (items + 255) / 256;
@@ -969,6 +1116,20 @@ int run_op(const xl_op &op, hipStream_t st)
         }
         case XL_OP_WINO_OUT: {
             // in: M [16][B*Th*Tw][C]; out [B,H,W,C] (Hi x Wi = output size); reserved_i = tiles per block
+            if (op.ksize == 4) {
+                const int Th4 = (op.Hi + 3) / 4, Tw4 = (op.Wi + 3) / 4;
+                const int CB = op.Cin < 512 ? op.Cin : 512;
+                if (op.Cin % 2 != 0 || op.Cin % CB != 0 || 256 % (CB / 2) != 0 || op.ld_out % 2 != 0 || op.reserved_i < 1 ||
+                    op.nchunks != (Th4 * Tw4 + op.reserved_i - 1) / op.reserved_i)
+                    return XL_ERR_ARG;
+                if (op.stats && (op.groups < 1 || op.Cin % op.groups != 0 || CB % (op.Cin / op.groups) != 0 ||
+                                 CB / (op.Cin / op.groups) > 256))
+                    return XL_ERR_ARG;
+                hipLaunchKernelGGL(wino4_out_kernel, dim3(op.nchunks, op.B, op.Cin / CB), dim3(256), 0, st, (const float *)op.in,
+                                   (const float *)op.bias, (float *)op.out, (double *)op.stats, op.B, op.Hi, op.Wi, op.Cin,
+                                   op.ld_out, Th4, Tw4, op.reserved_i, op.groups, op.nchunks);
+                return XL_OK;
+            }
             const int C4 = op.Cin / 4;
             if (op.Cin % 4 != 0 || C4 > 256 || 256 % C4 != 0 || op.ld_out % 4 != 0 || op.reserved_i < 1) return XL_ERR_ARG;
             const int Th = op.Hi / 2, Tw = op.Wi / 2;

@@ -212,17 +212,22 @@ class _Plan:
 
     # -- weights
     # Winograd F(2x2,3x3) weight transform U = G g G^T, G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]] (Lavin & Gray 2016)
-    _WINO_G = ((1.0, 0.0, 0.0), (0.5, 0.5, 0.5), (0.5, -0.5, 0.5), (0.0, 0.0, 1.0))
+    _WINO_G = {2: ((1.0, 0.0, 0.0), (0.5, 0.5, 0.5), (0.5, -0.5, 0.5), (0.0, 0.0, 1.0)),
+               # F(4x4,3x3), interpolation points 0, +-1, +-2, inf
+               4: ((1 / 4, 0.0, 0.0), (-1 / 6, -1 / 6, -1 / 6), (-1 / 6, 1 / 6, -1 / 6), (1 / 24, 1 / 12, 1 / 6),
+                   (1 / 24, -1 / 12, 1 / 6), (0.0, 0.0, 1.0))}
 
-    def pack_conv_wino(self, conv):
-        """[16][Cout][Cin] transformed weights of a 3x3 convolution (one plain [Cout][Cin] GEMM operand per frequency)."""
+    def pack_conv_wino(self, conv, m):
+        """[(m+2)^2][Cout][Cin] transformed weights of a 3x3 convolution: one plain [Cout][Cin] GEMM operand per
+        frequency of F(m x m, 3x3)."""
         w = conv.weight
-        key = (id(w), "wino")
+        kind = "wino%d" % m
+        key = (id(w), kind)
         if key not in self.packed:
             src = w.detach().to(device=self.device, dtype=torch.float32).contiguous()
-            dst = torch.empty(16 * src.shape[0] * src.shape[1], dtype=torch.float32, device=self.device)
-            self.packed[key] = (dst, src, "wino")
-            self._pack(dst, src, "wino")
+            dst = torch.empty((m + 2) ** 2 * src.shape[0] * src.shape[1], dtype=torch.float32, device=self.device)
+            self.packed[key] = (dst, src, kind)
+            self._pack(dst, src, kind)
         return self.packed[key][0]
 
     def pack_conv(self, conv, dgrad=False):
@@ -241,10 +246,11 @@ class _Plan:
         L = _bind()
         cout, cin, k, _ = src.shape
         stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-        if kind == "wino":
-            G = torch.tensor(self._WINO_G, dtype=torch.float64, device=self.device)
-            U = torch.einsum("ia,ocab,jb->ijoc", G, src.to(torch.float64), G)          # exact in fp64, rounded once
-            dst.view(4, 4, cout, cin).copy_(U)
+        if kind.startswith("wino"):
+            m = int(kind[4:])
+            G = torch.tensor(self._WINO_G[m], dtype=torch.float64, device=self.device)
+            U = torch.einsum("ia,ocab,jb->ijoc", G, src.to(torch.float64), G)          # fp64, rounded once
+            dst.view(m + 2, m + 2, cout, cin).copy_(U)
         elif kind == "conv1":                     # [(ky*3+kx)*Cin + c][Cout]
             dst.view(k, k, cin, cout).copy_(src.permute(2, 3, 1, 0))
         elif kind == "dgrad":
@@ -335,43 +341,51 @@ class _Plan:
                               nchunks=nchunks, gamma=gamma, beta=beta))
         return res
 
-    def wino_ok(self, act, conv):
-        """Inference plans run the stride-1 3x3 convolutions as Winograd F(2x2,3x3) (2.25x fewer multiplies)."""
+    def wino_tile(self, act, conv):
+        """Inference plans run the stride-1 3x3 convolutions as Winograd F(4x4,3x3) (4x fewer multiplies; 2.25x for
+        F(2x2,3x3), selected with XL_WINOGRAD=2).  Returns the output tile size m, or 0 for the direct kernel."""
         t, H, W, C, ld, off = act
-        return (not self.train and conv.kernel_size[0] == 3 and conv.stride[0] == 1 and H % 2 == 0 and W % 2 == 0
-                and C % 32 == 0 and conv.out_channels % 128 == 0 and conv.out_channels <= 1024
-                and 256 % (conv.out_channels // 4) == 0 and H * W >= 64 and not os.environ.get("XL_NO_WINOGRAD"))
+        if (self.train or conv.kernel_size[0] != 3 or conv.stride[0] != 1 or C % 32 != 0 or H * W < 64
+                or conv.out_channels not in (128, 256, 512, 1024) or os.environ.get("XL_NO_WINOGRAD")):
+            return 0
+        m = int(os.environ.get("XL_WINOGRAD", "4"))
+        if m == 2 and (H % 2 or W % 2):
+            return 0
+        return m if m in (2, 4) else 0
 
-    def conv_wino(self, act, conv, norm, flags, aux):
-        """conv3x3 + GroupNorm(+epilogue): input transform, 16 GEMMs in one batched launch, output transform that also
-        emits the GroupNorm partial sums, GN_FINAL, GN_APPLY (in place)."""
+    def conv_wino(self, act, conv, norm, flags, aux, m):
+        """conv3x3 + GroupNorm(+epilogue) as F(m x m, 3x3): input transform, (m+2)^2 GEMMs in one batched launch, output
+        transform that also emits the GroupNorm partial sums, GN_FINAL, GN_APPLY (in place)."""
         t, H, W, C, ld, off = act
         B, cout = self.B, conv.out_channels
-        Th, Tw = H // 2, W // 2
+        Th, Tw = -(-H // m), -(-W // m)
         T = B * Th * Tw
-        V = self.alloc(16 * T * C)
+        nf = (m + 2) ** 2
+        V = self.alloc(nf * T * C)
         op = XlOp()
         op.type = XL_OP_WINO_IN
+        op.ksize = m
         op.B, op.Hi, op.Wi, op.Cin, op.Ho, op.Wo, op.ld_in = B, H, W, C, Th, Tw, ld
         op.in_, op.out = t.data_ptr() + 4 * off, V.data_ptr()
         self.ops.append(op)
-        Mb = self.alloc(16 * T * cout)
+        Mb = self.alloc(nf * T * cout)
         op = XlOp()
         op.type = XL_OP_CONV
         op.B, op.Hi, op.Wi, op.Cin, op.Ho, op.Wo, op.Cout = B, Th, Tw, C, Th, Tw, cout
-        op.ksize, op.stride, op.ld_in, op.ld_out, op.nchunks2 = 1, 1, C, cout, 16
-        op.in_, op.w, op.out = V.data_ptr(), self.pack_conv_wino(conv).data_ptr(), Mb.data_ptr()
-        if -(-T // 128) * (cout // 128) * 16 <= 256:
+        op.ksize, op.stride, op.ld_in, op.ld_out, op.nchunks2 = 1, 1, C, cout, nf
+        op.in_, op.w, op.out = V.data_ptr(), self.pack_conv_wino(conv, m).data_ptr(), Mb.data_ptr()
+        if -(-T // 128) * (cout // 128) * nf <= 256:
             op.reserved_i = 64
         self.ops.append(op)
         self.wino_gemm_indices = getattr(self, "wino_gemm_indices", []) + [len(self.ops) - 1]
         self.release(V)
         out = self.alloc(B * H * W * cout)
         G = norm.num_groups
-        tpb = 32
+        tpb = 32 if m == 2 else 16
         nchunks = -(-(Th * Tw) // tpb)
         op = XlOp()
         op.type = XL_OP_WINO_OUT
+        op.ksize = m
         op.B, op.Hi, op.Wi, op.Cin, op.ld_out, op.groups, op.nchunks, op.reserved_i = B, H, W, cout, cout, G, nchunks, tpb
         op.in_, op.out = Mb.data_ptr(), out.data_ptr()
         op.bias = self.dev(conv.bias).data_ptr()
@@ -397,8 +411,9 @@ class _Plan:
         return y
 
     def cgr(self, act, conv, norm, flags=GN_RELU_IN, aux=None):
-        if self.wino_ok(act, conv):
-            return self.conv_wino(act, conv, norm, flags, aux)
+        m = self.wino_tile(act, conv)
+        if m:
+            return self.conv_wino(act, conv, norm, flags, aux, m)
         y = self.conv(act, conv)
         if not self.train and y[1] * y[2] >= 128 and not os.environ.get("XL_NO_FUSED_STATS"):
             # inference: the conv epilogue produces the GroupNorm statistics, the separate stats pass is dropped

@@ -38,9 +38,10 @@ enum {
     XL_OP_GNB_PARAMS = 8,/* d gamma, d beta and the bias gradient of the preceding conv */
     XL_OP_HEAD_BWD = 9,  /* backward of XL_OP_HEAD: d(input) NHWC, d(fc3 weight), d(fc3 bias) */
     XL_OP_CONV1_WGRAD = 10, /* weight + bias gradient of the NCHW-input first conv */
-    XL_OP_WINO_IN = 12,     /* Winograd F(2x2,3x3) input transform: in [B,Hi,Wi,Cin] -> out V [16][B*Ho*Wo][Cin], Ho = Hi/2 */
-    XL_OP_WINO_OUT = 13,    /* Winograd output transform + bias (+ GroupNorm partial sums): in M [16][B*Hi/2*Wi/2][Cin] ->
-                               out [B,Hi,Wi,Cin]; reserved_i = tiles per workgroup, nchunks = workgroups per image */
+    XL_OP_WINO_IN = 12,     /* Winograd input transform: in [B,Hi,Wi,Cin] -> out V [(m+2)^2][B*Ho*Wo][Cin] with Ho x Wo tiles
+                               of m x m outputs; ksize = m: 2 = F(2x2,3x3) (Hi, Wi even), 4 = F(4x4,3x3) (Ho = ceil(Hi/4)) */
+    XL_OP_WINO_OUT = 13,    /* Winograd output transform + bias (+ GroupNorm partial sums): in M [(m+2)^2][tiles][Cin] ->
+                               out [B,Hi,Wi,Cin]; ksize = m; reserved_i = tiles per workgroup, nchunks = workgroups per image */
     XL_OP_GN_FINAL = 11  /* per-(image, channel) GroupNorm scale/shift [B][C][2] from the partial sums (out);
                             GN_APPLY with aux2 = that buffer skips its own finalisation */
 };
