@@ -35,7 +35,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md: fp
 # PMC counters cannot be read from inside the process, so the profiled value is recorded per batch size.
 CONV512_TRAFFIC_BYTES = {24: (755733 * 2 + 259200) * 1024}
 # the batched Winograd GEMM launch of a 3x3 512->512 layer (profiles/r1_wino512_pmc.csv)
-WINO512_TRAFFIC_BYTES = {16: {24: (762829 * 2 + 1036800) * 1024}, 36: {}}   # by GEMMs per launch, then batch
+WINO512_TRAFFIC_BYTES = {16: {24: (762829 * 2 + 1036800) * 1024}, 36: {24: (472038 * 2 + 596160) * 1024}}   # by GEMMs per launch, then batch
 WINO_NAME = {16: "F(2x2,3x3)", 36: "F(4x4,3x3)"}
 FWD_GFLOP_PER_IMAGE = 295.41        # SURVEY.md §8(d), single-task net, 480x720
 FWD_GFLOP_PER_IMAGE_3ENC = 755.96   # SURVEY.md §8(d), CrossLoc 3-encoder net
