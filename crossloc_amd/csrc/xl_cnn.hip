@@ -907,6 +907,60 @@ void head_kernel(const float *__restrict__ in, const float *__restrict__ w, cons
     }
 }
 
+// Full-size (semantics) head, networks.py:259-273 + 344-358: the x8 pixel shuffle of the DUC activation is an index map
+//   shuffled[b][c][8h+i][8w+j] = in[b][h][w][c*64 + i*8 + j]          (in: NHWC, GroupNorm + ReLU already applied)
+// followed by F.interpolate(bilinear, align_corners=False) to H x W (the identity when H = 8 Hs and W = 8 Ws), the
+// 1x1 fc3 over the C shuffled channels, the mean offset / exp(hardtanh) epilogue.  out NCHW [B][C][H][W]; one output
+// pixel per thread (stores coalesced along x; the gathers of a wavefront fall into a few NHWC pixels).
+template <int CMAX>
+__global__ __launch_bounds__(256)
+void duc_head_kernel(const float *__restrict__ in, const float *__restrict__ w, const float *__restrict__ bias,
+                     const float *__restrict__ mean, float *__restrict__ out, int B, int Hs, int Ws, int C, int ldIn,
+                     int H, int W, int nTask, float lo, float hi)
+{
+    const int Hu = 8 * Hs, Wu = 8 * Ws;
+    const float sy = (float)Hu / (float)H, sx = (float)Wu / (float)W;       // area_pixel_compute_scale
+    const bool ident = (Hu == H) && (Wu == W);
+    const long long total = (long long)B * H * W;
+    for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < total; p += (long long)gridDim.x * 256) {
+        const int x = (int)(p % W);
+        const int y = (int)((p / W) % H);
+        const int n = (int)(p / ((long long)W * H));
+        float fy = sy * ((float)y + 0.5f) - 0.5f; if (fy < 0.f) fy = 0.f;
+        float fx = sx * ((float)x + 0.5f) - 0.5f; if (fx < 0.f) fx = 0.f;
+        const int y0 = (int)fy, x0 = (int)fx;
+        const int y1 = y0 + (y0 < Hu - 1 ? 1 : 0), x1 = x0 + (x0 < Wu - 1 ? 1 : 0);
+        const float ly1 = fy - (float)y0, lx1 = fx - (float)x0;
+        const float ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+        const float *img = in + (long long)n * Hs * Ws * ldIn;
+        const long long a00 = ((long long)(y0 >> 3) * Ws + (x0 >> 3)) * ldIn + (y0 & 7) * 8 + (x0 & 7);
+        const long long a01 = ((long long)(y0 >> 3) * Ws + (x1 >> 3)) * ldIn + (y0 & 7) * 8 + (x1 & 7);
+        const long long a10 = ((long long)(y1 >> 3) * Ws + (x0 >> 3)) * ldIn + (y1 & 7) * 8 + (x0 & 7);
+        const long long a11 = ((long long)(y1 >> 3) * Ws + (x1 >> 3)) * ldIn + (y1 & 7) * 8 + (x1 & 7);
+        float v[CMAX];
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c) {
+            v[c] = 0.f;
+            if (c < C) {
+                if (ident) v[c] = img[a00 + c * 64];
+                else v[c] = ly0 * (lx0 * img[a00 + c * 64] + lx1 * img[a01 + c * 64])
+                          + ly1 * (lx0 * img[a10 + c * 64] + lx1 * img[a11 + c * 64]);
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < CMAX; ++o) {
+            if (o < C) {
+                float acc = bias[o];
+#pragma unroll
+                for (int c = 0; c < CMAX; ++c) if (c < C) acc = fmaf(w[o * C + c], v[c], acc);
+                if (o < nTask) acc += mean[o];
+                else acc = expf(fminf(fmaxf(acc, lo), hi));
+                out[(((long long)n * C + o) * H + y) * W + x] = acc;
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- weight pack
 
 __global__ void pack_weight_kernel(const float *__restrict__ src, float *__restrict__ dst, int Cout, int Cin, int k)
@@ -1144,7 +1198,11 @@ int run_op(const xl_op &op, hipStream_t st)
             const int C4 = op.Cin / 4;
             if (op.Cin % 4 != 0 || op.Cin % op.groups != 0 || op.ld_in % 4 != 0) return XL_ERR_ARG;
             int T = 256;
-            if (C4 > 256) T = C4; else if (256 % C4 != 0) return XL_ERR_ARG;
+            if (C4 > 256) T = C4;
+            else if (256 % C4 != 0) {                        // e.g. 384 channels: 96 quads -> 192 threads (lcm with 64)
+                T = C4;
+                while (T % 64 != 0) T += C4;
+            }
             if (T > 1024 || T % 64 != 0 || op.groups > T) return XL_ERR_ARG;
             hipLaunchKernelGGL(gn_stats_kernel, dim3(op.nchunks, op.B), dim3(T), sizeof(double) * 8 * T, st,
                                (const float *)op.in, (double *)op.stats, op.Hi * op.Wi, op.Cin, op.ld_in, op.groups,
@@ -1178,6 +1236,17 @@ int run_op(const xl_op &op, hipStream_t st)
             hipLaunchKernelGGL(head_kernel<8>, dim3((unsigned)blocks), dim3(256), 0, st, (const float *)op.in,
                                (const float *)op.w, (const float *)op.bias, (const float *)op.aux, (float *)op.out,
                                op.B, op.Hi * op.Wi, op.Cin, op.ld_in, op.Cout, op.n_task, op.clamp_lo, op.clamp_hi);
+            return XL_OK;
+        }
+        case XL_OP_DUC_HEAD: {
+            // in [B,Hi,Wi,Cout*64] NHWC, out [B,Cout,Ho,Wo] NCHW
+            if (op.Cout < 1 || op.Cout > 8 || op.Cin != op.Cout * 64 || op.Ho < 1 || op.Wo < 1) return XL_ERR_ARG;
+            const long long pix = (long long)op.B * op.Ho * op.Wo;
+            long long blocks = (pix + 255) / 256;
+            if (blocks > 65536) blocks = 65536;
+            hipLaunchKernelGGL(duc_head_kernel<8>, dim3((unsigned)blocks), dim3(256), 0, st, (const float *)op.in,
+                               (const float *)op.w, (const float *)op.bias, (const float *)op.aux, (float *)op.out,
+                               op.B, op.Hi, op.Wi, op.Cout, op.ld_in, op.Ho, op.Wo, op.n_task, op.clamp_lo, op.clamp_hi);
             return XL_OK;
         }
         default:

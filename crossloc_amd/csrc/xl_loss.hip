@@ -308,6 +308,58 @@ void normal_loss_kernel(NormalArgs a)
     }
 }
 
+// ---------------------------------------------------------------------------------------------- semantics
+
+// CrossEntropyLoss2d (loss/semantics.py:10-18) inside semantics_classification_loss (:44-91): per pixel
+// -log softmax(logits)[label]; the "valid" count is the number of pixels whose arg-max class (first maximum, like
+// torch.argmax) equals the label.  Gradient: (softmax - onehot) * scale.  logits NCHW [B,C,N], labels [B,N] as floats.
+struct SemArgs {
+    const float *logits, *labels;
+    float *dlogits;
+    double *partials;
+    int B, C, N, nblk;
+    float gscale;
+};
+
+__global__ __launch_bounds__(kT)
+void semantics_loss_kernel(SemArgs a)
+{
+    __shared__ double sRed[16];
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * kT + threadIdx.x;
+    Sums s{ 0.0, 0.0, 0.0, 0.0 };
+    if (i < a.N) {
+        const float *l = a.logits + (long long)b * a.C * a.N + i;
+        const int lab = (int)a.labels[(long long)b * a.N + i];
+        float m = l[0];
+        int arg = 0;
+        for (int c = 1; c < a.C; ++c) {
+            const float v = l[(long long)c * a.N];
+            if (v > m) { m = v; arg = c; }
+        }
+        float se = 0.f;
+        for (int c = 0; c < a.C; ++c) se += expf(l[(long long)c * a.N] - m);
+        const float lse = logf(se);
+        const float xl = (lab >= 0 && lab < a.C) ? l[(long long)lab * a.N] : m;
+        const float loss = (lab >= 0 && lab < a.C) ? -((xl - m) - lse) : 0.f;
+        if (a.dlogits) {
+            float *d = a.dlogits + (long long)b * a.C * a.N + i;
+            const float inv = 1.0f / se;
+            for (int c = 0; c < a.C; ++c) {
+                float g = expf(l[(long long)c * a.N] - m) * inv;
+                if (c == lab) g -= 1.0f;
+                d[(long long)c * a.N] = (lab >= 0 && lab < a.C) ? g * a.gscale : 0.f;
+            }
+        }
+        s.a = (double)loss; s.c = (arg == lab) ? 1.0 : 0.0; s.d = 1.0;
+    }
+    const Sums r = block_reduce4(s, sRed);
+    if (threadIdx.x == 0) {
+        double *o = a.partials + ((long long)b * a.nblk + blockIdx.x) * 4;
+        o[0] = r.a; o[1] = r.b; o[2] = r.c; o[3] = r.d;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- finalise
 
 // out[0] = loss (mean over B*N), out[1] = valid rate, out[2..2+B) = per-image mean loss (reduction=None).
@@ -396,6 +448,20 @@ int xl_loss_normal(const float *logits, const float *unc, const float *gt_normal
     a.gscale = per_image_scale ? 1.0f / (float)a.N : 1.0f / ((float)B * (float)a.N);
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(normal_loss_kernel, dim3(a.nblk, B), dim3(kT), 0, st, a);
+    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(64), 0, st, workspace, B, a.nblk, a.N, 0, out);
+    return launch_ok();
+}
+
+int xl_loss_semantics(const float *logits, const float *labels, int B, int C, int H, int W, int per_image_scale,
+                      float *dlogits, double *workspace, float *out, void *stream)
+{
+    if (!logits || !labels || !workspace || !out || B <= 0 || C <= 0 || H <= 0 || W <= 0) return XL_ERR_ARG;
+    SemArgs a;
+    a.logits = logits; a.labels = labels; a.dlogits = dlogits; a.partials = workspace;
+    a.B = B; a.C = C; a.N = H * W; a.nblk = (a.N + kT - 1) / kT;
+    a.gscale = per_image_scale ? 1.0f / (float)a.N : 1.0f / ((float)B * (float)a.N);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(semantics_loss_kernel, dim3(a.nblk, B), dim3(kT), 0, st, a);
     hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(64), 0, st, workspace, B, a.nblk, a.N, 0, out);
     return launch_ok();
 }

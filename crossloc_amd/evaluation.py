@@ -99,6 +99,51 @@ def scene_coords_printout(t_err_ls, r_err_ls, est_xyz_ls, coords_error_ls, testi
     return stats
 
 
+# ------------------------------------------------------------------------------------------ semantics metrics
+
+def confusion_matrix(gt_label, pred_label, num_class):
+    """Rows = ground truth, columns = prediction; labels outside [0, num_class) are ignored
+    (utils/evaluation.py:373-378).  Tensors [..] of equal shape, any device; returns int64 [num_class, num_class]."""
+    g = gt_label.reshape(-1).to(torch.int64)
+    p = pred_label.reshape(-1).to(device=g.device, dtype=torch.int64)
+    m = (g >= 0) & (g < num_class)
+    idx = num_class * g[m] + p[m]
+    return torch.bincount(idx, minlength=num_class * num_class).reshape(num_class, num_class)
+
+
+def segmentation_metrics(cm):
+    """Pixel accuracy, mean IoU and frequency-weighted IoU of one confusion matrix (utils/evaluation.py:346-371;
+    classes absent from both ground truth and prediction are left out of the mean like np.nanmean does)."""
+    cm = np.asarray(cm.cpu() if isinstance(cm, torch.Tensor) else cm, np.float64)
+    diag = np.diag(cm)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        acc = diag.sum() / cm.sum()
+        iu = diag / (cm.sum(axis=1) + cm.sum(axis=0) - diag)
+        freq = cm.sum(axis=1) / cm.sum()
+    miou = float(np.nanmean(iu))
+    fwiou = float((freq[freq > 0] * iu[freq > 0]).sum())
+    return float(acc), miou, fwiou
+
+
+def semantic_eval(semantic_logits, gt_label, mute=False):
+    """utils/evaluation.py:388-415: per-image accuracy / mIoU / fwIoU of full-size class logits [B,6,H,W] against
+    gt_label [B,1,H,W].  Returns (class_prediction [B,H,W] on the CPU, miou[B], fwiou[B], acc[B]) like the reference;
+    arg-max and the confusion matrices are computed on the logits' device."""
+    num_class = semantic_logits.shape[1]
+    gt = gt_label.squeeze(1)
+    pred = torch.argmax(semantic_logits, dim=1)               # arg-max of log-softmax = arg-max of the logits
+    assert gt.shape == pred.shape
+    miou_ls, fwiou_ls, acc_ls = [], [], []
+    for g, p in zip(gt, pred):
+        acc, miou, fwiou = segmentation_metrics(confusion_matrix(g.to(p.device), p, num_class))
+        acc_ls.append(acc); miou_ls.append(miou); fwiou_ls.append(fwiou)
+    miou_ls, fwiou_ls, acc_ls = np.array(miou_ls), np.array(fwiou_ls), np.array(acc_ls)
+    if not mute:
+        print("Metrics within the batch: mean accuracy: {:.2f}%, mean IoU: {:.2f}%, frequency weighted IoU: {:.2f}%".
+              format(acc_ls.mean() * 100, miou_ls.mean() * 100, fwiou_ls.mean() * 100))
+    return pred.cpu(), miou_ls, fwiou_ls, acc_ls
+
+
 # ------------------------------------------------------------------------------------------ sharded evaluation
 
 def shard_indices(num_images, rank, world_size):

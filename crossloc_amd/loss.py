@@ -35,6 +35,8 @@ def _bind():
         L.xl_loss_depth.argtypes = [vp, vp, vp, ci, ci, ci, cf, cf, cf, ci, ci, vp, vp, vp, vp, vp]
         L.xl_loss_normal.restype = ci
         L.xl_loss_normal.argtypes = [vp, vp, vp, ci, ci, ci, cf, cf, ci, ci, vp, vp, vp, vp, vp]
+        L.xl_loss_semantics.restype = ci
+        L.xl_loss_semantics.argtypes = [vp, vp, ci, ci, ci, ci, ci, vp, vp, vp, vp]
         L._loss_bound = True
     return L
 
@@ -177,3 +179,45 @@ def normal_regression_loss(hard_clamp, uncertainty, nodata_value, normal_logits,
                                 mode, per_image, _ptr(dpred), _ptr(dunc), _ptr(ws), _ptr(out), stream)
 
     return _run("normal", args, normal_logits, unc, reduction)
+
+
+class CrossEntropyLoss2d(torch.nn.Module):
+    """loss/semantics.py:10-18 — the criterion object train_single_task.py:215 constructs.  Only the configuration the
+    reference uses (no class weights, reduction='none', default ignore_index) is supported; the fused kernel of
+    `semantics_classification_loss` implements it, this class just carries the settings."""
+
+    def __init__(self, weight=None, reduction='none', ignore_index=-100):
+        super().__init__()
+        if weight is not None or reduction != 'none' or ignore_index != -100:
+            raise NotImplementedError("only CrossEntropyLoss2d() as constructed by train_single_task.py:215")
+
+
+def semantics_classification_loss(uncertainty, semantic_logits, uncertainty_map, gt_labels, criterion, reduction):
+    """loss/semantics.py:44-91: cross entropy over the C class logits [B,C,H,W] against gt_labels [B,1,H,W];
+    returns (loss, share of correctly classified pixels).  One fused kernel computes the loss, the arg-max accuracy
+    and d loss / d logits; the reference's host synchronisation (.cpu().numpy(), :66) is gone, so the second return
+    value is a device scalar tensor."""
+    if uncertainty is not None:
+        raise NotImplementedError                              # semantics.py:78-81
+    if not isinstance(criterion, CrossEntropyLoss2d):
+        raise NotImplementedError("criterion must be crossloc_amd.loss.CrossEntropyLoss2d()")
+    if reduction not in ('mean', None):
+        raise NotImplementedError
+    per_image = reduction is None
+    B, C, H, W = semantic_logits.shape
+    dev = semantic_logits.device
+    L = _bind()
+    p32 = _prep(semantic_logits)
+    lab = gt_labels.detach().to(device=dev, dtype=torch.float32).reshape(B, H, W).contiguous()
+
+    def launch(dpred, dunc):
+        ws = torch.empty(L.xl_loss_workspace_doubles(B, H, W), dtype=torch.float64, device=dev)
+        out = torch.empty(2 + B, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+            rc = L.xl_loss_semantics(_ptr(p32), _ptr(lab), B, C, H, W, int(per_image), _ptr(dpred), _ptr(ws), _ptr(out), stream)
+        _lib.check(rc)
+        return out
+
+    loss, out = _FusedLoss.apply(launch, per_image, semantic_logits, None)
+    return loss, out[1]

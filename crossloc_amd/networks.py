@@ -25,6 +25,7 @@ GN_RELU_IN, GN_ADD, GN_RELU_OUT, GN_ACC_AUX, GN_NO_CONV_BIAS = 1, 2, 4, 8, 16
 XL_OP_WGRAD, XL_OP_GNB_STATS, XL_OP_GNB_APPLY, XL_OP_GNB_PARAMS, XL_OP_HEAD_BWD, XL_OP_CONV1_WGRAD = 5, 6, 7, 8, 9, 10
 XL_OP_GN_FINAL = 11
 XL_OP_WINO_IN, XL_OP_WINO_OUT = 12, 13
+XL_OP_DUC_HEAD = 14
 CONV_DGRAD, CONV_ACCUMULATE = 1, 2
 
 
@@ -123,14 +124,21 @@ class TransPoseNetEncoder(nn.Module):
             self.add_module('enc_add_res_block{:d}'.format(i + 1), block)
 
 
+class DenseUpsamplingConvolution(nn.Module):
+    """Parameter layout of networks.py:259-273 (conv 3x3 -> GroupNorm -> ReLU -> pixel shuffle x down_sampling_rate)."""
+
+    def __init__(self, down_sampling_rate, in_channel, num_classes, num_gn_channel=32):
+        super().__init__()
+        self.conv = nn.Conv2d(in_channel, (down_sampling_rate ** 2) * num_classes, 3, 1, 1)
+        self.norm = nn.GroupNorm(num_gn_channel, (down_sampling_rate ** 2) * num_classes)
+
+
 class TransPoseNetDecoder(nn.Module):
-    """Parameter layout of networks.py:276-317 (full_size_output / DUC branch is out of scope)."""
+    """Parameter layout of networks.py:276-317, including the full_size_output (DUC / semantics) branch."""
 
     def __init__(self, mean, tiny, dec_add_res_block=0, num_task_channel=3, num_pos_channel=1, num_gn_channel=32,
                  full_size_output=False):
         super().__init__()
-        if full_size_output:
-            raise NotImplementedError("full_size_output (semantics DUC head) is outside the hot path (SURVEY.md §8f f4)")
         self.register_buffer('mean', mean.clone().float())
         self.tiny, self.dec_add_res_block = tiny, dec_add_res_block
         self.num_task_channel, self.num_pos_channel = num_task_channel, num_pos_channel
@@ -152,7 +160,12 @@ class TransPoseNetDecoder(nn.Module):
         self.fc2_norm = nn.GroupNorm(min(c, g), c)
         assert num_task_channel > 0 and num_pos_channel >= 0
         assert num_task_channel == len(mean)
-        self.fc3 = nn.Conv2d(c, num_task_channel + num_pos_channel, 1, 1, 0)
+        if full_size_output:
+            nc = num_task_channel + num_pos_channel
+            self.duc_upsample = DenseUpsamplingConvolution(8, c, nc)
+            self.fc3 = nn.Conv2d(nc, nc, 1, 1, 0)
+        else:
+            self.fc3 = nn.Conv2d(c, num_task_channel + num_pos_channel, 1, 1, 0)
 
 
 # ------------------------------------------------------------------------------------------ lowering
@@ -415,7 +428,9 @@ class _Plan:
         if m:
             return self.conv_wino(act, conv, norm, flags, aux, m)
         y = self.conv(act, conv)
-        if not self.train and y[1] * y[2] >= 128 and not os.environ.get("XL_NO_FUSED_STATS"):
+        bn = 128 if conv.out_channels % 128 == 0 else 64
+        whole_groups = bn % (conv.out_channels // norm.num_groups) == 0       # a conv tile's columns cover whole groups
+        if not self.train and y[1] * y[2] >= 128 and whole_groups and not os.environ.get("XL_NO_FUSED_STATS"):
             # inference: the conv epilogue produces the GroupNorm statistics, the separate stats pass is dropped
             return self.gn_fused(y, norm, flags, aux, len(self.ops) - 1)
         r = self.gn(y, norm, flags, aux)
@@ -570,6 +585,29 @@ class _Plan:
         res = c
         a = self.cgr(res, dec.fc1, dec.fc1_norm); self.release(res[0])
         b = self.cgr(a, dec.fc2, dec.fc2_norm); self.release(a[0])
+        if dec.full_size_output:
+            if self.train:
+                raise NotImplementedError("training of the full-size (semantics) head is not lowered; run it under "
+                                          "torch.no_grad()")
+            # networks.py:344-349: DUC conv-GN-ReLU; pixel shuffle, bilinear trim and fc3 fused in one kernel
+            d = self.cgr(b, dec.duc_upsample.conv, dec.duc_upsample.norm); self.release(b[0])
+            t, H, W, C, ld, off = d
+            nc = dec.num_task_channel + dec.num_pos_channel
+            op = XlOp()
+            op.type = XL_OP_DUC_HEAD
+            op.B, op.Hi, op.Wi, op.Cin, op.Ho, op.Wo, op.Cout = self.B, H, W, C, self.H, self.W, nc
+            op.n_task, op.n_pos, op.ld_in = dec.num_task_channel, dec.num_pos_channel, ld
+            op.clamp_lo, op.clamp_hi = -16.10, 13.82
+            op.in_ = t.data_ptr() + 4 * off
+            w3 = dec.fc3.weight.detach().to(device=self.device, dtype=torch.float32).reshape(nc, nc).contiguous()
+            self.keep.append(w3)
+            op.w = w3.data_ptr()
+            op.bias = self.dev(dec.fc3.bias).data_ptr()
+            op.aux = self.dev(dec.mean).data_ptr()
+            self.ops.append(op)
+            self.out_op_index = len(self.ops) - 1
+            self.out_shape = (self.B, nc, self.H, self.W)
+            return
         t, H, W, C, ld, off = b
         op = XlOp()
         op.type = XL_OP_HEAD
@@ -826,7 +864,8 @@ _DUMMY = _Dummy()
 
 
 class TransPoseNet(nn.Module):
-    """Drop-in for networks.py:362-502.  forward(inputs[B,C,H,W] on the GPU) -> [B, n_task+n_pos, H/8, W/8]."""
+    """Drop-in for networks.py:362-502.  forward(inputs[B,C,H,W] on the GPU) -> [B, n_task+n_pos, H/8, W/8], or
+    [B, n_task+n_pos, H, W] with full_size_output (the DUC / semantics head, inference only)."""
 
     def __init__(self, mean, tiny, grayscale, enc_add_res_block=0, dec_add_res_block=0, num_task_channel=3,
                  num_pos_channel=1, num_gn_channel=32, num_mlr=0, num_unfrozen_encoder=0, full_size_output=False):

@@ -5,6 +5,7 @@
  *   scene_coords_regression_loss   /root/reference/loss/coord.py:87-188
  *   depth_regression_loss          /root/reference/loss/depth.py:7-76
  *   normal_regression_loss         /root/reference/loss/normal.py:8-127
+ *   semantics_classification_loss  /root/reference/loss/semantics.py:44-91 (with CrossEntropyLoss2d :10-18)
  * with one streaming kernel each that produces the loss terms AND the analytic gradients w.r.t. the
  * prediction and the uncertainty map in the same pass (what autograd derived in the reference), plus a
  * fixed-order finalisation.  No host synchronisation (the reference syncs 5x per call, coord.py:132,170-175).
@@ -42,6 +43,12 @@ int xl_loss_depth(const float *pred, const float *unc, const float *gt_depth, in
 int xl_loss_normal(const float *logits, const float *unc, const float *gt_normals, int B, int Ho, int Wo,
                    float hard_clamp, float nodata, int mode, int per_image_scale,
                    float *dlogits, float *dunc, double *workspace, float *out, void *stream);
+
+/* semantics_classification_loss with CrossEntropyLoss2d (loss/semantics.py:10-18, 44-91; no class weights, no
+ * uncertainty): logits [B,C,H,W], labels [B,H,W] class ids stored as floats (what the loader yields); out[1] is the
+ * share of pixels whose arg-max class equals the label; dlogits = (softmax - onehot) * scale. */
+int xl_loss_semantics(const float *logits, const float *labels, int B, int C, int H, int W, int per_image_scale,
+                      float *dlogits, double *workspace, float *out, void *stream);
 
 #ifdef __cplusplus
 }

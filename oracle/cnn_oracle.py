@@ -1,8 +1,8 @@
 """CPU fp32 restatement of the reference network graph — TEST INFRASTRUCTURE ONLY (see oracle/dsac_oracle.c).
 
 Follows /root/reference/networks/networks.py: encoder :221-256, residual block :133-146 and its callers
-:252-254 / :332-334, decoder :319-360, MLR fusion :483-494, written as a pure function of a state_dict with the
-reference's key names.  Pinned against tests/golden/net_forward.npz (outputs of the imported reference).
+:252-254 / :332-334, decoder :319-360 (incl. the full-size DUC head :259-273), MLR fusion :483-494, written as a pure function of a state_dict with the
+reference's key names.  Pinned against tests/golden/net_forward.npz and semantics.npz (outputs of the imported reference).
 The floating-point kernels of the product path are compared with this at fp32 tolerances.
 """
 import torch
@@ -44,7 +44,7 @@ def encoder_forward(sd, x, prefix="encoder", enc_add=2, groups=32):
     return res
 
 
-def decoder_forward(sd, res, dec_add=2, n_task=3, n_pos=1, groups=32):
+def decoder_forward(sd, res, dec_add=2, n_task=3, n_pos=1, groups=32, up_hw=None):
     p = "decoder."
     for i in range(dec_add):
         res = F.relu(res + _res_block(sd, p + "dec_add_res_block%d" % (i + 1), res, groups))
@@ -54,6 +54,11 @@ def decoder_forward(sd, res, dec_add=2, n_task=3, n_pos=1, groups=32):
     res = F.relu(res + x)
     sc = _cgr(sd, res, p + "fc1", p + "fc1_norm", groups=groups)
     sc = _cgr(sd, sc, p + "fc2", p + "fc2_norm", groups=groups)
+    if (p + "duc_upsample.conv.weight") in sd:
+        # full_size_output (networks.py:259-273, 344-349): DUC conv-GN-ReLU, pixel shuffle x8, bilinear trim
+        sc = _cgr(sd, sc, p + "duc_upsample.conv", p + "duc_upsample.norm", groups=groups)
+        sc = F.pixel_shuffle(sc, 8)
+        sc = F.interpolate(sc, up_hw, mode="bilinear", align_corners=False)
     sc = F.conv2d(sc, sd[p + "fc3.weight"], sd[p + "fc3.bias"])
     task = sc[:, :n_task] + sd[p + "mean"][None, :, None, None]
     if n_pos:
@@ -74,4 +79,4 @@ def transposenet_forward(sd, x, num_mlr=0, enc_add=2, dec_add=2, n_task=3, n_pos
         mlr = F.group_norm(mlr, groups, sd["mlr_norm.weight"], sd["mlr_norm.bias"], eps=1e-5)
         mlr = _res_block(sd, "mlr_forward", mlr, groups)
         res = F.relu(res + mlr)
-    return decoder_forward(sd, res, dec_add, n_task, n_pos, groups)
+    return decoder_forward(sd, res, dec_add, n_task, n_pos, groups, up_hw=tuple(x.shape[2:4]))

@@ -1,6 +1,7 @@
 """CPU restatement of the three per-pixel losses in plain torch (autograd supplies the gradients) —
 TEST INFRASTRUCTURE ONLY.  Follows /root/reference/loss/coord.py:87-188, loss/depth.py:7-76,
-loss/normal.py:8-127 and utils/learning.py:49-71, 401-440; pinned against tests/golden/losses.npz
+loss/normal.py:8-127, loss/semantics.py:10-18, 44-91 and utils/learning.py:49-71, 401-440; pinned against
+tests/golden/losses.npz and semantics.npz
 (values and autograd gradients captured from the imported reference)."""
 import math
 
@@ -79,3 +80,18 @@ def normal_loss(logits, sigma, gt, hard=10.0, nodata=-1.0, mle=True, reduction='
     valid = ~(torch.acos(cs) / math.pi * 180.0 > hard) & g
     l = _mle(E.square(), sigma.reshape(B, -1), 2.0) if mle else E
     return _reduce(l * g, valid, reduction)
+
+
+def semantics_loss(logits, labels, reduction='mean'):
+    """loss/semantics.py:44-91 with CrossEntropyLoss2d (:10-18, no class weights): per-pixel -log softmax at the
+    label; loss = sum / pixels ('mean') or per image (None); rate = share of pixels whose arg-max class (first maximum)
+    equals the label.  labels: [B,1,H,W] (any numeric dtype)."""
+    B = logits.shape[0]
+    lab = labels.squeeze(1).long()
+    ce = torch.nn.functional.nll_loss(torch.log_softmax(logits, dim=1), lab, reduction='none')     # [B,H,W]
+    pred = torch.argmax(torch.log_softmax(logits.detach(), dim=1), dim=1)
+    rate = (pred == lab).sum().item() / lab.numel()
+    per = ce.reshape(B, -1).sum(dim=1)
+    if reduction is None:
+        return per / lab[0].numel(), rate
+    return per.sum() / lab.numel(), rate

@@ -10,6 +10,8 @@ Reference entry points exercised:
   loss/depth.py:7-76            depth_regression_loss
   loss/normal.py:8-127          normal_regression_loss
   utils/learning.py:20-35       get_pixel_grid;  loss/coord.py:7-17 get_cam_mat
+  networks/networks.py:259-273, 311-349  DenseUpsamplingConvolution / full_size_output decoder (semantics.npz)
+  loss/semantics.py:10-18, 44-91         CrossEntropyLoss2d, semantics_classification_loss (semantics.npz)
 """
 import builtins
 import os
@@ -158,6 +160,44 @@ def loss_goldens():
     _print("losses.npz", sorted(out.keys()))
 
 
+def semantics_goldens():
+    """Full-size (semantics) head: 6 classes, no uncertainty channel (utils/evaluation.py:92-108)."""
+    from loss.semantics import semantics_classification_loss, CrossEntropyLoss2d
+    out = {}
+    net = quiet(TransPoseNet, torch.zeros(6), False, False, 2, 2, 6, 0, 32, 0, 0, True)
+    net.load_state_dict(seeded_state_dict(net, seed=2021), strict=True)
+    net.eval()
+    for tag, hw in (("sem", (64, 96)), ("sem_resize", (60, 92))):      # 60x92 -> 8x12 -> 64x96 -> bilinear to 60x92
+        rng = np.random.default_rng(31 + hw[0])
+        x = torch.from_numpy(rng.uniform(0, 1, size=(2, 3) + hw).astype(np.float32))
+        with torch.no_grad():
+            y = net(x)
+        out[tag + "_x"] = x.numpy(); out[tag + "_y"] = y.numpy()
+    out["sem_keys"] = np.array(["%s:%s" % (k, "x".join(map(str, v.shape))) for k, v in net.state_dict().items()])
+    rng = np.random.default_rng(9)
+    B, C, H, W = 2, 6, 16, 24
+    logits = rng.normal(0, 2.0, size=(B, C, H, W)).astype(np.float32)
+    labels = rng.integers(0, C, size=(B, 1, H, W)).astype(np.float32)
+    logits[0, :, 0, 0] = 0.0                                        # tie: argmax takes the first class
+    logits[1, 3, 2, 2] = 60.0                                       # saturated soft-max
+    for red in ("mean", None):
+        p = torch.tensor(logits, requires_grad=True)
+        loss, rate = quiet(semantics_classification_loss, None, p, None, torch.tensor(labels), CrossEntropyLoss2d(), red)
+        loss.sum().backward()
+        tag = "ce_%s" % (red or "none")
+        out[tag + "_loss"] = np.atleast_1d(loss.detach().numpy()).astype(np.float64)
+        out[tag + "_rate"] = np.array(float(rate))
+        out[tag + "_dlogits"] = p.grad.numpy().copy()
+    out.update(ce_logits=logits, ce_labels=labels)
+    np.savez_compressed(os.path.join(HERE, "semantics.npz"), **out)
+    _print("semantics.npz", {k: v.shape for k, v in out.items()})
+
+
 if __name__ == "__main__":
-    net_goldens()
-    loss_goldens()
+    which = sys.argv[1:] or ["net", "loss", "semantics"]
+    if "net" in which:
+        net_goldens()
+    if "loss" in which:
+        loss_goldens()
+    if "semantics" in which:
+        semantics_goldens()

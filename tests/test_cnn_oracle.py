@@ -43,3 +43,19 @@ def test_forward_requires_gpu_no_fallback():
         net(torch.zeros(1, 3, 64, 96))
     with pytest.raises(NotImplementedError):
         networks.TransPoseNet(MEAN, True, False)
+
+
+SEM = np.load(os.path.join(os.path.dirname(__file__), "golden", "semantics.npz"))
+
+
+def test_semantics_head_keys_and_oracle_match_reference_golden():
+    """full_size_output=True (networks.py:259-273, 311-349): DUC head, 6 classes, no uncertainty channel."""
+    net = networks.TransPoseNet(torch.zeros(6), False, False, 2, 2, 6, 0, 32, 0, 0, True)
+    ours = ["%s:%s" % (k, "x".join(map(str, v.shape))) for k, v in net.state_dict().items()]
+    assert ours == list(SEM["sem_keys"])
+    assert net.OUTPUT_SUBSAMPLE == 1
+    sd = seeded_state_dict(net, seed=2021)
+    for tag in ("sem", "sem_resize"):                       # 64x96 (pure pixel shuffle) and 60x92 (bilinear trim)
+        y = cnn_oracle.transposenet_forward(sd, torch.from_numpy(SEM[tag + "_x"]), 0, 2, 2, 6, 0)
+        ref = torch.from_numpy(SEM[tag + "_y"])
+        assert y.shape == ref.shape and torch.allclose(y, ref, atol=2e-5)

@@ -1,0 +1,90 @@
+"""GPU: the full-size (semantics) head — DUC conv + pixel shuffle + bilinear trim + fc3 — and the fused cross-entropy
+loss against golden vectors captured from the imported reference (tests/golden/semantics.npz), plus the segmentation
+metrics of the evaluation harness against a direct numpy restatement."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from crossloc_amd import evaluation, loss as xl_loss, networks
+from crossloc_amd.weights import seeded_state_dict
+from oracle import loss_oracle
+
+pytestmark = pytest.mark.gpu
+
+SEM = np.load(os.path.join(os.path.dirname(__file__), "golden", "semantics.npz"))
+
+
+@pytest.mark.parametrize("tag", ["sem", "sem_resize"])
+def test_semantics_network_matches_reference_golden(tag):
+    net = networks.TransPoseNet(torch.zeros(6), False, False, 2, 2, 6, 0, 32, 0, 0, True)
+    net.load_state_dict(seeded_state_dict(net, seed=2021), strict=True)
+    net = net.cuda().eval()
+    with torch.no_grad():
+        y = net(torch.from_numpy(SEM[tag + "_x"]).cuda())
+        y2 = net(torch.from_numpy(SEM[tag + "_x"]).cuda())
+    ref = torch.from_numpy(SEM[tag + "_y"])
+    assert tuple(y.shape) == tuple(ref.shape)
+    assert torch.equal(y, y2)
+    err = (y.cpu() - ref).abs().max().item()
+    assert err < 1e-3 * ref.abs().max().item(), err
+    # the class decisions agree wherever the reference's margin is not within rounding
+    top2 = torch.topk(ref, 2, dim=1).values
+    clear = (top2[:, 0] - top2[:, 1]) > 1e-2
+    assert torch.equal(torch.argmax(y.cpu(), 1)[clear], torch.argmax(ref, 1)[clear])
+
+
+def test_semantics_head_trains_only_under_no_grad():
+    net = networks.TransPoseNet(torch.zeros(6), False, False, 0, 0, 6, 0, 32, 0, 0, True).cuda()
+    with pytest.raises(NotImplementedError):
+        net(torch.rand(1, 3, 64, 96, device="cuda"))
+
+
+@pytest.mark.parametrize("red", ["mean", None])
+def test_semantics_loss_matches_reference_golden(red):
+    p = torch.tensor(SEM["ce_logits"], device="cuda", requires_grad=True)
+    lab = torch.tensor(SEM["ce_labels"], device="cuda")
+    loss, rate = xl_loss.semantics_classification_loss(None, p, None, lab, xl_loss.CrossEntropyLoss2d(), red)
+    loss.sum().backward()
+    tag = "ce_%s" % (red or "none")
+    assert np.allclose(np.atleast_1d(loss.detach().cpu().numpy()), SEM[tag + "_loss"], rtol=2e-5)
+    assert float(rate) == pytest.approx(float(SEM[tag + "_rate"]), abs=1e-7)
+    assert np.allclose(p.grad.cpu().numpy(), SEM[tag + "_dlogits"], rtol=2e-4, atol=1e-8)
+
+
+def test_semantics_loss_full_size_vs_oracle():
+    g = torch.Generator().manual_seed(3)
+    logits = torch.randn(2, 6, 480, 720, generator=g) * 3
+    labels = torch.randint(0, 6, (2, 1, 480, 720), generator=g).float()
+    p = logits.cuda().requires_grad_(True)
+    loss, rate = xl_loss.semantics_classification_loss(None, p, None, labels.cuda(), xl_loss.CrossEntropyLoss2d(), 'mean')
+    loss.backward()
+    q = logits.clone().requires_grad_(True)
+    lo, ro = loss_oracle.semantics_loss(q, labels, 'mean')
+    lo.backward()
+    assert loss.item() == pytest.approx(lo.item(), rel=2e-6)
+    assert float(rate) == pytest.approx(ro, abs=1e-6)
+    assert torch.allclose(p.grad.cpu(), q.grad, rtol=2e-4, atol=1e-11)
+    with pytest.raises(NotImplementedError):
+        xl_loss.semantics_classification_loss('MLE', p, None, labels.cuda(), xl_loss.CrossEntropyLoss2d(), 'mean')
+
+
+def test_segmentation_metrics():
+    rng = np.random.default_rng(0)
+    gt = rng.integers(0, 6, size=(3, 1, 40, 50))
+    gt[0, 0, :5] = 7                                           # out-of-range labels are ignored
+    logits = rng.normal(size=(3, 6, 40, 50)).astype(np.float32)
+    logits[np.arange(3)[:, None, None], np.clip(gt[:, 0], 0, 5), np.arange(40)[None, :, None], np.arange(50)[None, None, :]] += 1.5
+    pred, miou, fwiou, acc = evaluation.semantic_eval(torch.from_numpy(logits).cuda(), torch.from_numpy(gt).cuda(), mute=True)
+    cls = logits.argmax(1)
+    assert np.array_equal(pred.numpy(), cls)
+    for b in range(3):
+        m = (gt[b, 0] >= 0) & (gt[b, 0] < 6)
+        cm = np.bincount(6 * gt[b, 0][m] + cls[b][m], minlength=36).reshape(6, 6).astype(np.float64)
+        d = np.diag(cm)
+        iu = d / (cm.sum(1) + cm.sum(0) - d)
+        assert acc[b] == pytest.approx(d.sum() / cm.sum())
+        assert miou[b] == pytest.approx(np.nanmean(iu))
+        fr = cm.sum(1) / cm.sum()
+        assert fwiou[b] == pytest.approx((fr[fr > 0] * iu[fr > 0]).sum())
