@@ -643,7 +643,7 @@ void wino4_in_kernel(const float *__restrict__ in, float *__restrict__ V, int B,
 __global__ __launch_bounds__(256)
 void wino4_out_kernel(const float *__restrict__ M, const float *__restrict__ bias, float *__restrict__ out,
                       double *__restrict__ stats, int B, int H, int W, int C, int ldOut, int Th, int Tw, int tpb,
-                      int G, int nchunks)
+                      int G, int nchunks, int accumulate)
 {
     __shared__ double sS[256 * 4];
     const int tid = threadIdx.x;
@@ -683,8 +683,10 @@ void wino4_out_kernel(const float *__restrict__ M, const float *__restrict__ bia
             for (int qI = 0; qI < 4; ++qI) {
                 const int ox = 4 * tx + qI;
                 if (ox >= W) continue;
-                const f32x2 v = y[qI] + bv;
-                *reinterpret_cast<f32x2 *>(out + (((long long)n * H + oy) * W + ox) * ldOut + cch) = v;
+                f32x2 v = y[qI] + bv;
+                f32x2 *dst = reinterpret_cast<f32x2 *>(out + (((long long)n * H + oy) * W + ox) * ldOut + cch);
+                if (accumulate) v += *dst;                     // data gradients: second producer of a gradient tensor
+                *dst = v;
                 s1 += v; s2 += v * v;
             }
         }
@@ -1181,7 +1183,8 @@ int run_op(const xl_op &op, hipStream_t st)
                     return XL_ERR_ARG;
                 hipLaunchKernelGGL(wino4_out_kernel, dim3(op.nchunks, op.B, op.Cin / CB), dim3(256), 0, st, (const float *)op.in,
                                    (const float *)op.bias, (float *)op.out, (double *)op.stats, op.B, op.Hi, op.Wi, op.Cin,
-                                   op.ld_out, Th4, Tw4, op.reserved_i, op.groups, op.nchunks);
+                                   op.ld_out, Th4, Tw4, op.reserved_i, op.groups, op.nchunks,
+                                   (op.flags & XL_CONV_ACCUMULATE) ? 1 : 0);
                 return XL_OK;
             }
             const int C4 = op.Cin / 4;

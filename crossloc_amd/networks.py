@@ -230,11 +230,12 @@ class _Plan:
                4: ((1 / 4, 0.0, 0.0), (-1 / 6, -1 / 6, -1 / 6), (-1 / 6, 1 / 6, -1 / 6), (1 / 24, 1 / 12, 1 / 6),
                    (1 / 24, -1 / 12, 1 / 6), (0.0, 0.0, 1.0))}
 
-    def pack_conv_wino(self, conv, m):
+    def pack_conv_wino(self, conv, m, dgrad=False):
         """[(m+2)^2][Cout][Cin] transformed weights of a 3x3 convolution: one plain [Cout][Cin] GEMM operand per
-        frequency of F(m x m, 3x3)."""
+        frequency of F(m x m, 3x3).  dgrad: the data gradient is the convolution with the flipped kernel and the
+        channel roles swapped, so its operands are [(m+2)^2][Cin][Cout]."""
         w = conv.weight
-        kind = "wino%d" % m
+        kind = "wino%d%s" % (m, "d" if dgrad else "")
         key = (id(w), kind)
         if key not in self.packed:
             src = w.detach().to(device=self.device, dtype=torch.float32).contiguous()
@@ -242,6 +243,12 @@ class _Plan:
             self.packed[key] = (dst, src, kind)
             self._pack(dst, src, kind)
         return self.packed[key][0]
+
+    def wino_dgrad_ok(self, conv, H, W, C):
+        """Data gradient of a stride-1 3x3 layer as F(4x4,3x3) (C = the layer's input channels = gradient channels)."""
+        return (conv.kernel_size[0] == 3 and conv.stride[0] == 1 and C in (128, 256, 512, 1024)
+                and conv.out_channels % 32 == 0 and H * W >= 64
+                and not os.environ.get("XL_NO_WINOGRAD") and not os.environ.get("XL_NO_WINOGRAD_TRAIN"))
 
     def pack_conv(self, conv, dgrad=False):
         w = conv.weight
@@ -260,10 +267,13 @@ class _Plan:
         cout, cin, k, _ = src.shape
         stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         if kind.startswith("wino"):
-            m = int(kind[4:])
+            m = int(kind[4])
             G = torch.tensor(self._WINO_G[m], dtype=torch.float64, device=self.device)
-            U = torch.einsum("ia,ocab,jb->ijoc", G, src.to(torch.float64), G)          # fp64, rounded once
-            dst.view(m + 2, m + 2, cout, cin).copy_(U)
+            g = src.to(torch.float64)
+            if kind.endswith("d"):
+                g = g.flip(2, 3).permute(1, 0, 2, 3)                                    # [Cin, Cout, 3, 3]
+            U = torch.einsum("ia,ocab,jb->ijoc", G, g, G)                               # fp64, rounded once
+            dst.view(m + 2, m + 2, g.shape[0], g.shape[1]).copy_(U)
         elif kind == "conv1":                     # [(ky*3+kx)*Cin + c][Cout]
             dst.view(k, k, cin, cout).copy_(src.permute(2, 3, 1, 0))
         elif kind == "dgrad":
@@ -309,12 +319,14 @@ class _Plan:
         self.tape.append(dict(kind="conv", conv=conv, x=act, raw=res))
         return res
 
-    def gn(self, act, norm, flags, aux=None, out=None):
-        """GroupNorm (+fused epilogue) of `act`; in place unless `out` (tensor, ld, off) is given or training."""
+    def gn(self, act, norm, flags, aux=None, out=None, pre_stats=None):
+        """GroupNorm (+fused epilogue) of `act`; in place unless `out` (tensor, ld, off) is given or training.
+        pre_stats = (stats tensor, nchunks): the partial sums were already produced (Winograd output transform of a
+        training plan), no statistics pass is emitted."""
         t, H, W, C, ld, off = act
         G = norm.num_groups
         HW = H * W
-        nchunks = max(1, min(128, (HW + 255) // 256))
+        nchunks = max(1, min(128, (HW + 255) // 256)) if pre_stats is None else pre_stats[1]
         st = XlOp()
         st.type = XL_OP_GN_STATS
         st.B, st.Hi, st.Wi, st.Cin, st.groups, st.nchunks, st.ld_in = self.B, H, W, C, G, nchunks, ld
@@ -327,14 +339,19 @@ class _Plan:
         gamma, beta = self.dev(norm.weight), self.dev(norm.bias)
         ap.w, ap.bias = gamma.data_ptr(), beta.data_ptr()
         stats_t = None
-        if self.train:                      # the forward statistics are inputs of the backward pass: keep them
+        if pre_stats is not None:
+            assert self.train
+            stats_t = pre_stats[0]
+            ap.stats = stats_t.data_ptr()
+        elif self.train:                    # the forward statistics are inputs of the backward pass: keep them
             stats_t = torch.zeros(self.B * nchunks * G * 2, dtype=torch.float64, device=self.device)
             self.keep.append(stats_t)
             st.stats = ap.stats = stats_t.data_ptr()
         else:
             self.max_stats = max(self.max_stats, self.B * nchunks * G * 2)
             self.stats_ops += [len(self.ops), len(self.ops) + 1]
-        self.ops.append(st)
+        if pre_stats is None:
+            self.ops.append(st)
         if not self.train:
             self._emit_final(ap, gamma, beta, 0)
         if aux is not None:
@@ -358,10 +375,12 @@ class _Plan:
         """Inference plans run the stride-1 3x3 convolutions as Winograd F(4x4,3x3) (4x fewer multiplies; 2.25x for
         F(2x2,3x3), selected with XL_WINOGRAD=2).  Returns the output tile size m, or 0 for the direct kernel."""
         t, H, W, C, ld, off = act
-        if (self.train or conv.kernel_size[0] != 3 or conv.stride[0] != 1 or C % 32 != 0 or H * W < 64
+        if (conv.kernel_size[0] != 3 or conv.stride[0] != 1 or C % 32 != 0 or H * W < 64
                 or conv.out_channels not in (128, 256, 512, 1024) or os.environ.get("XL_NO_WINOGRAD")):
             return 0
         m = int(os.environ.get("XL_WINOGRAD", "4"))
+        if self.train and (m != 4 or os.environ.get("XL_NO_WINOGRAD_TRAIN")):
+            return 0                                         # training plans: F(4x4,3x3) only
         if m == 2 and (H % 2 or W % 2):
             return 0
         return m if m in (2, 4) else 0
@@ -402,11 +421,21 @@ class _Plan:
         op.B, op.Hi, op.Wi, op.Cin, op.ld_out, op.groups, op.nchunks, op.reserved_i = B, H, W, cout, cout, G, nchunks, tpb
         op.in_, op.out = Mb.data_ptr(), out.data_ptr()
         op.bias = self.dev(conv.bias).data_ptr()
+        y = (out, H, W, cout, cout, 0)
+        if self.train:
+            # the raw conv output and its statistics are inputs of the backward pass: keep both, record the tape
+            stats_t = torch.zeros(B * nchunks * G * 2, dtype=torch.float64, device=self.device)
+            self.keep.append(stats_t)
+            op.stats = stats_t.data_ptr()
+            self.ops.append(op)
+            self.free.setdefault(Mb.numel(), []).append(Mb)          # V / M are scratch even in training plans
+            self.free.setdefault(V.numel(), []).append(V)
+            self.tape.append(dict(kind="conv", conv=conv, x=act, raw=y))
+            return self.gn(y, norm, flags, aux, pre_stats=(stats_t, nchunks))
         self.max_stats = max(self.max_stats, B * nchunks * G * 2)
         self.stats_ops.append(len(self.ops))
         self.ops.append(op)
         self.release(Mb)
-        y = (out, H, W, cout, cout, 0)
         ap = XlOp()
         ap.type = XL_OP_GN_APPLY
         ap.B, ap.Hi, ap.Wi, ap.Cin, ap.groups, ap.nchunks, ap.ld_in = B, H, W, cout, G, nchunks, cout
@@ -780,6 +809,37 @@ class _Plan:
                 else:
                     gx = (self.alloc(B * H * W * C), C, 0)
                     grads[self._key(e["x"])] = gx
+                if self.wino_dgrad_ok(conv, H, W, C):
+                    # dX = conv3x3(dY, flipped kernel, channels swapped) as F(4x4,3x3): 4x fewer multiplies
+                    m = 4
+                    Th, Tw = -(-H // m), -(-W // m)
+                    T, nf = B * Th * Tw, (m + 2) ** 2
+                    Vb = self.alloc(nf * T * Cout)
+                    wi = XlOp()
+                    wi.type, wi.ksize = XL_OP_WINO_IN, m
+                    wi.B, wi.Hi, wi.Wi, wi.Cin, wi.Ho, wi.Wo, wi.ld_in = B, H, W, Cout, Th, Tw, Cout
+                    wi.in_, wi.out = dy.data_ptr(), Vb.data_ptr()
+                    bops.append(wi)
+                    Mb = self.alloc(nf * T * C)
+                    gm = XlOp()
+                    gm.type = XL_OP_CONV
+                    gm.B, gm.Hi, gm.Wi, gm.Cin, gm.Ho, gm.Wo, gm.Cout = B, Th, Tw, Cout, Th, Tw, C
+                    gm.ksize, gm.stride, gm.ld_in, gm.ld_out, gm.nchunks2 = 1, 1, Cout, C, nf
+                    gm.in_, gm.w, gm.out = Vb.data_ptr(), self.pack_conv_wino(conv, m, dgrad=True).data_ptr(), Mb.data_ptr()
+                    if -(-T // 128) * (C // 128) * nf <= 256:
+                        gm.reserved_i = 64
+                    bops.append(gm)
+                    wo = XlOp()
+                    wo.type, wo.ksize = XL_OP_WINO_OUT, m
+                    tpb = 16
+                    wo.B, wo.Hi, wo.Wi, wo.Cin, wo.ld_out, wo.groups = B, H, W, C, gx[1], 1
+                    wo.nchunks, wo.reserved_i = -(-(Th * Tw) // tpb), tpb
+                    wo.flags = op.flags & CONV_ACCUMULATE
+                    wo.in_, wo.out = Mb.data_ptr(), gx[0].data_ptr() + 4 * gx[2]
+                    bops.append(wo)
+                    self.release_grad(Vb); self.release_grad(Mb)
+                    self.release_grad(dy)
+                    continue
                 op.B, op.Hi, op.Wi, op.Cin, op.Ho, op.Wo, op.Cout = B, Ho, Wo, Cout, H, W, C
                 op.ksize, op.stride, op.ld_in, op.ld_out = k, s, Cout, gx[1]
                 op.in_, op.out = dy.data_ptr(), gx[0].data_ptr() + 4 * gx[2]

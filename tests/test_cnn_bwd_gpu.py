@@ -44,8 +44,16 @@ def _reference_grads(sd, x, wgt, enc_add, dec_add):
     return y.detach().float(), {k: v.grad.float() for k, v in leaves.items()}
 
 
+@pytest.mark.parametrize("form", ["direct", "winograd"])
 @pytest.mark.parametrize("B,H,W,enc_add,dec_add", [(2, 64, 96, 1, 1), (1, 128, 192, 2, 2), (3, 40, 56, 0, 0)])
-def test_parameter_gradients_vs_autograd(B, H, W, enc_add, dec_add):
+def test_parameter_gradients_vs_autograd(B, H, W, enc_add, dec_add, form, monkeypatch):
+    """form: training plans run the stride-1 3x3 layers (forward and data gradient) as Winograd F(4x4,3x3) by default;
+    "direct" pins the direct implicit-GEMM kernels (XL_NO_WINOGRAD_TRAIN=1, read when the plan is built).  Winograd's
+    forward rounding noise is ~10x the direct form's, so more pre-activations land on the other side of ReLU'(0) than
+    in the float64 reference: the max-norm criterion stays on the direct form, the Winograd form is held to a relative
+    L2 error per tensor (a flipped mask moves a few elements; a wiring error moves the whole tensor)."""
+    if form == "direct":
+        monkeypatch.setenv("XL_NO_WINOGRAD_TRAIN", "1")
     net = networks.TransPoseNet(MEAN, False, False, enc_add, dec_add, 3, 1)
     net.load_state_dict(seeded_state_dict(net, seed=11))
     g = torch.Generator().manual_seed(B * 100 + H)
@@ -62,20 +70,28 @@ def test_parameter_gradients_vs_autograd(B, H, W, enc_add, dec_add):
     torch.cuda.synchronize()
     scale = max(1.0, (yref[:, :3] - MEAN[None, :, None, None]).abs().max().item())
     assert (y.detach().cpu()[:, :3] - yref[:, :3]).abs().max().item() <= 1e-3 * scale
-    worst = []
+    worst, worst2 = [], []
     gmax = max(v.abs().max().item() for v in gref.values())
     for name, p in net.named_parameters():
         assert p.grad is not None, name
         ref = gref[name]
-        err = (p.grad.cpu() - ref).abs().max().item()
+        d = (p.grad.cpu() - ref).double()
+        err = d.abs().max().item()
         # per-tensor scale, floored at 1e-4 of the largest gradient in the network: conv1.bias is exactly 0 in
         # exact arithmetic (GroupNorm(32,32) is an instance norm), so both sides hold rounding noise only
         sc = max(ref.abs().max().item(), 1e-4 * gmax)
         worst.append((err / sc, name))
+        worst2.append((d.norm().item() / max(ref.double().norm().item(), 1e-4 * gmax * ref.numel() ** 0.5), name))
     worst.sort(reverse=True)
+    worst2.sort(reverse=True)
     worst = [w for w in worst if w[1] != "encoder.conv1.bias"]   # exactly 0 here; the reference holds noise
-    assert worst[0][0] <= 5e-2, worst[:5]
-    print("worst relative gradient error %.2e (%s), median %.2e" % (worst[0][0], worst[0][1], worst[len(worst) // 2][0]))
+    worst2 = [w for w in worst2 if w[1] != "encoder.conv1.bias"]
+    print("%s: worst max-norm error %.2e (%s), worst L2 error %.2e (%s), median %.2e" % (
+        form, worst[0][0], worst[0][1], worst2[0][0], worst2[0][1], worst[len(worst) // 2][0]))
+    if form == "direct":
+        assert worst[0][0] <= 5e-2, worst[:5]
+    else:
+        assert worst2[0][0] <= 1e-1 and worst[0][0] <= 0.5, (worst2[:5], worst[:5])
     assert net.encoder.conv1.bias.grad.abs().max().item() == 0.0
 
 
@@ -234,9 +250,13 @@ def test_groupnorm_backward_vs_autograd(B, H, W, C, flags):
         assert dbias.abs().max().item() == 0.0                        # instance norm: exactly zero
 
 
-def test_mlr_network_backward_with_frozen_encoders():
+@pytest.mark.parametrize("form", ["direct", "winograd"])
+def test_mlr_network_backward_with_frozen_encoders(form, monkeypatch):
     """finetune_decoder_single_task.py configuration: TransPoseNet(num_mlr=3, num_unfrozen_encoder=1)
-    (utils/learning.py:294-305) — gradients flow through the fusion block into encoder 1 only."""
+    (utils/learning.py:294-305) — gradients flow through the fusion block into encoder 1 only.  Criteria per form as
+    in test_parameter_gradients_vs_autograd."""
+    if form == "direct":
+        monkeypatch.setenv("XL_NO_WINOGRAD_TRAIN", "1")
     B, H, W = 1, 64, 96
     net = networks.TransPoseNet(MEAN, False, False, 1, 1, 3, 1, 32, 3, 1, False)
     net.load_state_dict(seeded_state_dict(net, seed=23))
@@ -264,13 +284,19 @@ def test_mlr_network_backward_with_frozen_encoders():
     torch.cuda.synchronize()
     assert (y.detach().cpu()[:, :3] - yref[:, :3]).abs().max().item() < 1e-3 * max(1.0, (yref[:, :3] - MEAN[None, :, None, None]).abs().max().item())
     gmax = max(sd[n].grad.abs().max().item() for n in trainable)
-    worst = []
+    worst, worst2 = [], []
     for name, p in net.named_parameters():
         if name not in trainable:
             assert p.grad is None, name
             continue
         ref = sd[name].grad.float()
         sc = max(ref.abs().max().item(), 1e-4 * gmax)
-        worst.append(((p.grad.cpu() - ref).abs().max().item() / sc, name))
+        d = (p.grad.cpu() - ref).double()
+        worst.append((d.abs().max().item() / sc, name))
+        worst2.append((d.norm().item() / max(ref.double().norm().item(), 1e-4 * gmax * ref.numel() ** 0.5), name))
     worst = sorted(w for w in worst if w[1] != "mlr_encoder_1.conv1.bias")
-    assert worst[-1][0] <= 5e-2, [(round(a, 5), b) for a, b in worst if a > 5e-2]
+    worst2 = sorted(w for w in worst2 if w[1] != "mlr_encoder_1.conv1.bias")
+    if form == "direct":
+        assert worst[-1][0] <= 5e-2, [(round(a, 5), b) for a, b in worst if a > 5e-2]
+    else:
+        assert worst2[-1][0] <= 1e-1 and worst[-1][0] <= 0.5, (worst2[-3:], worst[-3:])

@@ -261,3 +261,91 @@ def test_odd_image_sizes_and_grayscale(H, W, gray):
     assert y.shape == ref.shape
     _close(y[:, :3] - MEAN[None, :, None, None], ref[:, :3] - MEAN[None, :, None, None], 1e-3)
     assert torch.allclose(y[:, 3], ref[:, 3], rtol=2e-3)
+
+
+# ------------------------------------------------------------------------------------------ Winograd op sequence
+
+def _wino_weights(w, m, dgrad=False):
+    """[(m+2)^2][Cout][Cin] operands exactly as the plan packs them (crossloc_amd.networks._Plan._pack)."""
+    plan = networks._Plan.__new__(networks._Plan)
+    plan.device = torch.device("cuda")
+    src = w.detach().cuda().float().contiguous()
+    dst = torch.empty((m + 2) ** 2 * src.shape[0] * src.shape[1], dtype=torch.float32, device="cuda")
+    plan._pack(dst, src, "wino%d%s" % (m, "d" if dgrad else ""))
+    return dst
+
+
+def _wino_conv(x_nhwc, U, bias, m, B, H, W, cin, cout, out, ld_out, stats=None, groups=1, accumulate=False):
+    Th, Tw = -(-H // m), -(-W // m)
+    T, nf = B * Th * Tw, (m + 2) ** 2
+    V = torch.empty(nf * T * cin, device="cuda")
+    Mb = torch.empty(nf * T * cout, device="cuda")
+    a = networks.XlOp()
+    a.type, a.ksize = networks.XL_OP_WINO_IN, m
+    a.B, a.Hi, a.Wi, a.Cin, a.Ho, a.Wo, a.ld_in = B, H, W, cin, Th, Tw, cin
+    a.in_, a.out = x_nhwc.data_ptr(), V.data_ptr()
+    g = networks.XlOp()
+    g.type = networks.XL_OP_CONV
+    g.B, g.Hi, g.Wi, g.Cin, g.Ho, g.Wo, g.Cout = B, Th, Tw, cin, Th, Tw, cout
+    g.ksize, g.stride, g.ld_in, g.ld_out, g.nchunks2 = 1, 1, cin, cout, nf
+    g.in_, g.w, g.out = V.data_ptr(), U.data_ptr(), Mb.data_ptr()
+    tpb = 32 if m == 2 else 16
+    o = networks.XlOp()
+    o.type, o.ksize = networks.XL_OP_WINO_OUT, m
+    o.B, o.Hi, o.Wi, o.Cin, o.ld_out, o.groups = B, H, W, cout, ld_out, groups
+    o.nchunks, o.reserved_i = -(-(Th * Tw) // tpb), tpb
+    o.flags = networks.CONV_ACCUMULATE if accumulate else 0
+    o.in_, o.out = Mb.data_ptr(), out.data_ptr()
+    if bias is not None:
+        o.bias = bias.data_ptr()
+    if stats is not None:
+        o.stats = stats.data_ptr()
+    _run([a, g, o])
+    return o.nchunks
+
+
+@pytest.mark.parametrize("m,cin,cout,B,H,W", [(4, 256, 256, 2, 8, 12), (4, 512, 512, 1, 10, 14), (4, 256, 512, 2, 9, 13),
+                                              (4, 1536, 512, 1, 8, 12), (2, 256, 256, 2, 8, 12), (2, 512, 128, 1, 10, 14)])
+def test_winograd_conv_with_statistics_vs_float64(m, cin, cout, B, H, W):
+    """Input transform + batched GEMMs + output transform (bias, GroupNorm partial sums) against a float64 convolution;
+    9x13 and 10x14 exercise the partial tiles of F(4x4,3x3)."""
+    g = torch.Generator().manual_seed(m * 1000 + cin + cout + H)
+    x = torch.relu(torch.randn(B, cin, H, W, generator=g))
+    w = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (9 * cin)) ** 0.5
+    b = torch.randn(cout, generator=g)
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    out = torch.full((B, H, W, cout), float("nan"), device="cuda")
+    G = 32
+    tpb = 32 if m == 2 else 16
+    nch = -(-(-(-H // m) * -(-W // m)) // tpb)
+    stats = torch.full((B, nch, G, 2), float("nan"), dtype=torch.float64, device="cuda")
+    _wino_conv(_nhwc(x).cuda(), _wino_weights(w, m), b.cuda(), m, B, H, W, cin, cout, out, cout, stats, G)
+    got = out.permute(0, 3, 1, 2).cpu().double()
+    assert torch.isfinite(got).all()
+    _close(got, ref, 3e-5 if m == 4 else 5e-6)
+    st = stats.sum(1).cpu()                                    # [B, G, 2]
+    y = got.reshape(B, G, cout // G, H * W)
+    # (fp32 partial sums per thread, fp64 across threads and workgroups)
+    assert torch.allclose(st[..., 0], y.sum((2, 3)), rtol=1e-5, atol=2e-3)
+    assert torch.allclose(st[..., 1], (y * y).sum((2, 3)), rtol=1e-5, atol=2e-3)
+
+
+@pytest.mark.parametrize("cin,cout,B,H,W", [(256, 256, 2, 8, 12), (512, 256, 1, 9, 13), (128, 64, 2, 12, 16)])
+def test_winograd_data_gradient_vs_autograd_and_accumulate(cin, cout, B, H, W):
+    """dX of a stride-1 3x3 convolution as F(4x4,3x3) with the flipped, channel-swapped kernel; written into a channel
+    slice of a wider gradient tensor, then accumulated a second time."""
+    g = torch.Generator().manual_seed(cin + cout + W)
+    x = torch.randn(B, cin, H, W, generator=g, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (9 * cin)) ** 0.5
+    dy = torch.randn(B, cout, H, W, generator=g)
+    F.conv2d(x, w.double(), padding=1).backward(dy.double())
+    ref = x.grad
+    wide = torch.zeros((B, H, W, cin + 64), device="cuda")
+    sl = wide[..., 32:32 + cin]
+    U = _wino_weights(w, 4, dgrad=True)
+    _wino_conv(_nhwc(dy).cuda(), U, None, 4, B, H, W, cout, cin, sl, cin + 64)
+    got = sl.permute(0, 3, 1, 2).cpu().double()
+    _close(got, ref, 3e-5)
+    assert float(wide[..., :32].abs().max()) == 0.0 and float(wide[..., 32 + cin:].abs().max()) == 0.0
+    _wino_conv(_nhwc(dy).cuda(), U, None, 4, B, H, W, cout, cin, sl, cin + 64, accumulate=True)
+    _close(sl.permute(0, 3, 1, 2).cpu().double(), 2 * ref, 3e-5)
