@@ -23,6 +23,10 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise XlError("libcrossloc_hip.so is not built (%s). Run `python -m crossloc_amd.build` "
                           "(or __graft_entry__.build()); there is no CPU fallback." % LIB_PATH)
+        # torch first (like the reference: README.md:51 "import torch before dsacstar"): its HIP runtime must be the
+        # one already mapped when this library resolves libamdhip64, otherwise the process holds two runtimes and
+        # the second one sees no device
+        import torch  # noqa: F401
         L = ctypes.CDLL(LIB_PATH)
         L.xl_status_string.restype = ctypes.c_char_p
         L.xl_status_string.argtypes = [c_i32]
