@@ -131,6 +131,13 @@ __global__ __launch_bounds__(256, 2)
 void igemm_conv_kernel(ConvArgs a)
 {
     constexpr int PAD = KS / 2;
+    // SWAP: the MFMA row operand is the WEIGHT fragment, so an accumulator register quad holds 4 consecutive output
+    // channels of one pixel = 16 contiguous bytes of the NHWC result: the epilogue needs 16 dwordx4 stores per wave
+    // instead of 64 dword stores.  It matters because the epilogue runs beside the co-resident workgroup's MFMA stream,
+    // which lets the epilogue wave issue only about one instruction per MFMA slot (measured: 27k ticks for the 64-store
+    // form with two workgroups per CU, 5k alone).  Used where no bias / statistics epilogue exists: batched (Winograd)
+    // GEMMs and data gradients.
+    constexpr bool SWAP = (ZB != 0) || (MODE != 0);
     constexpr int NJ = BN / 64;                 // 32-wide MFMA tiles per wave along N
     constexpr int BROWS = BN / 32;              // B-tile rows loaded per thread
     constexpr int AROWS = BM / 32;              // A-tile rows loaded per thread
@@ -292,7 +299,8 @@ void igemm_conv_kernel(ConvArgs a)
         for (int i = 0; i < TI; ++i)
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][i][e], fb[set][j][e], acc[i][j], 0, 0, 0);
+                acc[i][j] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x2f32(fb[set][j][e], fa[set][i][e], acc[i][j], 0, 0, 0)
+                                 : __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][i][e], fb[set][j][e], acc[i][j], 0, 0, 0);
     };
     auto multiply = [&](int set) {
 #pragma unroll
@@ -408,6 +416,48 @@ void igemm_conv_kernel(ConvArgs a)
             }
         }
     };
+    if constexpr (SWAP) {
+        // C layout with swapped operands: pixel = tile column lane&31, channel = (r&3) + 8*(r>>2) + 4*(lane>>5)
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+        unsigned pixOff[TI];
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+            const int m = m0 + wm * (BM / 2) + i * 32 + (lane & 31);
+            int pix = m;
+            if constexpr (MODE == 2) {
+                const int nn = m / HoWo;
+                const int rem = m - nn * HoWo;
+                const int jy = rem / a.Wj, jx = rem - jy * a.Wj;
+                pix = (nn * a.Ho + 2 * jy + a.py) * a.Wo + 2 * jx + a.px;
+            }
+            pixOff[i] = (m < a.M) ? (unsigned)(pix * a.ldOut) * 4u : OOB;
+        }
+        const int nLane = n0 + wn * (BN / 2) + rhalf;                  // + j*32 + 8*q: first of 4 consecutive channels
+        auto store_swapped = [&](auto accTag) {                        // (the accumulate switch is hoisted, as above)
+            constexpr bool ACC = decltype(accTag)::value;
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    unsigned off[4];
+                    f32x4 old[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int n = nLane + j * 32 + 8 * q;
+                        off[q] = (n < a.Cout && pixOff[i] != OOB) ? pixOff[i] + (unsigned)n * 4u : OOB;
+                        if constexpr (ACC) old[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srdO, (int)off[q], 0, 0));
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        f32x4 v = f32x4{ acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3] };
+                        if constexpr (ACC) v += old[q];
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), srdO, (int)off[q], 0, 0);
+                    }
+                }
+        };
+        if (a.accumulate) store_swapped(std::true_type{});
+        else store_swapped(std::false_type{});
+    } else
     if (a.accumulate) store_tile(std::true_type{}, std::false_type{});       // gradients only: never with statistics
     else if (doStats) store_tile(std::false_type{}, std::true_type{});
     else store_tile(std::false_type{}, std::false_type{});
@@ -1046,6 +1096,7 @@ int launch_igemm(const xl_op &op, hipStream_t st, int py = 0, int px = 0)
     }
     a.inBytes = (unsigned)inBytes; a.wBytes = (unsigned)wBytes; a.outBytes = (unsigned)outBytes;
     a.accumulate = (op.flags & XL_CONV_ACCUMULATE) ? 1 : 0;
+    if ((ZB || MODE != 0) && (a.bias || a.stats || op.ld_out % 4 != 0)) return XL_ERR_ARG;   // swapped-operand epilogue
     if (a.accumulate && a.stats) return XL_ERR_ARG;
     const size_t lds = sizeof(float) * 2 * (BM + BN) * kBK;
     static bool configured = false;
