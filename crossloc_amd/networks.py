@@ -979,7 +979,9 @@ class TransPoseNet(nn.Module):
         self._plans = {}
         return super().load_state_dict(*a, **k)
 
-    def forward(self, inputs):
+    def forward(self, inputs, plan_slot=0):
+        """plan_slot: calls that may be in flight at the same time on different HIP streams (evaluation.PipelinedLocalizer
+        runs two half-batches concurrently) must use different slots: a plan owns its activation buffers."""
         if not isinstance(inputs, torch.Tensor) or inputs.dim() != 4:
             raise RuntimeError("TransPoseNet.forward expects a 4D tensor [B,C,H,W]")
         if not inputs.is_cuda:
@@ -1002,8 +1004,8 @@ class TransPoseNet(nn.Module):
         if B > max_b:
             if train:
                 raise RuntimeError("batch of %d frames exceeds the per-launch limit of %d at %dx%d" % (B, max_b, H, W))
-            return torch.cat([self.forward(x[i:i + max_b]) for i in range(0, B, max_b)], dim=0)
-        key = (B, H, W, x.device.index, train)
+            return torch.cat([self.forward(x[i:i + max_b], plan_slot) for i in range(0, B, max_b)], dim=0)
+        key = (B, H, W, x.device.index, train) if plan_slot == 0 else (B, H, W, x.device.index, train, plan_slot)
         with torch.cuda.device(x.device):
             plan = self._plans.get(key)
             if plan is None:
