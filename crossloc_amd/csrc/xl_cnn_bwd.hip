@@ -559,6 +559,85 @@ void head_bwd_kernel(const float *__restrict__ x, const float *__restrict__ w, c
     }
 }
 
+// Backward of the full-size (semantics) head for the pure pixel-shuffle case (H = 8 Hs, W = 8 Ws; duc_head_kernel in
+// xl_cnn.hip): one output pixel per thread.  dz = dout (x fout inside the clamp for exp channels); the gradient of the
+// DUC activation goes back through the shuffle index map (every input element has exactly one output pixel: plain
+// stores, no atomics); d fc3.weight / d fc3.bias are accumulated per thread, reduced per block in a fixed order and
+// written as one partial vector [C*C + C] per block.
+template <int CMAX>
+__global__ __launch_bounds__(256)
+void duc_head_bwd_kernel(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ dout,
+                         const float *__restrict__ fout, float *__restrict__ dx, float *__restrict__ partial,
+                         int B, int Hs, int Ws, int C, int ldX, int ldDx, int nTask, float lo, float hi)
+{
+    __shared__ float sRed[4][CMAX * CMAX + CMAX];
+    const int H = 8 * Hs, W = 8 * Ws;
+    const float elo = expf(lo), ehi = expf(hi);
+    const long long HW = (long long)H * W, total = (long long)B * HW;
+    float aW[CMAX][CMAX], aB[CMAX];
+#pragma unroll
+    for (int o = 0; o < CMAX; ++o) {
+        aB[o] = 0.f;
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c) aW[o][c] = 0.f;
+    }
+    for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < total; p += (long long)gridDim.x * 256) {
+        const int xx = (int)(p % W);
+        const int y = (int)((p / W) % H);
+        const int n = (int)(p / HW);
+        const long long pix = (long long)y * W + xx;
+        const long long src = (((long long)n * Hs + (y >> 3)) * Ws + (xx >> 3));
+        const int sub = (y & 7) * 8 + (xx & 7);
+        float dz[CMAX], v[CMAX];
+#pragma unroll
+        for (int o = 0; o < CMAX; ++o) {
+            dz[o] = 0.f; v[o] = 0.f;
+            if (o < C) {
+                const long long idx = ((long long)n * C + o) * HW + pix;
+                float g = dout[idx];
+                if (o >= nTask) {
+                    const float fo = fout[idx];
+                    g = (fo > elo && fo < ehi) ? g * fo : 0.f;
+                }
+                dz[o] = g;
+                v[o] = x[src * ldX + o * 64 + sub];
+                aB[o] += g;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c) {
+            if (c < C) {
+                float d = 0.f;
+#pragma unroll
+                for (int o = 0; o < CMAX; ++o) if (o < C) { d = fmaf(w[o * C + c], dz[o], d); aW[o][c] = fmaf(dz[o], v[c], aW[o][c]); }
+                dx[src * ldDx + c * 64 + sub] = d;
+            }
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 0; o < CMAX; ++o) {
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c) {
+            float t = aW[o][c];
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) t += __shfl_xor(t, off);
+            if (lane == 0) sRed[wave][o * CMAX + c] = t;
+        }
+        float t = aB[o];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) t += __shfl_xor(t, off);
+        if (lane == 0) sRed[wave][CMAX * CMAX + o] = t;
+    }
+    __syncthreads();
+    const int len = C * C + C;
+    if ((int)threadIdx.x < len) {
+        const int i = threadIdx.x;
+        const int k2 = (i < C * C) ? (i / C) * CMAX + (i % C) : CMAX * CMAX + (i - C * C);
+        partial[(long long)blockIdx.x * len + i] = ((sRed[0][k2] + sRed[1][k2]) + sRed[2][k2]) + sRed[3][k2];
+    }
+}
+
 // sums `count` partial vectors of length `len` in fixed order
 __global__ void partial_sum_kernel(const float *__restrict__ partial, float *__restrict__ out, int count, int len)
 {
@@ -657,7 +736,10 @@ int gnb_threads(int C)
 {
     const int C4 = C / 4;
     if (C4 > 256) return C4;
-    return (256 % C4 == 0) ? 256 : -1;
+    if (256 % C4 == 0) return 256;
+    int T = C4;                                         // e.g. 384 channels: 96 quads -> 192 threads (lcm with 64)
+    while (T % 64 != 0) T += C4;
+    return T <= 1024 ? T : -1;
 }
 
 }  // namespace
@@ -726,6 +808,25 @@ int xl_run_bwd_op(const xl_op &op, hipStream_t st)
             hipLaunchKernelGGL(partial_sum_kernel, dim3(8), dim3(256), 0, st, (const float *)pW, (float *)op.out2, waves,
                                op.Cout * op.Cin);
             hipLaunchKernelGGL(partial_sum_kernel, dim3(1), dim3(64), 0, st, (const float *)pB, (float *)op.stats, waves, op.Cout);
+            return XL_OK;
+        }
+        case XL_OP_DUC_HEAD_BWD: {
+            // in: DUC activation [B,Hi,Wi,Cout*64]; aux: dout, aux2: forward output [B,Cout,8Hi,8Wi]; out: d activation;
+            // out2: d fc3.weight [Cout][Cout]; stats: d fc3.bias; stats2: scratch (blocks x (Cout^2 + Cout) floats)
+            if (op.Cout < 1 || op.Cout > 8 || op.Cin != op.Cout * 64) return XL_ERR_ARG;
+            if (op.Ho != 8 * op.Hi || op.Wo != 8 * op.Wi) return XL_ERR_UNSUPPORTED;     // bilinear trim: forward only
+            const long long pix = (long long)op.B * op.Ho * op.Wo;
+            long long blocks = (pix + 255) / 256;
+            if (blocks > 1024) blocks = 1024;
+            const int len = op.Cout * op.Cout + op.Cout;
+            float *part = (float *)op.stats2;
+            hipLaunchKernelGGL(duc_head_bwd_kernel<8>, dim3((unsigned)blocks), dim3(256), 0, st, (const float *)op.in,
+                               (const float *)op.w, (const float *)op.aux, (const float *)op.aux2, (float *)op.out, part,
+                               op.B, op.Hi, op.Wi, op.Cout, op.ld_in, op.ld_out, op.n_task, op.clamp_lo, op.clamp_hi);
+            float *tot = part + blocks * len;                           // [len]: weights then bias
+            hipLaunchKernelGGL(partial_sum_kernel, dim3(1), dim3(128), 0, st, (const float *)part, tot, (int)blocks, len);
+            hipMemcpyAsync(op.out2, tot, sizeof(float) * op.Cout * op.Cout, hipMemcpyDeviceToDevice, st);
+            hipMemcpyAsync(op.stats, tot + op.Cout * op.Cout, sizeof(float) * op.Cout, hipMemcpyDeviceToDevice, st);
             return XL_OK;
         }
         case XL_OP_CONV1_WGRAD: {

@@ -26,6 +26,7 @@ XL_OP_WGRAD, XL_OP_GNB_STATS, XL_OP_GNB_APPLY, XL_OP_GNB_PARAMS, XL_OP_HEAD_BWD,
 XL_OP_GN_FINAL = 11
 XL_OP_WINO_IN, XL_OP_WINO_OUT = 12, 13
 XL_OP_DUC_HEAD = 14
+XL_OP_DUC_HEAD_BWD = 15
 CONV_DGRAD, CONV_ACCUMULATE = 1, 2
 
 
@@ -615,9 +616,9 @@ class _Plan:
         a = self.cgr(res, dec.fc1, dec.fc1_norm); self.release(res[0])
         b = self.cgr(a, dec.fc2, dec.fc2_norm); self.release(a[0])
         if dec.full_size_output:
-            if self.train:
-                raise NotImplementedError("training of the full-size (semantics) head is not lowered; run it under "
-                                          "torch.no_grad()")
+            if self.train and (self.H % 8 or self.W % 8):
+                raise NotImplementedError("training the full-size head needs H and W to be multiples of 8 (the backward "
+                                          "pass of the bilinear trim is not lowered)")
             # networks.py:344-349: DUC conv-GN-ReLU; pixel shuffle, bilinear trim and fc3 fused in one kernel
             d = self.cgr(b, dec.duc_upsample.conv, dec.duc_upsample.norm); self.release(b[0])
             t, H, W, C, ld, off = d
@@ -636,6 +637,7 @@ class _Plan:
             self.ops.append(op)
             self.out_op_index = len(self.ops) - 1
             self.out_shape = (self.B, nc, self.H, self.W)
+            self.tape.append(dict(kind="duc_head", fc3=dec.fc3, x=d, w3=w3, cout=nc, n_task=op.n_task))
             return
         t, H, W, C, ld, off = b
         op = XlOp()
@@ -706,6 +708,24 @@ class _Plan:
                 op.stats = pgrad(e["fc3"].bias).data_ptr()
                 waves = 4 * max(1, min(256, (B * H * W + 63) // 64))
                 scratch_f = max(scratch_f, waves * e["cout"] * (C + 1))
+                patch_f.append(len(bops))
+                self.head_bwd_index = len(bops)
+                bops.append(op)
+                grads[self._key(e["x"])] = (gin, C, 0)
+            elif kind == "duc_head":
+                t, H, W, C, ld, off = e["x"]
+                gin = self.alloc(B * H * W * C)
+                nc = e["cout"]
+                op = XlOp()
+                op.type = XL_OP_DUC_HEAD_BWD
+                op.B, op.Hi, op.Wi, op.Cin, op.Ho, op.Wo, op.Cout, op.n_task = B, H, W, C, self.H, self.W, nc, e["n_task"]
+                op.ld_in, op.ld_out = ld, C
+                op.clamp_lo, op.clamp_hi = -16.10, 13.82
+                op.in_, op.w, op.out = t.data_ptr() + 4 * off, e["w3"].data_ptr(), gin.data_ptr()
+                op.out2 = pgrad(e["fc3"].weight).data_ptr()
+                op.stats = pgrad(e["fc3"].bias).data_ptr()
+                blocks = max(1, min(1024, (B * self.H * self.W + 255) // 256))
+                scratch_f = max(scratch_f, (blocks + 1) * (nc * nc + nc))
                 patch_f.append(len(bops))
                 self.head_bwd_index = len(bops)
                 bops.append(op)

@@ -44,6 +44,7 @@ enum {
                                out [B,Hi,Wi,Cin]; ksize = m; reserved_i = tiles per workgroup, nchunks = workgroups per image */
     XL_OP_DUC_HEAD = 14,    /* full-size (semantics) head: x8 pixel shuffle of in [B,Hi,Wi,Cout*64] + bilinear resize to
                                Ho x Wo + fc3 (w [Cout][Cout], bias) + mean (aux) / exp(hardtanh) -> out NCHW [B,Cout,Ho,Wo] */
+    XL_OP_DUC_HEAD_BWD = 15, /* backward of XL_OP_DUC_HEAD (pure pixel-shuffle case): d activation, d fc3.weight / bias */
     XL_OP_GN_FINAL = 11  /* per-(image, channel) GroupNorm scale/shift [B][C][2] from the partial sums (out);
                             GN_APPLY with aux2 = that buffer skips its own finalisation */
 };

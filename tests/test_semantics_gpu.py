@@ -35,10 +35,49 @@ def test_semantics_network_matches_reference_golden(tag):
     assert torch.equal(torch.argmax(y.cpu(), 1)[clear], torch.argmax(ref, 1)[clear])
 
 
-def test_semantics_head_trains_only_under_no_grad():
+def test_semantics_network_gradients_vs_autograd(monkeypatch):
+    """Training the full-size head: cross-entropy loss, backward through fc3, the pixel shuffle, the DUC conv +
+    GroupNorm(32 groups of 12 channels) and the rest of the network, against float64 autograd on the CPU restatement
+    (criteria as in tests/test_cnn_bwd_gpu.py: direct convolutions, max-norm)."""
+    from oracle import cnn_oracle
+    monkeypatch.setenv("XL_NO_WINOGRAD_TRAIN", "1")
+    B, H, W = 2, 64, 96
+    net = networks.TransPoseNet(torch.zeros(6), False, False, 1, 1, 6, 0, 32, 0, 0, True)
+    net.load_state_dict(seeded_state_dict(net, seed=17))
+    g = torch.Generator().manual_seed(4)
+    x = torch.rand(B, 3, H, W, generator=g)
+    labels = torch.randint(0, 6, (B, 1, H, W), generator=g).float()
+    sd = {k: (v.double().clone().requires_grad_(True) if not k.endswith("mean") else v.double())
+          for k, v in net.state_dict().items()}
+    res = cnn_oracle.encoder_forward(sd, x.double(), "encoder", 1, 32)
+    yref = cnn_oracle.decoder_forward(sd, res, 1, 6, 0, 32, up_hw=(H, W))
+    lref, _ = loss_oracle.semantics_loss(yref, labels, 'mean')
+    lref.backward()
+
+    net = net.cuda().train()
+    y = net(x.cuda())
+    assert y.requires_grad and tuple(y.shape) == (B, 6, H, W)
+    loss, rate = xl_loss.semantics_classification_loss(None, y, None, labels.cuda(), xl_loss.CrossEntropyLoss2d(), 'mean')
+    loss.backward()
+    torch.cuda.synchronize()
+    assert loss.item() == pytest.approx(lref.item(), rel=1e-4)
+    gmax = max(v.grad.abs().max().item() for k, v in sd.items() if v.requires_grad and v.grad is not None)
+    worst = []
+    for name, p in net.named_parameters():
+        assert p.grad is not None, name
+        ref = sd[name].grad.float()
+        sc = max(ref.abs().max().item(), 1e-4 * gmax)
+        worst.append(((p.grad.cpu() - ref).abs().max().item() / sc, name))
+    worst = sorted(w for w in worst if w[1] != "encoder.conv1.bias")
+    assert worst[-1][0] <= 5e-2, worst[-5:]
+    head = {n: e for e, n in worst if n.startswith("decoder.fc3") or n.startswith("decoder.duc_upsample")}
+    assert max(head.values()) <= 2e-3, head                    # the new kernels themselves: no ReLU flips downstream
+
+
+def test_semantics_head_training_needs_multiples_of_eight():
     net = networks.TransPoseNet(torch.zeros(6), False, False, 0, 0, 6, 0, 32, 0, 0, True).cuda()
     with pytest.raises(NotImplementedError):
-        net(torch.rand(1, 3, 64, 96, device="cuda"))
+        net(torch.rand(1, 3, 60, 92, device="cuda"))
 
 
 @pytest.mark.parametrize("red", ["mean", None])
