@@ -247,8 +247,10 @@ class _Plan:
 
     def wino_dgrad_ok(self, conv, H, W, C):
         """Data gradient of a stride-1 3x3 layer as F(4x4,3x3) (C = the layer's input channels = gradient channels)."""
+        T = self.B * -(-H // 4) * -(-W // 4)
         return (conv.kernel_size[0] == 3 and conv.stride[0] == 1 and C in (128, 256, 512, 1024)
                 and conv.out_channels % 32 == 0 and H * W >= 64
+                and 36 * T * max(C, conv.out_channels) * 4 < 2 ** 31 - 1
                 and not os.environ.get("XL_NO_WINOGRAD") and not os.environ.get("XL_NO_WINOGRAD_TRAIN"))
 
     def pack_conv(self, conv, dgrad=False):
@@ -382,6 +384,11 @@ class _Plan:
         m = int(os.environ.get("XL_WINOGRAD", "4"))
         if self.train and (m != 4 or os.environ.get("XL_NO_WINOGRAD_TRAIN")):
             return 0                                         # training plans: F(4x4,3x3) only
+        if m in (2, 4):
+            # the transformed tensors are addressed with 32-bit byte offsets through one buffer descriptor
+            T = self.B * -(-H // m) * -(-W // m)
+            if (m + 2) ** 2 * T * max(C, conv.out_channels) * 4 >= 2 ** 31 - 1:
+                return 0
         if m == 2 and (H % 2 or W % 2):
             return 0
         return m if m in (2, 4) else 0
