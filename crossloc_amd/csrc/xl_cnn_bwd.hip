@@ -45,6 +45,9 @@ struct WgradArgs {
     int B, Hi, Wi, Cin, Ho, Wo, Cout, ldX, ldY, ksize, stride;
     int M, splits, mPerSplit, nbo, nbc;
     unsigned xBytes, dyBytes;
+    // batched launch (Winograd weight gradient: one [Cout x Cin] GEMM per frequency): zCount consecutive blocks of
+    // x / dy (zX / zY elements apart) and of the partial buffer
+    int zCount; long long zX, zY;
 };
 
 // tile BO (output channels) x BC (input channels) of ONE tap; K = output pixels of this split.
@@ -90,11 +93,14 @@ void wgrad_kernel(WgradArgs a)
     // the ~64 workgroups resident on an XCD stream the SAME pixel range (one split) through its L2 — the dY / X rows
     // are fetched once per XCD and tap group instead of once per workgroup.
     const int taps = a.ksize * a.ksize;
-    int t = xcd_remap(blockIdx.x, a.splits * taps * a.nbo * a.nbc);
+    int t = xcd_remap(blockIdx.x, a.zCount * a.splits * taps * a.nbo * a.nbc);
     const int cb = t % a.nbc; t /= a.nbc;
     const int ob = t % a.nbo; t /= a.nbo;
-    const int tap = t % taps;
-    const int split = t / taps;
+    const int tap = t % taps; t /= taps;
+    const int split = t % a.splits;
+    const int z = t / a.splits;
+    a.x += z * a.zX; a.dy += z * a.zY;
+    a.partial += (long long)z * a.splits * taps * a.Cout * a.Cin;
     const int ky = tap / a.ksize, kx = tap - ky * a.ksize;
     const int o0 = ob * BO, c0 = cb * BC;
     const int mBeg = split * a.mPerSplit;
@@ -264,6 +270,8 @@ __global__ void wgrad_reduce_kernel(const float *__restrict__ partial, float *__
                                     int Cout, int Cin)
 {
     const long long total = (long long)taps * Cout * Cin;
+    partial += (long long)blockIdx.y * splits * total;              // batched launch: one block of partials per GEMM
+    dw += (long long)blockIdx.y * total;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         float s = 0.f;
         for (int k = 0; k < splits; ++k) s += partial[(long long)k * total + i];
@@ -285,19 +293,115 @@ int launch_wgrad(const xl_op &op, hipStream_t st)
     a.M = op.B * op.Ho * op.Wo; a.splits = op.nchunks2;
     a.mPerSplit = ((a.M + a.splits - 1) / a.splits + 31) / 32 * 32;
     a.nbo = op.Cout / BO; a.nbc = op.Cin / BC;
+    a.zCount = op.groups > 1 ? op.groups : 1;                     // WGRAD: groups = GEMMs per launch
+    if (a.zCount > 1 && (op.ksize != 1 || op.ld_in != op.Cin || op.ld_aux != op.Cout)) return XL_ERR_ARG;
+    a.zX = (long long)a.M * op.Cin; a.zY = (long long)a.M * op.Cout;
     const long long xb = (((long long)op.B * op.Hi * op.Wi - 1) * op.ld_in + op.Cin) * 4;
     const long long yb = (((long long)a.M - 1) * op.ld_aux + op.Cout) * 4;
     if (xb >= 0x7fffffffLL || yb >= 0x7fffffffLL) return XL_ERR_ARG;
     if (op.Ho * op.Wo < 32) return XL_ERR_UNSUPPORTED;          // the kernel advances pixel coordinates by one K-step (32)
     a.xBytes = (unsigned)xb; a.dyBytes = (unsigned)yb;
     const int taps = op.ksize * op.ksize;
-    hipLaunchKernelGGL((wgrad_kernel<BO, BC, WO, WC>), dim3(taps * a.nbo * a.nbc * a.splits), dim3(64 * WO * WC), 0, st, a);
+    hipLaunchKernelGGL((wgrad_kernel<BO, BC, WO, WC>), dim3(a.zCount * taps * a.nbo * a.nbc * a.splits), dim3(64 * WO * WC), 0, st, a);
     const long long total = (long long)taps * op.Cout * op.Cin;
     long long blocks = (total + 255) / 256;
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float *)op.stats2,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks, a.zCount), dim3(256), 0, st, (const float *)op.stats2,
                        (float *)op.out, a.splits, taps, op.Cout, op.Cin);
     return XL_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- Winograd weight gradient
+
+// Weight gradient of a stride-1 3x3 layer through F(4x4,3x3): with V = B^T x B (wino4_in_kernel) and dM = A dY A^T per
+// 4x4 output tile, dU[xi][co][ci] = sum_tiles dM[xi][t][co] V[xi][t][ci] is 36 GEMMs with the TILES as the K dimension
+// (the batched wgrad_kernel above, 4x fewer multiplies than the 9-tap form), and dg = G^T dU G.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <typename V>
+__device__ __forceinline__ void wino4_a(const V (&d)[4], V (&o)[6])      // A = (A^T)^T, 6x4
+{
+    o[0] = d[0];
+    o[1] = d[0] + d[1] + d[2] + d[3];
+    o[2] = d[0] - d[1] + d[2] - d[3];
+    o[3] = d[0] + 2.f * d[1] + 4.f * d[2] + 8.f * d[3];
+    o[4] = d[0] - 2.f * d[1] + 4.f * d[2] - 8.f * d[3];
+    o[5] = d[3];
+}
+
+// dY [B,H,W,C] (pixel stride ld) -> dM [36][B*Th*Tw][C]; one tile x 2 channels per thread; pixels past H / W are zero
+__global__ __launch_bounds__(256)
+void wino4_dy_kernel(const float *__restrict__ dy, float *__restrict__ dM, int B, int H, int W, int C, int ld, int Th, int Tw)
+{
+    const int C2 = C >> 1;
+    const long long T = (long long)B * Th * Tw;
+    const long long items = T * C2;
+    const long long zs = T * C;
+    for (long long it = (long long)blockIdx.x * 256 + threadIdx.x; it < items; it += (long long)gridDim.x * 256) {
+        const int c2 = (int)(it % C2);
+        const long long t = it / C2;
+        const int tx = (int)(t % Tw);
+        const int ty = (int)((t / Tw) % Th);
+        const int n = (int)(t / ((long long)Tw * Th));
+        f32x2 w[6][4];                               // w[i][q] = (A dY)[i][q]
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int x = 4 * tx + q;
+            f32x2 col[4], o[6];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int y = 4 * ty + p;
+                if (y < H && x < W) col[p] = *reinterpret_cast<const f32x2 *>(dy + (((long long)n * H + y) * W + x) * ld + 2 * c2);
+                else col[p] = f32x2{ 0.f, 0.f };
+            }
+            wino4_a(col, o);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) w[i][q] = o[i];
+        }
+        float *op = dM + t * C + 2 * c2;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            f32x2 o[6];
+            wino4_a(w[i], o);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) *reinterpret_cast<f32x2 *>(op + (6 * i + j) * zs) = o[j];
+        }
+    }
+}
+
+// dg[o][c][a][b] = sum_ij G[i][a] dU[6i+j][o][c] G[j][b]  (G of F(4x4,3x3)); one (o, c) per thread, OIHW output
+__global__ __launch_bounds__(256)
+void wino4_wfinal_kernel(const float *__restrict__ dU, float *__restrict__ dw, int Cout, int Cin)
+{
+    const long long total = (long long)Cout * Cin;
+    const float G[6][3] = { { 0.25f, 0.f, 0.f }, { -1.f / 6, -1.f / 6, -1.f / 6 }, { -1.f / 6, 1.f / 6, -1.f / 6 },
+                            { 1.f / 24, 1.f / 12, 1.f / 6 }, { 1.f / 24, -1.f / 12, 1.f / 6 }, { 0.f, 0.f, 1.f } };
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        float u[6][6];
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int b = 0; b < 6; ++b) u[a][b] = dU[(long long)(6 * a + b) * total + i];
+        float t[3][6];                               // t = G^T u
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 6; ++b) {
+                float v = 0.f;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) v = fmaf(G[k][a], u[k][b], v);
+                t[a][b] = v;
+            }
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                float v = 0.f;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) v = fmaf(t[a][k], G[k][b], v);
+                dw[i * 9 + a * 3 + b] = v;
+            }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- GroupNorm backward
@@ -808,6 +912,23 @@ int xl_run_bwd_op(const xl_op &op, hipStream_t st)
             hipLaunchKernelGGL(partial_sum_kernel, dim3(8), dim3(256), 0, st, (const float *)pW, (float *)op.out2, waves,
                                op.Cout * op.Cin);
             hipLaunchKernelGGL(partial_sum_kernel, dim3(1), dim3(64), 0, st, (const float *)pB, (float *)op.stats, waves, op.Cout);
+            return XL_OK;
+        }
+        case XL_OP_WINO_DY: {
+            if (op.Cin % 2 != 0 || op.ld_in % 2 != 0 || op.Ho != (op.Hi + 3) / 4 || op.Wo != (op.Wi + 3) / 4) return XL_ERR_ARG;
+            const long long items = (long long)op.B * op.Ho * op.Wo * (op.Cin / 2);
+            long long blocks = (items + 255) / 256;
+            if (blocks > 262144) blocks = 262144;
+            hipLaunchKernelGGL(wino4_dy_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float *)op.in, (float *)op.out,
+                               op.B, op.Hi, op.Wi, op.Cin, op.ld_in, op.Ho, op.Wo);
+            return XL_OK;
+        }
+        case XL_OP_WINO_WFINAL: {
+            const long long total = (long long)op.Cout * op.Cin;
+            long long blocks = (total + 255) / 256;
+            if (blocks > 4096) blocks = 4096;
+            hipLaunchKernelGGL(wino4_wfinal_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float *)op.in, (float *)op.out,
+                               op.Cout, op.Cin);
             return XL_OK;
         }
         case XL_OP_DUC_HEAD_BWD: {

@@ -27,6 +27,7 @@ XL_OP_GN_FINAL = 11
 XL_OP_WINO_IN, XL_OP_WINO_OUT = 12, 13
 XL_OP_DUC_HEAD = 14
 XL_OP_DUC_HEAD_BWD = 15
+XL_OP_WINO_DY, XL_OP_WINO_WFINAL = 16, 17
 CONV_DGRAD, CONV_ACCUMULATE = 1, 2
 
 
@@ -798,12 +799,57 @@ class _Plan:
                 if dy is None:
                     continue
                 k, s = conv.kernel_size[0], conv.stride[0]
+                bo = 128 if Cout % 128 == 0 else 64
+                bc = 128 if C % 128 == 0 else (64 if C % 64 == 0 else 32)
+                Tw4 = B * -(-H // 4) * -(-W // 4)
+                wino_w = (k == 3 and s == 1 and H * W >= 64 and C % 64 == 0 and Cout % 128 == 0
+                          and 36 * Tw4 * max(C, Cout) * 4 < 2 ** 31 - 1 and Tw4 >= 64
+                          and not os.environ.get("XL_NO_WINOGRAD") and not os.environ.get("XL_NO_WINOGRAD_TRAIN")
+                          and not os.environ.get("XL_NO_WINOGRAD_WGRAD"))
+                if wino_w:
+                    # weight gradient through F(4x4,3x3): V = B^T x B, dM = A dY A^T, 36 GEMMs over the tiles, dg = G^T dU G
+                    Th, Tw = -(-H // 4), -(-W // 4)
+                    Vb = self.alloc(36 * Tw4 * C)
+                    wi = XlOp()
+                    wi.type, wi.ksize = XL_OP_WINO_IN, 4
+                    wi.B, wi.Hi, wi.Wi, wi.Cin, wi.Ho, wi.Wo, wi.ld_in = B, H, W, C, Th, Tw, ld
+                    wi.in_, wi.out = t.data_ptr() + 4 * off, Vb.data_ptr()
+                    bops.append(wi)
+                    dMb = self.alloc(36 * Tw4 * Cout)
+                    wd = XlOp()
+                    wd.type = XL_OP_WINO_DY
+                    wd.B, wd.Hi, wd.Wi, wd.Cin, wd.Ho, wd.Wo, wd.ld_in = B, H, W, Cout, Th, Tw, Cout
+                    wd.in_, wd.out = dy.data_ptr(), dMb.data_ptr()
+                    bops.append(wd)
+                    dU = self.alloc(36 * Cout * C)
+                    tiles = 36 * (Cout // bo) * (C // bc)
+                    steps_total = -(-Tw4 // 32)
+                    best, splits = None, 1
+                    for cand in range(1, 33):
+                        if cand > max(1, Tw4 // 256):
+                            break
+                        rounds = -(-(tiles * cand) // 512)
+                        cost = rounds * (-(-steps_total // cand) + 8) + (cand + 1) * tiles * bo * bc * 4 / 4e12 / 1.8e-6
+                        if best is None or cost < best - 1e-9:
+                            best, splits = cost, cand
+                    wg = XlOp()
+                    wg.type = XL_OP_WGRAD
+                    wg.B, wg.Hi, wg.Wi, wg.Cin, wg.Ho, wg.Wo, wg.Cout = 1, Tw4, 1, C, Tw4, 1, Cout
+                    wg.ksize, wg.stride, wg.ld_in, wg.ld_aux, wg.groups, wg.nchunks2 = 1, 1, C, Cout, 36, splits
+                    wg.in_, wg.aux, wg.out = Vb.data_ptr(), dMb.data_ptr(), dU.data_ptr()
+                    scratch_f = max(scratch_f, 36 * splits * Cout * C)
+                    patch_f.append(len(bops))
+                    bops.append(wg)
+                    wf = XlOp()
+                    wf.type = XL_OP_WINO_WFINAL
+                    wf.Cin, wf.Cout = C, Cout
+                    wf.in_, wf.out = dU.data_ptr(), pgrad(conv.weight).data_ptr()
+                    bops.append(wf)
+                    self.release_grad(Vb); self.release_grad(dMb); self.release_grad(dU)
                 op = XlOp()
                 op.type = XL_OP_WGRAD
                 op.B, op.Hi, op.Wi, op.Cin, op.Ho, op.Wo, op.Cout = B, H, W, C, Ho, Wo, Cout
                 op.ksize, op.stride, op.ld_in, op.ld_aux = k, s, ld, Cout
-                bo = 128 if Cout % 128 == 0 else 64
-                bc = 128 if C % 128 == 0 else (64 if C % 64 == 0 else 32)
                 tiles = k * k * (Cout // bo) * (C // bc)
                 M = B * Ho * Wo
                 # split-K factor from a cost model in units of one K-step (32 pixels) of a workgroup: rounds of the
@@ -822,10 +868,11 @@ class _Plan:
                         best, splits = cost, cand
                 op.nchunks2 = splits
                 op.in_, op.aux = t.data_ptr() + 4 * off, dy.data_ptr()
-                op.out = pgrad(conv.weight).data_ptr()
-                scratch_f = max(scratch_f, splits * k * k * Cout * C)
-                patch_f.append(len(bops))
-                bops.append(op)
+                if not wino_w:
+                    op.out = pgrad(conv.weight).data_ptr()
+                    scratch_f = max(scratch_f, splits * k * k * Cout * C)
+                    patch_f.append(len(bops))
+                    bops.append(op)
                 # data gradient into the gradient of x (second producers accumulate)
                 op = XlOp()
                 op.type = XL_OP_CONV

@@ -45,6 +45,8 @@ enum {
     XL_OP_DUC_HEAD = 14,    /* full-size (semantics) head: x8 pixel shuffle of in [B,Hi,Wi,Cout*64] + bilinear resize to
                                Ho x Wo + fc3 (w [Cout][Cout], bias) + mean (aux) / exp(hardtanh) -> out NCHW [B,Cout,Ho,Wo] */
     XL_OP_DUC_HEAD_BWD = 15, /* backward of XL_OP_DUC_HEAD (pure pixel-shuffle case): d activation, d fc3.weight / bias */
+    XL_OP_WINO_DY = 16,     /* Winograd F(4x4,3x3) weight gradient: in dY [B,Hi,Wi,Cin] -> out dM = A dY A^T [36][tiles][Cin] */
+    XL_OP_WINO_WFINAL = 17, /* in dU [36][Cout][Cin] -> out dg = G^T dU G, OIHW [Cout][Cin][3][3] */
     XL_OP_GN_FINAL = 11  /* per-(image, channel) GroupNorm scale/shift [B][C][2] from the partial sums (out);
                             GN_APPLY with aux2 = that buffer skips its own finalisation */
 };
@@ -73,6 +75,8 @@ typedef struct xl_op {
     int32_t n_task, n_pos;         /* XL_OP_HEAD: task channels (mean added) and positive channels */
     int32_t nchunks2, reserved_i;  /* backward: pixel chunks of the GNB stats pass / split-K factor of WGRAD;
                                       GN_APPLY: reserved_i = conv tile rows when the stats came from a conv epilogue;
+                                      WGRAD: groups > 1 = that many independent k=1 weight-gradient GEMMs over consecutive
+                                      blocks of in / aux / out (Winograd);
                                       forward CONV: nchunks2 > 1 = that many independent GEMMs over consecutive
                                       blocks of in / w / out (Winograd), reserved_i = 64 selects 64-row tiles */
     float eps;                     /* GroupNorm epsilon (1e-5) */

@@ -349,3 +349,43 @@ def test_winograd_data_gradient_vs_autograd_and_accumulate(cin, cout, B, H, W):
     assert float(wide[..., :32].abs().max()) == 0.0 and float(wide[..., 32 + cin:].abs().max()) == 0.0
     _wino_conv(_nhwc(dy).cuda(), U, None, 4, B, H, W, cout, cin, sl, cin + 64, accumulate=True)
     _close(sl.permute(0, 3, 1, 2).cpu().double(), 2 * ref, 3e-5)
+
+
+@pytest.mark.parametrize("cin,cout,B,H,W", [(256, 256, 2, 16, 24), (128, 256, 4, 9, 13), (512, 512, 2, 16, 20), (64, 128, 4, 12, 12)])
+def test_winograd_weight_gradient_vs_autograd(cin, cout, B, H, W):
+    """dW of a stride-1 3x3 layer through F(4x4,3x3): V = B^T x B, dM = A dY A^T, 36 batched tile-GEMMs, G^T dU G;
+    9x13 has partial tiles on both edges."""
+    g = torch.Generator().manual_seed(cin * 3 + cout + H)
+    x = torch.relu(torch.randn(B, cin, H, W, generator=g))
+    dy = torch.randn(B, cout, H, W, generator=g)
+    w = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.double(), w, padding=1).backward(dy.double())
+    ref = w.grad
+    Th, Tw = -(-H // 4), -(-W // 4)
+    T = B * Th * Tw
+    xd, dyd = _nhwc(x).cuda(), _nhwc(dy).cuda()
+    V = torch.empty(36 * T * cin, device="cuda")
+    dM = torch.empty(36 * T * cout, device="cuda")
+    dU = torch.empty(36 * cout * cin, device="cuda")
+    splits = 2
+    part = torch.empty(36 * splits * cout * cin, device="cuda")
+    dw = torch.full((cout, cin, 3, 3), float("nan"), device="cuda")
+    a = networks.XlOp()
+    a.type, a.ksize = networks.XL_OP_WINO_IN, 4
+    a.B, a.Hi, a.Wi, a.Cin, a.Ho, a.Wo, a.ld_in = B, H, W, cin, Th, Tw, cin
+    a.in_, a.out = xd.data_ptr(), V.data_ptr()
+    d = networks.XlOp()
+    d.type = networks.XL_OP_WINO_DY
+    d.B, d.Hi, d.Wi, d.Cin, d.Ho, d.Wo, d.ld_in = B, H, W, cout, Th, Tw, cout
+    d.in_, d.out = dyd.data_ptr(), dM.data_ptr()
+    wg = networks.XlOp()
+    wg.type = networks.XL_OP_WGRAD
+    wg.B, wg.Hi, wg.Wi, wg.Cin, wg.Ho, wg.Wo, wg.Cout = 1, T, 1, cin, T, 1, cout
+    wg.ksize, wg.stride, wg.ld_in, wg.ld_aux, wg.groups, wg.nchunks2 = 1, 1, cin, cout, 36, splits
+    wg.in_, wg.aux, wg.out, wg.stats2 = V.data_ptr(), dM.data_ptr(), dU.data_ptr(), part.data_ptr()
+    f = networks.XlOp()
+    f.type = networks.XL_OP_WINO_WFINAL
+    f.Cin, f.Cout = cin, cout
+    f.in_, f.out = dU.data_ptr(), dw.data_ptr()
+    _run([a, d, wg, f])
+    _close(dw.cpu().double(), ref, 1e-4)
