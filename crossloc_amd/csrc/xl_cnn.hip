@@ -87,6 +87,121 @@ void conv1_direct_kernel(const float *__restrict__ in, const float *__restrict__
     }
 }
 
+// Inference form of the first layer.  conv1 costs 27 MACs per output while its 32-channel full-resolution output is the
+// largest tensor of the network: evaluating it twice is cheaper than writing it raw, re-reading it for the GroupNorm
+// statistics and re-reading / re-writing it for the apply.  PASS 0 evaluates the convolution and keeps only the
+// per-(image, channel) partial sums (32 groups of 1 channel); PASS 1 evaluates it again and writes
+// relu(conv * scale + shift) once.  Thread = pixel x all 32 channels: the weights are wave-uniform, so they stream
+// through scalar loads and feed v_fmac as SGPR operands (no LDS traffic, no per-lane weight registers).
+// in NCHW [B,3,H,W]; w [(ky*3+kx)*3 + c][32]; out NHWC; grid (chunks, B), a workgroup covers ppt*256 pixels of one image.
+constexpr int kC1Pitch = 36;                       // LDS row pitch (floats) of the output transpose: 32 channels + 4 pad
+template <int PASS>
+__global__ __launch_bounds__(256)
+void conv1_fused_kernel(const float *__restrict__ in, const float *__restrict__ w, const float *__restrict__ bias,
+                        const float *__restrict__ coeff, float *__restrict__ out, double *__restrict__ stats,
+                        int H, int W, int ldOut, int ppt, int relu)
+{
+    constexpr int CO = 32, CI = 3, NT = 9 * CI;
+    __shared__ __attribute__((aligned(16))) float sRed[PASS == 0 ? CO * 256 : 256 * kC1Pitch];
+    const int n = blockIdx.y, tid = threadIdx.x;
+    const int HW = H * W;
+    const float *img = in + (long long)n * CI * HW;
+    float s[CO], q[CO];
+#pragma unroll
+    for (int j = 0; j < CO; ++j) { s[j] = 0.f; q[j] = 0.f; }
+    for (int k = 0; k < ppt; ++k) {
+        const int p = (blockIdx.x * ppt + k) * 256 + tid;
+        const bool live = p < HW;
+        const int pc = live ? p : HW - 1;
+        const int y = pc / W, x = pc - y * W;
+        float v[NT];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int iy = y + ky - 1, ix = x + kx - 1;
+                const bool inb = ((unsigned)iy < (unsigned)H) & ((unsigned)ix < (unsigned)W);
+                const int off = min(max(iy, 0), H - 1) * W + min(max(ix, 0), W - 1);
+#pragma unroll
+                for (int c = 0; c < CI; ++c) {
+                    const float t = img[(long long)c * HW + off];
+                    v[(ky * 3 + kx) * CI + c] = inb ? t : 0.f;          // a zero tap leaves the fma chain unchanged
+                }
+            }
+        }
+        // the weight offset is laundered per pixel: otherwise all 864 scalar loads are hoisted out of the loop and
+        // spilled into VGPR lanes (one v_readlane per weight per pixel - more VALU work than the convolution itself)
+        int zero = 0;
+        asm volatile("" : "+s"(zero));
+        const float *wk = w + zero;
+        float acc[CO];
+#pragma unroll
+        for (int j = 0; j < CO; ++j) acc[j] = bias[j];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+#pragma unroll
+            for (int j = 0; j < CO; ++j) acc[j] = fmaf(v[t], wk[t * CO + j], acc[j]);
+        }
+        if (PASS == 0) {
+#pragma unroll
+            for (int j = 0; j < CO; ++j) {
+                const float a = live ? acc[j] : 0.f;
+                s[j] += a;
+                q[j] = fmaf(a, a, q[j]);
+            }
+        } else {
+            // a wave owns 64 consecutive pixels = one contiguous 8 KB span of the NHWC output (ldOut == 32): transpose
+            // through LDS so that every store instruction writes 1 KB of consecutive addresses instead of 64 scattered
+            // 16-byte pieces
+            const float *cf = coeff + (long long)n * CO * 2;
+            const int lane = tid & 63;
+            float *row = sRed + (tid >> 6) * (64 * kC1Pitch);
+#pragma unroll
+            for (int j = 0; j < CO; j += 4) {
+                f32x4 r;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float t = acc[j + e] * cf[(j + e) * 2] + cf[(j + e) * 2 + 1];
+                    if (relu) t = fmaxf(t, 0.f);
+                    r[e] = t;
+                }
+                *reinterpret_cast<f32x4 *>(row + lane * kC1Pitch + j) = r;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const int p0 = (blockIdx.x * ppt + k) * 256 + (tid & ~63);     // first pixel of the wave
+            float *o = out + ((long long)n * HW + p0) * CO;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const int qd = c * 64 + lane;                               // 16-byte piece of the span
+                const int px = qd >> 3, part = qd & 7;
+                const f32x4 r = *reinterpret_cast<const f32x4 *>(row + px * kC1Pitch + part * 4);
+                if (p0 + px < HW) *reinterpret_cast<f32x4 *>(o + (long long)qd * 4) = r;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    if (PASS == 0) {
+        // per-thread fp32 partials -> fp64 across the workgroup: value-major transpose through LDS, 4 threads per value
+        const int vsel = tid >> 2, part = tid & 3;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < CO; ++j) sRed[j * 256 + tid] = half ? q[j] : s[j];
+            __syncthreads();
+            if (vsel < CO) {
+                double a = 0.0;
+                for (int i = 0; i < 64; ++i) a += (double)sRed[vsel * 256 + part * 64 + ((i + vsel + 16 * part) & 63)];
+                a += __shfl_xor(a, 1);
+                a += __shfl_xor(a, 2);
+                if (part == 0) stats[(((long long)n * gridDim.x + blockIdx.x) * CO + vsel) * 2 + half] = a;
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- igemm conv
 
 constexpr int kWaitVm0 = 0x0F70;                   // s_waitcnt vmcnt(0) (expcnt / lgkmcnt fields left at their maxima)
@@ -647,8 +762,13 @@ __device__ __forceinline__ void wino4_at(const V (&m)[6], V (&o)[4])
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // one tile x 2 channels per thread
+// DEFER: 0 = plain gather; 1 / 2 = the producer's GroupNorm (x*scale + shift; 2: + ReLU) is applied while gathering.
+// The deferred form loads through clamped addresses and masks afterwards: a use inside the bounds branch would put a
+// vmcnt(0) after every load and serialise the 36 gathers of a tile.
+template <int DEFER>
 __global__ __launch_bounds__(256)
-void wino4_in_kernel(const float *__restrict__ in, float *__restrict__ V, int B, int H, int W, int C, int ldIn, int Th, int Tw)
+void wino4_in_kernel(const float *__restrict__ in, float *__restrict__ V, int B, int H, int W, int C, int ldIn, int Th, int Tw,
+                     const float *__restrict__ coeff)
 {
     const int C2 = C >> 1;
     const long long T = (long long)B * Th * Tw;
@@ -660,6 +780,9 @@ void wino4_in_kernel(const float *__restrict__ in, float *__restrict__ V, int B,
         const int tx = (int)(t % Tw);
         const int ty = (int)((t / Tw) % Th);
         const int n = (int)(t / ((long long)Tw * Th));
+        // deferred GroupNorm of the producer: x*scale + shift (+ReLU) applied to the pixels as they are gathered
+        f32x4 ss = f32x4{ 1.f, 0.f, 1.f, 0.f };
+        if (DEFER) ss = *reinterpret_cast<const f32x4 *>(coeff + ((long long)n * C + 2 * c2) * 2);
         f32x2 w[6][6];                               // w[i][b] = (B^T d)[i][b]
 #pragma unroll
         for (int b = 0; b < 6; ++b) {
@@ -668,10 +791,23 @@ void wino4_in_kernel(const float *__restrict__ in, float *__restrict__ V, int B,
 #pragma unroll
             for (int a = 0; a < 6; ++a) {
                 const int y = 4 * ty - 1 + a;
-                if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W)
+                if (DEFER) {
+                    const int yc = min(max(y, 0), H - 1), xc = min(max(x, 0), W - 1);
+                    col[a] = *reinterpret_cast<const f32x2 *>(in + (((long long)n * H + yc) * W + xc) * ldIn + 2 * c2);
+                } else if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W)
                     col[a] = *reinterpret_cast<const f32x2 *>(in + (((long long)n * H + y) * W + x) * ldIn + 2 * c2);
                 else
                     col[a] = f32x2{ 0.f, 0.f };
+            }
+            if (DEFER) {
+#pragma unroll
+                for (int a = 0; a < 6; ++a) {
+                    const int y = 4 * ty - 1 + a;
+                    const bool inb = ((unsigned)y < (unsigned)H) & ((unsigned)x < (unsigned)W);
+                    float v0 = col[a][0] * ss[0] + ss[1], v1 = col[a][1] * ss[2] + ss[3];
+                    if (DEFER == 2) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+                    col[a] = f32x2{ inb ? v0 : 0.f, inb ? v1 : 0.f };
+                }
             }
             wino4_bt(col, o);
 #pragma unroll
@@ -1190,6 +1326,23 @@ int run_op(const xl_op &op, hipStream_t st)
 {
     switch (op.type) {
         case XL_OP_CONV1: {
+            if (op.stats || op.aux2) {
+                // inference form: statistics-only pass (stats, nchunks workgroups per image, reserved_i pixels/256 each)
+                // or conv + deferred GroupNorm (aux2 = {scale, shift} pairs) + ReLU (flags & XL_GN_RELU_IN)
+                if (op.Cin != 3 || op.Cout != 32 || op.ld_out != 32 || op.reserved_i < 1 ||
+                    (long long)op.nchunks * op.reserved_i * 256 < (long long)op.Hi * op.Wi || (op.stats && op.groups != 32))
+                    return XL_ERR_ARG;
+                if (op.stats)
+                    hipLaunchKernelGGL(conv1_fused_kernel<0>, dim3(op.nchunks, op.B), dim3(256), 0, st, (const float *)op.in,
+                                       (const float *)op.w, (const float *)op.bias, (const float *)nullptr, (float *)nullptr,
+                                       (double *)op.stats, op.Hi, op.Wi, op.ld_out, op.reserved_i, 0);
+                else
+                    hipLaunchKernelGGL(conv1_fused_kernel<1>, dim3(op.nchunks, op.B), dim3(256), 0, st, (const float *)op.in,
+                                       (const float *)op.w, (const float *)op.bias, (const float *)op.aux2, (float *)op.out,
+                                       (double *)nullptr, op.Hi, op.Wi, op.ld_out, op.reserved_i,
+                                       (op.flags & XL_GN_RELU_IN) ? 1 : 0);
+                return XL_OK;
+            }
             if (op.Cout % 8 != 0 || op.Cout > 64 || 256 % (op.Cout / 8) != 0 || op.ld_out % 4 != 0) return XL_ERR_ARG;
             const size_t lds = sizeof(float) * (size_t)(9 * op.Cin * op.Cout + op.Cout);
             const long long pix = (long long)op.B * op.Hi * op.Wi;
@@ -1209,10 +1362,13 @@ int run_op(const xl_op &op, hipStream_t st)
                 const long long items4 = (long long)op.B * op.Ho * op.Wo * (op.Cin / 2);
                 long long blocks4 = (items4 + 255) / 256;
                 if (blocks4 > 262144) blocks4 = 262144;
-                hipLaunchKernelGGL(wino4_in_kernel, dim3((unsigned)blocks4), dim3(256), 0, st, (const float *)op.in,
-                                   (float *)op.out, op.B, op.Hi, op.Wi, op.Cin, op.ld_in, op.Ho, op.Wo);
+                auto kin = !op.aux2 ? wino4_in_kernel<0> : (op.flags & XL_GN_RELU_IN) ? wino4_in_kernel<2> : wino4_in_kernel<1>;
+                hipLaunchKernelGGL(kin, dim3((unsigned)blocks4), dim3(256), 0, st, (const float *)op.in,
+                                   (float *)op.out, op.B, op.Hi, op.Wi, op.Cin, op.ld_in, op.Ho, op.Wo,
+                                   (const float *)op.aux2);
                 return XL_OK;
             }
+            if (op.aux2) return XL_ERR_ARG;                      // the deferred GroupNorm exists for F(4x4,3x3) only
             if (op.Cin % 4 != 0 || op.ld_in % 4 != 0 || op.Hi != 2 * op.Ho || op.Wi != 2 * op.Wo) return XL_ERR_ARG;
             const long long items = (long long)op.B * op.Ho * op.Wo * (op.Cin / 4);
             long long blocks = (items + 255) / 256;

@@ -199,13 +199,15 @@ class _Plan:
             self.op_array[i].stats = self.stats.data_ptr()
         self.coeff = torch.zeros(max(getattr(self, "max_coeff", 0), 1), dtype=torch.float32, device=device)
         for i, op in enumerate(self.ops):
+            # every GN_FINAL writes the shared coefficient buffer; its consumer - the following GN_APPLY, or the
+            # Winograd input transform of the next layer when the apply was deferred - runs before the next GN_FINAL
             if op.type == XL_OP_GN_FINAL:
                 self.op_array[i].out = self.coeff.data_ptr()
-                # the GN_APPLY that consumes it is the next GN_APPLY in program order
-                j = i + 1
-                while self.ops[j].type != XL_OP_GN_APPLY:
-                    j += 1
-                self.op_array[j].aux2 = self.coeff.data_ptr()
+            elif op.type == XL_OP_GN_APPLY and not train:
+                self.op_array[i].aux2 = self.coeff.data_ptr()
+        for i in getattr(self, "deferred_gn_consumers", []):
+            self.op_array[i].aux2 = self.coeff.data_ptr()
+        assert not getattr(self, "pending_gn", None), "a deferred GroupNorm was never consumed"
         if train:
             self._lower_backward()
 
@@ -394,7 +396,7 @@ class _Plan:
             return 0
         return m if m in (2, 4) else 0
 
-    def conv_wino(self, act, conv, norm, flags, aux, m):
+    def conv_wino(self, act, conv, norm, flags, aux, m, deferred=None):
         """conv3x3 + GroupNorm(+epilogue) as F(m x m, 3x3): input transform, (m+2)^2 GEMMs in one batched launch, output
         transform that also emits the GroupNorm partial sums, GN_FINAL, GN_APPLY (in place)."""
         t, H, W, C, ld, off = act
@@ -408,6 +410,9 @@ class _Plan:
         op.ksize = m
         op.B, op.Hi, op.Wi, op.Cin, op.Ho, op.Wo, op.ld_in = B, H, W, C, Th, Tw, ld
         op.in_, op.out = t.data_ptr() + 4 * off, V.data_ptr()
+        if deferred is not None:                      # the producer's GroupNorm(+ReLU) is applied while gathering
+            op.flags = deferred.flags
+            self.deferred_gn_consumers = getattr(self, "deferred_gn_consumers", []) + [len(self.ops)]
         self.ops.append(op)
         Mb = self.alloc(nf * T * cout)
         op = XlOp()
@@ -461,22 +466,36 @@ class _Plan:
         self.ops.append(ap)
         return y
 
-    def cgr(self, act, conv, norm, flags=GN_RELU_IN, aux=None):
+    def cgr(self, act, conv, norm, flags=GN_RELU_IN, aux=None, defer=False):
+        """conv -> GroupNorm -> epilogue.  `defer`: the caller promises that the next cgr() is the only consumer of the
+        result; when that consumer is an F(4x4,3x3) layer its input transform applies the normalisation and the separate
+        GN_APPLY pass (one read + one write of the activation) disappears."""
+        pend = getattr(self, "pending_gn", {}).pop(self._act_key(act), None)
         m = self.wino_tile(act, conv)
+        if pend is not None and m != 4:
+            self.stats_ops.append(len(self.ops))       # consumer cannot absorb it: materialise now
+            self.ops.append(pend)
+            pend = None
         if m:
-            return self.conv_wino(act, conv, norm, flags, aux, m)
+            return self.conv_wino(act, conv, norm, flags, aux, m, pend)
         y = self.conv(act, conv)
         bn = 128 if conv.out_channels % 128 == 0 else 64
         whole_groups = bn % (conv.out_channels // norm.num_groups) == 0       # a conv tile's columns cover whole groups
         if not self.train and y[1] * y[2] >= 128 and whole_groups and not os.environ.get("XL_NO_FUSED_STATS"):
             # inference: the conv epilogue produces the GroupNorm statistics, the separate stats pass is dropped
-            return self.gn_fused(y, norm, flags, aux, len(self.ops) - 1)
+            return self.gn_fused(y, norm, flags, aux, len(self.ops) - 1,
+                                 defer=defer and flags == GN_RELU_IN and aux is None
+                                 and not os.environ.get("XL_NO_DEFERRED_GN"))
         r = self.gn(y, norm, flags, aux)
         if r[0] is not y[0]:
             self.release(y[0])
         return r
 
-    def gn_fused(self, act, norm, flags, aux, conv_index, out=None):
+    @staticmethod
+    def _act_key(act):
+        return (act[0].data_ptr(), act[5], act[3])
+
+    def gn_fused(self, act, norm, flags, aux, conv_index, out=None, defer=False):
         """GroupNorm apply (in place) consuming statistics emitted by the epilogue of the conv op `conv_index`."""
         t, H, W, C, ld, off = act
         G, HW = norm.num_groups, H * W
@@ -504,6 +523,11 @@ class _Plan:
             ot, old, ooff = out
             ap.out, ap.ld_out = ot.data_ptr() + 4 * ooff, old
             res = (ot, H, W, C, old, ooff)
+        if defer and out is None:
+            if not hasattr(self, "pending_gn"):
+                self.pending_gn = {}
+            self.pending_gn[self._act_key(res)] = ap
+            return res
         self.stats_ops.append(len(self.ops))
         self.ops.append(ap)
         return res
@@ -523,7 +547,7 @@ class _Plan:
     def res_block(self, res, block):
         """relu(res + block(res)), networks.py:252-254 / :332-334"""
         x = self.cgr(res, block[0], block[1])
-        x2 = self.cgr(x, block[3], block[4])
+        x2 = self.cgr(x, block[3], block[4], defer=True)
         self.release(x[0])
         x3 = self.cgr(x2, block[6], block[7], GN_RELU_IN | GN_ADD | GN_RELU_OUT, aux=res)
         self.release(x2[0])
@@ -547,6 +571,10 @@ class _Plan:
         cin = enc.conv1.in_channels
         c1 = enc.conv1.out_channels
         t1 = self.alloc(B * H * W * c1)
+        if (not self.train and cin == 3 and c1 == 32 and enc.norm1.num_groups == 32
+                and not os.environ.get("XL_NO_CONV1_FUSED")):
+            x = self._conv1_fused(enc, image, t1)
+            return self._encoder_tail(enc, x, out)
         op = XlOp()
         op.type = XL_OP_CONV1
         op.B, op.Hi, op.Wi, op.Cin, op.Ho, op.Wo, op.Cout, op.ld_out = B, H, W, cin, H, W, c1, c1
@@ -559,16 +587,51 @@ class _Plan:
         raw1 = (t1, H, W, c1, c1, 0)
         self.tape.append(dict(kind="conv1", conv=enc.conv1, raw=raw1))
         x = self.gn(raw1, enc.norm1, GN_RELU_IN)
+        return self._encoder_tail(enc, x, out)
+
+    def _conv1_fused(self, enc, image, t1):
+        """Inference form of conv1 + GroupNorm + ReLU: a statistics-only evaluation of the convolution, GN_FINAL, then
+        a second evaluation that writes the normalised activation - the raw 32-channel full-resolution tensor (the
+        largest of the network) is never written, re-read for statistics or re-read for the apply."""
+        B, H, W = self.B, self.H, self.W
+        c1, G, ppt = enc.conv1.out_channels, enc.norm1.num_groups, 5
+        nchunks = -(-(H * W) // (256 * ppt))
+        w, bias = self.pack_conv(enc.conv1), self.dev(enc.conv1.bias)
+        gamma, beta = self.dev(enc.norm1.weight), self.dev(enc.norm1.bias)
+
+        def conv1_op():
+            op = XlOp()
+            op.type = XL_OP_CONV1
+            op.B, op.Hi, op.Wi, op.Cin, op.Ho, op.Wo, op.Cout, op.ld_out = B, H, W, 3, H, W, c1, c1
+            op.groups, op.nchunks, op.reserved_i, op.eps = G, nchunks, ppt, enc.norm1.eps
+            op.in_, op.w, op.bias = image.data_ptr(), w.data_ptr(), bias.data_ptr()
+            return op
+        st = conv1_op()
+        self.max_stats = max(self.max_stats, B * nchunks * G * 2)
+        self.stats_ops.append(len(self.ops))
+        self.image_op_indices.append(len(self.ops))
+        self.ops.append(st)
+        shape = XlOp()                                 # GN_FINAL sees the normalised tensor: c1 channels, G groups
+        shape.B, shape.Hi, shape.Wi, shape.Cin, shape.groups, shape.nchunks, shape.eps = B, H, W, c1, G, nchunks, enc.norm1.eps
+        self._emit_final(shape, gamma, beta, 0)
+        ap = conv1_op()
+        ap.out, ap.flags = t1.data_ptr(), GN_RELU_IN
+        self.deferred_gn_consumers = getattr(self, "deferred_gn_consumers", []) + [len(self.ops)]
+        self.image_op_indices.append(len(self.ops))
+        self.ops.append(ap)
+        return (t1, H, W, c1, c1, 0)
+
+    def _encoder_tail(self, enc, x, out=None):
         x2 = self.cgr(x, enc.conv2, enc.norm2); self.release(x[0])
         x3 = self.cgr(x2, enc.conv3, enc.norm3); self.release(x2[0])
         res = self.cgr(x3, enc.conv4, enc.norm4); self.release(x3[0])
         a = self.cgr(res, enc.res1_conv1, enc.res1_norm1)
-        b = self.cgr(a, enc.res1_conv2, enc.res1_norm2); self.release(a[0])
+        b = self.cgr(a, enc.res1_conv2, enc.res1_norm2, defer=True); self.release(a[0])
         c = self.cgr(b, enc.res1_conv3, enc.res1_norm3, GN_RELU_IN | GN_ADD | GN_RELU_OUT, aux=res)
         self.release(b[0]); self.release(res[0])
         res = c
         a = self.cgr(res, enc.res2_conv1, enc.res2_norm1)
-        b = self.cgr(a, enc.res2_conv2, enc.res2_norm2); self.release(a[0])
+        b = self.cgr(a, enc.res2_conv2, enc.res2_norm2, defer=True); self.release(a[0])
         c = self.cgr(b, enc.res2_conv3, enc.res2_norm3); self.release(b[0])
         n_add = len(enc.enc_add_res_block_ls)
         last_out = out if n_add == 0 else None
@@ -611,7 +674,7 @@ class _Plan:
             mlr = self.gn(mlr, net.mlr_norm, 0)
             f = net.mlr_forward
             a = self.cgr(mlr, f[0], f[1]); self.release(cat)
-            b = self.cgr(a, f[3], f[4]); self.release(a[0])
+            b = self.cgr(a, f[3], f[4], defer=True); self.release(a[0])
             res = self.cgr(b, f[6], f[7], GN_RELU_IN | GN_ADD | GN_RELU_OUT, aux=sk)
             self.release(b[0]); self.release(sk[0])
         for block in dec.dec_add_res_block_ls:

@@ -22,7 +22,10 @@ extern "C" {
 #endif
 
 enum {
-    XL_OP_CONV1 = 0,     /* 3x3 s1 p1 conv, Cin in {1,3} NCHW input -> NHWC, + bias (networks.py:186-189) */
+    XL_OP_CONV1 = 0,     /* 3x3 s1 p1 conv, Cin in {1,3} NCHW input -> NHWC, + bias (networks.py:186-189).  Inference form
+                            (Cin 3, Cout 32, 32 groups): with `stats` the op only emits the GroupNorm partial sums of its
+                            output (nchunks workgroups per image x reserved_i*256 pixels each); with aux2 = {scale, shift}
+                            pairs it writes relu(conv*scale+shift) - the raw output never exists in memory */
     XL_OP_CONV = 1,      /* 3x3 (pad 1) or 1x1 conv, stride 1 or 2, NHWC, implicit GEMM on fp32 MFMA, + bias.
                             With stats != NULL and groups > 0 the epilogue also emits the GroupNorm partial sums of
                             its output ([B][nchunks][groups][2], one entry per 128-row tile overlapping an image;
@@ -39,7 +42,9 @@ enum {
     XL_OP_HEAD_BWD = 9,  /* backward of XL_OP_HEAD: d(input) NHWC, d(fc3 weight), d(fc3 bias) */
     XL_OP_CONV1_WGRAD = 10, /* weight + bias gradient of the NCHW-input first conv */
     XL_OP_WINO_IN = 12,     /* Winograd input transform: in [B,Hi,Wi,Cin] -> out V [(m+2)^2][B*Ho*Wo][Cin] with Ho x Wo tiles
-                               of m x m outputs; ksize = m: 2 = F(2x2,3x3) (Hi, Wi even), 4 = F(4x4,3x3) (Ho = ceil(Hi/4)) */
+                               of m x m outputs; ksize = m: 2 = F(2x2,3x3) (Hi, Wi even), 4 = F(4x4,3x3) (Ho = ceil(Hi/4)).
+                               m = 4 only: aux2 = per-(image, channel) {scale, shift} pairs of a deferred GroupNorm, applied
+                               (with ReLU when flags has XL_GN_RELU_IN) to every in-image pixel before the transform */
     XL_OP_WINO_OUT = 13,    /* Winograd output transform + bias (+ GroupNorm partial sums): in M [(m+2)^2][tiles][Cin] ->
                                out [B,Hi,Wi,Cin]; ksize = m; reserved_i = tiles per workgroup, nchunks = workgroups per image */
     XL_OP_DUC_HEAD = 14,    /* full-size (semantics) head: x8 pixel shuffle of in [B,Hi,Wi,Cout*64] + bilinear resize to

@@ -114,6 +114,54 @@ def test_conv1_vs_torch(cin):
     _close(out.cpu().permute(0, 3, 1, 2), ref, 1e-5)
 
 
+@pytest.mark.parametrize("B,H,W,ppt", [(2, 24, 40, 5), (3, 37, 53, 2), (1, 64, 96, 1)])
+def test_conv1_inference_form_vs_torch(B, H, W, ppt):
+    """XL_OP_CONV1 with `stats` (statistics-only evaluation), GN_FINAL, XL_OP_CONV1 with aux2 (second evaluation that
+    writes relu(groupnorm(conv))) against torch conv2d -> group_norm(32 groups) -> relu; 37x53 leaves a ragged last
+    workgroup."""
+    g = torch.Generator().manual_seed(B * 100 + H)
+    x = torch.rand(B, 3, H, W, generator=g)
+    conv = nn.Conv2d(3, 32, 3, 1, 1)
+    gamma = 1.0 + 0.2 * torch.randn(32, generator=g)
+    beta = 0.3 * torch.randn(32, generator=g)
+    with torch.no_grad():
+        raw = conv(x.double().float()).double()
+        ref = torch.relu(F.group_norm(raw, 32, gamma.double(), beta.double(), 1e-5))
+    wd = conv.weight.detach().permute(2, 3, 1, 0).contiguous().cuda()
+    bd, xd, gd, btd = conv.bias.detach().cuda(), x.cuda(), gamma.cuda(), beta.cuda()
+    nch = -(-(H * W) // (256 * ppt))
+    stats = torch.full((B, nch, 32, 2), float("nan"), dtype=torch.float64, device="cuda")
+    coeff = torch.full((B, 32, 2), float("nan"), device="cuda")
+    out = torch.full((B, H, W, 32), float("nan"), device="cuda")
+
+    def conv1():
+        op = networks.XlOp()
+        op.type = networks.XL_OP_CONV1
+        op.B, op.Hi, op.Wi, op.Cin, op.Ho, op.Wo, op.Cout, op.ld_out = B, H, W, 3, H, W, 32, 32
+        op.groups, op.nchunks, op.reserved_i = 32, nch, ppt
+        op.in_, op.w, op.bias = xd.data_ptr(), wd.data_ptr(), bd.data_ptr()
+        return op
+    a = conv1()
+    a.stats = stats.data_ptr()
+    f = networks.XlOp()
+    f.type = networks.XL_OP_GN_FINAL
+    f.B, f.Hi, f.Wi, f.Cin, f.groups, f.nchunks, f.eps = B, H, W, 32, 32, nch, 1e-5
+    f.stats, f.w, f.bias, f.out = stats.data_ptr(), gd.data_ptr(), btd.data_ptr(), coeff.data_ptr()
+    b = conv1()
+    b.aux2, b.out, b.flags = coeff.data_ptr(), out.data_ptr(), networks.GN_RELU_IN
+    _run([a, f, b])
+    st = stats.sum(1).cpu()                                              # [B, 32, 2]: per-channel sums
+    assert torch.allclose(st[..., 0], raw.sum((2, 3)), rtol=1e-6, atol=1e-4)
+    assert torch.allclose(st[..., 1], (raw * raw).sum((2, 3)), rtol=1e-6, atol=1e-4)
+    got = out.cpu().permute(0, 3, 1, 2).double()
+    assert torch.isfinite(got).all()
+    _close(got, ref, 2e-5)
+    bad = conv1()                                                        # too few workgroups for the image
+    bad.stats, bad.nchunks = stats.data_ptr(), max(nch - 1, 0)
+    with pytest.raises(RuntimeError):
+        _run([bad])
+
+
 @pytest.mark.parametrize("C,H,W,flags", [(32, 24, 40, 1), (64, 12, 20, 1), (128, 6, 10, 1), (256, 9, 13, 7),
                                           (512, 9, 13, 6), (512, 60, 90, 7), (1536, 8, 12, 0), (32, 480, 720, 1)])
 def test_groupnorm_vs_torch(C, H, W, flags):
@@ -328,6 +376,47 @@ def test_winograd_conv_with_statistics_vs_float64(m, cin, cout, B, H, W):
     # (fp32 partial sums per thread, fp64 across threads and workgroups)
     assert torch.allclose(st[..., 0], y.sum((2, 3)), rtol=1e-5, atol=2e-3)
     assert torch.allclose(st[..., 1], (y * y).sum((2, 3)), rtol=1e-5, atol=2e-3)
+
+
+@pytest.mark.parametrize("relu", [True, False])
+def test_winograd_input_transform_applies_deferred_groupnorm(relu):
+    """XL_OP_WINO_IN with aux2 = per-(image, channel) {scale, shift}: the transform of relu(x*scale+shift) without the
+    separate GN_APPLY pass; zero padding stays zero (the affine map is applied to in-image pixels only)."""
+    B, C, H, W = 2, 64, 9, 13
+    g = torch.Generator().manual_seed(5 + relu)
+    x = torch.randn(B, H, W, C, generator=g)
+    co = torch.randn(B, C, 2, generator=g)
+    co[..., 1] += 0.5                                                    # non-zero shift: padding must not pick it up
+    Th, Tw = -(-H // 4), -(-W // 4)
+    T = B * Th * Tw
+
+    def transform(inp, coeff):
+        V = torch.full((36, T, C), float("nan"), device="cuda")
+        a = networks.XlOp()
+        a.type, a.ksize = networks.XL_OP_WINO_IN, 4
+        a.B, a.Hi, a.Wi, a.Cin, a.Ho, a.Wo, a.ld_in = B, H, W, C, Th, Tw, C
+        a.in_, a.out = inp.data_ptr(), V.data_ptr()
+        if coeff is not None:
+            a.aux2 = coeff.data_ptr()
+            a.flags = networks.GN_RELU_IN if relu else 0
+        _run([a])
+        return V.cpu()
+
+    y = x * co[:, None, None, :, 0] + co[:, None, None, :, 1]
+    if relu:
+        y = torch.relu(y)
+    ref = transform(y.cuda().contiguous(), None)
+    got = transform(x.cuda().contiguous(), co.cuda().contiguous())
+    assert torch.isfinite(got).all()
+    assert torch.allclose(got, ref, rtol=1e-6, atol=1e-5)
+    bad = networks.XlOp()                                                # the F(2x2,3x3) transform has no deferred form
+    bad.type, bad.ksize = networks.XL_OP_WINO_IN, 2
+    bad.B, bad.Hi, bad.Wi, bad.Cin, bad.Ho, bad.Wo, bad.ld_in = B, 8, 12, C, 4, 6, C
+    xs = torch.zeros(B, 8, 12, C, device="cuda")
+    Vs = torch.zeros(16 * B * 24 * C, device="cuda")
+    bad.in_, bad.out, bad.aux2 = xs.data_ptr(), Vs.data_ptr(), co.cuda().data_ptr()
+    with pytest.raises(RuntimeError):
+        _run([bad])
 
 
 @pytest.mark.parametrize("cin,cout,B,H,W", [(256, 256, 2, 8, 12), (512, 256, 1, 9, 13), (128, 64, 2, 12, 16)])
