@@ -84,6 +84,23 @@ def net_goldens():
     _print("net_forward.npz", {k: v.shape for k, v in out.items()})
 
 
+def net4_goldens():
+    """The 4-encoder (CrossLoc-SE) variant, 1+1 extra residual blocks to keep the fixture generation short."""
+    mean = torch.tensor([-455.934, 417.50, 520.31])
+    net = quiet(TransPoseNet, mean, False, False, 1, 1, 3, 1, 32, 4, 0, False)
+    net.load_state_dict(seeded_state_dict(net, seed=44), strict=True)
+    net.eval()
+    rng = np.random.default_rng(15)
+    x = torch.from_numpy(rng.uniform(0, 1, size=(2, 3, 72, 104)).astype(np.float32))
+    with torch.no_grad():
+        y = net(x)
+    out = dict(mlr4_x=x.numpy(), mlr4_y=y.numpy(),
+               mlr4_nparams=np.array(sum(p.numel() for p in net.parameters())),
+               mlr4_keys=np.array(["%s:%s" % (k, "x".join(map(str, v.shape))) for k, v in net.state_dict().items()]))
+    np.savez_compressed(os.path.join(HERE, "net_forward_mlr4.npz"), **out)
+    _print("net_forward_mlr4.npz", {k: v.shape for k, v in out.items()})
+
+
 def loss_goldens():
     rng = np.random.default_rng(5)
     B, H, W = 2, 8, 12
@@ -194,9 +211,11 @@ def semantics_goldens():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["net", "loss", "semantics"]
+    which = sys.argv[1:] or ["net", "net4", "loss", "semantics"]
     if "net" in which:
         net_goldens()
+    if "net4" in which:
+        net4_goldens()
     if "loss" in which:
         loss_goldens()
     if "semantics" in which:

@@ -235,6 +235,21 @@ def test_network_matches_reference_golden(tag, num_mlr):
     assert torch.allclose(y[:, 3], ref[:, 3], rtol=2e-3)
 
 
+def test_four_encoder_network_matches_reference_golden():
+    """The 4-encoder "CrossLoc-SE" fusion: four encoders write channel slices of one 2048-channel tensor,
+    GroupNorm(32, 2048), 1x1 2048->512 skip + 3 fusion layers; fixture generated from the reference network."""
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "net_forward_mlr4.npz"))
+    net = networks.TransPoseNet(MEAN, False, False, 1, 1, 3, 1, 32, 4, 0, False)
+    net.load_state_dict(seeded_state_dict(net, seed=44), strict=True)
+    net = net.cuda().eval()
+    with torch.no_grad():
+        y = net(torch.from_numpy(gold["mlr4_x"]).cuda()).cpu()
+    ref = torch.from_numpy(gold["mlr4_y"])
+    assert y.shape == ref.shape == (2, 4, 9, 13)
+    _close(y[:, :3] - MEAN[None, :, None, None], ref[:, :3] - MEAN[None, :, None, None], 1e-3)
+    assert torch.allclose(y[:, 3], ref[:, 3], rtol=2e-3)
+
+
 def test_network_full_size_vs_oracle_and_determinism():
     """480x720 (the BASELINE frame size), batch 2: fp32 restatement on the CPU as the checker."""
     net = networks.TransPoseNet(MEAN, False, False, 2, 2, 3, 1)

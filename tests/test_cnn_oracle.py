@@ -37,6 +37,19 @@ def test_oracle_matches_reference_golden(tag, num_mlr):
     assert torch.allclose(y[:, 3], ref[:, 3], rtol=1e-4)
 
 
+def test_four_encoder_variant_matches_reference_golden():
+    """CrossLoc-SE shape (4 encoders, 2048-channel fusion), fixture tests/golden/net_forward_mlr4.npz."""
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "net_forward_mlr4.npz"))
+    net = networks.TransPoseNet(MEAN, False, False, 1, 1, 3, 1, 32, 4, 0, False)
+    ours = ["%s:%s" % (k, "x".join(map(str, v.shape))) for k, v in net.state_dict().items()]
+    assert ours == list(gold["mlr4_keys"])
+    assert sum(p.numel() for p in net.parameters()) == int(gold["mlr4_nparams"])
+    y = cnn_oracle.transposenet_forward(seeded_state_dict(net, seed=44), torch.from_numpy(gold["mlr4_x"]), 4, 1, 1)
+    ref = torch.from_numpy(gold["mlr4_y"])
+    assert torch.allclose(y[:, :3] - MEAN[None, :, None, None], ref[:, :3] - MEAN[None, :, None, None], atol=2e-4)
+    assert torch.allclose(y[:, 3], ref[:, 3], rtol=1e-4)
+
+
 def test_forward_requires_gpu_no_fallback():
     net = networks.TransPoseNet(MEAN, False, False, 0, 0)
     with pytest.raises(RuntimeError):
