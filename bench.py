@@ -35,7 +35,9 @@ PEAK_F32_MFMA_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md: fp
 # PMC counters cannot be read from inside the process, so the profiled value is recorded per batch size.
 CONV512_TRAFFIC_BYTES = {24: (755733 * 2 + 259200) * 1024}
 # the batched Winograd GEMM launch of a 3x3 512->512 layer (profiles/r1_wino512_pmc.csv)
-WINO512_TRAFFIC_BYTES = {16: {24: (762829 * 2 + 1036800) * 1024}, 36: {24: (472038 * 2 + 596160) * 1024}}   # by GEMMs per launch, then batch
+# by GEMMs per launch, then batch (profiles/r1_wino512_pmc.csv: batch 24, profiles/r1_wino512_b44_pmc.csv: batch 44)
+WINO512_TRAFFIC_BYTES = {16: {24: (762829 * 2 + 1036800) * 1024},
+                         36: {24: (472038 * 2 + 596160) * 1024, 44: (842795 * 2 + 1092960) * 1024}}
 WINO_NAME = {16: "F(2x2,3x3)", 36: "F(4x4,3x3)"}
 FWD_GFLOP_PER_IMAGE = 295.41        # SURVEY.md §8(d), single-task net, 480x720
 FWD_GFLOP_PER_IMAGE_3ENC = 755.96   # SURVEY.md §8(d), CrossLoc 3-encoder net
@@ -46,8 +48,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=24,
-                    help="images per step per GPU (24 -> 4052 conv tiles = 7.9 full waves of 512 resident workgroups)")
+    ap.add_argument("--batch", type=int, default=None,
+                    help="images per step per GPU.  44: the batched Winograd GEMM launch has 119 x 4 x 36 = 17136 "
+                         "workgroups = 33.5 rounds of 512 resident ones and the fixed per-launch costs of the ~150 "
+                         "kernels of a forward are amortised over more frames (24: 843, 36: 866, 44: 880 images/s); "
+                         "47 is the per-launch maximum at 480x720 (32-bit byte offsets).  Default 44; 24 with --mlr 3 "
+                         "(the Winograd buffers of the 1536-channel fusion layer stay below 2 GiB)")
     ap.add_argument("--hyps", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cnn-streams", type=int, default=1,
@@ -58,6 +64,8 @@ def main():
                     help="3: BASELINE configs[4], the 3-encoder CrossLoc network (755.96 GFLOP per frame) instead of "
                          "the single-task one the headline metric is quoted on")
     args = ap.parse_args()
+    if args.batch is None:
+        args.batch = 24 if args.mlr else 44
 
     import torch
     from crossloc_amd import networks, synth, evaluation
