@@ -938,7 +938,8 @@ __global__ void gn_stats_kernel(const float *__restrict__ x, double *__restrict_
 // per-(image, channel) scale/shift from the fp64 partial sums, fixed summation order.  grid (B), 256 threads.
 __global__ __launch_bounds__(256)
 void gn_final_kernel(const double *__restrict__ stats, const float *__restrict__ gamma, const float *__restrict__ beta,
-                     float *__restrict__ coeff, int HW, int C, int G, int nchunks, float eps, int statTile)
+                     float *__restrict__ coeff, int HW, int C, int G, int nchunks, float eps, int statTile,
+                     float *__restrict__ murs)
 {
     __shared__ double sG[2 * 64];
     const int n = blockIdx.x, tid = threadIdx.x;
@@ -976,6 +977,10 @@ void gn_final_kernel(const double *__restrict__ stats, const float *__restrict__
         const double sc = (double)gamma[c] * sG[2 * g + 1];
         coeff[((long long)n * C + c) * 2] = (float)sc;
         coeff[((long long)n * C + c) * 2 + 1] = (float)((double)beta[c] - sG[2 * g] * sc);
+        if (murs) {                                  // training plans: mean / rstd for the GroupNorm backward kernels
+            murs[((long long)n * C + c) * 2] = (float)sG[2 * g];
+            murs[((long long)n * C + c) * 2 + 1] = (float)sG[2 * g + 1];
+        }
     }
 }
 
@@ -1435,7 +1440,7 @@ int run_op(const xl_op &op, hipStream_t st)
             if (op.groups > 32 || op.Cin % op.groups != 0) return XL_ERR_ARG;
             hipLaunchKernelGGL(gn_final_kernel, dim3(op.B), dim3(256), 0, st, (const double *)op.stats, (const float *)op.w,
                                (const float *)op.bias, (float *)op.out, op.Hi * op.Wi, op.Cin, op.groups, op.nchunks, op.eps,
-                               op.reserved_i);
+                               op.reserved_i, (float *)op.out2);
             return XL_OK;
         }
         case XL_OP_HEAD: {

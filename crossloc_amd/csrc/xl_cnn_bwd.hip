@@ -406,33 +406,14 @@ void wino4_wfinal_kernel(const float *__restrict__ dU, float *__restrict__ dw, i
 
 // ---------------------------------------------------------------------------------------------- GroupNorm backward
 
-// per-channel forward coefficients of image n from the forward fp64 partial sums
-__device__ __forceinline__ void gn_coeffs(const double *fstats, int n, int nchunks, int G, int c, int cpg, int HW,
-                                          float eps, const float *gamma, const float *beta,
-                                          float &mean, float &rstd, float &sc, float &sh, double *rstd64 = nullptr)
-{
-    const int g = c / cpg;
-    double s = 0.0, ss = 0.0;
-    const double *st = fstats + ((long long)n * nchunks * G + g) * 2;
-    for (int k = 0; k < nchunks; ++k) { s += st[(long long)k * G * 2]; ss += st[(long long)k * G * 2 + 1]; }
-    const double cnt = (double)HW * (double)cpg;
-    const double mu = s / cnt;
-    double var = ss / cnt - mu * mu;
-    if (var < 0.0) var = 0.0;
-    const double r = 1.0 / sqrt(var + (double)eps);
-    const double scd = (double)gamma[c] * r;
-    mean = (float)mu; rstd = (float)r; sc = (float)scd; sh = (float)((double)beta[c] - mu * scd);
-    if (rstd64) *rstd64 = r;
-}
-
 struct GnbArgs {
     const float *x, *dout, *outAct, *gamma, *beta;
-    const double *fstats;
+    const float *fco;        // forward coefficients from GN_FINAL: [B][C][2] {scale, shift}, then [B][C][2] {mean, rstd}
     double *bstats;          // [B][nchunks2][C][3]  (sum dv, sum dv*xhat, sum xhat)
     float *dx, *daux;
-    double *ncsums;          // [B][C][6]: A, Bc, Xh, S1, S2, rstd (written by apply block 0 of each image)
-    int HW, C, ldX, ldD, ldO, ldDx, ldAux, G, nchunks, nchunks2, flags;
-    float eps;
+    double *ncsums;          // [B][C][6]: A, Bc, Xh, S1, S2, rstd (gnb_final_kernel)
+    float *bco;              // [B][C][3]: rstd*gamma, rstd*S1/m, rstd*S2/m (gnb_final_kernel)
+    int B, HW, C, ldX, ldD, ldO, ldDx, ldAux, G, nchunks2, flags;
 };
 
 // dv (gradient w.r.t. v = gn(x)) of one element
@@ -449,13 +430,15 @@ __global__ void gnb_stats_kernel(GnbArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double smemD[];
     const int T = blockDim.x, tid = threadIdx.x;
-    const int C4 = a.C >> 2, cpg = a.C / a.G;
+    const int C4 = a.C >> 2;
     float *sCo = reinterpret_cast<float *>(smemD + (size_t)T * 12);          // mean, rstd, sc, sh per channel
     const int n = blockIdx.y, chunk = blockIdx.x;
-    for (int c = tid; c < a.C; c += T) {
-        float mu, rs, sc, sh;
-        gn_coeffs(a.fstats, n, a.nchunks, a.G, c, cpg, a.HW, a.eps, a.gamma, a.beta, mu, rs, sc, sh);
-        sCo[c] = mu; sCo[a.C + c] = rs; sCo[2 * a.C + c] = sc; sCo[3 * a.C + c] = sh;
+    {
+        const float *scsh = a.fco + (long long)n * a.C * 2;
+        const float *murs = a.fco + ((long long)a.B + n) * a.C * 2;
+        for (int c = tid; c < a.C; c += T) {
+            sCo[c] = murs[2 * c]; sCo[a.C + c] = murs[2 * c + 1]; sCo[2 * a.C + c] = scsh[2 * c]; sCo[3 * a.C + c] = scsh[2 * c + 1];
+        }
     }
     __syncthreads();
     const int c4 = tid % C4, prow = tid / C4, rows = T / C4;
@@ -492,44 +475,70 @@ __global__ void gnb_stats_kernel(GnbArgs a)
     }
 }
 
+// Totals of the per-chunk sums and everything the streaming apply pass needs per (image, channel), computed once per
+// image instead of in the prologue of every apply workgroup.  grid (B, C / CB), 1024 threads; a workgroup owns CB
+// channels (whole groups); 4 threads per channel each sum a contiguous quarter of the chunks, the quarters are added in
+// a fixed order.
+__global__ __launch_bounds__(1024)
+void gnb_final_kernel(GnbArgs a, int CB)
+{
+    extern __shared__ __attribute__((aligned(16))) double dA[];      // A, Bc, Xh totals per channel, then S1, S2 per group
+    const int tid = threadIdx.x, n = blockIdx.x;
+    const int C = a.C, cpg = C / a.G;
+    const int c0 = blockIdx.y * CB, g0 = c0 / cpg, GB = CB / cpg;
+    double *sS = dA + 3 * (size_t)CB;
+    const int part = tid & 3;
+    const int per = (a.nchunks2 + 3) >> 2;
+    const int k0 = part * per;
+    int k1 = k0 + per; if (k1 > a.nchunks2) k1 = a.nchunks2;
+    for (int cl = tid >> 2; cl < CB; cl += 256) {
+        double A = 0.0, Bc = 0.0, X = 0.0;
+        const double *bs = a.bstats + ((long long)n * a.nchunks2 * C + c0 + cl) * 3;
+#pragma unroll 4
+        for (int k = k0; k < k1; ++k) { A += bs[(long long)k * C * 3]; Bc += bs[(long long)k * C * 3 + 1]; X += bs[(long long)k * C * 3 + 2]; }
+        // quarters 0+1 and 2+3, then the halves: the same order for every channel
+        A += __shfl_xor(A, 1); Bc += __shfl_xor(Bc, 1); X += __shfl_xor(X, 1);
+        A += __shfl_xor(A, 2); Bc += __shfl_xor(Bc, 2); X += __shfl_xor(X, 2);
+        if (part == 0) { dA[3 * cl] = A; dA[3 * cl + 1] = Bc; dA[3 * cl + 2] = X; }
+    }
+    __syncthreads();
+    for (int gl = tid; gl < GB; gl += 1024) {
+        double S1 = 0.0, S2 = 0.0;
+        for (int cl = gl * cpg; cl < (gl + 1) * cpg; ++cl) {
+            S1 += (double)a.gamma[c0 + cl] * dA[3 * cl]; S2 += (double)a.gamma[c0 + cl] * dA[3 * cl + 1];
+        }
+        sS[2 * gl] = S1; sS[2 * gl + 1] = S2;
+    }
+    __syncthreads();
+    const double m = (double)cpg * (double)a.HW;
+    const float *murs = a.fco + ((long long)a.B + n) * C * 2;
+    for (int cl = tid; cl < CB; cl += 1024) {
+        const int c = c0 + cl, gl = cl / cpg;
+        const double rs = (double)murs[2 * c + 1];
+        float *bo = a.bco + ((long long)n * C + c) * 3;
+        bo[0] = (float)(rs * (double)a.gamma[c]);
+        bo[1] = (float)(rs * sS[2 * gl] / m);
+        bo[2] = (float)(rs * sS[2 * gl + 1] / m);
+        double *o = a.ncsums + ((long long)n * C + c) * 6;
+        o[0] = dA[3 * cl]; o[1] = dA[3 * cl + 1]; o[2] = dA[3 * cl + 2]; o[3] = sS[2 * gl]; o[4] = sS[2 * gl + 1]; o[5] = rs;
+    }
+    (void)g0;
+}
+
 // grid (achunks, B), 256 threads
 __global__ __launch_bounds__(256)
 void gnb_apply_kernel(GnbArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float sK[];      // per channel: mean, rstd, sc, sh, k1, k2, k3
-    __shared__ double sS[2 * 64];                                    // S1, S2 per group (G <= 64)
     const int tid = threadIdx.x, n = blockIdx.y;
-    const int C = a.C, cpg = C / a.G;
-    double *dA = reinterpret_cast<double *>(sK + 7 * C);            // A, Bc, Xh totals per channel (fp64)
-    double *dR = dA + 3 * C;                                        // rstd in fp64 per channel
-    for (int c = tid; c < C; c += 256) {
-        float mu, rs, sc, sh;
-        double r64;
-        gn_coeffs(a.fstats, n, a.nchunks, a.G, c, cpg, a.HW, a.eps, a.gamma, a.beta, mu, rs, sc, sh, &r64);
-        dR[c] = r64;
-        sK[c] = mu; sK[C + c] = rs; sK[2 * C + c] = sc; sK[3 * C + c] = sh;
-        double A = 0.0, Bc = 0.0, X = 0.0;
-        const double *bs = a.bstats + ((long long)n * a.nchunks2 * C + c) * 3;
-        for (int k = 0; k < a.nchunks2; ++k) { A += bs[(long long)k * C * 3]; Bc += bs[(long long)k * C * 3 + 1]; X += bs[(long long)k * C * 3 + 2]; }
-        dA[3 * c] = A; dA[3 * c + 1] = Bc; dA[3 * c + 2] = X;
-    }
-    __syncthreads();
-    for (int g = tid; g < a.G; g += 256) {
-        double S1 = 0.0, S2 = 0.0;
-        for (int c = g * cpg; c < (g + 1) * cpg; ++c) { S1 += (double)a.gamma[c] * dA[3 * c]; S2 += (double)a.gamma[c] * dA[3 * c + 1]; }
-        sS[2 * g] = S1; sS[2 * g + 1] = S2;
-    }
-    __syncthreads();
-    const double m = (double)cpg * (double)a.HW;
-    for (int c = tid; c < C; c += 256) {
-        const int g = c / cpg;
-        const double rs = (double)sK[C + c];
-        sK[4 * C + c] = (float)(rs * (double)a.gamma[c]);
-        sK[5 * C + c] = (float)(rs * sS[2 * g] / m);
-        sK[6 * C + c] = (float)(rs * sS[2 * g + 1] / m);
-        if (blockIdx.x == 0 && a.ncsums) {
-            double *o = a.ncsums + ((long long)n * C + c) * 6;
-            o[0] = dA[3 * c]; o[1] = dA[3 * c + 1]; o[2] = dA[3 * c + 2]; o[3] = sS[2 * g]; o[4] = sS[2 * g + 1]; o[5] = dR[c];
+    const int C = a.C;
+    {
+        const float *scsh = a.fco + (long long)n * C * 2;
+        const float *murs = a.fco + ((long long)a.B + n) * C * 2;
+        const float *bo = a.bco + (long long)n * C * 3;
+        for (int c = tid; c < C; c += 256) {
+            sK[c] = murs[2 * c]; sK[C + c] = murs[2 * c + 1]; sK[2 * C + c] = scsh[2 * c]; sK[3 * C + c] = scsh[2 * c + 1];
+            sK[4 * C + c] = bo[3 * c]; sK[5 * C + c] = bo[3 * c + 1]; sK[6 * C + c] = bo[3 * c + 2];
         }
     }
     __syncthreads();
@@ -859,33 +868,35 @@ int xl_run_bwd_op(const xl_op &op, hipStream_t st)
             return XL_ERR_UNSUPPORTED;
         }
         case XL_OP_GNB_STATS:
+        case XL_OP_GNB_FINAL:
         case XL_OP_GNB_APPLY: {
-            if (op.Cin % 4 != 0 || op.Cin % op.groups != 0 || op.groups > 64) return XL_ERR_ARG;
+            // stats = forward coefficient table of the layer (GN_FINAL with out2: [B][C][2] {scale, shift} followed by
+            // [B][C][2] {mean, rstd}); stats2 = scratch: per-chunk sums, per-(image, channel) sums, apply coefficients
+            if (op.Cin % 4 != 0 || op.Cin % op.groups != 0 || op.groups > 64 || op.nchunks2 < 1 || !op.stats || !op.stats2)
+                return XL_ERR_ARG;
             GnbArgs a;
             a.x = (const float *)op.in; a.dout = (const float *)op.aux; a.outAct = (const float *)op.aux2;
-            a.gamma = (const float *)op.w; a.beta = (const float *)op.bias; a.fstats = (const double *)op.stats;
-            a.bstats = (double *)op.stats2; a.dx = (float *)op.out; a.daux = (float *)op.out2; a.ncsums = nullptr;
-            a.HW = op.Hi * op.Wi; a.C = op.Cin; a.ldX = op.ld_in; a.ldD = op.ld_aux; a.ldO = op.ld_out; a.ldDx = op.ld_in;
-            a.ldAux = op.Cout > 0 ? op.Cout : op.ld_out; a.G = op.groups; a.nchunks = op.nchunks; a.nchunks2 = op.nchunks2; a.flags = op.flags;
-            a.eps = op.eps;
+            a.gamma = (const float *)op.w; a.beta = (const float *)op.bias; a.fco = (const float *)op.stats;
+            a.bstats = (double *)op.stats2; a.dx = (float *)op.out; a.daux = (float *)op.out2;
+            a.ncsums = a.bstats + (long long)op.B * op.nchunks2 * op.Cin * 3;
+            a.bco = reinterpret_cast<float *>(a.ncsums + (long long)op.B * op.Cin * 6);
+            a.B = op.B; a.HW = op.Hi * op.Wi; a.C = op.Cin; a.ldX = op.ld_in; a.ldD = op.ld_aux; a.ldO = op.ld_out; a.ldDx = op.ld_in;
+            a.ldAux = op.Cout > 0 ? op.Cout : op.ld_out; a.G = op.groups; a.nchunks2 = op.nchunks2; a.flags = op.flags;
             if (op.type == XL_OP_GNB_STATS) {
                 const int T = gnb_threads(op.Cin);
                 if (T < 0 || T > 1024) return XL_ERR_ARG;
                 const size_t lds = sizeof(double) * 12 * T + sizeof(float) * 4 * op.Cin;
                 hipLaunchKernelGGL(gnb_stats_kernel, dim3(op.nchunks2, op.B), dim3(T), lds, st, a);
+            } else if (op.type == XL_OP_GNB_FINAL) {
+                const int cpg = op.Cin / op.groups;
+                const int CB = (op.Cin % 64 == 0 && 64 % cpg == 0) ? 64 : op.Cin;      // whole groups per workgroup
+                const size_t lds = sizeof(double) * (3 * (size_t)CB + 2 * 64);
+                hipLaunchKernelGGL(gnb_final_kernel, dim3(op.B, op.Cin / CB), dim3(1024), lds, st, a, CB);
             } else {
-                // ncsums lives behind the per-chunk sums in the same scratch buffer
-                a.ncsums = a.bstats + (long long)op.B * op.nchunks2 * op.Cin * 3;
                 int achunks = (a.HW * (op.Cin / 4) + 256 * 16 - 1) / (256 * 16);
                 if (achunks < 1) achunks = 1;
                 if (achunks > 1024) achunks = 1024;
-                const size_t lds = sizeof(float) * 7 * op.Cin + sizeof(double) * 4 * op.Cin;
-                static size_t configured = 0;
-                if (lds > 64 * 1024 && lds > configured) {                         // C = 1536 (MLR concat): 92 KB
-                    if (hipFuncSetAttribute(reinterpret_cast<const void *>(gnb_apply_kernel),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return XL_ERR_HIP;
-                    configured = lds;
-                }
+                const size_t lds = sizeof(float) * 7 * op.Cin;
                 hipLaunchKernelGGL(gnb_apply_kernel, dim3(achunks, op.B), dim3(256), lds, st, a);
             }
             return XL_OK;

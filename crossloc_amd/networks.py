@@ -27,7 +27,7 @@ XL_OP_GN_FINAL = 11
 XL_OP_WINO_IN, XL_OP_WINO_OUT = 12, 13
 XL_OP_DUC_HEAD = 14
 XL_OP_DUC_HEAD_BWD = 15
-XL_OP_WINO_DY, XL_OP_WINO_WFINAL = 16, 17
+XL_OP_WINO_DY, XL_OP_WINO_WFINAL, XL_OP_GNB_FINAL = 16, 17, 18
 CONV_DGRAD, CONV_ACCUMULATE = 1, 2
 
 
@@ -201,7 +201,7 @@ class _Plan:
         for i, op in enumerate(self.ops):
             # every GN_FINAL writes the shared coefficient buffer; its consumer - the following GN_APPLY, or the
             # Winograd input transform of the next layer when the apply was deferred - runs before the next GN_FINAL
-            if op.type == XL_OP_GN_FINAL:
+            if op.type == XL_OP_GN_FINAL and not train:
                 self.op_array[i].out = self.coeff.data_ptr()
             elif op.type == XL_OP_GN_APPLY and not train:
                 self.op_array[i].aux2 = self.coeff.data_ptr()
@@ -325,10 +325,13 @@ class _Plan:
         self.tape.append(dict(kind="conv", conv=conv, x=act, raw=res))
         return res
 
-    def gn(self, act, norm, flags, aux=None, out=None, pre_stats=None):
+    def gn(self, act, norm, flags, aux=None, out=None, pre_stats=None, stat_tile=0):
         """GroupNorm (+fused epilogue) of `act`; in place unless `out` (tensor, ld, off) is given or training.
-        pre_stats = (stats tensor, nchunks): the partial sums were already produced (Winograd output transform of a
-        training plan), no statistics pass is emitted."""
+        pre_stats = (stats tensor, nchunks): the partial sums were already produced (Winograd output transform or conv
+        epilogue of a training plan; stat_tile = rows per conv tile in the latter case), no statistics pass is emitted.
+        Training plans keep one coefficient table per layer ({scale, shift} and {mean, rstd} per image and channel,
+        written by GN_FINAL): the apply pass and the three backward passes read it instead of re-reducing the partial
+        sums in the prologue of every workgroup."""
         t, H, W, C, ld, off = act
         G = norm.num_groups
         HW = H * W
@@ -358,8 +361,11 @@ class _Plan:
             self.stats_ops += [len(self.ops), len(self.ops) + 1]
         if pre_stats is None:
             self.ops.append(st)
-        if not self.train:
-            self._emit_final(ap, gamma, beta, 0)
+        table = None
+        if self.train:
+            table = torch.zeros(self.B * C * 4, dtype=torch.float32, device=self.device)
+            self.keep.append(table)
+        self._emit_final(ap, gamma, beta, stat_tile, table)
         if aux is not None:
             ap.aux = aux[0].data_ptr() + 4 * aux[5]
             ap.ld_aux = aux[4]
@@ -373,8 +379,8 @@ class _Plan:
             ap.out, ap.ld_out = ot.data_ptr() + 4 * ooff, old
             res = (ot, H, W, C, old, ooff)
         self.ops.append(ap)
-        self.tape.append(dict(kind="gn", norm=norm, raw=act, out=res, aux=aux, flags=flags, stats=stats_t,
-                              nchunks=nchunks, gamma=gamma, beta=beta))
+        self.tape.append(dict(kind="gn", norm=norm, raw=act, out=res, aux=aux, flags=flags, table=table,
+                              gamma=gamma, beta=beta))
         return res
 
     def wino_tile(self, act, conv):
@@ -442,9 +448,18 @@ class _Plan:
             self.keep.append(stats_t)
             op.stats = stats_t.data_ptr()
             self.ops.append(op)
-            self.free.setdefault(Mb.numel(), []).append(Mb)          # V / M are scratch even in training plans
-            self.free.setdefault(V.numel(), []).append(V)
-            self.tape.append(dict(kind="conv", conv=conv, x=act, raw=y))
+            self.free.setdefault(Mb.numel(), []).append(Mb)          # M is scratch even in training plans
+            # V = B^T x B is also the left operand of the Winograd weight gradient: keep it (407 MB per 512-channel
+            # layer at batch 16) instead of transforming the input again, within a fixed budget
+            kept_v = None
+            self.kept_v_bytes = getattr(self, "kept_v_bytes", 0)
+            if (m == 4 and conv.weight.requires_grad and self.kept_v_bytes + 4 * V.numel() <= (16 << 30)
+                    and not os.environ.get("XL_NO_KEEP_V") and not os.environ.get("XL_NO_WINOGRAD_WGRAD")):
+                kept_v = V
+                self.kept_v_bytes += 4 * V.numel()
+            else:
+                self.free.setdefault(V.numel(), []).append(V)
+            self.tape.append(dict(kind="conv", conv=conv, x=act, raw=y, v=kept_v))
             return self.gn(y, norm, flags, aux, pre_stats=(stats_t, nchunks))
         self.max_stats = max(self.max_stats, B * nchunks * G * 2)
         self.stats_ops.append(len(self.ops))
@@ -486,6 +501,18 @@ class _Plan:
             return self.gn_fused(y, norm, flags, aux, len(self.ops) - 1,
                                  defer=defer and flags == GN_RELU_IN and aux is None
                                  and not os.environ.get("XL_NO_DEFERRED_GN"))
+        if (self.train and y[1] * y[2] >= 128 and whole_groups and not os.environ.get("XL_NO_FUSED_STATS")
+                and self.ops[-1].type == XL_OP_CONV):
+            # training: same epilogue statistics, written to a buffer of the layer's own (they are inputs of the
+            # backward pass).  Slots a conv tile never touches stay zero, so the consumers may sum all of them.
+            cop = self.ops[-1]
+            tile = 64 if cop.reserved_i == 64 else 128
+            G = norm.num_groups
+            nchunks = (y[1] * y[2] + tile - 1) // tile + 1
+            stats_t = torch.zeros(self.B * nchunks * G * 2, dtype=torch.float64, device=self.device)
+            self.keep.append(stats_t)
+            cop.stats, cop.groups, cop.nchunks = stats_t.data_ptr(), G, nchunks
+            return self.gn(y, norm, flags, aux, pre_stats=(stats_t, nchunks), stat_tile=tile)
         r = self.gn(y, norm, flags, aux)
         if r[0] is not y[0]:
             self.release(y[0])
@@ -532,16 +559,23 @@ class _Plan:
         self.ops.append(ap)
         return res
 
-    def _emit_final(self, ap, gamma, beta, stat_tile):
+    def _emit_final(self, ap, gamma, beta, stat_tile, table=None):
         """GN_FINAL op: one tiny launch turns the partial sums into per-(image, channel) scale/shift so the
-        streaming apply kernel does no redundant reduction per workgroup."""
-        self.max_coeff = max(getattr(self, "max_coeff", 0), self.B * ap.Cin * 2)
+        streaming apply kernel does no redundant reduction per workgroup.  Inference: shared statistics and
+        coefficient buffers, patched in once their sizes are known.  Training (`table`): the layer's own statistics
+        (ap.stats) and its own table, {scale, shift} pairs first, {mean, rstd} pairs behind them."""
         fin = XlOp()
         fin.type = XL_OP_GN_FINAL
         fin.B, fin.Hi, fin.Wi, fin.Cin, fin.groups, fin.nchunks = ap.B, ap.Hi, ap.Wi, ap.Cin, ap.groups, ap.nchunks
         fin.eps, fin.reserved_i = ap.eps, stat_tile
         fin.w, fin.bias = gamma.data_ptr(), beta.data_ptr()
-        self.stats_ops.append(len(self.ops))
+        if table is None:
+            self.max_coeff = max(getattr(self, "max_coeff", 0), self.B * ap.Cin * 2)
+            self.stats_ops.append(len(self.ops))
+        else:
+            fin.stats = ap.stats
+            fin.out, fin.out2 = table.data_ptr(), table.data_ptr() + 4 * self.B * ap.Cin * 2
+            ap.aux2 = table.data_ptr()
         self.ops.append(fin)
 
     def res_block(self, res, block):
@@ -818,17 +852,17 @@ class _Plan:
                         grads[self._key(e["aux"])] = daux
                 prod = producers.get(self._key(e["raw"]))
                 G = e["norm"].num_groups
-                nch2 = max(1, min(128, (H * W + 255) // 256))
-                scratch_d = max(scratch_d, B * nch2 * C * 3 + B * C * 6)
-                for typ in (XL_OP_GNB_STATS, XL_OP_GNB_APPLY, XL_OP_GNB_PARAMS):
+                nch2 = max(1, min(128, (H * W + 63) // 64))
+                scratch_d = max(scratch_d, B * nch2 * C * 3 + B * C * 6 + (B * C * 3 + 1) // 2)
+                for typ in (XL_OP_GNB_STATS, XL_OP_GNB_FINAL, XL_OP_GNB_APPLY, XL_OP_GNB_PARAMS):
                     op = XlOp()
                     op.type = typ
                     op.B, op.Hi, op.Wi, op.Cin, op.groups = B, H, W, C, G
-                    op.nchunks, op.nchunks2, op.flags, op.eps = e["nchunks"], nch2, flags, e["norm"].eps
+                    op.nchunks2, op.flags, op.eps = nch2, flags, e["norm"].eps
                     op.ld_in, op.ld_aux, op.ld_out = ld, gout[1], e["out"][4]
                     op.in_ = t.data_ptr() + 4 * off
                     op.w, op.bias = e["gamma"].data_ptr(), e["beta"].data_ptr()
-                    op.stats = e["stats"].data_ptr()
+                    op.stats = e["table"].data_ptr()
                     op.aux = gout[0].data_ptr() + 4 * gout[2]
                     op.aux2 = e["out"][0].data_ptr() + 4 * e["out"][5]
                     if typ == XL_OP_GNB_APPLY:
@@ -872,12 +906,14 @@ class _Plan:
                 if wino_w:
                     # weight gradient through F(4x4,3x3): V = B^T x B, dM = A dY A^T, 36 GEMMs over the tiles, dg = G^T dU G
                     Th, Tw = -(-H // 4), -(-W // 4)
-                    Vb = self.alloc(36 * Tw4 * C)
-                    wi = XlOp()
-                    wi.type, wi.ksize = XL_OP_WINO_IN, 4
-                    wi.B, wi.Hi, wi.Wi, wi.Cin, wi.Ho, wi.Wo, wi.ld_in = B, H, W, C, Th, Tw, ld
-                    wi.in_, wi.out = t.data_ptr() + 4 * off, Vb.data_ptr()
-                    bops.append(wi)
+                    Vb = e.get("v")
+                    if Vb is None:
+                        Vb = self.alloc(36 * Tw4 * C)
+                        wi = XlOp()
+                        wi.type, wi.ksize = XL_OP_WINO_IN, 4
+                        wi.B, wi.Hi, wi.Wi, wi.Cin, wi.Ho, wi.Wo, wi.ld_in = B, H, W, C, Th, Tw, ld
+                        wi.in_, wi.out = t.data_ptr() + 4 * off, Vb.data_ptr()
+                        bops.append(wi)
                     dMb = self.alloc(36 * Tw4 * Cout)
                     wd = XlOp()
                     wd.type = XL_OP_WINO_DY
@@ -908,7 +944,7 @@ class _Plan:
                     wf.Cin, wf.Cout = C, Cout
                     wf.in_, wf.out = dU.data_ptr(), pgrad(conv.weight).data_ptr()
                     bops.append(wf)
-                    self.release_grad(Vb); self.release_grad(dMb); self.release_grad(dU)
+                    self.release_grad(Vb); self.release_grad(dMb); self.release_grad(dU)   # a kept V is dead from here on
                 op = XlOp()
                 op.type = XL_OP_WGRAD
                 op.B, op.Hi, op.Wi, op.Cin, op.Ho, op.Wo, op.Cout = B, H, W, C, Ho, Wo, Cout

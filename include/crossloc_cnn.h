@@ -36,8 +36,11 @@ enum {
     XL_OP_HEAD = 4,      /* fc3 1x1 conv to (n_task + n_pos) channels + mean offset + exp(hardtanh), NCHW out */
     /* ---- backward (what autograd + cuDNN dgrad/wgrad did for loss.backward(), train_single_task.py:298) */
     XL_OP_WGRAD = 5,     /* conv weight gradient: split-K implicit GEMM over pixels + fixed-order reduce -> OIHW */
-    XL_OP_GNB_STATS = 6, /* GroupNorm(+fused epilogue) backward, pass 1: per-(image, chunk, channel) sums */
-    XL_OP_GNB_APPLY = 7, /* pass 2: dx, optional d(residual), per-(image, channel) sums for the parameter grads */
+    XL_OP_GNB_STATS = 6, /* GroupNorm(+fused epilogue) backward, pass 1: per-(image, chunk, channel) sums.  All GNB ops:
+                            stats = the layer's forward coefficient table written by XL_OP_GN_FINAL with out2 set
+                            ([B][C][2] {scale, shift} followed by [B][C][2] {mean, rstd}); stats2 = scratch of
+                            B*nchunks2*C*3 + B*C*6 doubles + B*C*3 floats */
+    XL_OP_GNB_APPLY = 7, /* pass 3: dx, optional d(residual) */
     XL_OP_GNB_PARAMS = 8,/* d gamma, d beta and the bias gradient of the preceding conv */
     XL_OP_HEAD_BWD = 9,  /* backward of XL_OP_HEAD: d(input) NHWC, d(fc3 weight), d(fc3 bias) */
     XL_OP_CONV1_WGRAD = 10, /* weight + bias gradient of the NCHW-input first conv */
@@ -51,9 +54,12 @@ enum {
                                Ho x Wo + fc3 (w [Cout][Cout], bias) + mean (aux) / exp(hardtanh) -> out NCHW [B,Cout,Ho,Wo] */
     XL_OP_DUC_HEAD_BWD = 15, /* backward of XL_OP_DUC_HEAD (pure pixel-shuffle case): d activation, d fc3.weight / bias */
     XL_OP_WINO_DY = 16,     /* Winograd F(4x4,3x3) weight gradient: in dY [B,Hi,Wi,Cin] -> out dM = A dY A^T [36][tiles][Cin] */
+    XL_OP_GNB_FINAL = 18,   /* GroupNorm backward, pass 2 (between STATS and APPLY): totals of the chunk sums, per-(image,
+                               channel) apply coefficients and the sums XL_OP_GNB_PARAMS turns into d gamma / d beta / d bias */
     XL_OP_WINO_WFINAL = 17, /* in dU [36][Cout][Cin] -> out dg = G^T dU G, OIHW [Cout][Cin][3][3] */
     XL_OP_GN_FINAL = 11  /* per-(image, channel) GroupNorm scale/shift [B][C][2] from the partial sums (out);
-                            GN_APPLY with aux2 = that buffer skips its own finalisation */
+                            GN_APPLY with aux2 = that buffer skips its own finalisation.  out2 (training plans):
+                            [B][C][2] {mean, rstd} for the GroupNorm backward ops */
 };
 
 /* xl_op.flags for XL_OP_CONV */

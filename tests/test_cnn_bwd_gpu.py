@@ -217,18 +217,26 @@ def test_groupnorm_backward_vs_autograd(B, H, W, C, flags):
     ap.flags, ap.eps = flags, 1e-5
     ap.in_, ap.w, ap.bias, ap.aux, ap.stats, ap.out = (xd.data_ptr(), gd.data_ptr(), bd.data_ptr(), ad.data_ptr(),
                                                        stats.data_ptr(), outf.data_ptr())
-    scratch = torch.zeros(B * nch * C * 3 + B * C * 6, dtype=torch.float64, device="cuda")
+    table = torch.full((B * C * 4,), float("nan"), device="cuda")       # {scale, shift} pairs, then {mean, rstd} pairs
+    fin = networks.XlOp()
+    fin.type = networks.XL_OP_GN_FINAL
+    fin.B, fin.Hi, fin.Wi, fin.Cin, fin.groups, fin.nchunks, fin.eps = B, H, W, C, 32, nch, 1e-5
+    fin.stats, fin.w, fin.bias = stats.data_ptr(), gd.data_ptr(), bd.data_ptr()
+    fin.out, fin.out2 = table.data_ptr(), table.data_ptr() + 4 * B * C * 2
+    ap.aux2 = table.data_ptr()
+    nch2 = max(1, min(128, (HW + 63) // 64))
+    scratch = torch.zeros(B * nch2 * C * 3 + B * C * 6 + (B * C * 3 + 1) // 2, dtype=torch.float64, device="cuda")
     dx = torch.full_like(xd, float("nan"))
     daux = torch.full_like(xd, float("nan"))
     dg, db, dbias = (torch.empty(C, device="cuda") for _ in range(3))
-    ops = [st, ap]
-    for typ in (networks.XL_OP_GNB_STATS, networks.XL_OP_GNB_APPLY, networks.XL_OP_GNB_PARAMS):
+    ops = [st, fin, ap]
+    for typ in (networks.XL_OP_GNB_STATS, networks.XL_OP_GNB_FINAL, networks.XL_OP_GNB_APPLY, networks.XL_OP_GNB_PARAMS):
         op = networks.XlOp()
         op.type = typ
         op.B, op.Hi, op.Wi, op.Cin, op.groups = B, H, W, C, 32
-        op.nchunks, op.nchunks2, op.flags, op.eps = nch, nch, flags, 1e-5
+        op.nchunks2, op.flags, op.eps = nch2, flags, 1e-5
         op.ld_in, op.ld_aux, op.ld_out = C, C, C
-        op.in_, op.w, op.bias, op.stats, op.aux, op.aux2 = (xd.data_ptr(), gd.data_ptr(), bd.data_ptr(), stats.data_ptr(),
+        op.in_, op.w, op.bias, op.stats, op.aux, op.aux2 = (xd.data_ptr(), gd.data_ptr(), bd.data_ptr(), table.data_ptr(),
                                                             dd.data_ptr(), outf.data_ptr())
         op.stats2 = scratch.data_ptr()
         if typ == networks.XL_OP_GNB_APPLY:

@@ -264,9 +264,25 @@ def test_network_full_size_vs_oracle_and_determinism():
     y = y.cpu()
     _close(y[:, :3] - MEAN[None, :, None, None], ref[:, :3] - MEAN[None, :, None, None], 1e-3)
     assert torch.allclose(y[:, 3], ref[:, 3], rtol=2e-3)
-    # batch-size independence of per-image results
+    # per-image results do not depend on the batch they are in (GroupNorm is per image).  The fp64 partial sums of the
+    # statistics are grouped by conv tile, and tiles straddle image boundaries differently for other batch sizes, so
+    # the match is to the last fp32 bit or two rather than bitwise
     y1 = net(x[1:].cuda()).cpu()
-    assert torch.equal(y1[0], y[1])
+    assert torch.allclose(y1[0, :3], y[1, :3], rtol=0, atol=2e-4)        # |X| ~ 500 m: 2e-4 = 3 ulp
+    assert torch.allclose(y1[0, 3], y[1, 3], rtol=1e-4)                  # sigma = exp(s) amplifies the last bits of s
+
+
+def test_separate_statistics_passes_are_batch_independent_bitwise(monkeypatch):
+    """With XL_NO_FUSED_STATS=1 the GroupNorm sums are chunked per image, and a frame's result is bitwise the same in any
+    batch (the default groups them by conv tile: equal to the last bit or two, see the test above)."""
+    monkeypatch.setenv("XL_NO_FUSED_STATS", "1")
+    net = networks.TransPoseNet(MEAN, False, False, 1, 1, 3, 1)
+    net.load_state_dict(seeded_state_dict(net, seed=5))
+    net = net.cuda().eval()
+    x = torch.rand(3, 3, 128, 192, generator=torch.Generator().manual_seed(2)).cuda()
+    with torch.no_grad():
+        y = net(x)
+        assert torch.equal(net(x[2:])[0], y[2]) and torch.equal(net(x[:2])[1], y[1])
 
 
 def test_weight_update_invalidates_packed_weights():

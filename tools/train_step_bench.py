@@ -64,7 +64,7 @@ def main():
         idx, typ, tms = (ctypes.c_int32 * cap)(), (ctypes.c_int32 * cap)(), (ctypes.c_float * cap)()
         n = L.xl_cnn_prof_end(idx, typ, tms, cap)
         names = {0: "conv1", 1: "conv", 2: "gn_stats", 3: "gn_apply", 4: "head", 5: "wgrad", 6: "gnb_stats", 7: "gnb_apply",
-                 8: "gnb_params", 9: "head_bwd", 10: "conv1_wgrad", 12: "wino_in", 13: "wino_out", 14: "duc_head", 15: "duc_head_bwd", 16: "wino_dy", 17: "wino_wfinal"}
+                 8: "gnb_params", 9: "head_bwd", 10: "conv1_wgrad", 12: "wino_in", 13: "wino_out", 14: "duc_head", 15: "duc_head_bwd", 16: "wino_dy", 17: "wino_wfinal", 18: "gnb_final", 11: "gn_final"}
         tot = {}
         for i in range(n):
             arr = plan.op_array if i < nf else plan.bwd_array
