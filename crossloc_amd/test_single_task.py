@@ -67,6 +67,8 @@ def main():
 
     mean = torch.tensor(synth.SCENE_MEAN, dtype=torch.float32)
     net = networks.TransPoseNet(mean, False, False, 2, 2, 3, 1, 32, opt.num_mlr, 0, False)   # evaluation.py:105-109
+    # a frame's result must not depend on the batch (hence on the rank count) it lands in: per-image statistics passes
+    net.batch_invariant = True
     if opt.network_in:
         net.load_state_dict(torch.load(opt.network_in, map_location="cpu"), strict=True)     # evaluation.py:113
     else:
