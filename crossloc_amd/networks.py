@@ -437,6 +437,8 @@ class _Plan:
         out = self.alloc(B * H * W * cout)
         G = norm.num_groups
         tpb = 32 if m == 2 else 16
+        while tpb > 1 and B * -(-(Th * Tw) // tpb) * max(1, cout // 512) < 1024:
+            tpb //= 2                                # small batches: more, shorter workgroups (latency-bound otherwise)
         nchunks = -(-(Th * Tw) // tpb)
         op = XlOp()
         op.type = XL_OP_WINO_OUT
