@@ -1250,13 +1250,14 @@ int launch_igemm(const xl_op &op, hipStream_t st, int py = 0, int px = 0)
     static const bool clkDbg = getenv("XL_CONV_CLK") != nullptr;
     a.clk = nullptr;
     const int nwg = a.nbm * a.nbn * a.zCount;
-    if (clkDbg) hipMalloc(&a.clk, sizeof(long long) * 8 * nwg);
+    if (clkDbg && hipMalloc(&a.clk, sizeof(long long) * 8 * nwg) != hipSuccess) return XL_ERR_HIP;
     hipLaunchKernelGGL((igemm_conv_kernel<KS, STRIDE, BN, CIN, MODE, BM, ZB>), dim3(nwg), dim3(256), lds, st, a);
     if (clkDbg) {
-        hipStreamSynchronize(st);
         std::vector<long long> h(8 * (size_t)nwg);
-        hipMemcpy(h.data(), a.clk, sizeof(long long) * 8 * nwg, hipMemcpyDeviceToHost);
-        hipFree(a.clk);
+        const bool copied = hipStreamSynchronize(st) == hipSuccess &&
+                            hipMemcpy(h.data(), a.clk, sizeof(long long) * 8 * nwg, hipMemcpyDeviceToHost) == hipSuccess;
+        (void)hipFree(a.clk);
+        if (!copied) return XL_ERR_HIP;
         double pro = 0, loop = 0, epi = 0, tot = 0, wall = 0;
         long long wmin = h[1], wmax = h[5];
         std::map<long long, int> perCu;

@@ -957,8 +957,9 @@ int xl_run_bwd_op(const xl_op &op, hipStream_t st)
                                op.B, op.Hi, op.Wi, op.Cout, op.ld_in, op.ld_out, op.n_task, op.clamp_lo, op.clamp_hi);
             float *tot = part + blocks * len;                           // [len]: weights then bias
             hipLaunchKernelGGL(partial_sum_kernel, dim3(1), dim3(128), 0, st, (const float *)part, tot, (int)blocks, len);
-            hipMemcpyAsync(op.out2, tot, sizeof(float) * op.Cout * op.Cout, hipMemcpyDeviceToDevice, st);
-            hipMemcpyAsync(op.stats, tot + op.Cout * op.Cout, sizeof(float) * op.Cout, hipMemcpyDeviceToDevice, st);
+            if (hipMemcpyAsync(op.out2, tot, sizeof(float) * op.Cout * op.Cout, hipMemcpyDeviceToDevice, st) != hipSuccess ||
+                hipMemcpyAsync(op.stats, tot + op.Cout * op.Cout, sizeof(float) * op.Cout, hipMemcpyDeviceToDevice, st) != hipSuccess)
+                return XL_ERR_HIP;
             return XL_OK;
         }
         case XL_OP_CONV1_WGRAD: {
