@@ -182,3 +182,60 @@ def test_small_and_ragged_grids(oracle):
         pose = oracle.forward_rgb(sc["coords"], 16, 10.0, 480.0, sc["ppx"], sc["ppy"], 100.0, 100.0, 8)
         t_err, r_err = synth.pose_error(sc["pose"], pose)
         assert t_err < 1e-2 and r_err < 1e-2
+
+
+def test_refinement_agrees_with_scipy_least_squares(oracle):
+    """Independent implementation of the non-linear PnP the refinement performs (dsacstar_util.h:570-580: minimise the
+    summed squared reprojection error over the inlier set from the current pose): scipy's MINPACK Levenberg-Marquardt
+    with scipy's own Rodrigues map.  Small noise and no outliers keep every cell an inlier in every round, so the
+    refined pose must be THE minimiser over all 5400 cells — and the second round must stop on `count <= best`."""
+    from scipy.optimize import least_squares
+    from scipy.spatial.transform import Rotation
+    for s in range(3):
+        sc = synth.make_scene(300 + s, noise=0.05, outlier_ratio=0.0)
+        pose, d = _run(oracle, sc, image=s)
+        assert d["inliers"] == 5400 and d["rounds"] == 1
+        Ho, Wo = sc["coords"].shape[1:]
+        X = sc["coords"].reshape(3, -1).T.astype(np.float64)                       # row-major cells: index = y*Wo + x
+        ys, xs = np.divmod(np.arange(Ho * Wo), Wo)
+        px = np.stack([xs * 8 + 4, ys * 8 + 4], 1).astype(np.float64)
+        f, cx, cy = sc["focal"], sc["ppx"], sc["ppy"]
+
+        def resid(p):
+            Xc = X @ Rotation.from_rotvec(p[:3]).as_matrix().T + p[3:]
+            return np.concatenate([f * Xc[:, 0] / Xc[:, 2] + cx - px[:, 0], f * Xc[:, 1] / Xc[:, 2] + cy - px[:, 1]])
+
+        R0, t0 = d["pose0"][:9].reshape(3, 3), d["pose0"][9:]                      # winning hypothesis (world -> camera)
+        R1, t1 = d["pose1"][:9].reshape(3, 3), d["pose1"][9:]                      # after refinement
+        p0 = np.concatenate([Rotation.from_matrix(R0).as_rotvec(), t0])
+        sol = least_squares(resid, p0, method="lm", xtol=1e-15, ftol=1e-15, gtol=1e-15)
+        Rs, ts = Rotation.from_rotvec(sol.x[:3]).as_matrix(), sol.x[3:]
+        ang = np.linalg.norm(Rotation.from_matrix(Rs.T @ R1).as_rotvec())
+        assert ang < 1e-7, ang                                                      # radians
+        assert np.abs(ts - t1).max() < 1e-4, np.abs(ts - t1).max()                  # metres, |t| ~ 700 m
+        cost1 = 0.5 * np.sum(resid(np.concatenate([Rotation.from_matrix(R1).as_rotvec(), t1])) ** 2)
+        assert cost1 <= sol.cost * (1 + 1e-9) + 1e-12
+        # the pose handed back is the inverse, as float32 (dsacstar_util.h:759-770)
+        inv = np.eye(4); inv[:3, :3] = R1.T; inv[:3, 3] = -R1.T @ t1
+        assert np.allclose(pose, inv.astype(np.float32), rtol=0, atol=1e-4)
+
+
+def test_rotation_maps_agree_with_scipy(oracle):
+    """cv::Rodrigues as restated in the oracle (matrix -> vector and the Jacobian of vector -> matrix) against scipy's
+    rotation-vector map, including the small-angle and near-pi branches."""
+    from scipy.spatial.transform import Rotation
+    rng = np.random.default_rng(9)
+    for r in ([1e-5, -2e-5, 1e-5], [0.3, -0.2, 0.1], [3.0, 0.9, -0.2], list(np.array([0.6, 0.0, 0.8]) * (math.pi - 1e-3)),
+              list(np.array([0.6, 0.0, 0.8]) * (math.pi - 1e-6))):
+        R = Rotation.from_rotvec(r).as_matrix()
+        got = oracle.log_so3(R)                                                     # matrix -> vector (backward's inverse map)
+        # within 1e-5 of pi the restatement, like cv::Rodrigues, takes the axis from the diagonal and drops the O(pi-angle)
+        # antisymmetric part: exact to ~1e-6 there, to rounding elsewhere
+        near_pi = abs(np.linalg.norm(r) - math.pi) < 1e-5
+        assert np.allclose(Rotation.from_rotvec(got).as_matrix(), R, atol=2e-6 if near_pi else 1e-9)
+        J = oracle.rodrigues_jac(np.asarray(r, np.float64))                         # dR/dr, 9x3
+        eps = 1e-6
+        for k in range(3):
+            dr = np.zeros(3); dr[k] = eps
+            num = (Rotation.from_rotvec(np.add(r, dr)).as_matrix() - Rotation.from_rotvec(np.subtract(r, dr)).as_matrix()) / (2 * eps)
+            assert np.allclose(np.asarray(J).reshape(9, 3)[:, k], num.reshape(9), atol=2e-6), (r, k)
