@@ -674,12 +674,17 @@ class _Plan:
         c = self.cgr(b, enc.res2_conv3, enc.res2_norm3); self.release(b[0])
         n_add = len(enc.enc_add_res_block_ls)
         last_out = out if n_add == 0 else None
-        sk = self.conv(res, enc.res2_skip)
-        self.release(res[0])
-        res = self.gn(sk, enc.res2_skip_norm, GN_ADD | GN_RELU_OUT, aux=c, out=last_out)
-        self.release(c[0])
-        if res[0] is not sk[0]:
-            self.release(sk[0])
+        if last_out is None:                        # conv -> GroupNorm with the statistics out of the conv epilogue
+            skip_in = res
+            res = self.cgr(skip_in, enc.res2_skip, enc.res2_skip_norm, GN_ADD | GN_RELU_OUT, aux=c)
+            self.release(skip_in[0]); self.release(c[0])
+        else:
+            sk = self.conv(res, enc.res2_skip)
+            self.release(res[0])
+            res = self.gn(sk, enc.res2_skip_norm, GN_ADD | GN_RELU_OUT, aux=c, out=last_out)
+            self.release(c[0])
+            if res[0] is not sk[0]:
+                self.release(sk[0])
         for i, block in enumerate(enc.enc_add_res_block_ls):
             if i == n_add - 1 and out is not None:
                 x = self.cgr(res, block[0], block[1])
@@ -708,8 +713,7 @@ class _Plan:
             for i, enc in enumerate(net.mlr_encoder_ls):
                 self.encoder(enc, _DUMMY, out=(cat, ctot, i * c))
             mlr = (cat, Ho, Wo, ctot, ctot, 0)
-            sk = self.conv(mlr, net.mlr_skip[0])
-            sk = self.gn(sk, net.mlr_skip[1], 0)
+            sk = self.cgr(mlr, net.mlr_skip[0], net.mlr_skip[1], 0)
             mlr = self.gn(mlr, net.mlr_norm, 0)
             f = net.mlr_forward
             a = self.cgr(mlr, f[0], f[1]); self.release(cat)
