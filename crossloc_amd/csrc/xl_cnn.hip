@@ -20,6 +20,7 @@
 // fp32 end to end: the MFMA used is bitwise an fmaf chain, so parity with the fp32 reference is at
 // summation-order level (tests compare against torch fp32 on CPU and the golden vectors).
 #include <hip/hip_runtime.h>
+#include <array>
 #include <map>
 #include <vector>
 #include <stdint.h>
@@ -1271,6 +1272,19 @@ int launch_igemm(const xl_op &op, hipStream_t st, int py = 0, int px = 0)
         }
         int cmin = 1 << 30, cmax = 0;
         for (auto &kv : perCu) { if (kv.second < cmin) cmin = kv.second; if (kv.second > cmax) cmax = kv.second; }
+        // residency: workgroup-lifetime per CU over that CU's active span (2.0 = both slots always occupied)
+        std::map<long long, std::array<double, 3>> occ;               // busy, first start, last end (100 MHz wall ticks)
+        for (int i = 0; i < nwg; ++i) {
+            const long long *c = &h[8 * (size_t)i];
+            auto &o = occ[((c[7] & 15) << 16) | ((c[6] >> 8) & 0xff)];
+            if (o[0] == 0.0) { o[1] = (double)c[1]; o[2] = (double)c[5]; }
+            o[0] += (double)(c[5] - c[1]);
+            if ((double)c[1] < o[1]) o[1] = (double)c[1];
+            if ((double)c[5] > o[2]) o[2] = (double)c[5];
+        }
+        double resid = 0.0;
+        for (auto &kv : occ) resid += kv.second[0] / (kv.second[2] - kv.second[1]);
+        fprintf(stderr, "[clk] mean resident workgroups per CU %.3f, mean lifetime %.2f us\n", resid / occ.size(), wall / nwg / 100.0);
         fprintf(stderr, "[clk] wgs %d nk %d: prologue %.0f loop %.0f (%.1f/step) epilogue %.0f total %.0f ticks; clock %.1f MHz; kernel span %.3f ms; CUs seen %zu, tiles per CU %d..%d\n",
                 nwg, a.K / kBK, pro / nwg, loop / nwg, loop / nwg / (a.K / kBK), epi / nwg, tot / nwg, tot / wall * 100.0,
                 (wmax - wmin) / 1e5, perCu.size(), cmin, cmax);
