@@ -10,8 +10,12 @@ import sys
 def main():
     src, needle, dst = sys.argv[1:4]
     rows = []
-    for f in sorted(glob.glob(os.path.join(src, "pmc_*", "*", "*counter_collection.csv"))):
+    newest = {}                                       # one run per pass directory: the most recent one
+    for f in glob.glob(os.path.join(src, "pmc_*", "*", "*counter_collection.csv")):
         p = f[len(src):].strip("/").split("/")[0]
+        if p not in newest or os.path.getmtime(f) > os.path.getmtime(newest[p]):
+            newest[p] = f
+    for p, f in sorted(newest.items()):
         for r in csv.DictReader(open(f)):
             if needle in r["Kernel_Name"]:
                 rows.append((p, int(r["Dispatch_Id"]), r["Kernel_Name"][:80], r["Counter_Name"], r["Counter_Value"]))
