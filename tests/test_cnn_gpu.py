@@ -272,6 +272,28 @@ def test_network_full_size_vs_oracle_and_determinism():
     assert torch.allclose(y1[0, 3], y[1, 3], rtol=1e-4)                  # sigma = exp(s) amplifies the last bits of s
 
 
+def test_fused_forms_match_the_plain_form_at_full_size(monkeypatch):
+    """BASELINE frame size, batch 3: the default inference plan (Winograd F(4x4,3x3), conv-epilogue statistics, GroupNorm
+    folded into the Winograd input transform, first layer evaluated twice) against the plainest lowering of the same
+    network (direct convolutions, separate statistics and apply passes, first layer materialised) - two independent HIP
+    paths, no CPU oracle in the loop, so the check runs at the full size."""
+    x = torch.rand(3, 3, 480, 720, generator=torch.Generator().manual_seed(8)).cuda()
+
+    def run():
+        net = networks.TransPoseNet(MEAN, False, False, 2, 2, 3, 1)
+        net.load_state_dict(seeded_state_dict(net, seed=12))
+        net = net.cuda().eval()
+        with torch.no_grad():
+            return net(x).cpu()
+    fused = run()
+    for k in ("XL_NO_WINOGRAD", "XL_NO_FUSED_STATS", "XL_NO_DEFERRED_GN", "XL_NO_CONV1_FUSED"):
+        monkeypatch.setenv(k, "1")
+    plain = run()
+    assert torch.isfinite(fused).all() and fused.shape == (3, 4, 60, 90)
+    assert (fused[:, :3] - plain[:, :3]).abs().max().item() < 5e-4      # metres at |X| ~ 500 m (1 ulp = 6e-5)
+    assert torch.allclose(fused[:, 3], plain[:, 3], rtol=1e-3)
+
+
 def test_batch_invariant_mode_is_bitwise_batch_independent():
     """net.batch_invariant = True (what the test harness sets: results must not depend on the rank count): the GroupNorm
     sums are chunked per image, and a frame's result is bitwise the same in any batch (the default groups them by conv
