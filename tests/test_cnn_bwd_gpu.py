@@ -115,6 +115,36 @@ def test_gradients_accumulate_and_second_step_matches():
     assert all(torch.isfinite(p.grad).all() for p in net.parameters())
 
 
+def test_training_forms_agree_at_full_size(monkeypatch):
+    """BASELINE configs[1] frame size (480x720, batch 2 here): the default training plan (Winograd forward / data /
+    weight gradients, conv-epilogue statistics, coefficient tables) against the direct-convolution plan with separate
+    statistics passes - two HIP lowerings, no CPU oracle in the loop.  Relative L2 per tensor: ReLU-mask flips between
+    the two forward roundings move single elements (module docstring), not norms."""
+    x = torch.rand(2, 3, 480, 720, generator=torch.Generator().manual_seed(6)).cuda()
+    wgt = torch.randn(2, 4, 60, 90, generator=torch.Generator().manual_seed(7)).cuda()
+
+    def run():
+        net = networks.TransPoseNet(MEAN, False, False, 2, 2, 3, 1)
+        net.load_state_dict(seeded_state_dict(net, seed=21))
+        net = net.cuda().train()
+        y = net(x)
+        (y * wgt).sum().backward()
+        return y.detach().cpu(), {n: p.grad.detach().cpu() for n, p in net.named_parameters()}
+    y_w, g_w = run()
+    for k in ("XL_NO_WINOGRAD_TRAIN", "XL_NO_FUSED_STATS"):
+        monkeypatch.setenv(k, "1")
+    y_d, g_d = run()
+    assert (y_w[:, :3] - y_d[:, :3]).abs().max().item() < 5e-4
+    assert len(g_w) == len(g_d) == 114                                  # 116 state_dict entries minus the two `mean` buffers
+    worst = 0.0
+    for n in g_d:
+        assert torch.isfinite(g_w[n]).all(), n
+        den = g_d[n].double().norm().item()
+        if den > 0:
+            worst = max(worst, (g_w[n].double() - g_d[n].double()).norm().item() / den)
+    assert worst < 5e-2, worst
+
+
 def test_frozen_parameters_and_no_grad_inference():
     net = networks.TransPoseNet(MEAN, False, False, 0, 0, 3, 1).cuda()
     for p in net.encoder.parameters():
