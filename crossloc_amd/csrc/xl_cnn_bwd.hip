@@ -751,57 +751,92 @@ void duc_head_bwd_kernel(const float *__restrict__ x, const float *__restrict__ 
     }
 }
 
-// sums `count` partial vectors of length `len` in fixed order
-__global__ void partial_sum_kernel(const float *__restrict__ partial, float *__restrict__ out, int count, int len)
+// sums `count` partial vectors of length `len` in a fixed order.  grid ceil(len / 32), 256 threads = 32 elements x 8
+// parts: a part sums a contiguous eighth of the vectors with 4 loads in flight, the eighths are added in order (one
+// thread per element walking all `count` vectors is a serial chain of `count` load latencies).
+__global__ __launch_bounds__(256)
+void partial_sum_kernel(const float *__restrict__ partial, float *__restrict__ out, int count, int len)
 {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < len; i += gridDim.x * blockDim.x) {
-        double s = 0.0;
-        for (int k = 0; k < count; ++k) s += (double)partial[(long long)k * len + i];
-        out[i] = (float)s;
+    __shared__ double sP[8 * 32];
+    const int e = threadIdx.x & 31, part = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + e;
+    const int per = (count + 7) >> 3;
+    const int k0 = part * per;
+    int k1 = k0 + per; if (k1 > count) k1 = count;
+    double s = 0.0;
+    if (i < len) {
+#pragma unroll 4
+        for (int k = k0; k < k1; ++k) s += (double)partial[(long long)k * len + i];
+    }
+    sP[part * 32 + e] = s;
+    __syncthreads();
+    if (part == 0 && i < len) {
+        double t = 0.0;
+        for (int q = 0; q < 8; ++q) t += sP[q * 32 + e];
+        out[i] = (float)t;
     }
 }
 
 // ---------------------------------------------------------------------------------------------- conv1 wgrad
 
-// dW[o][c][ky][kx] = sum dY[n,y,x,o] * img[n,c,y+ky-1,x+kx-1]; db[o] = sum dY.  Thread = (o, pixel lane j of 8).
+// dW[o][c][ky][kx] = sum dY[n,y,x,o] * img[n,c,y+ky-1,x+kx-1]; db[o] = sum dY.  Cout = 32.
+// Thread = (4 consecutive output channels og, pixel lane pl of 32): per pixel one 16-byte dY load (the 8 threads of a
+// pixel read its 128 contiguous bytes) and 9 ds_read_b128 of the image taps feed 108 FMAs - 12 per LDS read; with one
+// output channel per thread (3 per read) the kernel sat on the LDS pipe at 6x its HBM time.
 // A block walks `rowsPerBlock` output rows of one image two at a time; the 4 image rows (with halo, channels padded
-// to a float4) they touch are staged in LDS, so the 27 taps of a pixel are 9 broadcast ds_read_b128.
-// partial [gridDim.y * gridDim.x][28][Cout]
+// to a float4) they touch are staged in LDS.  partial [gridDim.y * gridDim.x][28][32]
 __global__ __launch_bounds__(256)
 void conv1_wgrad_kernel(const float *__restrict__ img, const float *__restrict__ dy, float *__restrict__ partial,
-                        int B, int Cin, int H, int W, int Cout, int ldY, int rowsPerBlock)
+                        int B, int Cin, int H, int W, int ldY, int rowsPerBlock)
 {
-    constexpr int R = 2;
+    constexpr int R = 2, CO = 32;
     extern __shared__ __attribute__((aligned(16))) float sDyn[];
     f32x4 *sImg = reinterpret_cast<f32x4 *>(sDyn);                 // [(R+2)][W+2]
-    float *sRed = sDyn;                                            // [8][Cout][28], reuses the tile after the loop
-    const int o = threadIdx.x % Cout, j = threadIdx.x / Cout, lanes = 256 / Cout;
+    float *sRed = sDyn;                                            // [4 waves][32][28], reuses the tile after the loop
+    const int og = threadIdx.x & 7, pl = threadIdx.x >> 3;
     const int n = blockIdx.y;
     const long long HW = (long long)H * W;
     const int yBeg = blockIdx.x * rowsPerBlock;
     int yEnd = yBeg + rowsPerBlock; if (yEnd > H) yEnd = H;
-    float acc[28];
+    f32x4 acc[28];                                                 // [tap*3 + c] (27: bias) x 4 output channels
 #pragma unroll
-    for (int k = 0; k < 28; ++k) acc[k] = 0.f;
+    for (int k = 0; k < 28; ++k) acc[k] = f32x4{ 0.f, 0.f, 0.f, 0.f };
     const int W2 = W + 2;
     for (int y0 = yBeg; y0 < yEnd; y0 += R) {
         __syncthreads();
-        for (int idx = threadIdx.x; idx < (R + 2) * W2; idx += 256) {
-            const int r = idx / W2, xx = idx - r * W2 - 1;
-            const int iy = y0 - 1 + r;
-            f32x4 v = { 0.f, 0.f, 0.f, 0.f };
-            if ((unsigned)iy < (unsigned)H && (unsigned)xx < (unsigned)W) {
-                const float *q = img + (long long)n * Cin * HW + (long long)iy * W + xx;
-                v.x = q[0];
-                if (Cin > 1) { v.y = q[HW]; v.z = q[2 * HW]; }
+        // staging in batches of 4 entries per thread: all loads of a batch are in flight before the first LDS write
+        // (clamped addresses + a select instead of a branch around the loads)
+        for (int base = threadIdx.x; base < (R + 2) * W2; base += 4 * 256) {
+            f32x4 v[4];
+            bool ok[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = base + u * 256;
+                const int r = idx / W2, xx = idx - r * W2 - 1;
+                const int iy = y0 - 1 + r;
+                ok[u] = (idx < (R + 2) * W2) & ((unsigned)iy < (unsigned)H) & ((unsigned)xx < (unsigned)W);
+                const int iyc = min(max(iy, 0), H - 1), xc = min(max(xx, 0), W - 1);
+                const float *q = img + (long long)n * Cin * HW + (long long)iyc * W + xc;
+                v[u] = f32x4{ q[0], Cin > 1 ? q[HW] : 0.f, Cin > 1 ? q[2 * HW] : 0.f, 0.f };
             }
-            sImg[idx] = v;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = base + u * 256;
+                if (idx < (R + 2) * W2) sImg[idx] = ok[u] ? v[u] : f32x4{ 0.f, 0.f, 0.f, 0.f };
+            }
         }
         __syncthreads();
         const int rows = (yEnd - y0 < R) ? (yEnd - y0) : R;
-        for (int p = j; p < rows * W; p += lanes) {
+        // rows y0.. are consecutive in memory: pixel p of the step is dyRow + p*ldY.  The load of the next pixel is
+        // issued before the FMAs of the current one (one HBM round trip per iteration otherwise).
+        const float *dyRow = dy + ((long long)n * H + y0) * W * ldY + 4 * og;
+        const int np = rows * W;
+        f32x4 gNext = f32x4{ 0.f, 0.f, 0.f, 0.f };
+        if (pl < np) gNext = *reinterpret_cast<const f32x4 *>(dyRow + (long long)pl * ldY);
+        for (int p = pl; p < np; p += 32) {
             const int ry = p / W, x = p - ry * W;
-            const float g = dy[(((long long)n * H + (y0 + ry)) * W + x) * ldY + o];
+            const f32x4 g = gNext;
+            if (p + 32 < np) gNext = *reinterpret_cast<const f32x4 *>(dyRow + (long long)(p + 32) * ldY);
             acc[27] += g;
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
@@ -809,40 +844,66 @@ void conv1_wgrad_kernel(const float *__restrict__ img, const float *__restrict__
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
                     const f32x4 v = row[kx];
-                    acc[(ky * 3 + kx) * 3 + 0] = fmaf(g, v.x, acc[(ky * 3 + kx) * 3 + 0]);
-                    acc[(ky * 3 + kx) * 3 + 1] = fmaf(g, v.y, acc[(ky * 3 + kx) * 3 + 1]);
-                    acc[(ky * 3 + kx) * 3 + 2] = fmaf(g, v.z, acc[(ky * 3 + kx) * 3 + 2]);
+                    acc[(ky * 3 + kx) * 3 + 0] += g * v.x;
+                    acc[(ky * 3 + kx) * 3 + 1] += g * v.y;
+                    acc[(ky * 3 + kx) * 3 + 2] += g * v.z;
                 }
             }
         }
     }
-    // reduce over the pixel lanes j in fixed order
-    __syncthreads();
+    // fixed-order reduction: the 8 pixel lanes of a wave (lane bits 3..5), then the 4 waves through LDS
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-    for (int k = 0; k < 28; ++k) sRed[(j * Cout + o) * 28 + k] = acc[k];
-    __syncthreads();
-    if (j == 0) {
-        const long long blk = (long long)blockIdx.y * gridDim.x + blockIdx.x;
-        for (int k = 0; k < 28; ++k) {
-            float s = 0.f;
-            for (int jj = 0; jj < lanes; ++jj) s += sRed[(jj * Cout + o) * 28 + k];
-            partial[(blk * 28 + k) * Cout + o] = s;
+    for (int k = 0; k < 28; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v = acc[k][e];
+            v += __shfl_xor(v, 8);
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            acc[k][e] = v;
         }
+    __syncthreads();
+    if (lane < 8) {
+#pragma unroll
+        for (int k = 0; k < 28; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sRed[(wave * CO + 4 * og + e) * 28 + k] = acc[k][e];
+    }
+    __syncthreads();
+    const long long blk = (long long)blockIdx.y * gridDim.x + blockIdx.x;
+    for (int i = threadIdx.x; i < 28 * CO; i += 256) {
+        const int k = i / CO, o = i - k * CO;
+        float s = 0.f;
+        for (int w = 0; w < 4; ++w) s += sRed[(w * CO + o) * 28 + k];
+        partial[(blk * 28 + k) * CO + o] = s;
     }
 }
 
-// out: dW OIHW [Cout][Cin][3][3] and db[Cout] from the block partials
-__global__ void conv1_wgrad_reduce_kernel(const float *__restrict__ partial, float *__restrict__ dw, float *__restrict__ db,
-                                          int blocks, int Cin, int Cout)
+// out: dW OIHW [Cout][Cin][3][3] and db[Cout] from the block partials.  grid (28): one tap/channel slot k per block;
+// 256 threads = 32 output channels x 8 parts, each part sums a contiguous eighth of the blocks (4 loads in flight), the
+// eighths are added in order.  (One thread per output walking all partials serially was a 0.5 ms chain of loads.)
+__global__ __launch_bounds__(256)
+void conv1_wgrad_reduce_kernel(const float *__restrict__ partial, float *__restrict__ dw, float *__restrict__ db,
+                               int blocks, int Cin)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;          // over 28*Cout
-    if (i >= 28 * Cout) return;
-    const int k = i / Cout, o = i - k * Cout;
+    constexpr int CO = 32;
+    __shared__ double sP[8 * CO];
+    const int k = blockIdx.x, o = threadIdx.x & 31, part = threadIdx.x >> 5;
+    const int per = (blocks + 7) >> 3;
+    const int b0 = part * per;
+    int b1 = b0 + per; if (b1 > blocks) b1 = blocks;
     double s = 0.0;
-    for (int b = 0; b < blocks; ++b) s += (double)partial[((long long)b * 28 + k) * Cout + o];
-    if (k == 27) { db[o] = (float)s; return; }
+#pragma unroll 4
+    for (int b = b0; b < b1; ++b) s += (double)partial[((long long)b * 28 + k) * CO + o];
+    sP[part * CO + o] = s;
+    __syncthreads();
+    if (part != 0) return;
+    double t = 0.0;
+    for (int q = 0; q < 8; ++q) t += sP[q * CO + o];
+    if (k == 27) { db[o] = (float)t; return; }
     const int tap = k / 3, c = k - tap * 3;
-    if (c < Cin) dw[((long long)o * Cin + c) * 9 + tap] = (float)s;
+    if (c < Cin) dw[((long long)o * Cin + c) * 9 + tap] = (float)t;
 }
 
 int gnb_threads(int C)
@@ -920,9 +981,10 @@ int xl_run_bwd_op(const xl_op &op, hipStream_t st)
             hipLaunchKernelGGL((head_bwd_kernel<4, 4>), dim3((unsigned)blocks), dim3(256), 0, st, (const float *)op.in,
                                (const float *)op.w, (const float *)op.aux, (const float *)op.aux2, (float *)op.out, pW, pB,
                                op.B, op.Hi * op.Wi, op.Cin, op.ld_in, op.ld_out, op.Cout, op.n_task, op.clamp_lo, op.clamp_hi);
-            hipLaunchKernelGGL(partial_sum_kernel, dim3(8), dim3(256), 0, st, (const float *)pW, (float *)op.out2, waves,
-                               op.Cout * op.Cin);
-            hipLaunchKernelGGL(partial_sum_kernel, dim3(1), dim3(64), 0, st, (const float *)pB, (float *)op.stats, waves, op.Cout);
+            hipLaunchKernelGGL(partial_sum_kernel, dim3((op.Cout * op.Cin + 31) / 32), dim3(256), 0, st, (const float *)pW,
+                               (float *)op.out2, waves, op.Cout * op.Cin);
+            hipLaunchKernelGGL(partial_sum_kernel, dim3((op.Cout + 31) / 32), dim3(256), 0, st, (const float *)pB,
+                               (float *)op.stats, waves, op.Cout);
             return XL_OK;
         }
         case XL_OP_WINO_DY: {
@@ -956,7 +1018,7 @@ int xl_run_bwd_op(const xl_op &op, hipStream_t st)
                                (const float *)op.w, (const float *)op.aux, (const float *)op.aux2, (float *)op.out, part,
                                op.B, op.Hi, op.Wi, op.Cout, op.ld_in, op.ld_out, op.n_task, op.clamp_lo, op.clamp_hi);
             float *tot = part + blocks * len;                           // [len]: weights then bias
-            hipLaunchKernelGGL(partial_sum_kernel, dim3(1), dim3(128), 0, st, (const float *)part, tot, (int)blocks, len);
+            hipLaunchKernelGGL(partial_sum_kernel, dim3((len + 31) / 32), dim3(256), 0, st, (const float *)part, tot, (int)blocks, len);
             if (hipMemcpyAsync(op.out2, tot, sizeof(float) * op.Cout * op.Cout, hipMemcpyDeviceToDevice, st) != hipSuccess ||
                 hipMemcpyAsync(op.stats, tot + op.Cout * op.Cout, sizeof(float) * op.Cout, hipMemcpyDeviceToDevice, st) != hipSuccess)
                 return XL_ERR_HIP;
@@ -964,16 +1026,17 @@ int xl_run_bwd_op(const xl_op &op, hipStream_t st)
         }
         case XL_OP_CONV1_WGRAD: {
             if (op.Cout != 32 || op.Cin > 3) return XL_ERR_UNSUPPORTED;
-            const int rowsPerBlock = 16;
+            const int rowsPerBlock = op.reserved_i > 0 ? op.reserved_i : 16;     // scratch: B*ceil(Hi/rows)*28*Cout floats
+            if (op.ld_aux % 4 != 0) return XL_ERR_ARG;
             const int rb = (op.Hi + rowsPerBlock - 1) / rowsPerBlock;
-            const int blocks = rb * op.B;                                    // scratch: blocks*28*Cout floats
+            const int blocks = rb * op.B;
             size_t lds = sizeof(float) * (size_t)4 * (op.Wi + 2) * 4;
-            if (lds < sizeof(float) * (size_t)8 * op.Cout * 28) lds = sizeof(float) * (size_t)8 * op.Cout * 28;
+            if (lds < sizeof(float) * (size_t)4 * op.Cout * 28) lds = sizeof(float) * (size_t)4 * op.Cout * 28;
             if (lds > 64 * 1024) return XL_ERR_UNSUPPORTED;
             hipLaunchKernelGGL(conv1_wgrad_kernel, dim3(rb, op.B), dim3(256), lds, st, (const float *)op.in, (const float *)op.aux,
-                               (float *)op.stats2, op.B, op.Cin, op.Hi, op.Wi, op.Cout, op.ld_aux, rowsPerBlock);
-            hipLaunchKernelGGL(conv1_wgrad_reduce_kernel, dim3((28 * op.Cout + 255) / 256), dim3(256), 0, st,
-                               (const float *)op.stats2, (float *)op.out, (float *)op.out2, blocks, op.Cin, op.Cout);
+                               (float *)op.stats2, op.B, op.Cin, op.Hi, op.Wi, op.ld_aux, rowsPerBlock);
+            hipLaunchKernelGGL(conv1_wgrad_reduce_kernel, dim3(28), dim3(256), 0, st,
+                               (const float *)op.stats2, (float *)op.out, (float *)op.out2, blocks, op.Cin);
             return XL_OK;
         }
         default:

@@ -364,22 +364,41 @@ void semantics_loss_kernel(SemArgs a)
 
 // out[0] = loss (mean over B*N), out[1] = valid rate, out[2..2+B) = per-image mean loss (reduction=None).
 // `gate`: 1 -> the sum in slot b only counts if any cell of the batch is valid (coord.py:141).
-__global__ void finalize_kernel(const double *partials, int B, int nblk, int N, int gate, float *out)
+// One workgroup of 256 threads: per image, thread t sums the block partials t, t+256, ... and a fixed-order tree
+// finishes (a single thread walking B*nblk partials is a serial chain of load latencies: 21600 of them for a
+// full-resolution semantics batch).
+__global__ __launch_bounds__(256)
+void finalize_kernel(const double *partials, int B, int nblk, int N, int gate, float *out)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    __shared__ double sR[3][256];
+    __shared__ double sImgA[64], sImgB[64];           // per-image sums when B <= 64 (else recomputed below)
+    const int tid = threadIdx.x;
     double totA = 0.0, totB = 0.0, totC = 0.0;
-    for (int b = 0; b < B; ++b)
-        for (int k = 0; k < nblk; ++k) totC += partials[((long long)b * nblk + k) * 4 + 2];
-    const bool useB = !gate || totC > 0.0;
     for (int b = 0; b < B; ++b) {
-        double sa = 0.0, sb = 0.0;
-        for (int k = 0; k < nblk; ++k) {
+        double sa = 0.0, sb = 0.0, sc = 0.0;
+        for (int k = tid; k < nblk; k += 256) {
             const double *p = partials + ((long long)b * nblk + k) * 4;
-            sa += p[0]; sb += p[1];
+            sa += p[0]; sb += p[1]; sc += p[2];
         }
-        const double li = sa + (useB ? sb : 0.0);
-        out[2 + b] = (float)(li / (double)N);
-        totA += sa; totB += sb;
+        sR[0][tid] = sa; sR[1][tid] = sb; sR[2][tid] = sc;
+        __syncthreads();
+        for (int w = 128; w > 0; w >>= 1) {
+            if (tid < w) { sR[0][tid] += sR[0][tid + w]; sR[1][tid] += sR[1][tid + w]; sR[2][tid] += sR[2][tid + w]; }
+            __syncthreads();
+        }
+        if (tid == 0) {
+            totA += sR[0][0]; totB += sR[1][0]; totC += sR[2][0];
+            if (b < 64) { sImgA[b] = sR[0][0]; sImgB[b] = sR[1][0]; }
+        }
+        __syncthreads();
+    }
+    if (tid != 0) return;
+    const bool useB = !gate || totC > 0.0;
+    for (int b = 0; b < B && b < 64; ++b) out[2 + b] = (float)((sImgA[b] + (useB ? sImgB[b] : 0.0)) / (double)N);
+    for (int b = 64; b < B; ++b) {                    // beyond the LDS table: recompute serially (not a hot case)
+        double sa = 0.0, sb = 0.0;
+        for (int k = 0; k < nblk; ++k) { const double *p = partials + ((long long)b * nblk + k) * 4; sa += p[0]; sb += p[1]; }
+        out[2 + b] = (float)((sa + (useB ? sb : 0.0)) / (double)N);
     }
     out[0] = (float)((totA + (useB ? totB : 0.0)) / ((double)B * (double)N));
     out[1] = (float)(totC / ((double)B * (double)N));
@@ -415,7 +434,7 @@ int xl_loss_coord(const float *pred, const float *unc, const float *gt_poses, co
     a.gscale = per_image_scale ? 1.0f / (float)a.N : 1.0f / ((float)B * (float)a.N);
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(coord_loss_kernel, dim3(a.nblk, B), dim3(kT), 0, st, a);
-    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(64), 0, st, workspace, B, a.nblk, a.N, 1, out);
+    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, st, workspace, B, a.nblk, a.N, 1, out);
     return launch_ok();
 }
 
@@ -432,7 +451,7 @@ int xl_loss_depth(const float *pred, const float *unc, const float *gt_depth, in
     a.gscale = per_image_scale ? 1.0f / (float)a.N : 1.0f / ((float)B * (float)a.N);
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(depth_loss_kernel, dim3(a.nblk, B), dim3(kT), 0, st, a);
-    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(64), 0, st, workspace, B, a.nblk, a.N, 0, out);
+    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, st, workspace, B, a.nblk, a.N, 0, out);
     return launch_ok();
 }
 
@@ -448,7 +467,7 @@ int xl_loss_normal(const float *logits, const float *unc, const float *gt_normal
     a.gscale = per_image_scale ? 1.0f / (float)a.N : 1.0f / ((float)B * (float)a.N);
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(normal_loss_kernel, dim3(a.nblk, B), dim3(kT), 0, st, a);
-    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(64), 0, st, workspace, B, a.nblk, a.N, 0, out);
+    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, st, workspace, B, a.nblk, a.N, 0, out);
     return launch_ok();
 }
 
@@ -462,7 +481,7 @@ int xl_loss_semantics(const float *logits, const float *labels, int B, int C, in
     a.gscale = per_image_scale ? 1.0f / (float)a.N : 1.0f / ((float)B * (float)a.N);
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(semantics_loss_kernel, dim3(a.nblk, B), dim3(kT), 0, st, a);
-    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(64), 0, st, workspace, B, a.nblk, a.N, 0, out);
+    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, st, workspace, B, a.nblk, a.N, 0, out);
     return launch_ok();
 }
 

@@ -1043,7 +1043,8 @@ class _Plan:
                 # kernel also produces goes to a scratch vector
                 self.conv1_db_unused = torch.empty(Cout, dtype=torch.float32, device=dev)
                 op.out2 = self.conv1_db_unused.data_ptr()
-                scratch_f = max(scratch_f, B * ((H + 15) // 16) * 28 * Cout)
+                op.reserved_i = 8                                   # image rows per workgroup
+                scratch_f = max(scratch_f, B * ((H + 7) // 8) * 28 * Cout)
                 patch_f.append(len(bops))
                 self.conv1_wgrad_indices.append(len(bops))
                 bops.append(op)

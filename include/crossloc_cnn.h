@@ -43,7 +43,8 @@ enum {
     XL_OP_GNB_APPLY = 7, /* pass 3: dx, optional d(residual) */
     XL_OP_GNB_PARAMS = 8,/* d gamma, d beta and the bias gradient of the preceding conv */
     XL_OP_HEAD_BWD = 9,  /* backward of XL_OP_HEAD: d(input) NHWC, d(fc3 weight), d(fc3 bias) */
-    XL_OP_CONV1_WGRAD = 10, /* weight + bias gradient of the NCHW-input first conv */
+    XL_OP_CONV1_WGRAD = 10, /* weight + bias gradient of the NCHW-input first conv (Cout 32); reserved_i = image rows per
+                               workgroup (default 16), stats2 = scratch of B*ceil(Hi/rows)*28*Cout floats */
     XL_OP_WINO_IN = 12,     /* Winograd input transform: in [B,Hi,Wi,Cin] -> out V [(m+2)^2][B*Ho*Wo][Cin] with Ho x Wo tiles
                                of m x m outputs; ksize = m: 2 = F(2x2,3x3) (Hi, Wi even), 4 = F(4x4,3x3) (Ho = ceil(Hi/4)).
                                m = 4 only: aux2 = per-(image, channel) {scale, shift} pairs of a deferred GroupNorm, applied

@@ -71,7 +71,7 @@ def main():
             op = arr[idx[i]]
             key = names[typ[i]] + ("_dgrad" if (typ[i] == 1 and i >= nf) else "") + ("_bwd" if i >= nf and typ[i] != 1 else "")
             tot[key] = tot.get(key, 0.0) + tms[i]
-            if i >= nf and tms[i] > 1.0:
+            if i >= nf and tms[i] > float(os.environ.get("XL_BENCH_VERBOSE_MS", "1.0")):
                 sys.stderr.write("bwd op %3d %-10s k%d s%d %4d->%4d %3dx%3d  %.3f ms\n" % (
                     idx[i], names[typ[i]], op.ksize, op.stride, op.Cin, op.Cout, op.Hi, op.Wi, tms[i]))
         sys.stderr.write("totals (ms): %s\n" % {k: round(v, 2) for k, v in sorted(tot.items(), key=lambda kv: -kv[1])})
