@@ -38,7 +38,7 @@ CONV512_TRAFFIC_BYTES = {24: (755733 * 2 + 259200) * 1024}
 # by GEMMs per launch, then batch (profiles/r1_wino512_pmc.csv: batch 24, profiles/r1_wino512_b44_pmc.csv: batch 44)
 WINO512_TRAFFIC_BYTES = {16: {24: (762829 * 2 + 1036800) * 1024},
                          36: {24: (472038 * 2 + 596160) * 1024, 44: (832879 * 2 + 1092960) * 1024}}
-WINO_NAME = {16: "F(2x2,3x3)", 36: "F(4x4,3x3)"}
+WINO_NAME = {16: "F(2x2,3x3)", 36: "F(4x4,3x3)", 64: "F(6x6,3x3)"}
 FWD_GFLOP_PER_IMAGE = 295.41        # SURVEY.md §8(d), single-task net, 480x720
 FWD_GFLOP_PER_IMAGE_3ENC = 755.96   # SURVEY.md §8(d), CrossLoc 3-encoder net
 

@@ -235,7 +235,10 @@ class _Plan:
     _WINO_G = {2: ((1.0, 0.0, 0.0), (0.5, 0.5, 0.5), (0.5, -0.5, 0.5), (0.0, 0.0, 1.0)),
                # F(4x4,3x3), interpolation points 0, +-1, +-2, inf
                4: ((1 / 4, 0.0, 0.0), (-1 / 6, -1 / 6, -1 / 6), (-1 / 6, 1 / 6, -1 / 6), (1 / 24, 1 / 12, 1 / 6),
-                   (1 / 24, -1 / 12, 1 / 6), (0.0, 0.0, 1.0))}
+                   (1 / 24, -1 / 12, 1 / 6), (0.0, 0.0, 1.0)),
+               # F(6x6,3x3), interpolation points 0, +-1, +-2, +-1/2, inf (the scaling of Lavin's wincnn set)
+               6: ((1.0, 0.0, 0.0), (-2 / 9, -2 / 9, -2 / 9), (-2 / 9, 2 / 9, -2 / 9), (1 / 90, 1 / 45, 2 / 45),
+                   (1 / 90, -1 / 45, 2 / 45), (1 / 45, 1 / 90, 1 / 180), (1 / 45, -1 / 90, 1 / 180), (0.0, 0.0, 1.0))}
 
     def pack_conv_wino(self, conv, m, dgrad=False):
         """[(m+2)^2][Cout][Cin] transformed weights of a 3x3 convolution: one plain [Cout][Cin] GEMM operand per
@@ -387,23 +390,31 @@ class _Plan:
         return res
 
     def wino_tile(self, act, conv):
-        """Inference plans run the stride-1 3x3 convolutions as Winograd F(4x4,3x3) (4x fewer multiplies; 2.25x for
-        F(2x2,3x3), selected with XL_WINOGRAD=2).  Returns the output tile size m, or 0 for the direct kernel."""
+        """Stride-1 3x3 convolutions run as Winograd F(m x m, 3x3).  Returns the output tile size m, or 0 for the direct
+        kernel.  Inference plans choose between F(6x6,3x3) (64 multiplies per 36 outputs) and F(4x4,3x3) (36 per 16)
+        by the number of multiplies the feature map needs with each tiling - (m+2)^2 * ceil(H/m) * ceil(W/m): 9600 vs
+        12420 per channel pair at 60x90, where 6 divides both sides, but F(4x4) wins on small maps with ragged 6x6
+        tiles.  XL_WINOGRAD=4 / 2 forces F(4x4,3x3) / F(2x2,3x3).  Training plans: F(4x4,3x3) only."""
         t, H, W, C, ld, off = act
         if (conv.kernel_size[0] != 3 or conv.stride[0] != 1 or C % 32 != 0 or H * W < 64
                 or conv.out_channels not in (128, 256, 512, 1024) or os.environ.get("XL_NO_WINOGRAD")):
             return 0
-        m = int(os.environ.get("XL_WINOGRAD", "4"))
-        if self.train and (m != 4 or os.environ.get("XL_NO_WINOGRAD_TRAIN")):
-            return 0                                         # training plans: F(4x4,3x3) only
-        if m in (2, 4):
+        want = int(os.environ.get("XL_WINOGRAD", "6"))
+        if self.train:
+            if os.environ.get("XL_NO_WINOGRAD_TRAIN") or want not in (4, 6):
+                return 0
+            cands = [4]
+        elif want == 2:
+            cands = [2] if not (H % 2 or W % 2) else []
+        else:
+            cands = [m for m in (6, 4) if m <= want]
+            cands.sort(key=lambda m: ((m + 2) ** 2 * -(-H // m) * -(-W // m), -m))
+        for m in cands:
             # the transformed tensors are addressed with 32-bit byte offsets through one buffer descriptor
             T = self.B * -(-H // m) * -(-W // m)
-            if (m + 2) ** 2 * T * max(C, conv.out_channels) * 4 >= 2 ** 31 - 1:
-                return 0
-        if m == 2 and (H % 2 or W % 2):
-            return 0
-        return m if m in (2, 4) else 0
+            if (m + 2) ** 2 * T * max(C, conv.out_channels) * 4 < 2 ** 31 - 1:
+                return m
+        return 0
 
     def conv_wino(self, act, conv, norm, flags, aux, m, deferred=None):
         """conv3x3 + GroupNorm(+epilogue) as F(m x m, 3x3): input transform, (m+2)^2 GEMMs in one batched launch, output
@@ -437,7 +448,8 @@ class _Plan:
         out = self.alloc(B * H * W * cout)
         G = norm.num_groups
         tpb = 32 if m == 2 else 16
-        while tpb > 1 and B * -(-(Th * Tw) // tpb) * max(1, cout // 512) < 1024:
+        zblocks = max(1, cout // (256 if m == 6 else 512))          # channel blocks of the output-transform grid
+        while tpb > 1 and B * -(-(Th * Tw) // tpb) * zblocks < 1024:
             tpb //= 2                                # small batches: more, shorter workgroups (latency-bound otherwise)
         nchunks = -(-(Th * Tw) // tpb)
         op = XlOp()
@@ -492,7 +504,7 @@ class _Plan:
         GN_APPLY pass (one read + one write of the activation) disappears."""
         pend = getattr(self, "pending_gn", {}).pop(self._act_key(act), None)
         m = self.wino_tile(act, conv)
-        if pend is not None and m != 4:
+        if pend is not None and m not in (4, 6):
             self.stats_ops.append(len(self.ops))       # consumer cannot absorb it: materialise now
             self.ops.append(pend)
             pend = None

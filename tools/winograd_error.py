@@ -1,7 +1,8 @@
 """End-to-end output error of the inference network against the reference golden (tests/golden/net_forward.npz,
 generated from the reference's own PyTorch code) for the three forms of the stride-1 3x3 layers: direct implicit GEMM,
-Winograd F(2x2,3x3), Winograd F(4x4,3x3).  Run once per form (the choice is read when a plan is built):
-    XL_NO_WINOGRAD=1 python tools/winograd_error.py ; XL_WINOGRAD=2 python ... ; XL_WINOGRAD=4 python ...
+Winograd F(2x2,3x3), F(4x4,3x3), F(6x6,3x3) (the default where it needs the fewest multiplies).  Run once per form (the
+choice is read when a plan is built):
+    XL_NO_WINOGRAD=1 python tools/winograd_error.py ; XL_WINOGRAD=2 python ... ; XL_WINOGRAD=4 python ... ; python ...
 Also the 480x720 network against a float64 PyTorch-CPU evaluation of the same graph."""
 import os
 import sys
@@ -14,7 +15,7 @@ from crossloc_amd import networks, synth          # noqa: E402
 from crossloc_amd.weights import seeded_state_dict  # noqa: E402
 from oracle import cnn_oracle                       # noqa: E402
 
-form = "direct" if os.environ.get("XL_NO_WINOGRAD") else "winograd F(%sx%s,3x3)" % ((os.environ.get("XL_WINOGRAD", "4"),) * 2)
+form = "direct" if os.environ.get("XL_NO_WINOGRAD") else "winograd F(%sx%s,3x3)" % ((os.environ.get("XL_WINOGRAD", "6"),) * 2)
 MEAN = torch.tensor(synth.SCENE_MEAN, dtype=torch.float32)
 gold = np.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "net_forward.npz"))
 for tag, mlr in (("single", 0), ("mlr3", 3)):
