@@ -35,9 +35,11 @@ PEAK_F32_MFMA_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md: fp
 # PMC counters cannot be read from inside the process, so the profiled value is recorded per batch size.
 CONV512_TRAFFIC_BYTES = {24: (755733 * 2 + 259200) * 1024}
 # the batched Winograd GEMM launch of a 3x3 512->512 layer (profiles/r1_wino512_pmc.csv)
-# by GEMMs per launch, then batch (profiles/r1_wino512_pmc.csv: batch 24, profiles/r1_wino512_b44_pmc.csv: batch 44)
+# by GEMMs per launch, then batch (profiles/r1_wino512_pmc.csv: F(4x4) batch 24, r1_wino512_b44_pmc.csv: F(4x4) batch 44,
+# r1_wino512_f6_b44_pmc.csv: F(6x6) batch 44)
 WINO512_TRAFFIC_BYTES = {16: {24: (762829 * 2 + 1036800) * 1024},
-                         36: {24: (472038 * 2 + 596160) * 1024, 44: (832879 * 2 + 1092960) * 1024}}
+                         36: {24: (472038 * 2 + 596160) * 1024, 44: (832879 * 2 + 1092960) * 1024},
+                         64: {44: (652157 * 2 + 844800) * 1024}}
 WINO_NAME = {16: "F(2x2,3x3)", 36: "F(4x4,3x3)", 64: "F(6x6,3x3)"}
 FWD_GFLOP_PER_IMAGE = 295.41        # SURVEY.md §8(d), single-task net, 480x720
 FWD_GFLOP_PER_IMAGE_3ENC = 755.96   # SURVEY.md §8(d), CrossLoc 3-encoder net
@@ -49,9 +51,9 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=None,
-                    help="images per step per GPU.  44: the batched Winograd GEMM launch has 119 x 4 x 36 = 17136 "
-                         "workgroups = 33.5 rounds of 512 resident ones and the fixed per-launch costs of the ~150 "
-                         "kernels of a forward are amortised over more frames (24: 843, 36: 866, 44: 880 images/s); "
+                    help="images per step per GPU.  44: the batched F(6x6,3x3) GEMM launch has 52 x 4 x 64 = 13312 "
+                         "workgroups = exactly 26 rounds of the 512 resident ones, and the fixed per-launch costs of "
+                         "the ~150 kernels of a forward are amortised over more frames (24: 963, 44: 972-989 images/s); "
                          "47 is the per-launch maximum at 480x720 (32-bit byte offsets).  Default 44; 24 with --mlr 3 "
                          "(the Winograd buffers of the 1536-channel fusion layer stay below 2 GiB)")
     ap.add_argument("--hyps", type=int, default=256)

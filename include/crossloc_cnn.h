@@ -46,8 +46,9 @@ enum {
     XL_OP_CONV1_WGRAD = 10, /* weight + bias gradient of the NCHW-input first conv (Cout 32); reserved_i = image rows per
                                workgroup (default 16), stats2 = scratch of B*ceil(Hi/rows)*28*Cout floats */
     XL_OP_WINO_IN = 12,     /* Winograd input transform: in [B,Hi,Wi,Cin] -> out V [(m+2)^2][B*Ho*Wo][Cin] with Ho x Wo tiles
-                               of m x m outputs; ksize = m: 2 = F(2x2,3x3) (Hi, Wi even), 4 = F(4x4,3x3) (Ho = ceil(Hi/4)).
-                               m = 4 only: aux2 = per-(image, channel) {scale, shift} pairs of a deferred GroupNorm, applied
+                               of m x m outputs; ksize = m: 2 = F(2x2,3x3) (Hi, Wi even), 4 = F(4x4,3x3) (Ho = ceil(Hi/4)), 6 = F(6x6,3x3)
+                               (Ho = ceil(Hi/6)).
+                               m = 4 and 6: aux2 = per-(image, channel) {scale, shift} pairs of a deferred GroupNorm, applied
                                (with ReLU when flags has XL_GN_RELU_IN) to every in-image pixel before the transform */
     XL_OP_WINO_OUT = 13,    /* Winograd output transform + bias (+ GroupNorm partial sums): in M [(m+2)^2][tiles][Cin] ->
                                out [B,Hi,Wi,Cin]; ksize = m; reserved_i = tiles per workgroup, nchunks = workgroups per image */
