@@ -1000,7 +1000,7 @@ template <int VW>
 __global__ __launch_bounds__(256)
 void wino6_out_kernel(const float *__restrict__ M, const float *__restrict__ bias, float *__restrict__ out,
                       double *__restrict__ stats, int B, int H, int W, int C, int ldOut, int Th, int Tw, int tpb,
-                      int G, int nchunks)
+                      int G, int nchunks, int accumulate)
 {
     typedef typename WinoVec<VW>::type V;
     __shared__ double sS[256 * 2 * VW];
@@ -1041,8 +1041,10 @@ void wino6_out_kernel(const float *__restrict__ M, const float *__restrict__ bia
             for (int qI = 0; qI < 6; ++qI) {
                 const int ox = 6 * tx + qI;
                 if (ox >= W) continue;
-                const V v = y[qI] + bv;
-                *reinterpret_cast<V *>(out + (((long long)n * H + oy) * W + ox) * ldOut + cch) = v;
+                V v = y[qI] + bv;
+                V *dst = reinterpret_cast<V *>(out + (((long long)n * H + oy) * W + ox) * ldOut + cch);
+                if (accumulate) v += *dst;                     // data gradients: second producer of a gradient tensor
+                *dst = v;
                 s1 += v; s2 += v * v;
             }
         }
@@ -1586,14 +1588,15 @@ int run_op(const xl_op &op, hipStream_t st)
                 const int Th6 = (op.Hi + 5) / 6, Tw6 = (op.Wi + 5) / 6;
                 const int CB = op.Cin < 256 ? op.Cin : 256;
                 if (op.Cin % 2 != 0 || op.Cin % CB != 0 || 256 % CB != 0 || op.ld_out % 2 != 0 || op.reserved_i < 1 ||
-                    op.nchunks != (Th6 * Tw6 + op.reserved_i - 1) / op.reserved_i || (op.flags & XL_CONV_ACCUMULATE))
+                    op.nchunks != (Th6 * Tw6 + op.reserved_i - 1) / op.reserved_i)
                     return XL_ERR_ARG;
                 if (op.stats && (op.groups < 1 || op.Cin % op.groups != 0 || CB % (op.Cin / op.groups) != 0 ||
                                  CB / (op.Cin / op.groups) > 256))
                     return XL_ERR_ARG;
                 hipLaunchKernelGGL(wino6_out_kernel<1>, dim3(op.nchunks, op.B, op.Cin / CB), dim3(256), 0, st, (const float *)op.in,
                                    (const float *)op.bias, (float *)op.out, (double *)op.stats, op.B, op.Hi, op.Wi, op.Cin,
-                                   op.ld_out, Th6, Tw6, op.reserved_i, op.groups, op.nchunks);
+                                   op.ld_out, Th6, Tw6, op.reserved_i, op.groups, op.nchunks,
+                                   (op.flags & XL_CONV_ACCUMULATE) ? 1 : 0);
                 return XL_OK;
             }
             if (op.ksize == 4) {

@@ -254,13 +254,27 @@ class _Plan:
             self._pack(dst, src, kind)
         return self.packed[key][0]
 
-    def wino_dgrad_ok(self, conv, H, W, C):
-        """Data gradient of a stride-1 3x3 layer as F(4x4,3x3) (C = the layer's input channels = gradient channels)."""
-        T = self.B * -(-H // 4) * -(-W // 4)
-        return (conv.kernel_size[0] == 3 and conv.stride[0] == 1 and C in (128, 256, 512, 1024)
-                and conv.out_channels % 32 == 0 and H * W >= 64
-                and 36 * T * max(C, conv.out_channels) * 4 < 2 ** 31 - 1
-                and not os.environ.get("XL_NO_WINOGRAD") and not os.environ.get("XL_NO_WINOGRAD_TRAIN"))
+    def wino_pick(self, H, W, chan_max, allowed=(6, 4)):
+        """Output tile m of F(m x m, 3x3) for an H x W map: the allowed size (capped by XL_WINOGRAD) with the fewest
+        multiplies, (m+2)^2 * ceil(H/m) * ceil(W/m), whose transformed tensors stay below 2 GiB (32-bit byte offsets
+        through one buffer descriptor); 0 if none."""
+        want = int(os.environ.get("XL_WINOGRAD", "6"))
+        cands = [m for m in allowed if m <= want]
+        cands.sort(key=lambda m: ((m + 2) ** 2 * -(-H // m) * -(-W // m), -m))
+        for m in cands:
+            T = self.B * -(-H // m) * -(-W // m)
+            if (m + 2) ** 2 * T * chan_max * 4 < 2 ** 31 - 1:
+                return m
+        return 0
+
+    def wino_dgrad_m(self, conv, H, W, C):
+        """Data gradient of a stride-1 3x3 layer as F(m x m, 3x3) (C = the layer's input channels = gradient channels):
+        the tile size, or 0 for the direct MODE 1 kernel."""
+        if (conv.kernel_size[0] != 3 or conv.stride[0] != 1 or C not in (128, 256, 512, 1024)
+                or conv.out_channels % 32 != 0 or H * W < 64
+                or os.environ.get("XL_NO_WINOGRAD") or os.environ.get("XL_NO_WINOGRAD_TRAIN")):
+            return 0
+        return self.wino_pick(H, W, max(C, conv.out_channels))
 
     def pack_conv(self, conv, dgrad=False):
         w = conv.weight
@@ -394,27 +408,18 @@ class _Plan:
         kernel.  Inference plans choose between F(6x6,3x3) (64 multiplies per 36 outputs) and F(4x4,3x3) (36 per 16)
         by the number of multiplies the feature map needs with each tiling - (m+2)^2 * ceil(H/m) * ceil(W/m): 9600 vs
         12420 per channel pair at 60x90, where 6 divides both sides, but F(4x4) wins on small maps with ragged 6x6
-        tiles.  XL_WINOGRAD=4 / 2 forces F(4x4,3x3) / F(2x2,3x3).  Training plans: F(4x4,3x3) only."""
+        tiles.  XL_WINOGRAD=4 / 2 forces F(4x4,3x3) / F(2x2,3x3) (the latter for inference only).  Training plans make the
+        same choice, for the forward pass and for both gradients."""
         t, H, W, C, ld, off = act
         if (conv.kernel_size[0] != 3 or conv.stride[0] != 1 or C % 32 != 0 or H * W < 64
                 or conv.out_channels not in (128, 256, 512, 1024) or os.environ.get("XL_NO_WINOGRAD")):
             return 0
         want = int(os.environ.get("XL_WINOGRAD", "6"))
-        if self.train:
-            if os.environ.get("XL_NO_WINOGRAD_TRAIN") or want not in (4, 6):
-                return 0
-            cands = [4]
-        elif want == 2:
-            cands = [2] if not (H % 2 or W % 2) else []
-        else:
-            cands = [m for m in (6, 4) if m <= want]
-            cands.sort(key=lambda m: ((m + 2) ** 2 * -(-H // m) * -(-W // m), -m))
-        for m in cands:
-            # the transformed tensors are addressed with 32-bit byte offsets through one buffer descriptor
-            T = self.B * -(-H // m) * -(-W // m)
-            if (m + 2) ** 2 * T * max(C, conv.out_channels) * 4 < 2 ** 31 - 1:
-                return m
-        return 0
+        if self.train and (os.environ.get("XL_NO_WINOGRAD_TRAIN") or want not in (4, 6)):
+            return 0
+        if want == 2:
+            return 2 if not (H % 2 or W % 2) and 16 * self.B * (H // 2) * (W // 2) * max(C, conv.out_channels) * 4 < 2 ** 31 - 1 else 0
+        return self.wino_pick(H, W, max(C, conv.out_channels))
 
     def conv_wino(self, act, conv, norm, flags, aux, m, deferred=None):
         """conv3x3 + GroupNorm(+epilogue) as F(m x m, 3x3): input transform, (m+2)^2 GEMMs in one batched launch, output
@@ -470,13 +475,13 @@ class _Plan:
             # layer at batch 16) instead of transforming the input again, within a fixed budget
             kept_v = None
             self.kept_v_bytes = getattr(self, "kept_v_bytes", 0)
-            if (m == 4 and conv.weight.requires_grad and self.kept_v_bytes + 4 * V.numel() <= (16 << 30)
+            if (m in (4, 6) and conv.weight.requires_grad and self.kept_v_bytes + 4 * V.numel() <= (16 << 30)
                     and not os.environ.get("XL_NO_KEEP_V") and not os.environ.get("XL_NO_WINOGRAD_WGRAD")):
                 kept_v = V
                 self.kept_v_bytes += 4 * V.numel()
             else:
                 self.free.setdefault(V.numel(), []).append(V)
-            self.tape.append(dict(kind="conv", conv=conv, x=act, raw=y, v=kept_v))
+            self.tape.append(dict(kind="conv", conv=conv, x=act, raw=y, v=kept_v, wm=m))
             return self.gn(y, norm, flags, aux, pre_stats=(stats_t, nchunks))
         self.max_stats = max(self.max_stats, B * nchunks * G * 2)
         self.stats_ops.append(len(self.ops))
@@ -919,30 +924,35 @@ class _Plan:
                 k, s = conv.kernel_size[0], conv.stride[0]
                 bo = 128 if Cout % 128 == 0 else 64
                 bc = 128 if C % 128 == 0 else (64 if C % 64 == 0 else 32)
-                Tw4 = B * -(-H // 4) * -(-W // 4)
-                wino_w = (k == 3 and s == 1 and H * W >= 64 and C % 64 == 0 and Cout % 128 == 0
-                          and 36 * Tw4 * max(C, Cout) * 4 < 2 ** 31 - 1 and Tw4 >= 64
-                          and not os.environ.get("XL_NO_WINOGRAD") and not os.environ.get("XL_NO_WINOGRAD_TRAIN")
-                          and not os.environ.get("XL_NO_WINOGRAD_WGRAD"))
+                wm = 0
+                if (k == 3 and s == 1 and H * W >= 64 and C % 64 == 0 and Cout % 128 == 0
+                        and not os.environ.get("XL_NO_WINOGRAD") and not os.environ.get("XL_NO_WINOGRAD_TRAIN")
+                        and not os.environ.get("XL_NO_WINOGRAD_WGRAD")):
+                    # a V kept by the forward pass fixes the tile size; otherwise the cheapest form for this map
+                    wm = e.get("wm", 0) if e.get("v") is not None else self.wino_pick(H, W, max(C, Cout))
+                Tw4 = B * -(-H // wm) * -(-W // wm) if wm else 0          # tiles = K dimension of the GEMMs
+                wino_w = wm in (4, 6) and Tw4 >= 64
+                nfw = (wm + 2) ** 2
                 if wino_w:
-                    # weight gradient through F(4x4,3x3): V = B^T x B, dM = A dY A^T, 36 GEMMs over the tiles, dg = G^T dU G
-                    Th, Tw = -(-H // 4), -(-W // 4)
+                    # weight gradient through F(m x m,3x3): V = B^T x B, dM = A dY A^T, (m+2)^2 GEMMs over the tiles,
+                    # dg = G^T dU G
+                    Th, Tw = -(-H // wm), -(-W // wm)
                     Vb = e.get("v")
                     if Vb is None:
-                        Vb = self.alloc(36 * Tw4 * C)
+                        Vb = self.alloc(nfw * Tw4 * C)
                         wi = XlOp()
-                        wi.type, wi.ksize = XL_OP_WINO_IN, 4
+                        wi.type, wi.ksize = XL_OP_WINO_IN, wm
                         wi.B, wi.Hi, wi.Wi, wi.Cin, wi.Ho, wi.Wo, wi.ld_in = B, H, W, C, Th, Tw, ld
                         wi.in_, wi.out = t.data_ptr() + 4 * off, Vb.data_ptr()
                         bops.append(wi)
-                    dMb = self.alloc(36 * Tw4 * Cout)
+                    dMb = self.alloc(nfw * Tw4 * Cout)
                     wd = XlOp()
-                    wd.type = XL_OP_WINO_DY
+                    wd.type, wd.ksize = XL_OP_WINO_DY, wm
                     wd.B, wd.Hi, wd.Wi, wd.Cin, wd.Ho, wd.Wo, wd.ld_in = B, H, W, Cout, Th, Tw, Cout
                     wd.in_, wd.out = dy.data_ptr(), dMb.data_ptr()
                     bops.append(wd)
-                    dU = self.alloc(36 * Cout * C)
-                    tiles = 36 * (Cout // bo) * (C // bc)
+                    dU = self.alloc(nfw * Cout * C)
+                    tiles = nfw * (Cout // bo) * (C // bc)
                     steps_total = -(-Tw4 // 32)
                     best, splits = None, 1
                     for cand in range(1, 33):
@@ -955,13 +965,13 @@ class _Plan:
                     wg = XlOp()
                     wg.type = XL_OP_WGRAD
                     wg.B, wg.Hi, wg.Wi, wg.Cin, wg.Ho, wg.Wo, wg.Cout = 1, Tw4, 1, C, Tw4, 1, Cout
-                    wg.ksize, wg.stride, wg.ld_in, wg.ld_aux, wg.groups, wg.nchunks2 = 1, 1, C, Cout, 36, splits
+                    wg.ksize, wg.stride, wg.ld_in, wg.ld_aux, wg.groups, wg.nchunks2 = 1, 1, C, Cout, nfw, splits
                     wg.in_, wg.aux, wg.out = Vb.data_ptr(), dMb.data_ptr(), dU.data_ptr()
-                    scratch_f = max(scratch_f, 36 * splits * Cout * C)
+                    scratch_f = max(scratch_f, nfw * splits * Cout * C)
                     patch_f.append(len(bops))
                     bops.append(wg)
                     wf = XlOp()
-                    wf.type = XL_OP_WINO_WFINAL
+                    wf.type, wf.ksize = XL_OP_WINO_WFINAL, wm
                     wf.Cin, wf.Cout = C, Cout
                     wf.in_, wf.out = dU.data_ptr(), pgrad(conv.weight).data_ptr()
                     bops.append(wf)
@@ -1003,9 +1013,9 @@ class _Plan:
                 else:
                     gx = (self.alloc(B * H * W * C), C, 0)
                     grads[self._key(e["x"])] = gx
-                if self.wino_dgrad_ok(conv, H, W, C):
-                    # dX = conv3x3(dY, flipped kernel, channels swapped) as F(4x4,3x3): 4x fewer multiplies
-                    m = 4
+                m = self.wino_dgrad_m(conv, H, W, C)
+                if m:
+                    # dX = conv3x3(dY, flipped kernel, channels swapped) as F(m x m,3x3): 4x / 5x fewer multiplies
                     Th, Tw = -(-H // m), -(-W // m)
                     T, nf = B * Th * Tw, (m + 2) ** 2
                     Vb = self.alloc(nf * T * Cout)
@@ -1026,6 +1036,8 @@ class _Plan:
                     wo = XlOp()
                     wo.type, wo.ksize = XL_OP_WINO_OUT, m
                     tpb = 16
+                    while tpb > 1 and B * -(-(Th * Tw) // tpb) * max(1, C // (256 if m == 6 else 512)) < 1024:
+                        tpb //= 2
                     wo.B, wo.Hi, wo.Wi, wo.Cin, wo.ld_out, wo.groups = B, H, W, C, gx[1], 1
                     wo.nchunks, wo.reserved_i = -(-(Th * Tw) // tpb), tpb
                     wo.flags = op.flags & CONV_ACCUMULATE

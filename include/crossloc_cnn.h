@@ -55,10 +55,11 @@ enum {
     XL_OP_DUC_HEAD = 14,    /* full-size (semantics) head: x8 pixel shuffle of in [B,Hi,Wi,Cout*64] + bilinear resize to
                                Ho x Wo + fc3 (w [Cout][Cout], bias) + mean (aux) / exp(hardtanh) -> out NCHW [B,Cout,Ho,Wo] */
     XL_OP_DUC_HEAD_BWD = 15, /* backward of XL_OP_DUC_HEAD (pure pixel-shuffle case): d activation, d fc3.weight / bias */
-    XL_OP_WINO_DY = 16,     /* Winograd F(4x4,3x3) weight gradient: in dY [B,Hi,Wi,Cin] -> out dM = A dY A^T [36][tiles][Cin] */
+    XL_OP_WINO_DY = 16,     /* Winograd weight gradient: in dY [B,Hi,Wi,Cin] -> out dM = A dY A^T [(m+2)^2][tiles][Cin]; ksize = m
+                               (6 = F(6x6,3x3); anything else = F(4x4,3x3)) */
     XL_OP_GNB_FINAL = 18,   /* GroupNorm backward, pass 2 (between STATS and APPLY): totals of the chunk sums, per-(image,
                                channel) apply coefficients and the sums XL_OP_GNB_PARAMS turns into d gamma / d beta / d bias */
-    XL_OP_WINO_WFINAL = 17, /* in dU [36][Cout][Cin] -> out dg = G^T dU G, OIHW [Cout][Cin][3][3] */
+    XL_OP_WINO_WFINAL = 17, /* in dU [(m+2)^2][Cout][Cin] -> out dg = G^T dU G, OIHW [Cout][Cin][3][3]; ksize = m as above */
     XL_OP_GN_FINAL = 11  /* per-(image, channel) GroupNorm scale/shift [B][C][2] from the partial sums (out);
                             GN_APPLY with aux2 = that buffer skips its own finalisation.  out2 (training plans):
                             [B][C][2] {mean, rstd} for the GroupNorm backward ops */

@@ -476,9 +476,10 @@ def test_winograd_input_transform_applies_deferred_groupnorm(relu, m):
         _run([bad])
 
 
+@pytest.mark.parametrize("m", [4, 6])
 @pytest.mark.parametrize("cin,cout,B,H,W", [(256, 256, 2, 8, 12), (512, 256, 1, 9, 13), (128, 64, 2, 12, 16)])
-def test_winograd_data_gradient_vs_autograd_and_accumulate(cin, cout, B, H, W):
-    """dX of a stride-1 3x3 convolution as F(4x4,3x3) with the flipped, channel-swapped kernel; written into a channel
+def test_winograd_data_gradient_vs_autograd_and_accumulate(cin, cout, B, H, W, m):
+    """dX of a stride-1 3x3 convolution as F(m x m,3x3) with the flipped, channel-swapped kernel; written into a channel
     slice of a wider gradient tensor, then accumulated a second time."""
     g = torch.Generator().manual_seed(cin + cout + W)
     x = torch.randn(B, cin, H, W, generator=g, dtype=torch.float64, requires_grad=True)
@@ -488,18 +489,20 @@ def test_winograd_data_gradient_vs_autograd_and_accumulate(cin, cout, B, H, W):
     ref = x.grad
     wide = torch.zeros((B, H, W, cin + 64), device="cuda")
     sl = wide[..., 32:32 + cin]
-    U = _wino_weights(w, 4, dgrad=True)
-    _wino_conv(_nhwc(dy).cuda(), U, None, 4, B, H, W, cout, cin, sl, cin + 64)
+    U = _wino_weights(w, m, dgrad=True)
+    _wino_conv(_nhwc(dy).cuda(), U, None, m, B, H, W, cout, cin, sl, cin + 64)
     got = sl.permute(0, 3, 1, 2).cpu().double()
-    _close(got, ref, 3e-5)
+    _close(got, ref, 3e-5 if m == 4 else 6e-5)
     assert float(wide[..., :32].abs().max()) == 0.0 and float(wide[..., 32 + cin:].abs().max()) == 0.0
-    _wino_conv(_nhwc(dy).cuda(), U, None, 4, B, H, W, cout, cin, sl, cin + 64, accumulate=True)
-    _close(sl.permute(0, 3, 1, 2).cpu().double(), 2 * ref, 3e-5)
+    _wino_conv(_nhwc(dy).cuda(), U, None, m, B, H, W, cout, cin, sl, cin + 64, accumulate=True)
+    _close(sl.permute(0, 3, 1, 2).cpu().double(), 2 * ref, 3e-5 if m == 4 else 6e-5)
 
 
-@pytest.mark.parametrize("cin,cout,B,H,W", [(256, 256, 2, 16, 24), (128, 256, 4, 9, 13), (512, 512, 2, 16, 20), (64, 128, 4, 12, 12)])
-def test_winograd_weight_gradient_vs_autograd(cin, cout, B, H, W):
-    """dW of a stride-1 3x3 layer through F(4x4,3x3): V = B^T x B, dM = A dY A^T, 36 batched tile-GEMMs, G^T dU G;
+@pytest.mark.parametrize("m,cin,cout,B,H,W", [(4, 256, 256, 2, 16, 24), (4, 128, 256, 4, 9, 13), (4, 512, 512, 2, 16, 20),
+                                              (4, 64, 128, 4, 12, 12), (6, 256, 256, 3, 18, 24), (6, 128, 256, 6, 9, 13),
+                                              (6, 512, 512, 2, 24, 30), (6, 64, 128, 4, 18, 18)])
+def test_winograd_weight_gradient_vs_autograd(m, cin, cout, B, H, W):
+    """dW of a stride-1 3x3 layer through F(m x m,3x3): V = B^T x B, dM = A dY A^T, (m+2)^2 batched tile-GEMMs, G^T dU G;
     9x13 has partial tiles on both edges."""
     g = torch.Generator().manual_seed(cin * 3 + cout + H)
     x = torch.relu(torch.randn(B, cin, H, W, generator=g))
@@ -507,30 +510,31 @@ def test_winograd_weight_gradient_vs_autograd(cin, cout, B, H, W):
     w = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
     F.conv2d(x.double(), w, padding=1).backward(dy.double())
     ref = w.grad
-    Th, Tw = -(-H // 4), -(-W // 4)
+    Th, Tw = -(-H // m), -(-W // m)
+    nf = (m + 2) ** 2
     T = B * Th * Tw
     xd, dyd = _nhwc(x).cuda(), _nhwc(dy).cuda()
-    V = torch.empty(36 * T * cin, device="cuda")
-    dM = torch.empty(36 * T * cout, device="cuda")
-    dU = torch.empty(36 * cout * cin, device="cuda")
+    V = torch.empty(nf * T * cin, device="cuda")
+    dM = torch.empty(nf * T * cout, device="cuda")
+    dU = torch.empty(nf * cout * cin, device="cuda")
     splits = 2
-    part = torch.empty(36 * splits * cout * cin, device="cuda")
+    part = torch.empty(nf * splits * cout * cin, device="cuda")
     dw = torch.full((cout, cin, 3, 3), float("nan"), device="cuda")
     a = networks.XlOp()
-    a.type, a.ksize = networks.XL_OP_WINO_IN, 4
+    a.type, a.ksize = networks.XL_OP_WINO_IN, m
     a.B, a.Hi, a.Wi, a.Cin, a.Ho, a.Wo, a.ld_in = B, H, W, cin, Th, Tw, cin
     a.in_, a.out = xd.data_ptr(), V.data_ptr()
     d = networks.XlOp()
-    d.type = networks.XL_OP_WINO_DY
+    d.type, d.ksize = networks.XL_OP_WINO_DY, m
     d.B, d.Hi, d.Wi, d.Cin, d.Ho, d.Wo, d.ld_in = B, H, W, cout, Th, Tw, cout
     d.in_, d.out = dyd.data_ptr(), dM.data_ptr()
     wg = networks.XlOp()
     wg.type = networks.XL_OP_WGRAD
     wg.B, wg.Hi, wg.Wi, wg.Cin, wg.Ho, wg.Wo, wg.Cout = 1, T, 1, cin, T, 1, cout
-    wg.ksize, wg.stride, wg.ld_in, wg.ld_aux, wg.groups, wg.nchunks2 = 1, 1, cin, cout, 36, splits
+    wg.ksize, wg.stride, wg.ld_in, wg.ld_aux, wg.groups, wg.nchunks2 = 1, 1, cin, cout, nf, splits
     wg.in_, wg.aux, wg.out, wg.stats2 = V.data_ptr(), dM.data_ptr(), dU.data_ptr(), part.data_ptr()
     f = networks.XlOp()
-    f.type = networks.XL_OP_WINO_WFINAL
+    f.type, f.ksize = networks.XL_OP_WINO_WFINAL, m
     f.Cin, f.Cout = cin, cout
     f.in_, f.out = dU.data_ptr(), dw.data_ptr()
     _run([a, d, wg, f])
