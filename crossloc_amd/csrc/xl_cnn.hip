@@ -1241,6 +1241,65 @@ void head_kernel(const float *__restrict__ in, const float *__restrict__ w, cons
     const int nWaves = (gridDim.x * 256) >> 6;
     const int nq = Cin >> 8;                                  // float4 per lane (Cin / 256), <= 8
     const long long total = (long long)B * HW;
+    if (nq == 2 && Cout <= 4) {
+        // the coordinate head (512 -> 4): the lane's 8 x 4 weights stay in registers across the pixel loop (re-reading
+        // them per pixel made 8 of the 10 loads of a pixel weight loads), two pixels in flight per iteration
+        f32x4 wr[4][2];
+#pragma unroll
+        for (int o = 0; o < 4; ++o)
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                wr[o][q] = o < Cout ? *reinterpret_cast<const f32x4 *>(w + (long long)o * Cin + q * 256 + lane * 4)
+                                    : f32x4{ 0.f, 0.f, 0.f, 0.f };
+        for (long long p0 = waveGlobal; p0 < total; p0 += 2LL * nWaves) {
+            const long long p1 = p0 + nWaves;
+            const bool two = p1 < total;
+            const long long p1c = two ? p1 : p0;
+            f32x4 v[2][2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                v[0][q] = *reinterpret_cast<const f32x4 *>(in + p0 * ldIn + q * 256 + lane * 4);
+                v[1][q] = *reinterpret_cast<const f32x4 *>(in + p1c * ldIn + q * 256 + lane * 4);
+            }
+            float acc[2][4];
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int o = 0; o < 4; ++o) {
+                    float t = 0.f;
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        t = fmaf(v[u][q].x, wr[o][q].x, t); t = fmaf(v[u][q].y, wr[o][q].y, t);
+                        t = fmaf(v[u][q].z, wr[o][q].z, t); t = fmaf(v[u][q].w, wr[o][q].w, t);
+                    }
+                    acc[u][o] = t;
+                }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1)
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int o = 0; o < 4; ++o) acc[u][o] += __shfl_xor(acc[u][o], off);
+            if (lane < 2 * Cout) {
+                const int u = lane / Cout, o = lane - u * Cout;
+                if (u == 0 || two) {
+                    float r = 0.f;
+#pragma unroll
+                    for (int uu = 0; uu < 2; ++uu)
+#pragma unroll
+                        for (int oo = 0; oo < 4; ++oo) if (uu == u && oo == o) r = acc[uu][oo];
+                    r += bias[o];
+                    if (o < nTask) r += mean[o];
+                    else r = expf(fminf(fmaxf(r, lo), hi));
+                    const long long p = u ? p1 : p0;
+                    const int n = (int)(p / HW);
+                    const int pix = (int)(p - (long long)n * HW);
+                    out[((long long)n * Cout + o) * HW + pix] = r;
+                }
+            }
+        }
+        return;
+    }
     for (long long p = waveGlobal; p < total; p += nWaves) {
         float acc[COUT_MAX];
 #pragma unroll
