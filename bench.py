@@ -117,6 +117,13 @@ def main():
     sub_b = [round((i + 1) * B / n_sub) - round(i * B / n_sub) for i in range(n_sub)]
     plan = net._plans[(sub_b[0], H, IMW, dev.index, False, 1)]           # sub-batch 0 (all sub-batches have the same ops)
     n_ops = len(plan.op_array)
+    # events only around the launches the roofline object reports (the batched Winograd GEMMs; the conv ops when the
+    # plan has none), every op with XL_BENCH_VERBOSE: ~100 extra event pairs per step cost 1.5 % of the step
+    has_wino = any(op.type == 1 and op.nchunks2 > 1 for op in plan.ops)
+    if os.environ.get("XL_BENCH_VERBOSE"):
+        L.xl_cnn_prof_filter(-1, 0)
+    else:
+        L.xl_cnn_prof_filter(1, 2 if has_wino else 0)
     L.xl_cnn_prof_begin(n_ops * K * n_sub)
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True),

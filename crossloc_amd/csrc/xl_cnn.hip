@@ -1430,6 +1430,7 @@ struct ProfRec { hipEvent_t a, b; int opIndex; int type; };
 ProfRec *g_prof = nullptr;
 int g_profCap = 0, g_profCount = 0;
 bool g_profOn = false;
+int g_profType = -1, g_profMinBatched = 0;     // record only ops of this type (-1: all) with nchunks2 >= the minimum
 
 template <int KS, int STRIDE, int BN, int CIN, int MODE = 0, int BM = 128, int ZB = 0>
 int launch_igemm(const xl_op &op, hipStream_t st, int py = 0, int px = 0)
@@ -1752,7 +1753,8 @@ int xl_cnn_run(const xl_op *ops, int n_ops, void *stream)
     if (!ops || n_ops < 0) return XL_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     for (int i = 0; i < n_ops; ++i) {
-        const bool rec = g_profOn && g_profCount < g_profCap;
+        const bool rec = g_profOn && g_profCount < g_profCap && (g_profType < 0 || ops[i].type == g_profType) &&
+                         ops[i].nchunks2 >= g_profMinBatched;
         if (rec) (void)hipEventRecord(g_prof[g_profCount].a, st);
         const int rc = run_op(ops[i], st);
         if (rc != XL_OK) return rc;
@@ -1807,6 +1809,8 @@ int xl_cnn_prof_begin(int max_records)
 }
 
 int xl_cnn_prof_pause(int on) { g_profOn = (on != 0) && g_prof; return XL_OK; }
+
+int xl_cnn_prof_filter(int op_type, int min_nchunks2) { g_profType = op_type; g_profMinBatched = min_nchunks2; return XL_OK; }
 
 int xl_cnn_prof_end(int32_t *op_index, int32_t *op_type, float *ms, int capacity)
 {

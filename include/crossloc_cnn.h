@@ -127,9 +127,12 @@ int xl_cnn_pack_conv_weight_dgrad(const float *w_oihw_dev, float *w_dgrad_dev, i
 /* Per-op HIP-event timing for measurement (bench.py): between prof_begin and prof_end every op launched by
  * xl_cnn_run is bracketed by two events on its own stream (up to max_records ops).  prof_end waits for the
  * recorded events, writes (index in the op list, op type, elapsed ms) per record and returns the record count
- * (or a negative status); prof_pause(0/1) suspends/resumes recording. */
+ * (or a negative status); prof_pause(0/1) suspends/resumes recording; prof_filter restricts recording to ops of one
+ * type (-1: all) whose nchunks2 is at least the given value (2: the batched Winograd GEMM launches only), so that a
+ * throughput run pays the two event records only around the launches it reports. */
 int xl_cnn_prof_begin(int max_records);
 int xl_cnn_prof_pause(int on);
+int xl_cnn_prof_filter(int op_type, int min_nchunks2);
 int xl_cnn_prof_end(int32_t *op_index, int32_t *op_type, float *ms, int capacity);
 
 /* Text of the last HIP failure reported by an xl_cnn_* call on this thread. */
