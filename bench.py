@@ -53,7 +53,7 @@ def main():
     ap.add_argument("--batch", type=int, default=None,
                     help="images per step per GPU.  44: the batched F(6x6,3x3) GEMM launch has 52 x 4 x 64 = 13312 "
                          "workgroups = exactly 26 rounds of the 512 resident ones, and the fixed per-launch costs of "
-                         "the ~150 kernels of a forward are amortised over more frames (24: 963, 44: 972-989 images/s); "
+                         "the ~100 kernels of a forward are amortised over more frames (24: 997, 44: 1006 images/s); "
                          "47 is the per-launch maximum at 480x720 (32-bit byte offsets).  Default 44; 24 with --mlr 3 "
                          "(the Winograd buffers of the 1536-channel fusion layer stay below 2 GiB)")
     ap.add_argument("--hyps", type=int, default=256)
