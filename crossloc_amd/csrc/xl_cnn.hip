@@ -32,6 +32,7 @@
 #include "../../include/crossloc_dsac.h"   // status codes
 
 int xl_run_bwd_op(const xl_op &op, hipStream_t st);   // xl_cnn_bwd.hip
+int xl_run_split_gemm(const xl_op &op, hipStream_t st);   // xl_gemm_split.hip
 
 namespace {
 
@@ -929,8 +930,25 @@ __device__ __forceinline__ void wino6_at(const V (&m)[8], V (&o)[6])
     o[5] = d12 + 32.f * d34 + d56 + m[7];
 }
 
-// one tile x 2 channels per thread; DEFER as in wino4_in_kernel
-template <int DEFER>
+// fp32 -> bf16 (round to nearest even) and back; a = h1 + h2 + h3 splits 24 mantissa bits exactly
+__device__ __forceinline__ unsigned bf16_rn(float x)
+{
+    unsigned u = __builtin_bit_cast(unsigned, x);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+__device__ __forceinline__ float bf16_f(unsigned h) { return __builtin_bit_cast(float, h << 16); }
+__device__ __forceinline__ void bf16_split3(float a, unsigned &h1, unsigned &h2, unsigned &h3)
+{
+    h1 = bf16_rn(a);
+    const float r1 = a - bf16_f(h1);
+    h2 = bf16_rn(r1);
+    h3 = bf16_rn(r1 - bf16_f(h2));
+}
+
+// one tile x 2 channels per thread; DEFER as in wino4_in_kernel.  SPLIT: V is written as three bf16 planes
+// ([plane][64][tiles][C], the operand form of csrc/xl_gemm_split.hip) instead of fp32.
+template <int DEFER, int SPLIT = 0>
 __global__ __launch_bounds__(256)
 void wino6_in_kernel(const float *__restrict__ in, float *__restrict__ V, int B, int H, int W, int C, int ldIn, int Th, int Tw,
                      const float *__restrict__ coeff)
@@ -976,6 +994,24 @@ void wino6_in_kernel(const float *__restrict__ in, float *__restrict__ V, int B,
             wino6_bt(col, o);
 #pragma unroll
             for (int i = 0; i < 8; ++i) w[i][b] = o[i];
+        }
+        if (SPLIT) {
+            unsigned *op = reinterpret_cast<unsigned *>(V) + ((t * C + 2 * c2) >> 1);      // 2 bf16 per 32-bit word
+            const long long plane = (64 * zs) >> 1;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                f32x2 o[8];
+                wino6_bt(w[i], o);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    unsigned a1, a2, a3, b1, b2, b3;
+                    bf16_split3(o[j][0], a1, a2, a3);
+                    bf16_split3(o[j][1], b1, b2, b3);
+                    unsigned *q = op + (((8 * i + j) * zs) >> 1);
+                    q[0] = a1 | (b1 << 16); q[plane] = a2 | (b2 << 16); q[2 * plane] = a3 | (b3 << 16);
+                }
+            }
+            continue;
         }
         float *op = V + t * C + 2 * c2;
 #pragma unroll
@@ -1559,6 +1595,7 @@ int run_conv(const xl_op &op, hipStream_t st)
         if (small) return wide ? XL_FWD(3, 2, 128, 0, 64) : XL_FWD(3, 2, 64, 0, 64);
         return wide ? XL_FWD(3, 2, 128, 0, 128) : XL_FWD(3, 2, 64, 0, 128);
     }
+    if (op.flags & XL_CONV_SPLIT_BF16) return xl_run_split_gemm(op, st);
     if (op.ksize == 1 && op.stride == 1 && op.nchunks2 > 1) {         // Winograd: nchunks2 GEMMs in one launch
         if (!wide) return XL_ERR_UNSUPPORTED;
         if (small) return op.Cin == 512 ? launch_igemm<1, 1, 128, 512, 0, 64, 1>(op, st) : launch_igemm<1, 1, 128, 0, 0, 64, 1>(op, st);
@@ -1617,6 +1654,8 @@ int run_op(const xl_op &op, hipStream_t st)
                 long long blocks6 = (items6 + 255) / 256;
                 if (blocks6 > 262144) blocks6 = 262144;
                 auto kin = !op.aux2 ? wino6_in_kernel<0> : (op.flags & XL_GN_RELU_IN) ? wino6_in_kernel<2> : wino6_in_kernel<1>;
+                if (op.flags & XL_CONV_SPLIT_BF16)
+                    kin = !op.aux2 ? wino6_in_kernel<0, 1> : (op.flags & XL_GN_RELU_IN) ? wino6_in_kernel<2, 1> : wino6_in_kernel<1, 1>;
                 hipLaunchKernelGGL(kin, dim3((unsigned)blocks6), dim3(256), 0, st, (const float *)op.in,
                                    (float *)op.out, op.B, op.Hi, op.Wi, op.Cin, op.ld_in, op.Ho, op.Wo,
                                    (const float *)op.aux2);

@@ -28,7 +28,7 @@ XL_OP_WINO_IN, XL_OP_WINO_OUT = 12, 13
 XL_OP_DUC_HEAD = 14
 XL_OP_DUC_HEAD_BWD = 15
 XL_OP_WINO_DY, XL_OP_WINO_WFINAL, XL_OP_GNB_FINAL = 16, 17, 18
-CONV_DGRAD, CONV_ACCUMULATE = 1, 2
+CONV_DGRAD, CONV_ACCUMULATE, CONV_SPLIT_BF16 = 1, 2, 64
 
 
 class XlOp(ctypes.Structure):
@@ -186,6 +186,7 @@ class _Plan:
         # conv tile, i.e. by the position of a frame inside the batch): results bitwise independent of the batch
         self.separate_stats = bool(getattr(net, "batch_invariant", False) or os.environ.get("XL_NO_FUSED_STATS"))
         self.ops = []
+        self.packed_split = {}
         self.keep = []                      # tensors the op pointers reference
         self.free = {}                      # numel -> [tensor]
         self.packed = {}                    # (id(param), kind) -> packed weight tensor
@@ -254,6 +255,22 @@ class _Plan:
             self._pack(dst, src, kind)
         return self.packed[key][0]
 
+    @staticmethod
+    def split_bf16(x):
+        """fp32 tensor -> [3, ...] bf16 planes with x = p0 + p1 + p2 exactly (8 + 8 + 8 mantissa bits), as int16 storage."""
+        p0 = x.to(torch.bfloat16)
+        r1 = x - p0.to(torch.float32)
+        p1 = r1.to(torch.bfloat16)
+        p2 = (r1 - p1.to(torch.float32)).to(torch.bfloat16)
+        return torch.stack([p0, p1, p2]).contiguous().view(torch.int16)
+
+    def pack_conv_wino_split(self, conv, m):
+        """The transformed weights of pack_conv_wino as three bf16 planes (operands of csrc/xl_gemm_split.hip)."""
+        key = (id(conv.weight), "wino%d_split" % m)
+        if key not in self.packed_split:
+            self.packed_split[key] = self.split_bf16(self.pack_conv_wino(conv, m))
+        return self.packed_split[key]
+
     def wino_pick(self, H, W, chan_max, allowed=(6, 4)):
         """Output tile m of F(m x m, 3x3) for an H x W map: the allowed size (capped by XL_WINOGRAD) with the fewest
         multiplies, (m+2)^2 * ceil(H/m) * ceil(W/m), whose transformed tensors stay below 2 GiB (32-bit byte offsets
@@ -312,6 +329,8 @@ class _Plan:
         GroupNorm affine parameters and fc3 are read through pointers to the live parameters."""
         for dst, src, kind in self.packed.values():
             self._pack(dst, src, kind)
+        for (wid, kind), planes in self.packed_split.items():
+            planes.copy_(self.split_bf16(self.packed[(wid, kind[:-len("_split")])][0]))
 
     def dev(self, p):
         t = p.detach().to(device=self.device, dtype=torch.float32).contiguous()
@@ -429,14 +448,19 @@ class _Plan:
         Th, Tw = -(-H // m), -(-W // m)
         T = B * Th * Tw
         nf = (m + 2) ** 2
-        V = self.alloc(nf * T * C)
+        # opt-in: the GEMMs on the bf16 matrix pipe with every fp32 operand split into three bf16 terms (fp32-accurate)
+        split = (m == 6 and not self.train and bool(os.environ.get("XL_GEMM_SPLIT_BF16")) and C % 32 == 0
+                 and nf * T * max(C, cout) * 6 < 2 ** 31 - 1)
+        V = self.alloc(nf * T * C * 3 // 2 if split else nf * T * C)
         op = XlOp()
         op.type = XL_OP_WINO_IN
         op.ksize = m
         op.B, op.Hi, op.Wi, op.Cin, op.Ho, op.Wo, op.ld_in = B, H, W, C, Th, Tw, ld
         op.in_, op.out = t.data_ptr() + 4 * off, V.data_ptr()
+        if split:
+            op.flags = CONV_SPLIT_BF16
         if deferred is not None:                      # the producer's GroupNorm(+ReLU) is applied while gathering
-            op.flags = deferred.flags
+            op.flags |= deferred.flags
             self.deferred_gn_consumers = getattr(self, "deferred_gn_consumers", []) + [len(self.ops)]
         self.ops.append(op)
         Mb = self.alloc(nf * T * cout)
@@ -445,6 +469,8 @@ class _Plan:
         op.B, op.Hi, op.Wi, op.Cin, op.Ho, op.Wo, op.Cout = B, Th, Tw, C, Th, Tw, cout
         op.ksize, op.stride, op.ld_in, op.ld_out, op.nchunks2 = 1, 1, C, cout, nf
         op.in_, op.w, op.out = V.data_ptr(), self.pack_conv_wino(conv, m).data_ptr(), Mb.data_ptr()
+        if split:
+            op.flags, op.w = CONV_SPLIT_BF16, self.pack_conv_wino_split(conv, m).data_ptr()
         if -(-T // 128) * (cout // 128) * nf <= 256:
             op.reserved_i = 64
         self.ops.append(op)

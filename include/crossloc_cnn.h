@@ -65,6 +65,10 @@ enum {
                             [B][C][2] {mean, rstd} for the GroupNorm backward ops */
 };
 
+/* xl_op.flags for XL_OP_CONV / XL_OP_WINO_IN (opt-in split-bf16 GEMMs, csrc/xl_gemm_split.hip): the batched GEMM reads
+ * its operands as three bf16 planes per fp32 value (a = a1 + a2 + a3, exact) and multiplies six term pairs on the bf16
+ * matrix pipe with fp32 accumulation; XL_OP_WINO_IN (ksize 6) with the flag writes V in that form. */
+#define XL_CONV_SPLIT_BF16 64
 /* xl_op.flags for XL_OP_CONV */
 #define XL_CONV_DGRAD 1        /* data gradient: `in` is dY (Hi x Wi x Cin = forward output), result is dX; weights
                                   packed with xl_cnn_pack_conv_weight_dgrad; `stride` is the forward stride */

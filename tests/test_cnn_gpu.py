@@ -434,6 +434,62 @@ def test_winograd_conv_with_statistics_vs_float64(m, cin, cout, B, H, W):
     assert torch.allclose(st[..., 1], (y * y).sum((2, 3)), rtol=1e-5, atol=2e-3)
 
 
+@pytest.mark.parametrize("cin,cout,B,H,W", [(512, 512, 2, 12, 18), (256, 512, 1, 10, 14), (512, 512, 2, 60, 90), (1536, 512, 1, 8, 12)])
+def test_winograd_split_bf16_gemm_matches_float64_like_fp32(cin, cout, B, H, W):
+    """Opt-in GEMM path (csrc/xl_gemm_split.hip): V and U as three bf16 planes each (exact 24-bit splits), six bf16 MFMA
+    passes with fp32 accumulation.  Same tolerance as the fp32-MFMA F(6x6,3x3) path, and the two paths agree with each
+    other far below it: the error is Winograd's, not the GEMM's."""
+    m = 6
+    g = torch.Generator().manual_seed(cin + cout + H)
+    x = torch.relu(torch.randn(B, cin, H, W, generator=g))
+    w = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (9 * cin)) ** 0.5
+    b = torch.randn(cout, generator=g)
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    Th, Tw = -(-H // m), -(-W // m)
+    T, nf = B * Th * Tw, 64
+    xd = _nhwc(x).cuda()
+    U = _wino_weights(w, m)
+    planes = networks._Plan.split_bf16(U)
+    assert torch.equal(planes.view(torch.bfloat16).float().sum(0), U)          # the split is exact
+    outs, Ms, V32 = [], [], None
+    for split in (False, True):
+        V = torch.zeros(nf * T * cin * (3 if split else 2) // 2, device="cuda")
+        Mb = torch.full((nf * T * cout,), float("nan"), device="cuda")
+        out = torch.full((B, H, W, cout), float("nan"), device="cuda")
+        a = networks.XlOp()
+        a.type, a.ksize = networks.XL_OP_WINO_IN, m
+        a.B, a.Hi, a.Wi, a.Cin, a.Ho, a.Wo, a.ld_in = B, H, W, cin, Th, Tw, cin
+        a.in_, a.out = xd.data_ptr(), V.data_ptr()
+        gm = networks.XlOp()
+        gm.type = networks.XL_OP_CONV
+        gm.B, gm.Hi, gm.Wi, gm.Cin, gm.Ho, gm.Wo, gm.Cout = B, Th, Tw, cin, Th, Tw, cout
+        gm.ksize, gm.stride, gm.ld_in, gm.ld_out, gm.nchunks2 = 1, 1, cin, cout, nf
+        gm.in_, gm.w, gm.out = V.data_ptr(), (planes if split else U).data_ptr(), Mb.data_ptr()
+        if split:
+            a.flags = gm.flags = networks.CONV_SPLIT_BF16
+        o = networks.XlOp()
+        o.type, o.ksize = networks.XL_OP_WINO_OUT, m
+        o.B, o.Hi, o.Wi, o.Cin, o.ld_out, o.groups = B, H, W, cout, cout, 1
+        o.nchunks, o.reserved_i = -(-(Th * Tw) // 16), 16
+        o.in_, o.out, o.bias = Mb.data_ptr(), out.data_ptr(), b.cuda().data_ptr()
+        bias_keep = b.cuda()
+        o.bias = bias_keep.data_ptr()
+        _run([a, gm, o])
+        outs.append(out.permute(0, 3, 1, 2).cpu().double())
+        Ms.append(Mb.view(nf, T, cout).double())
+        if not split:
+            V32 = V.view(nf, T, cin).double()
+    assert torch.isfinite(outs[1]).all()
+    _close(outs[1], ref, 6e-5)
+    _close(outs[1], outs[0], 6e-5)            # two roundings of the same ill-conditioned transform chain
+    # the GEMM itself: both paths against a float64 product of the same fp32 operands - the split path is fp32-class
+    Mref = torch.matmul(V32, U.view(nf, cout, cin).double().transpose(1, 2))
+    scale = Mref.abs().max().item()
+    e32 = (Ms[0] - Mref).abs().max().item() / scale
+    esp = (Ms[1] - Mref).abs().max().item() / scale
+    assert esp < 2e-6 and esp < 4 * e32 + 2e-7, (esp, e32)
+
+
 @pytest.mark.parametrize("m", [4, 6])
 @pytest.mark.parametrize("relu", [True, False])
 def test_winograd_input_transform_applies_deferred_groupnorm(relu, m):
