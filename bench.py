@@ -29,17 +29,49 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+
+def kernel_source_hash():
+    """sha256 (first 16 hex digits) of the conv kernel source: ties a traffic record to the code it was measured on."""
+    import hashlib
+    with open(os.path.join(ROOT, "crossloc_amd", "csrc", "xl_cnn.hip"), "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
+
+
+def lookup_traffic(form, frames):
+    """(bytes per launch or None, provenance string) for the dominant kernel in `form` ('wino64', 'wino36', 'direct')."""
+    try:
+        with open(TRAFFIC_JSON) as f:
+            recs = json.load(f)["records"]
+    except (OSError, ValueError, KeyError):
+        return None, "profiles/traffic.json missing"
+    for r in recs:
+        if r["form"] == form and r["frames_per_launch"] == frames:
+            stale = r.get("kernel_source_sha256_16") != kernel_source_hash()
+            return int(r["bytes_per_launch"]), "%s%s" % (r["source"], " (STALE: measured on an older xl_cnn.hip)" if stale else "")
+    return None, "no record for %s at %d frames per launch in profiles/traffic.json" % (form, frames)
+
+
+def gather_and_median(local_err, world, dist=None, group=None):
+    """Per-image (t_err [m], r_err [deg]) rows of every rank -> (median cm, median deg, rows gathered).  Equal shards
+    (each rank localises batch x steps images), ONE all-gather (RCCL on GPU tensors, gloo on CPU tensors in the test);
+    the median is not decomposable, hence gather not reduce."""
+    import torch
+    if world > 1:
+        gathered = [torch.empty_like(local_err) for _ in range(world)]
+        dist.all_gather(gathered, local_err, group=group)
+        allerr = torch.cat(gathered, 0)
+    else:
+        allerr = local_err
+    return (float(torch.median(allerr[:, 0]).item() * 100.0), float(torch.median(allerr[:, 1]).item()),
+            int(allerr.shape[0]))
+
+
 PEAK_F32_MFMA_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md: fp32-input MFMA = vector fp32 peak
-# HBM-side bytes per launch of the dominant kernel from rocprofv3 PMC passes (profiles/r1_conv512_pmc.csv):
-# FETCH_SIZE (KB, doubled per the gfx950 note of MI355X_MICROARCH.md §HBM) + WRITE_SIZE (KB), batch 24.
-# PMC counters cannot be read from inside the process, so the profiled value is recorded per batch size.
-CONV512_TRAFFIC_BYTES = {24: (755733 * 2 + 259200) * 1024}
-# the batched Winograd GEMM launch of a 3x3 512->512 layer (profiles/r1_wino512_pmc.csv)
-# by GEMMs per launch, then batch (profiles/r1_wino512_pmc.csv: F(4x4) batch 24, r1_wino512_b44_pmc.csv: F(4x4) batch 44,
-# r1_wino512_f6_b44_pmc.csv: F(6x6) batch 44)
-WINO512_TRAFFIC_BYTES = {16: {24: (762829 * 2 + 1036800) * 1024},
-                         36: {24: (472038 * 2 + 596160) * 1024, 44: (832879 * 2 + 1092960) * 1024},
-                         64: {44: (652157 * 2 + 844800) * 1024}}
+# HBM-side bytes per launch of the dominant kernel cannot be read from inside the process (PMC counters need
+# rocprofv3): they come from the committed record profiles/traffic.json, written by tools/traffic_record.py from the
+# rocprofv3 PMC passes (FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md §HBM, + WRITE_SIZE), keyed by
+# kernel form and frames per launch, and carrying the hash of the kernel source it was measured on.
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "traffic.json")
 WINO_NAME = {16: "F(2x2,3x3)", 36: "F(4x4,3x3)", 64: "F(6x6,3x3)"}
 FWD_GFLOP_PER_IMAGE = 295.41        # SURVEY.md §8(d), single-task net, 480x720
 FWD_GFLOP_PER_IMAGE_3ENC = 755.96   # SURVEY.md §8(d), CrossLoc 3-encoder net
@@ -65,6 +97,9 @@ def main():
     ap.add_argument("--mlr", type=int, default=0, choices=[0, 3],
                     help="3: BASELINE configs[4], the 3-encoder CrossLoc network (755.96 GFLOP per frame) instead of "
                          "the single-task one the headline metric is quoted on")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the secondary configurations (BASELINE configs[1] batch-16 training step vs PyTorch-ROCm "
+                         "eager, configs[4] 3-encoder network) that N=1 runs report outside the timed region")
     args = ap.parse_args()
     if args.batch is None:
         args.batch = 24 if args.mlr else 44
@@ -78,10 +113,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
+    rccl_ranks = 1
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))       # "nccl" IS RCCL on ROCm
+        rccl_ranks = dist.get_world_size()
+        assert dist.get_backend() == "nccl" and rccl_ranks == world, (dist.get_backend(), rccl_ranks, world)
+        if world != args.gpus:
+            raise SystemExit("bench.py --gpus %d launched with WORLD_SIZE=%d" % (args.gpus, world))
+        probe = torch.ones(1, device=torch.device("cuda", local_rank))
+        dist.all_reduce(probe)                                                # one RCCL collective before the timed region
+        assert int(probe.item()) == world, "RCCL all-reduce over %d ranks returned %s" % (world, probe.item())
+    elif args.gpus != 1:
+        raise SystemExit("bench.py --gpus %d needs torch.distributed.run with %d ranks (WORLD_SIZE is 1)" % (args.gpus, args.gpus))
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
@@ -101,9 +146,12 @@ def main():
     # step s runs on a side stream under the CNN of step s+1 (evaluation.PipelinedLocalizer)
     pipe = evaluation.PipelinedLocalizer(net, NH, synth.FOCAL, H, IMW, cnn_streams=args.cnn_streams)
 
+    # The solver consumes the network's OWN output tensor (the strided NCHW view pred[:, :3], produced on the CNN stream,
+    # read on the solver stream) like test_single_task.py:347-363.  Untrained weights do not predict a scene, so the
+    # synthetic scene coordinates are written into the coordinate channels of that tensor after the head (`plant`).
     def step(s):
         image0 = (s * world + rank) * B                                   # global image index keys the sampler
-        return pipe.submit(images, image0=image0, scene_coords=coords)
+        return pipe.submit(images, image0=image0, plant=coords)
 
     for s in range(W):
         step(s)
@@ -135,7 +183,7 @@ def main():
     t0 = time.perf_counter()
     for s in range(K):
         ev[s][0].record(pipe.cnn[0])
-        pred, done = pipe.forward_cnn(images)
+        pred, done = pipe.forward_cnn(images, plant=coords)
         ev[s][1].record(pipe.cnn[0])                                     # stream 0 joins the others before the concat
         poses = torch.zeros((B, 4, 4), dtype=torch.float32, device=dev)
         for e in done:
@@ -143,7 +191,7 @@ def main():
         pipe.side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(pipe.side):
             ev[s][2].record()
-            dsacstar.forward_rgb_batch(coords, poses, NH, 10.0, synth.FOCAL, IMW / 2.0, H / 2.0, 100.0, 100.0, 8,
+            dsacstar.forward_rgb_batch(pred[:, :3], poses, NH, 10.0, synth.FOCAL, IMW / 2.0, H / 2.0, 100.0, 100.0, 8,
                                        image0=(s * world + rank) * B)
             ev[s][3].record()
         pred.record_stream(pipe.side)
@@ -200,21 +248,22 @@ def main():
     t_err, r_err = evaluation.pose_errors(gt_poses.repeat(K, 1, 1), est)
     local = torch.stack([t_err, r_err], 1)
     total_imgs = world * B * K
-    if world > 1:
-        gathered = [torch.empty_like(local) for _ in range(world)]
-        dist.all_gather(gathered, local)
-        allerr = torch.cat(gathered, 0)
-    else:
-        allerr = local
-    med_t_cm = float(torch.median(allerr[:, 0]).item() * 100.0)
-    med_r_deg = float(torch.median(allerr[:, 1]).item())
+    med_t_cm, med_r_deg, n_rows = gather_and_median(local, world, dist)
+    assert n_rows == total_imgs
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(net, images, coords_np, NH, args.mlr)
+    secondary = {}
+    if rank == 0 and world == 1 and not args.no_secondary and not args.mlr:
+        del pipe, plan
+        net.invalidate()
+        torch.cuda.empty_cache()
+        secondary = secondary_configs(dev, NH)
 
     if rank == 0:
         value = total_imgs / elapsed
+        traffic, traffic_source = lookup_traffic("wino%d" % wino if wino else "direct", Bl)
         out = {
             "metric": "images/sec localized (480x720, 256 hyps)", "value": round(value, 2), "unit": "images/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(elapsed / K * 1e3, 3),
@@ -225,8 +274,11 @@ def main():
                                    + " + HIP dsacstar.forward_rgb, 480x720 frames, 60x90 coordinate grid",
                        "hypotheses": NH, "batch_per_gpu": B, "global_batch": B * world,
                        "parallelism": "images sharded over %d GPU(s), no data-path collective" % world,
-                       "solver_input": "synthetic scene coordinates (0.5 m noise, 30% outliers); CNN runs seeded "
-                                       "random weights on random images (no trained weights offline)",
+                       "rccl_ranks": rccl_ranks,
+                       "solver_input": "the network's own output tensor pred[:, :3] (strided NCHW view, CNN stream -> solver "
+                                       "stream); untrained seeded weights do not predict a scene, so synthetic scene "
+                                       "coordinates (0.5 m noise, 30% outliers) are written into its coordinate channels "
+                                       "after the head",
                        "cnn_ms_per_batch": round(cnn_ms, 3), "dsac_ms_per_batch": round(dsac_ms, 3),
                        "pipeline": "CNN of a step as %d sub-batches on %d streams; solver(s) on a side stream under "
                                    "CNN(s+1), ordered by events" % (n_sub, n_sub),
@@ -245,17 +297,182 @@ def main():
                                      "igemm_conv_kernel<3,1,128,512> (3x3 512->512 @60x90") + " x%d images per launch)" % Bl),
                          "achieved": round(conv_tflops, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(conv_tflops / PEAK_F32_MFMA_TFLOPS, 4),
-                         "traffic": (WINO512_TRAFFIC_BYTES.get(wino, {}) if wino else CONV512_TRAFFIC_BYTES).get(Bl),
+                         "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": (wino * (2 * Bl * wino_tiles * 512 + 512 * 512) * 4 if wino else
                                                           2 * Bl * 5400 * 512 * 4 + 512 * 4608 * 4),
                          "avg_launch_ms": round(conv_avg_ms, 4), "launches_timed": len(conv_ms),
                          "algorithmic_gflop_per_launch": round(conv_flop / 1e9, 2)},
             "cpu_baseline": cpu,
         }
+        out["config"].update(secondary)
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def _eager_forward(sd, x, enc_add=2, dec_add=2, groups=32):
+    """The single-task graph of networks/networks.py:221-256, 328-360 in plain PyTorch ops on the GPU (PyTorch-ROCm eager:
+    MIOpen convolutions, native GroupNorm) - the BASELINE configs[1] comparison point, not part of the product path."""
+    import torch
+    import torch.nn.functional as F
+
+    def cgr(t, conv, norm, stride=1, relu=True):
+        w = sd[conv + ".weight"]
+        t = F.conv2d(t, w, sd[conv + ".bias"], stride=stride, padding=w.shape[2] // 2)
+        t = F.group_norm(t, groups, sd[norm + ".weight"], sd[norm + ".bias"], 1e-5)
+        return F.relu(t) if relu else t
+
+    def block(t, prefix):
+        y = cgr(t, prefix + ".0", prefix + ".1")
+        y = cgr(y, prefix + ".3", prefix + ".4")
+        y = cgr(y, prefix + ".6", prefix + ".7")
+        return F.relu(t + y)
+    e = "encoder."
+    t = cgr(x, e + "conv1", e + "norm1")
+    t = cgr(t, e + "conv2", e + "norm2", 2)
+    t = cgr(t, e + "conv3", e + "norm3", 2)
+    res = cgr(t, e + "conv4", e + "norm4", 2)
+    t = cgr(res, e + "res1_conv1", e + "res1_norm1")
+    t = cgr(t, e + "res1_conv2", e + "res1_norm2")
+    t = cgr(t, e + "res1_conv3", e + "res1_norm3")
+    res = F.relu(res + t)
+    t = cgr(res, e + "res2_conv1", e + "res2_norm1")
+    t = cgr(t, e + "res2_conv2", e + "res2_norm2")
+    t = cgr(t, e + "res2_conv3", e + "res2_norm3")
+    res = F.relu(cgr(res, e + "res2_skip", e + "res2_skip_norm", relu=False) + t)
+    for i in range(enc_add):
+        res = block(res, e + "enc_add_res_block%d" % (i + 1))
+    d = "decoder."
+    for i in range(dec_add):
+        res = block(res, d + "dec_add_res_block%d" % (i + 1))
+    t = cgr(res, d + "res3_conv1", d + "res3_norm1")
+    t = cgr(t, d + "res3_conv2", d + "res3_norm2")
+    t = cgr(t, d + "res3_conv3", d + "res3_norm3")
+    res = F.relu(res + t)
+    t = cgr(res, d + "fc1", d + "fc1_norm")
+    t = cgr(t, d + "fc2", d + "fc2_norm")
+    sc = F.conv2d(t, sd[d + "fc3.weight"], sd[d + "fc3.bias"])
+    coords = sc[:, :3] + sd[d + "mean"][None, :, None, None]
+    sigma = torch.exp(F.hardtanh(sc[:, 3:], -16.10, 13.82))
+    return coords, sigma
+
+
+def _eager_coord_loss(sc, unc, poses, gt, focal=480.0, W=720, H=480):
+    """loss/coord.py:87-188 (MLE mode, default clamps) in plain PyTorch ops, for the eager baseline."""
+    import torch
+    B = sc.shape[0]
+    X, G = sc.reshape(B, 3, -1), gt.reshape(B, 3, -1)
+    P = torch.linalg.inv(poses)[:, :3, :]
+    one = torch.ones(B, 1, X.shape[2], device=sc.device)
+    Xc, Gc = torch.bmm(P, torch.cat([X, one], 1)), torch.bmm(P, torch.cat([G, one], 1))
+    d = torch.norm(Xc - Gc, dim=1)
+    K = torch.tensor([[focal, 0, W / 2.0], [0, focal, H / 2.0], [0, 0, 1.0]], device=sc.device)
+    p = torch.bmm(K.expand(B, 3, 3), Xc)
+    uv = p[:, :2] / torch.clamp(p[:, 2:], min=0.1)
+    ys, xs = torch.meshgrid(torch.arange(H // 8, device=sc.device) * 8.0 + 4, torch.arange(W // 8, device=sc.device) * 8.0 + 4,
+                            indexing="ij")
+    e = (uv - torch.stack([xs, ys]).reshape(1, 2, -1)).norm(dim=1).clamp(min=1e-7)
+    g = (G == -1).sum(1) == 0
+    m = ~(Xc[:, 2] < 0.1) & ~(e > 1000.0) & ~((d > 50.0) & g)
+    ep = e * m
+    lr = (ep * (ep <= 100.0)).clamp(min=1e-7) + torch.sqrt(100.0 * (ep * (ep > 100.0)).clamp(min=1e-7) + 1e-7).clamp(min=1e-7)
+    s = unc.reshape(B, -1).clamp(min=1e-7)
+    lu = 3.0 * torch.log(s) + d.square().clamp(min=1e-7) / (2.0 * s.square().clamp(min=1e-7))
+    return (lu * g + lr).sum() / g.numel()
+
+
+def secondary_configs(dev, n_hyp, train_batch=16, mlr_batch=24, steps=5):
+    """Outside the timed region of the headline, N=1 only - the other single-GPU BASELINE configurations, so that their
+    figures are driver-visible:
+      configs[1]  batch-16 480x720 coord network forward + MLE coordinate loss + backward (train_single_task.py:245-301
+                  without the optimizer), HIP path vs PyTorch-ROCm eager on the same graph, weights and inputs;
+      configs[4]  the 3-encoder CrossLoc network forward + HIP dsacstar at 256 hypotheses (single-GPU share of it)."""
+    import torch
+    from crossloc_amd import evaluation, loss as xl_loss, networks, synth
+    from crossloc_amd.weights import seeded_state_dict
+    out = {}
+    mean = torch.tensor(synth.SCENE_MEAN, dtype=torch.float32)
+    H, W = 480, 720
+
+    def timed(fn, warm=2):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            r = fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps * 1e3, r
+
+    # ---- configs[1]
+    B = train_batch
+    net = networks.TransPoseNet(mean, False, False, 2, 2, 3, 1)
+    net.load_state_dict(seeded_state_dict(net, seed=2021))
+    net = net.to(dev).train()
+    images = torch.rand((B, 3, H, W), generator=torch.Generator().manual_seed(16)).to(dev)
+    _, gt, poses = synth.make_batch(1, B, noise=0.5, outlier_ratio=0.0)
+    gt_t, poses_t = torch.from_numpy(gt).to(dev), torch.from_numpy(poses.astype(np.float32)).to(dev)
+    grid, cam = xl_loss.get_pixel_grid(8), xl_loss.get_cam_mat(W, H, synth.FOCAL)
+
+    def hip_step():
+        net.zero_grad(set_to_none=True)
+        pred = net(images)
+        sc, unc = torch.split(pred, [3, 1], dim=1)                          # train_single_task.py:269
+        loss, _ = xl_loss.scene_coords_regression_loss(0.1, 100.0, 1000.0, 50.0, "MLE", grid, -1, cam, sc, unc,
+                                                       poses_t, gt_t)
+        loss.backward()
+        return loss
+    ms, loss = timed(hip_step)
+    out["train16_ms_per_step"] = round(ms, 2)
+    out["train16_loss"] = round(float(loss.item()), 4)
+    out["train16_fwd_bwd_algorithmic_tflops"] = round(885.64 * B / ms, 1)     # SURVEY.md 8(d): 885.64 GFLOP per image
+    sd = {k: v.detach().clone().requires_grad_(v.dtype.is_floating_point and not k.endswith("mean"))
+          for k, v in net.state_dict().items()}
+    del net
+    torch.cuda.empty_cache()
+
+    def eager_step():
+        for v in sd.values():
+            v.grad = None
+        sc, unc = _eager_forward(sd, images)
+        loss = _eager_coord_loss(sc, unc, poses_t, gt_t)
+        loss.backward()
+        return loss
+    try:
+        ems, eloss = timed(eager_step)
+        out["train16_eager_ms"] = round(ems, 2)
+        out["train16_eager_loss"] = round(float(eloss.item()), 4)
+        out["train16_speedup_vs_eager"] = round(ems / ms, 2)
+    except RuntimeError as e:                                                 # MIOpen unavailable / out of workspace
+        out["train16_eager_ms"] = None
+        out["train16_eager_error"] = str(e)[:200]
+    del sd
+    torch.cuda.empty_cache()
+
+    # ---- configs[4], single-GPU share
+    B = mlr_batch
+    net = networks.TransPoseNet(mean, False, False, 2, 2, 3, 1, num_mlr=3)
+    net.load_state_dict(seeded_state_dict(net, seed=2021))
+    net = net.to(dev).eval()
+    images = torch.rand((B, 3, H, W), generator=torch.Generator().manual_seed(24)).to(dev)
+    coords_np, _, poses_np = synth.make_batch(5000, B, noise=0.5, outlier_ratio=0.3)
+    coords = torch.from_numpy(coords_np).to(dev)
+    pipe = evaluation.PipelinedLocalizer(net, n_hyp, synth.FOCAL, H, W)
+    last = {}
+
+    def mlr_step():
+        last["poses"], _ = pipe.submit(images, image0=0, plant=coords)
+    ms, _ = timed(lambda: mlr_step())
+    pipe.finish()
+    torch.cuda.synchronize()
+    t_err, r_err = evaluation.pose_errors(torch.from_numpy(poses_np).to(dev), last["poses"])
+    out["mlr3_images_per_s"] = round(B / ms * 1e3, 1)
+    out["mlr3_batch"] = B
+    out["mlr3_ms_per_step"] = round(ms, 2)
+    out["mlr3_fwd_algorithmic_tflops"] = round(FWD_GFLOP_PER_IMAGE_3ENC * B / ms, 1)
+    out["mlr3_median_err_cm"] = round(float(torch.median(t_err).item()) * 100.0, 3)
+    return out
 
 
 def cpu_baseline(net, images, coords_np, n_hyp, num_mlr=0):

@@ -19,13 +19,28 @@ def sources():
     return [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
 
 
+STAMP = LIB + ".srchash"
+
+
+def source_hash():
+    """Content hash of everything the library is built from (sources, private and public headers, flags): the
+    rebuild decision must not depend on file times, which a snapshot copy of the tree does not preserve."""
+    import hashlib
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    deps = sources() + sorted(os.path.join(INC, f) for f in os.listdir(INC))
+    deps += sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h"))
+    for d in deps:
+        h.update(os.path.basename(d).encode())
+        with open(d, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def needs_build():
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or not os.path.exists(STAMP):
         return True
-    t = os.path.getmtime(LIB)
-    deps = sources() + [os.path.join(INC, f) for f in os.listdir(INC)]
-    deps += [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+    with open(STAMP) as f:
+        return f.read().strip() != source_hash()
 
 
 def build(force=False, verbose=False):
@@ -46,6 +61,8 @@ def build(force=False, verbose=False):
         if p.wait() != 0:
             raise RuntimeError("hipcc failed: " + " ".join(cmd))
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+    with open(STAMP, "w") as f:
+        f.write(source_hash() + "\n")
     return LIB
 
 

@@ -30,6 +30,7 @@
 
 #include "../../include/crossloc_cnn.h"
 #include "../../include/crossloc_dsac.h"   // status codes
+#include "xl_common.h"
 
 int xl_run_bwd_op(const xl_op &op, hipStream_t st);   // xl_cnn_bwd.hip
 int xl_run_split_gemm(const xl_op &op, hipStream_t st);   // xl_gemm_split.hip
@@ -1502,21 +1503,46 @@ int launch_igemm(const xl_op &op, hipStream_t st, int py = 0, int px = 0)
     const long long inBytes = (((long long)op.B * op.Hi * op.Wi - 1) * op.ld_in + op.Cin) * 4;
     const long long wBytes = (long long)op.Cout * a.K * 4;
     const long long outBytes = (((long long)op.B * op.Ho * op.Wo - 1) * op.ld_out + op.Cout) * 4;
-    if (inBytes >= 0x7fffffffLL || wBytes >= 0x7fffffffLL || outBytes >= 0x7fffffffLL) {
-        snprintf(g_err, sizeof(g_err), "conv tensors of %lld / %lld bytes exceed 32-bit buffer addressing; split the batch", inBytes, outBytes);
-        return XL_ERR_ARG;
+    if (wBytes >= 0x7fffffffLL) { snprintf(g_err, sizeof(g_err), "conv weights of %lld bytes", wBytes); return XL_ERR_ARG; }
+    if (inBytes >= 0x7fffffffLL || outBytes >= 0x7fffffffLL) {
+        // The kernel addresses a tensor with 32-bit byte offsets through one buffer descriptor (2 GiB).  Larger batches
+        // run as several launches over image ranges, each with its own base pointers.  A range starts on a tile
+        // boundary of the un-split launch (b0 * Ho*Wo divisible by BM), so every output tile - and every
+        // (image, tile) slot of the fused GroupNorm statistics - is the same as in one launch.
+        const long long perIn = (long long)op.Hi * op.Wi * op.ld_in * 4, perOut = (long long)op.Ho * op.Wo * op.ld_out * 4;
+        const long long perMax = perIn > perOut ? perIn : perOut;
+        int g = op.Ho * op.Wo;                                    // gcd(Ho*Wo, BM)
+        for (int y = BM; y; ) { const int t = g % y; g = y; y = t; }
+        const int align = BM / g;
+        long long seg = (0x7ffffff0LL - 4LL * (op.Cin > op.Cout ? op.Cin : op.Cout)) / perMax;
+        seg -= seg % align;
+        if (ZB || MODE == 2 || seg < 1 || seg >= op.B) {
+            snprintf(g_err, sizeof(g_err), "conv tensors of %lld / %lld bytes exceed 32-bit buffer addressing", inBytes, outBytes);
+            return XL_ERR_ARG;
+        }
+        for (int b0 = 0; b0 < op.B; b0 += (int)seg) {
+            xl_op part = op;
+            part.B = (op.B - b0 < (int)seg) ? op.B - b0 : (int)seg;
+            part.in = (const char *)op.in + (long long)b0 * perIn;
+            part.out = (char *)op.out + (long long)b0 * perOut;
+            if (op.stats) part.stats = (char *)op.stats + (long long)b0 * op.nchunks * op.groups * 2 * sizeof(double);
+            const int rc = launch_igemm<KS, STRIDE, BN, CIN, MODE, BM, ZB>(part, st, py, px);
+            if (rc != XL_OK) return rc;
+        }
+        return XL_OK;
     }
     a.inBytes = (unsigned)inBytes; a.wBytes = (unsigned)wBytes; a.outBytes = (unsigned)outBytes;
     a.accumulate = (op.flags & XL_CONV_ACCUMULATE) ? 1 : 0;
     if ((ZB || MODE != 0) && (a.bias || a.stats || op.ld_out % 4 != 0)) return XL_ERR_ARG;   // swapped-operand epilogue
     if (a.accumulate && a.stats) return XL_ERR_ARG;
     const size_t lds = sizeof(float) * 2 * (BM + BN) * kBK;
-    static bool configured = false;
-    if (!configured) {
+    static XlLdsLimit configured;                    // one per template instantiation, tracked per device
+    int cfgDev;
+    if (configured.needs(lds, &cfgDev)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(igemm_conv_kernel<KS, STRIDE, BN, CIN, MODE, BM, ZB>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { snprintf(g_err, sizeof(g_err), "hipFuncSetAttribute: %s", hipGetErrorString(e)); return XL_ERR_HIP; }
-        configured = true;
+        configured.done(lds, cfgDev);
     }
     static const bool clkDbg = getenv("XL_CONV_CLK") != nullptr;
     a.clk = nullptr;

@@ -31,6 +31,7 @@
 #include <string.h>
 
 #include "../../include/crossloc_dsac.h"
+#include "xl_common.h"
 
 namespace {
 
@@ -1574,15 +1575,16 @@ int xl_dsac_forward_rgb_batch(const float *coords_dev, int64_t sb, int64_t sc, i
 
     size_t lds = ((sizeof(Smem) + 15) & ~size_t(15)) + (size_t)3 * P.Npad * sizeof(float);
     if (lds > 160 * 1024) return XL_ERR_GRID;
-    static size_t configured = 0;
-    if (lds > configured) {
+    static XlLdsLimit configured;
+    int cfgDev;
+    if (configured.needs(lds, &cfgDev)) {
         XL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(xl_dsac_forward_kernel<0>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         XL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(xl_dsac_forward_kernel<1>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         XL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(xl_dsac_forward_kernel<2>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        configured = lds;
+        configured.done(lds, cfgDev);
     }
     hipStream_t st = (hipStream_t)stream;
     // sub-blocks per image: fill ~2 workgroups per CU, at least one hypothesis per wavefront
@@ -1707,15 +1709,16 @@ int xl_dsac_backward_rgb_batch(const float *coords_dev, int64_t sb, int64_t sc, 
 
     size_t lds = ((sizeof(Smem) + 15) & ~size_t(15)) + (size_t)3 * P.Npad * sizeof(float);
     if (lds > 160 * 1024) { (void)hipFreeAsync(ws, st); return XL_ERR_GRID; }
-    static size_t configured = 0;
-    if (lds > configured) {
+    static XlLdsLimit configured;
+    int cfgDev;
+    if (configured.needs(lds, &cfgDev)) {
         XL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(xl_dsac_forward_kernel<1>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         XL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(xl_dsac_bwd_hyp_kernel),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         XL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(xl_dsac_bwd_score_kernel),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        configured = lds;
+        configured.done(lds, cfgDev);
     }
     hipLaunchKernelGGL(xl_dsac_forward_kernel<1>, dim3(S, B), dim3(kThreads), lds, st, P);
     hipLaunchKernelGGL(xl_dsac_bwd_hyp_kernel, dim3(n_hyp, B), dim3(kThreads), lds, st, Q);

@@ -173,20 +173,37 @@ def gather_errors(local_vals, num_images, rank, world_size, group=None):
     return out[:num_images]
 
 
+def _focal_args(focal, n):
+    """focal: one number for the whole batch, or one per frame (sequence / tensor: the dataset computes it per frame from
+    calibration/*.txt scaled by the stored image height, dataloader/dataloader.py:263-266).  -> (scalar, focals kwarg)."""
+    if isinstance(focal, (int, float)):
+        return float(focal), None
+    f = torch.as_tensor(focal, dtype=torch.float32).reshape(-1)
+    if f.numel() != n:
+        raise RuntimeError("expected %d focal lengths, got %d" % (n, f.numel()))
+    return float(f[0]), f
+
+
 def localize_batch(network, images, n_hyp, focal, image_h, image_w, image0=0, image_stride=1,
-                   threshold=10.0, inlier_alpha=100.0, max_pixel_error=100.0, scene_coords=None):
+                   threshold=10.0, inlier_alpha=100.0, max_pixel_error=100.0, scene_coords=None, plant=None):
     """One batch of the test_single_task.py:347-366 loop on the GPU: eval-mode CNN forward, sigma dropped
     (:354), HIP DSAC* on all images of the batch.  Returns (poses [B,4,4] cuda, predictions [B,4,Ho,Wo]).
-    `scene_coords` overrides the solver input (synthetic scenes: untrained weights do not predict a scene)."""
+    `focal`: a number, or one focal length per frame.
+    `scene_coords` overrides the solver input (synthetic scenes: untrained weights do not predict a scene).
+    `plant` [B,3,Ho,Wo]: written into the coordinate channels of the network output after the head; the solver then
+    consumes the network's own output tensor (the strided `pred[:, :3]` view) exactly as with trained weights."""
     import dsacstar
     with torch.no_grad():
         pred = network(images)
     nt = network.num_task_channel
+    if plant is not None:
+        pred[:, :nt].copy_(plant)
     coords = pred[:, :nt] if scene_coords is None else scene_coords
     poses = torch.zeros((coords.shape[0], 4, 4), dtype=torch.float32, device=coords.device)
-    dsacstar.forward_rgb_batch(coords, poses, n_hyp, threshold, focal, float(image_w / 2), float(image_h / 2),
+    f0, focals = _focal_args(focal, coords.shape[0])
+    dsacstar.forward_rgb_batch(coords, poses, n_hyp, threshold, f0, float(image_w / 2), float(image_h / 2),
                                inlier_alpha, max_pixel_error, network.OUTPUT_SUBSAMPLE,
-                               image0=image0, image_stride=image_stride)
+                               image0=image0, image_stride=image_stride, focals=focals)
     return poses, pred
 
 
@@ -205,18 +222,21 @@ class PipelinedLocalizer:
         self.side = torch.cuda.Stream()
         self.cnn = [torch.cuda.Stream() for _ in range(max(1, cnn_streams))]
 
-    def forward_cnn(self, images):
+    def forward_cnn(self, images, plant=None):
         """The network on `images`, split over the CNN streams.  Returns (predictions, events): the prediction tensor is
-        complete once every event has fired (the caller's stream is NOT made to wait)."""
+        complete once every event has fired (the caller's stream is NOT made to wait).  `plant`: see localize_batch."""
         main = torch.cuda.current_stream()
         n = min(len(self.cnn), images.shape[0])
         bounds = [round(i * images.shape[0] / n) for i in range(n + 1)]
+        nt = self.net.num_task_channel
         outs, events = [], []
         for i in range(n):
             st = self.cnn[i]
-            st.wait_stream(main)                           # the images are ready on the caller's stream
+            st.wait_stream(main)                           # the images (and `plant`) are ready on the caller's stream
             with torch.cuda.stream(st), torch.no_grad():
                 outs.append(self.net(images[bounds[i]:bounds[i + 1]], plan_slot=i + 1))
+                if plant is not None:
+                    outs[-1][:, :nt].copy_(plant[bounds[i]:bounds[i + 1]])
                 ev = torch.cuda.Event()
                 ev.record(st)
                 events.append(ev)
@@ -232,11 +252,11 @@ class PipelinedLocalizer:
             o.record_stream(self.cnn[0])
         return pred, [ev]
 
-    def submit(self, images, image0=0, image_stride=1, scene_coords=None):
+    def submit(self, images, image0=0, image_stride=1, scene_coords=None, plant=None):
         """Enqueue one batch; returns (poses [B,4,4], predictions).  Both are valid after finish() (or after
         synchronising the side stream)."""
         import dsacstar
-        pred, events = self.forward_cnn(images)
+        pred, events = self.forward_cnn(images, plant)
         coords = pred[:, :self.net.num_task_channel] if scene_coords is None else scene_coords
         poses = torch.zeros((coords.shape[0], 4, 4), dtype=torch.float32, device=coords.device)
         for ev in events:

@@ -81,8 +81,9 @@ class _FusedLoss(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, launch, per_image, pred, unc):
-        dpred = torch.empty_like(pred, dtype=torch.float32)
-        dunc = torch.empty_like(unc, dtype=torch.float32) if unc is not None else None
+        # the kernels write dense NCHW gradients: never inherit the memory format of `pred` (channels_last inputs)
+        dpred = torch.empty(pred.shape, dtype=torch.float32, device=pred.device)
+        dunc = torch.empty(unc.shape, dtype=torch.float32, device=unc.device) if unc is not None else None
         out = launch(dpred, dunc)
         ctx.per_image = per_image
         ctx.has_unc = unc is not None

@@ -14,6 +14,7 @@ raises.  The backward pass covers the single-task and the 3-encoder MLR networks
 import ctypes
 import math
 import os
+import weakref
 
 import torch
 import torch.nn as nn
@@ -273,14 +274,15 @@ class _Plan:
 
     def wino_pick(self, H, W, chan_max, allowed=(6, 4)):
         """Output tile m of F(m x m, 3x3) for an H x W map: the allowed size (capped by XL_WINOGRAD) with the fewest
-        multiplies, (m+2)^2 * ceil(H/m) * ceil(W/m), whose transformed tensors stay below 2 GiB (32-bit byte offsets
-        through one buffer descriptor); 0 if none."""
+        multiplies, (m+2)^2 * ceil(H/m) * ceil(W/m); 0 if none.  The transformed tensors V / M hold (m+2)^2 independent
+        GEMM operands of [tiles][channels] each: the batched GEMM launch gives every one of them its own buffer
+        descriptor (64-bit base, 32-bit offsets inside), so only ONE operand has to stay below 2 GiB, not the tensor."""
         want = int(os.environ.get("XL_WINOGRAD", "6"))
         cands = [m for m in allowed if m <= want]
         cands.sort(key=lambda m: ((m + 2) ** 2 * -(-H // m) * -(-W // m), -m))
         for m in cands:
             T = self.B * -(-H // m) * -(-W // m)
-            if (m + 2) ** 2 * T * chan_max * 4 < 2 ** 31 - 1:
+            if T * chan_max * 4 < 2 ** 31 - 1:
                 return m
         return 0
 
@@ -437,7 +439,7 @@ class _Plan:
         if self.train and (os.environ.get("XL_NO_WINOGRAD_TRAIN") or want not in (4, 6)):
             return 0
         if want == 2:
-            return 2 if not (H % 2 or W % 2) and 16 * self.B * (H // 2) * (W // 2) * max(C, conv.out_channels) * 4 < 2 ** 31 - 1 else 0
+            return 2 if not (H % 2 or W % 2) and self.B * (H // 2) * (W // 2) * max(C, conv.out_channels) * 4 < 2 ** 31 - 1 else 0
         return self.wino_pick(H, W, max(C, conv.out_channels))
 
     def conv_wino(self, act, conv, norm, flags, aux, m, deferred=None):
@@ -450,7 +452,7 @@ class _Plan:
         nf = (m + 2) ** 2
         # opt-in: the GEMMs on the bf16 matrix pipe with every fp32 operand split into three bf16 terms (fp32-accurate)
         split = (m == 6 and not self.train and bool(os.environ.get("XL_GEMM_SPLIT_BF16")) and C % 32 == 0
-                 and nf * T * max(C, cout) * 6 < 2 ** 31 - 1)
+                 and nf * T * max(C, cout) * 6 < 2 ** 31 - 1)           # (xl_gemm_split.hip addresses a plane as a whole)
         V = self.alloc(nf * T * C * 3 // 2 if split else nf * T * C)
         op = XlOp()
         op.type = XL_OP_WINO_IN
@@ -482,6 +484,8 @@ class _Plan:
         zblocks = max(1, cout // (256 if m == 6 else 512))          # channel blocks of the output-transform grid
         while tpb > 1 and B * -(-(Th * Tw) // tpb) * zblocks < 1024:
             tpb //= 2                                # small batches: more, shorter workgroups (latency-bound otherwise)
+        if self.separate_stats:
+            tpb = 4          # batch-invariant plans: the grouping of the partial sums must not depend on the batch size
         nchunks = -(-(Th * Tw) // tpb)
         op = XlOp()
         op.type = XL_OP_WINO_OUT
@@ -1137,14 +1141,35 @@ class _NetFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, plan, x, *params):
         ctx.plan, ctx.params = plan, params
-        return plan.run(x)
+        out = plan.run(x)
+        # the plan's buffers hold this graph's activations until its backward ran or the graph is dropped
+        plan.generation = gen = getattr(plan, "generation", 0) + 1
+        plan.busy = True
+        ctx.generation = gen
+        ctx.token = _Token()
+        weakref.finalize(ctx.token, _release_plan, weakref.ref(plan), gen)
+        return out
 
     @staticmethod
     def backward(ctx, gout):
+        if ctx.generation != ctx.plan.generation:
+            raise RuntimeError("the activations of this graph were overwritten by a later forward of the same plan "
+                               "(backward twice through one graph after another forward?)")
         produced = {id(p): g for p, g in ctx.plan.run_backward(gout)}
+        ctx.plan.busy = False
         grads = tuple(produced[id(p)].view_as(p).clone() if (p.requires_grad and id(p) in produced) else None
                       for p in ctx.params)
         return (None, None) + grads
+
+
+class _Token:
+    """Lives as long as the autograd node of one training forward (see _NetFunction.forward)."""
+
+
+def _release_plan(plan_ref, generation):
+    plan = plan_ref()
+    if plan is not None and getattr(plan, "generation", 0) == generation:
+        plan.busy = False
 
 
 class _Dummy:
@@ -1234,14 +1259,12 @@ class TransPoseNet(nn.Module):
             self._plan_version = ver
         params = [p for p in self.parameters()]
         train = torch.is_grad_enabled() and any(p.requires_grad for p in params)
-        # the kernels address each tensor with 32-bit byte offsets: the largest one (conv1 output, 32 channels at
-        # full resolution) must stay below 2 GiB -> at most 48 frames of 480x720 per launch; larger inference
-        # batches are split transparently
+        # The conv kernel addresses a tensor with 32-bit byte offsets; inference launches whose tensors pass 2 GiB (the
+        # 32-channel full-resolution activation does at 48 frames of 480x720) are issued per image range inside the
+        # library (launch_igemm), so inference batches have no limit here.  The backward kernels are not segmented.
         max_b = max(1, (2 ** 31 - 1) // (H * W * self.num_gn_channel * 4) - 1)
-        if B > max_b:
-            if train:
-                raise RuntimeError("batch of %d frames exceeds the per-launch limit of %d at %dx%d" % (B, max_b, H, W))
-            return torch.cat([self.forward(x[i:i + max_b], plan_slot) for i in range(0, B, max_b)], dim=0)
+        if B > max_b and train:
+            raise RuntimeError("training batch of %d frames exceeds the per-launch limit of %d at %dx%d" % (B, max_b, H, W))
         key = (B, H, W, x.device.index, train) if plan_slot == 0 else (B, H, W, x.device.index, train, plan_slot)
         if getattr(self, "batch_invariant", False):
             key = key + ("batch_invariant",)
@@ -1252,18 +1275,18 @@ class TransPoseNet(nn.Module):
                 self._plans[key] = plan
             if not train:
                 return plan.run(x)
-            # one forward may be outstanding per plan: its activations live in the plan until backward
+            # a training plan holds the activations of ONE graph until its backward ran (or the graph was dropped): a
+            # second grad-enabled forward before that (gradient accumulation over two forwards, two losses) gets a
+            # plan of its own instead of silently overwriting the first graph's activations
+            n = 0
+            while getattr(plan, "busy", False):
+                n += 1
+                if n >= 4:
+                    raise RuntimeError("4 training forwards of shape %s are outstanding without a backward; run "
+                                       "inference under torch.no_grad()" % (tuple(x.shape),))
+                k2 = key + ("outstanding", n)
+                plan = self._plans.get(k2)
+                if plan is None:
+                    plan = self._plans[k2] = _Plan(self, B, H, W, x.device, train=True)
             return _NetFunction.apply(plan, x, *params)
 
-
-def smoke_check(device):
-    """Tiny forward against the fp32 torch restatement (used by __graft_entry__.smoke)."""
-    from .weights import seeded_state_dict
-    from oracle import cnn_oracle
-    net = TransPoseNet(torch.tensor([-455.934, 417.50, 520.31]), False, False, 1, 1, 3, 1)
-    net.load_state_dict(seeded_state_dict(net, seed=7))
-    x = torch.rand(1, 3, 64, 96)
-    ref = cnn_oracle.transposenet_forward(net.state_dict(), x, 0, 1, 1)
-    got = net.to(device)(x.to(device)).cpu()
-    err = (got - ref).abs().max().item()
-    assert err < 2e-3 * max(1.0, ref.abs().max().item()), "CNN forward mismatch: %g" % err

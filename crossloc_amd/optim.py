@@ -36,9 +36,17 @@ class Adam(torch.optim.Optimizer):
         self._tables = {}
 
     def _table(self, gi, group):
-        """Device table of chunks for one param group; rebuilt when the set of gradient pointers changes."""
+        """Device table of chunks for one param group; rebuilt when any pointer it holds changes - parameters,
+        gradients, or the moment tensors (load_state_dict replaces the state tensors: a table keyed on parameters and
+        gradients alone would keep updating the freed ones)."""
         ps = [p for p in group["params"] if p.grad is not None]
-        sig = tuple((p.data_ptr(), p.grad.data_ptr()) for p in ps)
+
+        def moments(p):
+            st = self.state.get(p)
+            if not st or "exp_avg" not in st:
+                return (0, 0)
+            return (st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr())
+        sig = tuple((p.data_ptr(), p.grad.data_ptr()) + moments(p) for p in ps)
         cached = self._tables.get(gi)
         if cached is not None and cached[0] == sig:
             return cached[1], cached[2]
@@ -51,6 +59,10 @@ class Adam(torch.optim.Optimizer):
                 st["step"] = 0
                 st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                 st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+            for k in ("exp_avg", "exp_avg_sq"):         # a loaded state may be strided / on another device or dtype
+                m = st[k]
+                if m.device != p.device or m.dtype != torch.float32 or not m.is_contiguous():
+                    st[k] = m.to(device=p.device, dtype=torch.float32).contiguous()
             n = p.numel()
             for o in range(0, n, CHUNK):
                 rows.append(_Chunk(p.data_ptr() + 4 * o, p.grad.data_ptr() + 4 * o, st["exp_avg"].data_ptr() + 4 * o,
@@ -58,8 +70,17 @@ class Adam(torch.optim.Optimizer):
         host = (_Chunk * len(rows))(*rows)
         dev = torch.empty(ctypes.sizeof(host), dtype=torch.uint8, device=ps[0].device)
         dev.copy_(torch.frombuffer(bytearray(bytes(host)), dtype=torch.uint8))
+        sig = tuple((p.data_ptr(), p.grad.data_ptr()) + moments(p) for p in ps)      # the state may just have been made
         self._tables[gi] = (sig, dev, len(rows))
         return dev, len(rows)
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._tables = {}
+
+    def add_param_group(self, param_group):
+        super().add_param_group(param_group)
+        self._tables = {}
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -72,7 +93,7 @@ class Adam(torch.optim.Optimizer):
             dev, n = self._table(gi, group)
             for p in ps:
                 self.state[p]["step"] += 1
-            t = self.state[ps[0]]["step"]
+            t = int(self.state[ps[0]]["step"])
             b1, b2 = group["betas"]
             with torch.cuda.device(ps[0].device):
                 stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -43,9 +43,11 @@ def _parse():
     p.add_argument('--batch', type=int, default=16)
     p.add_argument('--noise', type=float, default=0.5)
     p.add_argument('--outliers', type=float, default=0.3)
-    p.add_argument('--solver_input', choices=['synthetic', 'network', 'labels'], default='synthetic',
-                   help="what the solver consumes: synthetic scene maps, the network output, or the ground-truth labels "
-                        "(the `predictions = gt_label  # debug only!` switch of test_single_task.py:361)")
+    p.add_argument('--solver_input', choices=['synthetic', 'network', 'planted', 'labels'], default='synthetic',
+                   help="what the solver consumes: synthetic scene maps (side input), the network output, the network "
+                        "output tensor with the synthetic scene written into its coordinate channels after the head "
+                        "(`planted`: the CNN -> solver hand-off of `network` with untrained weights), or the ground-truth "
+                        "labels (the `predictions = gt_label  # debug only!` switch of test_single_task.py:361)")
     p.add_argument('--scene_dir', type=str, default=None,
                    help='CrossLoc on-disk scene section (rgb/ poses/ calibration/ init/), read by crossloc_amd.dataset')
     p.add_argument('--num_mlr', type=int, default=0, help='3 = CrossLoc three-encoder network')
@@ -84,7 +86,6 @@ def main():
     K = len(ds) if ds is not None else opt.synthetic
     mine = evaluation.shard_indices(K, rank, world)
     H, W = synth.IMAGE_H, synth.IMAGE_W
-    g = torch.Generator().manual_seed(2021)
     rows, coord_errs = [], []
     t0 = time.time()
     for s in range(0, len(mine), opt.batch):
@@ -94,12 +95,16 @@ def main():
             images = torch.stack([it[0] for it in items]).to(dev)
             gt_pose = torch.stack([it[1] for it in items]).to(dev)
             gt_coords = torch.stack([it[2] for it in items]).to(dev)
-            focal = float(items[0][3])                                          # one camera per section
+            # per frame, like the reference's batch-1 loop: sections may mix cameras / stored image heights
+            focal = torch.tensor([float(it[3]) for it in items], dtype=torch.float32)
             coords = gt_coords
             H, W = images.shape[2], images.shape[3]
         else:
             scenes = [synth.make_scene(2021 + i, noise=opt.noise, outlier_ratio=opt.outliers) for i in idx]
-            images = torch.rand((len(idx), 3, H, W), generator=g).to(dev)       # raw_image=True: un-normalised [0,1]
+            # raw_image=True: un-normalised [0,1].  Seeded per GLOBAL image index, so a frame's input (hence its
+            # network output) does not depend on the rank count or the batch it lands in
+            images = torch.stack([torch.rand((3, H, W), generator=torch.Generator().manual_seed(77000 + i))
+                                  for i in idx]).to(dev)
             coords = torch.from_numpy(np.stack([sc["coords"] for sc in scenes])).to(dev)
             gt_pose = torch.from_numpy(np.stack([sc["pose"] for sc in scenes])).to(dev)
             gt_coords = torch.from_numpy(np.stack([sc["gt_coords"] for sc in scenes])).to(dev)
@@ -108,10 +113,11 @@ def main():
         poses, pred = evaluation.localize_batch(net, images, opt.hypotheses, focal, H, W, image0=idx[0],
                                                 image_stride=world, threshold=opt.threshold,
                                                 inlier_alpha=opt.inlieralpha, max_pixel_error=opt.maxpixelerror,
-                                                scene_coords=None if opt.solver_input == 'network' else coords)
+                                                scene_coords=coords if opt.solver_input in ('synthetic', 'labels') else None,
+                                                plant=coords if opt.solver_input == 'planted' else None)
         t_err, r_err = evaluation.pose_errors(gt_pose, poses)
         rows.append(torch.stack([t_err, r_err], 1))
-        used = pred[:, :3] if opt.solver_input == 'network' else coords
+        used = pred[:, :3] if opt.solver_input in ('network', 'planted') else coords
         mask = evaluation.pick_valid_points(gt_coords.flatten(2), synth.NODATA)
         coord_errs.append(torch.norm(gt_coords.flatten(2) - used.flatten(2), dim=1)[mask].cpu())
     torch.cuda.synchronize()

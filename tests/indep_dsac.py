@@ -1,0 +1,306 @@
+"""A second, deliberately DIFFERENT restatement of `dsacstar.forward_rgb` in numpy / scipy — TEST INFRASTRUCTURE ONLY.
+
+Purpose ("independent pin for the solver oracle"): oracle/dsac_oracle.c was written together with the
+HIP kernels (wave-shaped reductions, polynomial exp/sincos, Ferrari quartic, frame-based alignment, Cholesky LM on a
+left-multiplicative increment).  This file follows the REFERENCE's control flow and data types instead
+(/root/reference/dsacstar/dsacstar.cpp:63-178, dsacstar_util.h) and gets every piece of third-party arithmetic from an
+unrelated implementation:
+
+  piece                         reference                              here                         oracle / HIP
+  ----------------------------  -------------------------------------  ---------------------------  -----------------------------
+  minimal solver                cv::solvePnP(P3P) util.h:104-112,185   law-of-cosines system        closed-form Grunert
+                                                                       eliminated numerically       coefficients + Ferrari +
+                                                                       (np.polymul resultant),      Newton polish + triangle
+                                                                       np.roots (companion eig),    frames
+                                                                       Kabsch/SVD alignment
+  pose parametrisation          Rodrigues vector (types.h:42-44)       scipy Rotation rotvec        rotation matrix
+  projection                    cv::projectPoints util.h:199,395       same formula, numpy          same formula, scalar
+  soft-inlier score             serial x-major sum, std::exp :324-340  x-major np.cumsum, np.exp    64 lane partials + butterfly,
+                                                                                                    polynomial exp
+  selection                     softMax + draw(argmax) :684-752        the same two functions       arg-max of the scores
+  refinement optimiser          cv::solvePnP(ITERATIVE, guess) :570    MINPACK lmder through        hand-written CvLevMarq state
+                                                                       scipy least_squares('lm')    machine, 6x6 Cholesky
+                                                                       on (rotvec, t)
+  RNG                           mt19937 per thread (not reproducible)  the build's counter-based    same spec
+                                                                       splitmix64 spec, restated
+                                                                       with Python integers
+
+Only the RNG *specification* (key = seed, image, hypothesis, try; draw x then y) is shared, because
+"the same sampled cells" is only definable on a shared stream.
+"""
+import math
+
+import numpy as np
+from scipy.optimize import fsolve, least_squares
+from scipy.spatial.transform import Rotation
+
+M64 = (1 << 64) - 1
+GOLDEN = 0x9E3779B97F4A7C15
+MAX_REF_STEPS = 100                 # dsacstar.cpp:47
+MAX_HYPOTHESES_TRIES = 1000000      # dsacstar.cpp:48
+EPS = 1e-8                          # dsacstar_types.h: probabilities below it are skipped by draw()
+POLISH_DISTANCES = True             # see p3p_plus_one
+
+
+# ------------------------------------------------------------------------------------------ RNG (shared specification)
+
+def _mix64(z):
+    z &= M64
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M64
+    return z ^ (z >> 31)
+
+
+def draw_cells(seed, image, hyp, t, Wo, Ho):
+    """The 4 (x, y) cells of try `t` of hypothesis `hyp`: x first, then y (dsacstar_util.h:171-172)."""
+    s = _mix64(seed + GOLDEN * (image + 1))
+    s = _mix64(s ^ ((hyp << 32) | t))
+    out = []
+    for j in range(4):
+        rx = _mix64(s + GOLDEN * (2 * j + 1)) >> 32
+        ry = _mix64(s + GOLDEN * (2 * j + 2)) >> 32
+        out.append(((rx * Wo) >> 32, (ry * Ho) >> 32))
+    return out
+
+
+# ------------------------------------------------------------------------------------------ geometry
+
+def project(rvec, tvec, X, f, cx, cy):
+    """cv::projectPoints without distortion: X [n,3] float64 -> pixels [n,2] as float32 (the reference stores Point2f).
+    No cheirality test; only z == 0 is guarded."""
+    R = Rotation.from_rotvec(rvec).as_matrix()
+    Xc = X @ R.T + tvec
+    z = np.where(Xc[:, 2] != 0.0, 1.0 / np.where(Xc[:, 2] != 0.0, Xc[:, 2], 1.0), 1.0)
+    u = Xc[:, 0] * z * f + cx
+    v = Xc[:, 1] * z * f + cy
+    return np.stack([u, v], 1).astype(np.float32)
+
+
+def _norm2f(d):
+    """cv::norm(Point2f): the float differences squared and summed in double."""
+    d = d.astype(np.float64)
+    return np.sqrt(d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1])
+
+
+def _kabsch(Pw, Pc):
+    """Rigid (R, t) with Pc ~ R Pw + t (Arun et al. 1987, SVD)."""
+    mw, mc = Pw.mean(0), Pc.mean(0)
+    H = (Pw - mw).T @ (Pc - mc)
+    U, S, Vt = np.linalg.svd(H)
+    d = np.sign(np.linalg.det(Vt.T @ U.T))
+    R = Vt.T @ np.diag([1.0, 1.0, d]) @ U.T
+    return R, mc - R @ mw
+
+
+def p3p_plus_one(P, uv, f, cx, cy):
+    """cv::solvePnP(SOLVEPNP_P3P) call-site contract: the first three correspondences give up to four poses, the
+    fourth picks the one with the smallest reprojection error.  Returns (rvec, tvec) or None."""
+    m = np.stack([(uv[:3, 0] - cx) / f, (uv[:3, 1] - cy) / f, np.ones(3)], 1)
+    fb = m / np.linalg.norm(m, axis=1, keepdims=True)
+    ca, cb, cg = fb[1] @ fb[2], fb[0] @ fb[2], fb[0] @ fb[1]
+    a2 = np.sum((P[1] - P[2]) ** 2)
+    b2 = np.sum((P[0] - P[2]) ** 2)
+    c2 = np.sum((P[0] - P[1]) ** 2)
+    if not (a2 > 0 and b2 > 0 and c2 > 0):
+        return None
+    if np.linalg.norm(np.cross(P[1] - P[0], P[2] - P[0])) == 0.0:
+        return None
+    # distances s1, s2 = u s1, s3 = v s1 (law of cosines).  Eliminating s1^2 leaves two quadratics in u with polynomial
+    # coefficients in v (highest power first):
+    #   b2 u^2 - 2 b2 ca v u + (b2 v^2 - a2 w(v)) = 0,   b2 u^2 - 2 b2 cg u + (b2 - c2 w(v)) = 0,   w = v^2 - 2 cb v + 1
+    w = np.array([1.0, -2.0 * cb, 1.0])
+    B1 = np.array([-2.0 * b2 * ca, 0.0])
+    C1 = np.array([b2, 0.0, 0.0]) - a2 * w
+    B2 = np.array([-2.0 * b2 * cg])
+    C2 = np.array([0.0, 0.0, b2]) - c2 * w
+    dB = np.polysub(B1, B2)                       # their difference is linear in u:  dB u + dC = 0
+    dC = np.polysub(C1, C2)
+    quartic = np.polyadd(np.polysub(b2 * np.polymul(dC, dC), np.polymul(np.polymul(B2, dC), dB)),
+                         np.polymul(C2, np.polymul(dB, dB)))
+    if not np.all(np.isfinite(quartic)) or quartic[0] == 0.0:
+        return None
+    best, best_e = None, None
+    for root in np.roots(quartic):
+        if abs(root.imag) > 1e-9 * max(1.0, abs(root.real)):
+            continue
+        v = root.real
+        den = np.polyval(dB, v)
+        if not v > 0.0 or den == 0.0:
+            continue
+        u = -np.polyval(dC, v) / den
+        wv = np.polyval(w, v)
+        if not (u > 0.0 and wv > 0.0):
+            continue
+        s = np.array([1.0, u, v]) * math.sqrt(b2 / wv)
+        if POLISH_DISTANCES:
+            # the quartic's roots carry ~1e-10 relative error (companion-matrix eigenvalues) which an ill-conditioned
+            # triangle amplifies to ~1e-6 in the pose: MINPACK hybrd on the three law-of-cosines equations removes it
+            s = fsolve(lambda q: [q[1] * q[1] + q[2] * q[2] - 2 * q[1] * q[2] * ca - a2,
+                                  q[0] * q[0] + q[2] * q[2] - 2 * q[0] * q[2] * cb - b2,
+                                  q[0] * q[0] + q[1] * q[1] - 2 * q[0] * q[1] * cg - c2], s, xtol=1e-15)
+            if not np.all(s > 0.0):
+                continue
+        Pc = s[:, None] * fb
+        R, t = _kabsch(P[:3], Pc)
+        Xc = R @ P[3] + t
+        e = (cx + f * Xc[0] / Xc[2] - uv[3, 0]) ** 2 + (cy + f * Xc[1] / Xc[2] - uv[3, 1]) ** 2
+        if best is None or e < best_e:
+            best, best_e = (R, t), e
+    if best is None:
+        return None
+    return Rotation.from_matrix(best[0]).as_rotvec(), best[1]
+
+
+# ------------------------------------------------------------------------------------------ pipeline stages
+
+class Frame:
+    """Scene coordinates [3,Ho,Wo] float32 with the two cell orders the reference uses."""
+
+    def __init__(self, coords, sub):
+        self.c = np.asarray(coords, np.float32)
+        _, self.Ho, self.Wo = self.c.shape
+        self.sub = sub
+        # x-major order of getReproErrs / refineHyp (x outer, y inner; dsacstar_util.h:375-376, 547-548)
+        xs, ys = np.meshgrid(np.arange(self.Wo), np.arange(self.Ho), indexing="ij")
+        self.xs, self.ys = xs.ravel(), ys.ravel()
+        self.X = self.c[:, self.ys, self.xs].T.astype(np.float64)                  # [N,3], x-major
+        # createSampling (dsacstar_util.h:59-76): integer pixel centres
+        self.pix = np.stack([self.xs * sub + sub // 2, self.ys * sub + sub // 2], 1).astype(np.float32)
+
+    def errors(self, hyp, f, cx, cy, max_reproj):
+        """getReproErrs with calcJ=false (dsacstar_util.h:356-446), x-major float32 vector."""
+        proj = project(hyp[0], hyp[1], self.X, f, cx, cy)
+        n = _norm2f(self.pix - proj).astype(np.float32)
+        return np.minimum(n, np.float32(max_reproj))
+
+
+def sample_hypothesis(fr, seed, image, h, thr, f, cx, cy, max_tries):
+    """One iteration of the `h` loop of sampleHypotheses (dsacstar_util.h:157-220)."""
+    hyp = (np.zeros(3), np.zeros(3))
+    cells = None
+    for t in range(max_tries):
+        cells = draw_cells(seed, image, h, t, fr.Wo, fr.Ho)
+        P = np.array([[fr.c[0, y, x], fr.c[1, y, x], fr.c[2, y, x]] for x, y in cells], np.float64)
+        uv32 = np.array([[x * fr.sub + fr.sub // 2, y * fr.sub + fr.sub // 2] for x, y in cells], np.float32)
+        sol = p3p_plus_one(P, uv32.astype(np.float64), f, cx, cy)
+        if sol is None:
+            hyp = (np.zeros(3), np.zeros(3))              # safeSolvePnP zeroes both on failure (:114-116)
+            continue
+        hyp = sol
+        proj = project(hyp[0], hyp[1], P, f, cx, cy)
+        if np.all(_norm2f(uv32 - proj) < thr):            # :208-219
+            return hyp, cells, t + 1
+    return hyp, cells, -max_tries
+
+
+def hyp_score(errs, thr, alpha, Wo, Ho):
+    """getHypScores (dsacstar_util.h:316-343): float beta and soft threshold argument, double logistic, SERIAL x-major
+    accumulation (np.cumsum adds left to right), then `*= alpha / cols / rows` in float."""
+    beta = np.float32(5.0) / np.float32(thr)
+    st = (beta * (errs - np.float32(thr))).astype(np.float64)
+    st = 1.0 / (1.0 + np.exp(-st))
+    total = np.cumsum(1.0 - st)[-1]
+    fac = np.float32(alpha) / np.float32(Wo) / np.float32(Ho)
+    return float(total * np.float64(fac))
+
+
+def soft_max(scores):
+    """dsacstar_util.h:684-704"""
+    sf = np.exp(np.asarray(scores) - np.max(scores))
+    return sf / np.cumsum(sf)[-1]
+
+
+def draw_argmax(probs):
+    """draw(probs, training=false), dsacstar_util.h:727-752: first maximum among probs >= EPS."""
+    max_prob, max_idx = -1.0, 0
+    for i, p in enumerate(probs):
+        if p < EPS:
+            continue
+        if max_prob < 0 or p > max_prob:
+            max_prob, max_idx = p, i
+    return max_idx
+
+
+def refine(fr, hyp, errs, thr, f, cx, cy, max_reproj):
+    """refineHyp (dsacstar_util.h:522-597).  Returns (hyp, rounds accepted, final inlier count)."""
+    best, rounds, final = 4, 0, 0
+    for _ in range(MAX_REF_STEPS):
+        inl = errs < np.float32(thr)
+        n = int(inl.sum())
+        if n <= best:
+            break
+        best = n
+        X, pix = fr.X[inl], fr.pix[inl].astype(np.float64)
+
+        def resid(p):
+            R = Rotation.from_rotvec(p[:3]).as_matrix()
+            Xc = X @ R.T + p[3:]
+            return np.concatenate([Xc[:, 0] / Xc[:, 2] * f + cx - pix[:, 0], Xc[:, 1] / Xc[:, 2] * f + cy - pix[:, 1]])
+        sol = least_squares(resid, np.concatenate(hyp), method="lm", xtol=1e-14, ftol=1e-14, gtol=1e-14, max_nfev=2000)
+        if not np.all(np.isfinite(sol.x)):
+            break
+        hyp = (sol.x[:3], sol.x[3:])
+        rounds, final = rounds + 1, n
+        errs = fr.errors(hyp, f, cx, cy, max_reproj)
+    return hyp, rounds, final
+
+
+def pose2trans(hyp):
+    """dsacstar_util.h:759-770: [R t; 0 1]^-1 through a general inverse, stored as float32 (dsacstar.cpp:172-177)."""
+    T = np.eye(4)
+    T[:3, :3] = Rotation.from_rotvec(hyp[0]).as_matrix()
+    T[:3, 3] = hyp[1]
+    return np.linalg.inv(T).astype(np.float32)
+
+
+def forward_rgb(coords, n_hyp, thr, focal, ppx, ppy, alpha, max_reproj, sub, seed=1305, image=0,
+                max_tries=MAX_HYPOTHESES_TRIES):
+    """dsacstar_rgb_forward (dsacstar.cpp:63-178).  Returns (out_pose [4,4] float32, info dict)."""
+    fr = Frame(coords, sub)
+    f, cx, cy = float(np.float32(focal)), float(np.float32(ppx)), float(np.float32(ppy))
+    hyps, cells, tries, scores = [], [], [], []
+    for h in range(n_hyp):
+        hyp, c4, t = sample_hypothesis(fr, seed, image, h, thr, f, cx, cy, max_tries)
+        hyps.append(hyp)
+        cells.append([y * fr.Wo + x for x, y in c4])
+        tries.append(t)
+        scores.append(hyp_score(fr.errors(hyp, f, cx, cy, max_reproj), thr, alpha, fr.Wo, fr.Ho))
+    win = draw_argmax(soft_max(scores))
+    hyp0 = hyps[win]
+    hyp, rounds, inliers = refine(fr, hyp0, fr.errors(hyp0, f, cx, cy, max_reproj), thr, f, cx, cy, max_reproj)
+    return pose2trans(hyp), dict(cells=np.array(cells, np.int32), tries=np.array(tries, np.int32),
+                                 scores=np.array(scores), winner=win, rounds=rounds, inliers=inliers,
+                                 pose0=pose2trans(hyp0))
+
+
+# ------------------------------------------------------------------------------------------ comparison with the oracle
+
+def compare_with_oracle(coords, n_hyp, image, gt_pose=None, thr=10.0, focal=480.0, ppx=360.0, ppy=240.0, alpha=100.0,
+                        max_reproj=100.0, sub=8):
+    """Runs this restatement and oracle/dsac_oracle.c on one frame and returns a flat record of agreements.
+    Duplicate-cell hypotheses (the 4th draw repeats one of the first three: allowed, dsacstar_util.h:168-183) are
+    reported separately: the 4th point then cannot disambiguate the P3P solutions and the choice among them is decided
+    by rounding in ANY implementation, OpenCV's included."""
+    from oracle import dsac_oracle as xo
+    from crossloc_amd import synth
+    pose, info = forward_rgb(coords, n_hyp, thr, focal, ppx, ppy, alpha, max_reproj, sub, image=image)
+    ref, rd = xo.forward_rgb(coords, n_hyp, thr, focal, ppx, ppy, alpha, max_reproj, sub, image=image, debug=True)
+    same_cells = np.all(info["cells"] == rd["cells"], axis=1) & (info["tries"] == rd["tries"])
+    dup = np.array([len(set(c[:3])) < 3 or c[3] in c[:3] for c in rd["cells"].tolist()])
+    ds = np.abs(info["scores"] - rd["scores"])
+    clean = same_cells & ~dup
+    order = np.argsort(-rd["scores"])
+    dt, dr = synth.pose_error(ref.astype(np.float64), pose.astype(np.float64))
+    rec = dict(image=int(image), n_hyp=int(n_hyp), cells_equal=bool(same_cells.all()),
+               n_cell_mismatch=int((~same_cells).sum()), n_duplicate_cell_hyps=int(dup.sum()),
+               winner_indep=int(info["winner"]), winner_oracle=int(rd["winner"]),
+               score_gap_top2=float(rd["scores"][order[0]] - rd["scores"][order[1]]) if n_hyp > 1 else 0.0,
+               max_dscore_clean=float(ds[clean].max()) if clean.any() else 0.0,
+               median_dscore_clean=float(np.median(ds[clean])) if clean.any() else 0.0,
+               max_dscore_dup=float(ds[same_cells & dup].max()) if (same_cells & dup).any() else 0.0,
+               rounds_indep=int(info["rounds"]), rounds_oracle=int(rd["rounds"]),
+               inliers_indep=int(info["inliers"]), inliers_oracle=int(rd["inliers"]),
+               dpose_m=float(dt), dpose_deg=float(dr), pose_bits_equal=bool(np.array_equal(ref, pose)))
+    if gt_pose is not None:
+        rec["gt_err_m"], rec["gt_err_deg"] = (float(v) for v in synth.pose_error(gt_pose, pose))
+    return rec

@@ -111,3 +111,26 @@ def test_gradient_allreduce_averages_over_ranks(tmp_path):
     g0, g1 = np.load(tmp_path / "g0.npy"), np.load(tmp_path / "g1.npy")
     assert np.array_equal(g0, g1)
     assert np.allclose(g0[:15], 1.5) and np.allclose(g0[15:], np.arange(7) * 1.5)
+
+
+def _bench_worker(rank, world, port, out_dir):
+    """bench.py's own gather + median code path (gather_and_median) under gloo."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench
+    rows = torch.tensor([[0.01 * (3 * i + rank + 1), 0.001 * (i + 7 * rank)] for i in range(6)], dtype=torch.float64)
+    med = bench.gather_and_median(rows, world, dist)
+    np.save(os.path.join(out_dir, "bench_rank%d.npy" % rank), np.array(med))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_gather_and_median_two_ranks(tmp_path):
+    import bench
+    mp.spawn(_bench_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "bench_rank0.npy"), np.load(tmp_path / "bench_rank1.npy")
+    rows = torch.tensor([[0.01 * (3 * i + r + 1), 0.001 * (i + 7 * r)] for r in range(2) for i in range(6)], dtype=torch.float64)
+    want = bench.gather_and_median(rows, 1)
+    assert np.array_equal(r0, r1) and np.allclose(r0, want) and int(r0[2]) == 12
+    assert abs(want[0] - 100.0 * float(torch.median(rows[:, 0]))) < 1e-12

@@ -1,0 +1,80 @@
+"""CPU: the solver oracle (oracle/dsac_oracle.c) against an INDEPENDENT numpy / scipy restatement that follows the
+reference's control flow (tests/indep_dsac.py: serial x-major sums with exp, np.roots P3P + Kabsch, Rodrigues-vector
+poses, softMax + draw, MINPACK Levenberg-Marquardt).  The reference binary cannot be built here (OpenCV 3.4.2 absent),
+so this is the strongest pin available: two implementations that share only the RNG specification must agree on every
+discrete decision of the pipeline and on the pose.
+
+The whole tools/parity_sweep.py frame set (1536 frames, 256 hypotheses) is compared offline by
+tools/independent_pin_sweep.py; its result is committed as profiles/r2_independent_pin.json and summarised in
+DESIGN.md §2.  This test runs a slice of the same frames so the CPU suite stays within minutes."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import indep_dsac
+from crossloc_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_rng_specification_restated_with_python_integers(oracle):
+    for image, hyp, t in [(0, 0, 0), (3, 17, 5), (1023, 255, 999999), (2 ** 40 + 7, 63, 1)]:
+        got = np.array(indep_dsac.draw_cells(1305, image, hyp, t, 90, 60))
+        assert np.array_equal(got, oracle.draws(1305, image, hyp, t, 90, 60))
+
+
+def test_p3p_implementations_agree_on_well_conditioned_samples(oracle):
+    rng = np.random.default_rng(5)
+    checked = 0
+    for _ in range(200):
+        sc_pose = synth.random_pose(rng)
+        Rt = np.linalg.inv(sc_pose)                                        # world -> camera
+        uv = np.stack([rng.uniform(40, 680, 4), rng.uniform(40, 440, 4)], 1)
+        depth = rng.uniform(150, 350, 4)
+        Xc = np.stack([(uv[:, 0] - 360) / 480 * depth, (uv[:, 1] - 240) / 480 * depth, depth], 1)
+        P = (Xc - Rt[:3, 3]) @ Rt[:3, :3]                                  # R^T (Xc - t)
+        a = indep_dsac.p3p_plus_one(P, uv, 480.0, 360.0, 240.0)
+        b = oracle.p3p(P, uv, 480.0, 360.0, 240.0)
+        assert (a is None) == (b is None)
+        if a is None:
+            continue
+        from scipy.spatial.transform import Rotation
+        Ra = Rotation.from_rotvec(a[0]).as_matrix()
+        assert np.abs(Ra - b[0]).max() < 1e-7 and np.abs(a[1] - b[1]).max() < 1e-4
+        assert np.abs(Ra - Rt[:3, :3]).max() < 1e-6                        # and both recover the true pose
+        checked += 1
+    assert checked > 150
+
+
+@pytest.mark.parametrize("rho,frames,n_hyp", [(0.0, 3, 64), (0.3, 3, 64), (0.6, 2, 64), (0.3, 1, 256)])
+def test_oracle_agrees_with_independent_restatement(rho, frames, n_hyp):
+    """Per frame: identical sampled cells and accepted try for EVERY hypothesis, identical winner, identical refinement
+    path (rounds, inlier counts), scores of hypotheses within 1e-6 of each other (median ~1e-13; the tail is the
+    conditioning of single P3P solves, see indep_dsac.p3p_plus_one), final pose within 1 cm / 0.1 deg (observed: equal
+    to the last float32 bit in most frames)."""
+    for i in range(frames):
+        sc = synth.make_scene(9000 + int(rho * 10) * 1000 + i, noise=0.5, outlier_ratio=rho)      # parity_sweep frames
+        r = indep_dsac.compare_with_oracle(sc["coords"], n_hyp, i, gt_pose=sc["pose"])
+        assert r["cells_equal"], r
+        assert r["winner_indep"] == r["winner_oracle"], r
+        assert (r["rounds_indep"], r["inliers_indep"]) == (r["rounds_oracle"], r["inliers_oracle"]), r
+        assert r["max_dscore_clean"] < 1e-6 and r["median_dscore_clean"] < 1e-9, r
+        assert r["dpose_m"] < 0.01 and r["dpose_deg"] < 0.1, r
+        assert r["gt_err_m"] < 0.5 and r["gt_err_deg"] < 0.1, r
+
+
+def test_committed_sweep_result_meets_the_acceptance_bar():
+    """profiles/r2_independent_pin.json is the record of the full sweep (regenerate with
+    tools/independent_pin_sweep.py): every frame within 1 cm / 0.1 deg, and every disagreement listed with its cause."""
+    path = os.path.join(ROOT, "profiles", "r2_independent_pin.json")
+    if not os.path.exists(path):
+        pytest.skip("sweep record not generated yet")
+    rec = json.load(open(path))
+    assert rec["frames"] >= 1536 and rec["hypotheses"] == 256
+    for rho, s in rec["summary"].items():
+        assert s["max_dpose_cm"] < 1.0 and s["max_dpose_deg"] < 0.1, (rho, s)
+        assert s["frames_winner_identical"] >= s["frames"] - 2, (rho, s)
+    for d in rec["disagreeing_frames"]:
+        assert d["cause"], d

@@ -71,3 +71,65 @@ def test_training_steps_reduce_loss_and_track_cpu_replica():
         y = net(images.cuda()).cpu()
     yref = cnn_oracle.transposenet_forward({k: v.detach() for k, v in net.state_dict().items()}, images, 0, 1, 1)
     assert (y[:, :3] - yref[:, :3]).abs().max().item() < 1e-2
+
+
+def test_adam_resume_from_state_dict_uses_the_loaded_moments():
+    """load_state_dict replaces the moment tensors: the cached device table of raw pointers must be rebuilt (it used
+    to keep updating the freed ones and ignore the loaded moments)."""
+    g = torch.Generator().manual_seed(3)
+    shapes = [(64, 32, 3, 3), (64,), (70001,)]
+    ours = [torch.randn(s, generator=g).cuda().requires_grad_(True) for s in shapes]
+    ref = [p.detach().clone().requires_grad_(True) for p in ours]
+    oa, ob = optim.Adam(ours, lr=1e-3), torch.optim.Adam(ref, lr=1e-3)
+
+    def step(n):
+        for _ in range(n):
+            for a, b in zip(ours, ref):
+                gr = torch.randn(a.shape, generator=g).cuda()
+                a.grad.copy_(gr) if a.grad is not None else setattr(a, "grad", gr.clone())
+                b.grad = gr.clone()
+            oa.step(); ob.step()
+    step(2)
+    saved = {"a": oa.state_dict(), "b": ob.state_dict()}
+    saved = {k: {"state": {i: {n: (v.clone() if torch.is_tensor(v) else v) for n, v in st.items()}
+                           for i, st in sd["state"].items()}, "param_groups": sd["param_groups"]}
+             for k, sd in saved.items()}
+    step(2)                                                  # moves the moments away from the saved ones
+    with torch.no_grad():
+        for a, b in zip(ours, ref):
+            b.copy_(a)
+    oa.load_state_dict(saved["a"]); ob.load_state_dict(saved["b"])
+    step(3)
+    for a, b in zip(ours, ref):
+        assert torch.allclose(a, b, rtol=2e-6, atol=1e-7)
+    for a, b in zip(ours, ref):
+        assert torch.allclose(oa.state[a]["exp_avg"], ob.state[b]["exp_avg"], rtol=1e-5, atol=1e-7)
+        assert torch.allclose(oa.state[a]["exp_avg_sq"], ob.state[b]["exp_avg_sq"], rtol=1e-5, atol=1e-9)
+    assert int(oa.state[ours[0]]["step"]) == int(ob.state[ref[0]]["step"]) == 5
+
+
+def test_second_training_forward_before_backward_keeps_the_first_graph_intact():
+    """Two grad-enabled forwards of one shape before any backward (gradient accumulation over two forwards): the second
+    gets a plan of its own; both backward passes see their own activations."""
+    net = networks.TransPoseNet(MEAN, False, False, 0, 0, 3, 1)
+    net.load_state_dict(seeded_state_dict(net, seed=8))
+    net = net.cuda().train()
+    xa = torch.rand(1, 3, 64, 96, generator=torch.Generator().manual_seed(1)).cuda()
+    xb = torch.rand(1, 3, 64, 96, generator=torch.Generator().manual_seed(2)).cuda()
+
+    def grads(order):
+        net.zero_grad(set_to_none=True)
+        if order == "interleaved":
+            ya, yb = net(xa), net(xb)
+            ya.sum().backward(); yb.sum().backward()
+        else:
+            net(xa).sum().backward(); net(xb).sum().backward()
+        return [p.grad.clone() for p in net.parameters()]
+    seq, inter = grads("sequential"), grads("interleaved")
+    for a, b in zip(seq, inter):
+        assert torch.equal(a, b)
+    # the graph of a dropped forward releases its plan; inference under no_grad never takes one
+    for _ in range(6):
+        net(xa)
+    with torch.no_grad():
+        net(xa)
