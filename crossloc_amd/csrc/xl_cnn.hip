@@ -39,6 +39,7 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // ---------------------------------------------------------------------------------------------- conv1
 
@@ -223,6 +224,9 @@ struct ConvArgs {
     // batched launch (Winograd: 16 independent GEMMs): tile t of the grid belongs to GEMM z = t / (nbm*nbn)
     int zCount; long long zIn, zW, zOut;   // element strides between consecutive GEMMs
     long long *clk;                 // diagnostics (XL_CONV_CLK=1): per-workgroup shader-clock phase timings, else NULL
+    // NORM launches: the producer's GroupNorm is applied to the A operand on its way into LDS ("normalise on load"):
+    // coef = {scale, shift} pairs [B][Cin][2] from GN_FINAL, x -> max(x*scale + shift, normLo), normLo = 0 (ReLU) or -inf
+    const float *coef; float normLo;
 };
 
 // bijective XCD remap: block b runs on XCD b%8; give each XCD a contiguous run of tiles
@@ -243,19 +247,26 @@ __device__ __forceinline__ int xcd_remap(int b, int nwg)
 // for the taps whose offset is divisible by the forward stride S (others are zero-filled by the bounds check).
 // MODE 2: the stride-2 data gradient split by result-pixel parity (py,px): only the 1/2/2/4 taps that can reach a
 // pixel of that class are multiplied (9 tap-GEMMs in total over the four launches instead of 36).
-template <int KS, int STRIDE, int BN, int CIN, int MODE = 0, int BM = 128, int ZB = 0>   // CIN = compile-time Cin tag (0: runtime);
+// NORM (1x1 forward launches only): the A operand is the RAW output of the producing convolution and its GroupNorm
+// (+ReLU) is applied on the way into LDS, so the producer's separate apply pass (one read + one write of the
+// activation) does not exist.  The A tile then goes global -> registers -> x*scale + shift -> ds_write instead of by
+// DMA (the weights still go by DMA); the per-(image, channel) coefficients of the at most two images a tile touches
+// sit in LDS behind the tiles.
+template <int KS, int STRIDE, int BN, int CIN, int MODE = 0, int BM = 128, int ZB = 0, int NORM = 0>   // CIN = compile-time Cin tag (0: runtime);
                                          // BM = 64 for launches that would not fill the chip; ZB 1 = batched GEMMs (Winograd)
 __global__ __launch_bounds__(256, 2)
 void igemm_conv_kernel(ConvArgs a)
 {
+    static_assert(!NORM || (KS == 1 && STRIDE == 1 && MODE == 0 && ZB == 0), "normalise-on-load exists for 1x1 forward convs");
     constexpr int PAD = KS / 2;
-    // SWAP: the MFMA row operand is the WEIGHT fragment, so an accumulator register quad holds 4 consecutive output
+    // The MFMA row operand is the WEIGHT fragment ("swapped"), so an accumulator register quad holds 4 consecutive output
     // channels of one pixel = 16 contiguous bytes of the NHWC result: the epilogue needs 16 dwordx4 stores per wave
-    // instead of 64 dword stores.  It matters because the epilogue runs beside the co-resident workgroup's MFMA stream,
-    // which lets the epilogue wave issue only about one instruction per MFMA slot (measured: 27k ticks for the 64-store
-    // form with two workgroups per CU, 5k alone).  Used where no bias / statistics epilogue exists: batched (Winograd)
-    // GEMMs and data gradients.
-    constexpr bool SWAP = (ZB != 0) || (MODE != 0);
+    // instead of 64 dword stores.  It matters because the epilogue runs beside the co-resident workgroup's MFMA stream
+    // and pays per INSTRUCTION there (XL_CONV_CLK: 27k ticks for the 64-store form with two workgroups per CU, 50k with
+    // the per-element statistics on top, 6k for this form); while a workgroup sits in its epilogue its partner cannot
+    // keep the matrix pipe full alone, so a long epilogue costs pipe time, not only latency: the 1x1 512->512 layers
+    // ran at 78 % with the long one.  Forward launches start the accumulators at the bias instead of adding it per
+    // element, and take the GroupNorm statistics from per-lane partial sums (below).
     constexpr int NJ = BN / 64;                 // 32-wide MFMA tiles per wave along N
     constexpr int BROWS = BN / 32;              // B-tile rows loaded per thread
     constexpr int AROWS = BM / 32;              // A-tile rows loaded per thread
@@ -371,23 +382,105 @@ void igemm_conv_kernel(ConvArgs a)
     auto load_dma = [&](int kk, int buf) {
         unsigned voff[AROWS], kbytes;
         tile_offsets(kk, voff, kbytes);
-        issue_dma_a(voff, buf);
+        if constexpr (!NORM) issue_dma_a(voff, buf);
         issue_dma_b(kbytes, buf);
     };
-
-    f32x16 acc[TI][NJ];
+    // ---- NORM: A through registers.  This thread owns the 16-byte slot (row lrow + 32p, physical slot tid&7) of every
+    // K-step - the slot the DMA form fills through it - holding channels 4*kq .. 4*kq+3 of the step's 32-channel chunk.
+    float *sCoef = smem + 2 * (BM + BN) * kBK;                  // [2 image slots][Cin][2]
+    int coefSlot[AROWS];                                        // float offset of this row's image slot in sCoef
+    f32x4 aReg[AROWS];
+    auto load_a_regs = [&](const unsigned (&voff)[AROWS]) {
 #pragma unroll
-    for (int i = 0; i < TI; ++i)
+        for (int p = 0; p < AROWS; ++p)
+            aReg[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srdA, (int)voff[p], 0, 0));
+    };
+    f32x4 cf[AROWS][2];                                         // {s0 t0 s1 t1}, {s2 t2 s3 t3} of the row's image
+    auto load_coefs = [&](int kk) {                             // issued a K-step ahead: never waited for in the tail
+        const int c = kk * kBK + 4 * kq;                        // first of this thread's 4 channels
+#pragma unroll
+        for (int p = 0; p < AROWS; ++p) {
+            cf[p][0] = *reinterpret_cast<const f32x4 *>(sCoef + coefSlot[p] + 2 * c);
+            cf[p][1] = *reinterpret_cast<const f32x4 *>(sCoef + coefSlot[p] + 2 * c + 4);
+        }
+    };
+    auto store_a_regs = [&](int buf, int pLo, int pHi) {        // normalise + ds_write rows [pLo, pHi) into stage `buf`
+#pragma unroll
+        for (int p = 0; p < AROWS; ++p) {
+            if (p < pLo || p >= pHi) continue;
+            f32x4 v = aReg[p];
+            v[0] = fmaxf(fmaf(v[0], cf[p][0][0], cf[p][0][1]), a.normLo);
+            v[1] = fmaxf(fmaf(v[1], cf[p][0][2], cf[p][0][3]), a.normLo);
+            v[2] = fmaxf(fmaf(v[2], cf[p][1][0], cf[p][1][1]), a.normLo);
+            v[3] = fmaxf(fmaf(v[3], cf[p][1][2], cf[p][1][3]), a.normLo);
+            *reinterpret_cast<f32x4 *>(As + (buf * BM + 32 * p + lrow) * kBK + 4 * (tid & 7)) = v;
+        }
+    };
+
+    // C layout (swapped operands): pixel = tile column lane&31, channel = (r&3) + 8*(r>>2) + 4*(lane>>5) of a 32x32 block
+    const int rhalf = (lane >> 5) * 4;
+    const int nLane = n0 + wn * (BN / 2) + rhalf;                  // + j*32 + 8*q: first of 4 consecutive channels
+    f32x16 acc[TI][NJ];
+    if constexpr (MODE == 0 && ZB == 0) {
+        // forward: the accumulators start at the bias (a null bias reads as zeros through the bounds check)
+        const __amdgpu_buffer_rsrc_t srdBias = __builtin_amdgcn_make_buffer_rsrc((void *)a.bias, 0, a.bias ? a.Cout * 4 : 0, 0x00020000);
+        typedef unsigned int u32x4b __attribute__((ext_vector_type(4)));
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 b4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srdBias, (nLane + j * 32 + 8 * q) * 4, 0, 0));
+#pragma unroll
+                for (int i = 0; i < TI; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[i][j][4 * q + e] = b4[e];
+            }
+    } else {
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    }
 
     long long tc0 = 0, tw0 = 0, tc1 = 0, tc2 = 0;
     if (a.clk) { tc0 = clock64(); tw0 = wall_clock64(); }
     const int nk = (MODE == 2) ? a.ntaps * (a.Cin / kBK) : a.K / kBK;
     load_dma(0, 0);
     load_dma(1, 1);                                   // (nk == 1: an unused tile, drained with the others below)
+    if constexpr (NORM) {
+        // coefficient rows of the two images this tile can touch (HW >= BM) by DMA, the first two A stages through
+        // registers; everything is issued before the first wait
+        const int nLoN = m0 / a.HW;
+        const int splitN = (nLoN + 1) * a.HW - m0;              // first tile row of the second image
+#pragma unroll
+        for (int p = 0; p < AROWS; ++p) coefSlot[p] = (lrow + 32 * p >= splitN) ? 2 * a.Cin : 0;
+        const int n1 = (nLoN + 1 < a.B) ? nLoN + 1 : nLoN;
+        const __amdgpu_buffer_rsrc_t srdC = __builtin_amdgcn_make_buffer_rsrc((void *)a.coef, 0, a.B * a.Cin * 8, 0x00020000);
+        // a wave instruction moves 1 KB = 128 {scale, shift} pairs; wave w copies pieces w, w+4, ... of 2*Cin/128
+        for (int pc = wave; pc < (2 * a.Cin) / 128; pc += 4) {
+            const int img = pc / (a.Cin / 128), part = pc - img * (a.Cin / 128);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srdC, (lds_void *)(sCoef + img * 2 * a.Cin + part * 256), 16,
+                                                     (int)(((img ? n1 : nLoN) * a.Cin + part * 128) * 8 + lane * 16), 0, 0, 0);
+        }
+        unsigned v0[AROWS], v1[AROWS], kb;
+        f32x4 aReg1[AROWS];
+        tile_offsets(0, v0, kb);
+        tile_offsets(1, v1, kb);
+        load_a_regs(v0);
+#pragma unroll
+        for (int p = 0; p < AROWS; ++p)
+            aReg1[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srdA, (int)v1[p], 0, 0));
+        __builtin_amdgcn_s_waitcnt(kWaitVm0);
+        __syncthreads();                                        // the table is complete
+        load_coefs(0);
+        store_a_regs(0, 0, AROWS);
+#pragma unroll
+        for (int p = 0; p < AROWS; ++p) aReg[p] = aReg1[p];
+        load_coefs(1);
+        store_a_regs(1, 0, AROWS);
+    }
     // An LDS-DMA is ordered for other waves' ds_reads only by the issuing wave's vmcnt wait followed by a barrier;
     // the workgroup fence of __syncthreads() waits for LDS operations (lgkmcnt) only, so the vmcnt(0) is explicit.
     __builtin_amdgcn_s_waitcnt(kWaitVm0);
@@ -417,8 +510,7 @@ void igemm_conv_kernel(ConvArgs a)
         for (int i = 0; i < TI; ++i)
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
-                acc[i][j] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x2f32(fb[set][j][e], fa[set][i][e], acc[i][j], 0, 0, 0)
-                                 : __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][i][e], fb[set][j][e], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[set][j][e], fa[set][i][e], acc[i][j], 0, 0, 0);
     };
     auto multiply = [&](int set) {
 #pragma unroll
@@ -438,6 +530,13 @@ void igemm_conv_kernel(ConvArgs a)
         const int buf = kk & 1;
         unsigned voffN[AROWS], kbytesN;                // offsets of step kk+2, computed under the MFMAs of this one
         tile_offsets(kk + 2, voffN, kbytesN);
+        if constexpr (NORM) {
+            // A of step kk+2 and its coefficients: issued first (in the shadow of the MFMAs still executing), in flight
+            // for the whole K-step (past the last step: reads of unused data inside the allocations)
+            load_a_regs(voffN);
+            load_coefs(kk + 2);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         read_frags(1, buf, 1);
         multiply(0);
         read_frags(0, buf, 2);
@@ -459,7 +558,8 @@ void igemm_conv_kernel(ConvArgs a)
         // (ALU may move across the fences, MFMA / LDS / VMEM instructions may not)
         multiply_e(1, 0);
         __builtin_amdgcn_sched_barrier(0x6);
-        issue_dma_a(voffN, buf);
+        if constexpr (NORM) store_a_regs(buf, 0, AROWS / 2);
+        else issue_dma_a(voffN, buf);
         __builtin_amdgcn_sched_barrier(0x6);
         multiply_e(1, 1);
         __builtin_amdgcn_sched_barrier(0x6);
@@ -467,150 +567,140 @@ void igemm_conv_kernel(ConvArgs a)
         read_frags(0, buf ^ 1, 0);
         __builtin_amdgcn_sched_barrier(0x6);
         multiply_e(1, 2);
+        if constexpr (NORM) {
+            __builtin_amdgcn_sched_barrier(0x6);
+            store_a_regs(buf, AROWS / 2, AROWS);
+            __builtin_amdgcn_sched_barrier(0x6);
+        }
         multiply_e(1, 3);
     }
     __builtin_amdgcn_s_waitcnt(kWaitVm0);             // drain the trailing DMAs before the epilogue reuses the LDS
     __syncthreads();
 
     if (a.clk) tc2 = clock64();
-    // ---- epilogue: bias + store. C layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    const int col = lane & 31, rhalf = (lane >> 5) * 4;
-    // fused GroupNorm statistics: a BM-row tile touches at most two images (HW >= BM); `split` = first tile row
-    // of the second image.  Per lane: sums over its 32 rows per column and image slot, then half-wave, wave-pair
-    // and channel-group reductions in a fixed order; every (image, tile, group) entry has exactly one writer.
-    const bool doStats = (MODE == 0) && a.stats != nullptr;
-    const int nLo = doStats ? m0 / a.HW : 0;
-    const int split = doStats ? (nLo + 1) * a.HW - m0 : 0;
-    float ps[2][NJ], pss[2][NJ];
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) { ps[0][j] = ps[1][j] = 0.f; pss[0][j] = pss[1][j] = 0.f; }
-    // The accumulate / statistics switches are hoisted out of the element loop as compile-time tags: a per-element
-    // "maybe load" makes the compiler wait for every store before the next element (64 serialized round trips).
-    // Branch-free: out-of-range rows / columns get an out-of-range buffer offset (stores dropped, loads return 0).
-    // With branches the compiler must assume a load pending at every block entry and emits vmcnt(0) before each
-    // store; loads and stores share that counter, so every store would wait for the one before it.
+    // ---- epilogue.  Branch-free stores: out-of-range rows / columns get an out-of-range buffer offset (stores dropped,
+    // loads return 0); with branches the compiler must assume a load pending at every block entry and emits vmcnt(0)
+    // before each store.  The accumulate switch is a compile-time tag for the same reason.
     const __amdgpu_buffer_rsrc_t srdO = __builtin_amdgcn_make_buffer_rsrc((void *)a.out, 0, (int)a.outBytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t srdBias = __builtin_amdgcn_make_buffer_rsrc((void *)a.bias, 0, a.bias ? a.Cout * 4 : 0, 0x00020000);
-    float bv[NJ];
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    unsigned pixOff[TI];
 #pragma unroll
-    for (int j = 0; j < NJ; ++j)
-        bv[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srdBias, (n0 + wn * (BN / 2) + j * 32 + col) * 4, 0, 0));
-    auto store_tile = [&](auto accTag, auto statTag) {
-        constexpr bool ACC = decltype(accTag)::value, STATS = decltype(statTag)::value;
+    for (int i = 0; i < TI; ++i) {
+        const int m = m0 + wm * (BM / 2) + i * 32 + (lane & 31);
+        int pix = m;
+        if constexpr (MODE == 2) {
+            const int nn = m / HoWo;
+            const int rem = m - nn * HoWo;
+            const int jy = rem / a.Wj, jx = rem - jy * a.Wj;
+            pix = (nn * a.Ho + 2 * jy + a.py) * a.Wo + 2 * jx + a.px;
+        }
+        pixOff[i] = (m < a.M) ? (unsigned)(pix * a.ldOut) * 4u : OOB;
+    }
+    auto store_swapped = [&](auto accTag) {
+        constexpr bool ACC = decltype(accTag)::value;
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const int n = n0 + wn * (BN / 2) + j * 32 + col;
-            const bool colOk = n < a.Cout;              // narrow outputs (Cout < BN): columns beyond Cout are padding
+        for (int i = 0; i < TI; ++i)
 #pragma unroll
-            for (int i = 0; i < TI; ++i) {
-                unsigned off[16];
-                float old[16];
+            for (int j = 0; j < NJ; ++j) {
+                unsigned off[4];
+                f32x4 old[4];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + rhalf;
-                    const int m = m0 + row;
-                    int pix = m;
-                    if constexpr (MODE == 2) {
-                        const int nn = m / HoWo;
-                        const int rem = m - nn * HoWo;
-                        const int jy = rem / a.Wj, jx = rem - jy * a.Wj;
-                        pix = (nn * a.Ho + 2 * jy + a.py) * a.Wo + 2 * jx + a.px;
-                    }
-                    off[r] = (colOk && m < a.M) ? (unsigned)(pix * a.ldOut + n) * 4u : OOB;
-                    if constexpr (ACC) old[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srdO, (int)off[r], 0, 0));
+                for (int q = 0; q < 4; ++q) {
+                    const int n = nLane + j * 32 + 8 * q;
+                    off[q] = (n < a.Cout && pixOff[i] != OOB) ? pixOff[i] + (unsigned)n * 4u : OOB;
+                    if constexpr (ACC) old[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srdO, (int)off[q], 0, 0));
                 }
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float v = acc[i][j][r] + bv[j];
-                    if constexpr (STATS) {
-                        const int row = wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + rhalf;
-                        const float vs = (off[r] != OOB) ? v : 0.f;
-                        if (row >= split) { ps[1][j] += vs; pss[1][j] += vs * vs; }
-                        else { ps[0][j] += vs; pss[0][j] += vs * vs; }
-                    }
-                    if constexpr (ACC) v = old[r] + v;
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), srdO, (int)off[r], 0, 0);
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 v = f32x4{ acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3] };
+                    if constexpr (ACC) v += old[q];
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), srdO, (int)off[q], 0, 0);
                 }
             }
-        }
     };
-    if constexpr (SWAP) {
-        // C layout with swapped operands: pixel = tile column lane&31, channel = (r&3) + 8*(r>>2) + 4*(lane>>5)
-        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-        unsigned pixOff[TI];
+    if (a.accumulate) store_swapped(std::true_type{});
+    else store_swapped(std::false_type{});
+
+    // Fused GroupNorm statistics of the OUTPUT (forward only).  A BM-row tile touches at most two images (HW >= BM):
+    // slot 0 = rows before `split`, slot 1 = the rest.  Three fixed-order stages, one writer per (image, tile, group):
+    //   1. per lane, fp32: sum and sum of squares of each PG-channel piece of its TI pixels, per slot -> LDS
+    //      (a lane holds 16 channels per 32-wide block as 4 quads; PG = 4, or 2 when a group has only 2 channels);
+    //   2. per (piece, slot), fp64: over the 2 waves and 32 pixel lanes that hold the piece, in index order;
+    //   3. per (group, slot), fp64: over the pieces of the group, in channel order.
+    if constexpr (MODE == 0 && ZB == 0) {
+        if (a.stats != nullptr) {
+            const int nLo = m0 / a.HW;
+            const int split = (nLo + 1) * a.HW - m0;
+            float *sP = smem;                                      // [256 threads][2 slots][NP][2], tiles are dead now
+            auto stage1 = [&](auto pgTag) {
+                constexpr int PG = decltype(pgTag)::value;         // channels per piece
+                constexpr int PQ = 4 / PG;                         // pieces per register quad
+                constexpr int NP = NJ * 4 * PQ;                    // pieces per lane
 #pragma unroll
-        for (int i = 0; i < TI; ++i) {
-            const int m = m0 + wm * (BM / 2) + i * 32 + (lane & 31);
-            int pix = m;
-            if constexpr (MODE == 2) {
-                const int nn = m / HoWo;
-                const int rem = m - nn * HoWo;
-                const int jy = rem / a.Wj, jx = rem - jy * a.Wj;
-                pix = (nn * a.Ho + 2 * jy + a.py) * a.Wo + 2 * jx + a.px;
-            }
-            pixOff[i] = (m < a.M) ? (unsigned)(pix * a.ldOut) * 4u : OOB;
-        }
-        const int nLane = n0 + wn * (BN / 2) + rhalf;                  // + j*32 + 8*q: first of 4 consecutive channels
-        auto store_swapped = [&](auto accTag) {                        // (the accumulate switch is hoisted, as above)
-            constexpr bool ACC = decltype(accTag)::value;
+                for (int j = 0; j < NJ; ++j)
 #pragma unroll
-            for (int i = 0; i < TI; ++i)
+                    for (int q = 0; q < 4; ++q)
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    unsigned off[4];
-                    f32x4 old[4];
+                        for (int h = 0; h < PQ; ++h) {
+                            float s[2] = { 0.f, 0.f }, ss[2] = { 0.f, 0.f };
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int n = nLane + j * 32 + 8 * q;
-                        off[q] = (n < a.Cout && pixOff[i] != OOB) ? pixOff[i] + (unsigned)n * 4u : OOB;
-                        if constexpr (ACC) old[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srdO, (int)off[q], 0, 0));
-                    }
+                            for (int i = 0; i < TI; ++i) {
+                                const int row = wm * (BM / 2) + i * 32 + (lane & 31);
+                                float t = 0.f, tt = 0.f;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        f32x4 v = f32x4{ acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3] };
-                        if constexpr (ACC) v += old[q];
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), srdO, (int)off[q], 0, 0);
-                    }
-                }
-        };
-        if (a.accumulate) store_swapped(std::true_type{});
-        else store_swapped(std::false_type{});
-    } else
-    if (a.accumulate) store_tile(std::true_type{}, std::false_type{});       // gradients only: never with statistics
-    else if (doStats) store_tile(std::false_type{}, std::true_type{});
-    else store_tile(std::false_type{}, std::false_type{});
-    if (doStats) {
-        double *sS = reinterpret_cast<double *>(smem);              // [wm][BN cols][slot][2]; tiles are dead now
+                                for (int e = 0; e < PG; ++e) {
+                                    const float v = acc[i][j][4 * q + h * PG + e];
+                                    t += v;
+                                    tt = fmaf(v, v, tt);
+                                }
+                                const bool live = m0 + row < a.M, hi = row >= split;
+                                s[0] += (live && !hi) ? t : 0.f; ss[0] += (live && !hi) ? tt : 0.f;
+                                s[1] += (live && hi) ? t : 0.f;  ss[1] += (live && hi) ? tt : 0.f;
+                            }
 #pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int sl = 0; sl < 2; ++sl) {
-                double s1 = (double)ps[sl][j], s2 = (double)pss[sl][j];
-                s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
-                if (lane < 32) {
-                    const int c = wn * (BN / 2) + j * 32 + col;
-                    sS[((wm * BN + c) * 2 + sl) * 2] = s1;
-                    sS[((wm * BN + c) * 2 + sl) * 2 + 1] = s2;
-                }
-            }
-        __syncthreads();
-        const int groupsInTile = BN / a.cpg;
-        if (tid < groupsInTile * 2) {
-            const int gi = tid >> 1, sl = tid & 1;
-            const int n = nLo + sl;
-            const int firstRow = sl ? split : 0;
-            if (n < a.B && m0 + firstRow < a.M && (sl == 0 || split < BM)) {
+                            for (int sl = 0; sl < 2; ++sl) {
+                                float *o = sP + ((tid * 2 + sl) * NP + (j * 4 + q) * PQ + h) * 2;
+                                o[0] = s[sl]; o[1] = ss[sl];
+                            }
+                        }
+            };
+            const int PGr = (a.cpg >= 4) ? 4 : 2;                  // launch_igemm admits cpg = 2 or a multiple of 4
+            if (PGr == 4) stage1(std::integral_constant<int, 4>{});
+            else stage1(std::integral_constant<int, 2>{});
+            __syncthreads();
+            const int PQr = 4 / PGr, NPr = NJ * 4 * PQr;
+            const int pieces = BN / PGr;                           // pieces of the tile's BN channels
+            double *sC = reinterpret_cast<double *>(smem + 256 * 2 * NPr * 2);      // [pieces][2 slots][2]
+            for (int w = tid; w < pieces * 2; w += 256) {
+                const int pc = w >> 1, sl = w & 1;
+                const int c = pc * PGr;                            // first channel of the piece within the tile
+                const int wnP = c / (BN / 2), l = c - wnP * (BN / 2);
+                const int j = l >> 5, q = (l & 31) >> 3, half = ((l & 31) & 7) >> 2, h = ((l & 3) / PGr);
                 double s1 = 0.0, s2 = 0.0;
-                for (int w = 0; w < 2; ++w)
-                    for (int c = gi * a.cpg; c < (gi + 1) * a.cpg; ++c) {
-                        s1 += sS[((w * BN + c) * 2 + sl) * 2];
-                        s2 += sS[((w * BN + c) * 2 + sl) * 2 + 1];
+                for (int wmP = 0; wmP < 2; ++wmP)
+                    for (int pl = 0; pl < 32; ++pl) {
+                        const int t = (wmP * 2 + wnP) * 64 + half * 32 + pl;
+                        const float *o = sP + ((t * 2 + sl) * NPr + (j * 4 + q) * PQr + h) * 2;
+                        s1 += (double)o[0]; s2 += (double)o[1];
                     }
-                const int g = (n0 + gi * a.cpg) / a.cpg;
-                if (g < a.G) {
-                    const int k = mt - (int)(((long long)n * a.HW) / BM);       // tile index within the image
-                    double *o = a.stats + (((long long)n * a.nchunks + k) * a.G + g) * 2;
-                    o[0] = s1; o[1] = s2;
+                sC[w * 2] = s1; sC[w * 2 + 1] = s2;
+            }
+            __syncthreads();
+            const int groupsInTile = BN / a.cpg;
+            if (tid < groupsInTile * 2) {
+                const int gi = tid >> 1, sl = tid & 1;
+                const int n = nLo + sl;
+                const int firstRow = sl ? split : 0;
+                if (n < a.B && m0 + firstRow < a.M && (sl == 0 || split < BM)) {
+                    double s1 = 0.0, s2 = 0.0;
+                    const int ppg = a.cpg / PGr;                   // pieces per group
+                    for (int pc = gi * ppg; pc < (gi + 1) * ppg; ++pc) { s1 += sC[(pc * 2 + sl) * 2]; s2 += sC[(pc * 2 + sl) * 2 + 1]; }
+                    const int g = (n0 + gi * a.cpg) / a.cpg;
+                    if (g < a.G) {
+                        const int k = mt - (int)(((long long)n * a.HW) / BM);       // tile index within the image
+                        double *o = a.stats + (((long long)n * a.nchunks + k) * a.G + g) * 2;
+                        o[0] = s1; o[1] = s2;
+                    }
                 }
             }
         }
@@ -761,8 +851,6 @@ __device__ __forceinline__ void wino4_at(const V (&m)[6], V (&o)[4])
     o[2] = m[1] + m[2] + 4.f * m[3] + 4.f * m[4];
     o[3] = m[1] - m[2] + 8.f * m[3] - 8.f * m[4] + m[5];
 }
-
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // one tile x 2 channels per thread
 // DEFER: 0 = plain gather; 1 / 2 = the producer's GroupNorm (x*scale + shift; 2: + ReLU) is applied while gathering.
@@ -1271,8 +1359,10 @@ template <int COUT_MAX>
 __global__ __launch_bounds__(256)
 void head_kernel(const float *__restrict__ in, const float *__restrict__ w, const float *__restrict__ bias,
                  const float *__restrict__ mean, float *__restrict__ out, int B, int HW, int Cin, int ldIn,
-                 int Cout, int nTask, float lo, float hi)
+                 int Cout, int nTask, float lo, float hi, const float *__restrict__ coef, float normLo)
 {
+    // coef != NULL (512 -> <=4 form only): `in` is the raw output of the producing convolution and its GroupNorm (+ReLU)
+    // is applied on load: x -> max(x*scale + shift, normLo) with {scale, shift} pairs [B][Cin][2] (XL_OP_GN_FINAL)
     const int lane = threadIdx.x & 63;
     const int waveGlobal = (blockIdx.x * 256 + threadIdx.x) >> 6;
     const int nWaves = (gridDim.x * 256) >> 6;
@@ -1297,6 +1387,22 @@ void head_kernel(const float *__restrict__ in, const float *__restrict__ w, cons
             for (int q = 0; q < 2; ++q) {
                 v[0][q] = *reinterpret_cast<const f32x4 *>(in + p0 * ldIn + q * 256 + lane * 4);
                 v[1][q] = *reinterpret_cast<const f32x4 *>(in + p1c * ldIn + q * 256 + lane * 4);
+            }
+            if (coef) {
+                const long long pp[2] = { p0, p1c };
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const float *cf = coef + ((pp[u] / HW) * Cin) * 2;
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const f32x4 c0 = *reinterpret_cast<const f32x4 *>(cf + 2 * (q * 256 + lane * 4));
+                        const f32x4 c1 = *reinterpret_cast<const f32x4 *>(cf + 2 * (q * 256 + lane * 4) + 4);
+                        v[u][q].x = fmaxf(fmaf(v[u][q].x, c0[0], c0[1]), normLo);
+                        v[u][q].y = fmaxf(fmaf(v[u][q].y, c0[2], c0[3]), normLo);
+                        v[u][q].z = fmaxf(fmaf(v[u][q].z, c1[0], c1[1]), normLo);
+                        v[u][q].w = fmaxf(fmaf(v[u][q].w, c1[2], c1[3]), normLo);
+                    }
+                }
             }
             float acc[2][4];
 #pragma unroll
@@ -1469,10 +1575,16 @@ int g_profCap = 0, g_profCount = 0;
 bool g_profOn = false;
 int g_profType = -1, g_profMinBatched = 0;     // record only ops of this type (-1: all) with nchunks2 >= the minimum
 
-template <int KS, int STRIDE, int BN, int CIN, int MODE = 0, int BM = 128, int ZB = 0>
+template <int KS, int STRIDE, int BN, int CIN, int MODE = 0, int BM = 128, int ZB = 0, int NORM = 0>
 int launch_igemm(const xl_op &op, hipStream_t st, int py = 0, int px = 0)
 {
     ConvArgs a;
+    a.coef = nullptr; a.normLo = 0.f;
+    if (NORM) {
+        if (!op.aux2 || op.Ho * op.Wo < BM) return XL_ERR_ARG;
+        a.coef = (const float *)op.aux2;
+        a.normLo = (op.flags & XL_CONV_NORM_RELU) ? 0.f : -__builtin_huge_valf();
+    }
     a.in = (const float *)op.in; a.w = (const float *)op.w; a.bias = (const float *)op.bias; a.out = (float *)op.out;
     a.B = op.B; a.Hi = op.Hi; a.Wi = op.Wi; a.Cin = op.Cin; a.Ho = op.Ho; a.Wo = op.Wo; a.Cout = op.Cout;
     a.ldIn = op.ld_in; a.ldOut = op.ld_out;
@@ -1488,6 +1600,7 @@ int launch_igemm(const xl_op &op, hipStream_t st, int py = 0, int px = 0)
     if (MODE == 0 && op.stats && op.groups > 0) {
         a.G = op.groups; a.cpg = op.Cout / op.groups; a.nchunks = op.nchunks;
         if (a.HW < BM || op.Cout % op.groups != 0 || BN % a.cpg != 0 || a.nchunks < (a.HW + BM - 1) / BM + 1) return XL_ERR_ARG;
+        if (a.cpg != 2 && a.cpg % 4 != 0) return XL_ERR_ARG;         // the statistics epilogue sums 2- or 4-channel pieces
         a.stats = (double *)op.stats;
     }
     if (MODE == 2) {
@@ -1526,20 +1639,28 @@ int launch_igemm(const xl_op &op, hipStream_t st, int py = 0, int px = 0)
             part.in = (const char *)op.in + (long long)b0 * perIn;
             part.out = (char *)op.out + (long long)b0 * perOut;
             if (op.stats) part.stats = (char *)op.stats + (long long)b0 * op.nchunks * op.groups * 2 * sizeof(double);
-            const int rc = launch_igemm<KS, STRIDE, BN, CIN, MODE, BM, ZB>(part, st, py, px);
+            if (NORM) part.aux2 = (const char *)op.aux2 + (long long)b0 * op.Cin * 2 * sizeof(float);
+            const int rc = launch_igemm<KS, STRIDE, BN, CIN, MODE, BM, ZB, NORM>(part, st, py, px);
             if (rc != XL_OK) return rc;
         }
         return XL_OK;
     }
     a.inBytes = (unsigned)inBytes; a.wBytes = (unsigned)wBytes; a.outBytes = (unsigned)outBytes;
     a.accumulate = (op.flags & XL_CONV_ACCUMULATE) ? 1 : 0;
-    if ((ZB || MODE != 0) && (a.bias || a.stats || op.ld_out % 4 != 0)) return XL_ERR_ARG;   // swapped-operand epilogue
+    if (op.ld_out % 4 != 0) return XL_ERR_ARG;                    // dwordx4 stores of 4 consecutive channels
+    if ((ZB || MODE != 0) && (a.bias || a.stats)) return XL_ERR_ARG;
     if (a.accumulate && a.stats) return XL_ERR_ARG;
-    const size_t lds = sizeof(float) * 2 * (BM + BN) * kBK;
+    size_t lds = sizeof(float) * 2 * (BM + BN) * kBK;
+    if (NORM) lds += sizeof(float) * (4 * (size_t)op.Cin + 256);   // {scale, shift} of two images (+ slack for the unused tail stage)
+    if (a.stats) {                                   // the statistics epilogue reuses the tile storage: make sure it fits
+        const int pg = a.cpg >= 4 ? 4 : 2, np = (BN / 64) * 4 * (4 / pg);
+        const size_t need = sizeof(float) * 256 * 2 * np * 2 + sizeof(double) * (BN / pg) * 2 * 2;
+        if (need > lds) lds = need;
+    }
     static XlLdsLimit configured;                    // one per template instantiation, tracked per device
     int cfgDev;
     if (configured.needs(lds, &cfgDev)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(igemm_conv_kernel<KS, STRIDE, BN, CIN, MODE, BM, ZB>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(igemm_conv_kernel<KS, STRIDE, BN, CIN, MODE, BM, ZB, NORM>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { snprintf(g_err, sizeof(g_err), "hipFuncSetAttribute: %s", hipGetErrorString(e)); return XL_ERR_HIP; }
         configured.done(lds, cfgDev);
@@ -1548,7 +1669,7 @@ int launch_igemm(const xl_op &op, hipStream_t st, int py = 0, int px = 0)
     a.clk = nullptr;
     const int nwg = a.nbm * a.nbn * a.zCount;
     if (clkDbg && hipMalloc(&a.clk, sizeof(long long) * 8 * nwg) != hipSuccess) return XL_ERR_HIP;
-    hipLaunchKernelGGL((igemm_conv_kernel<KS, STRIDE, BN, CIN, MODE, BM, ZB>), dim3(nwg), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((igemm_conv_kernel<KS, STRIDE, BN, CIN, MODE, BM, ZB, NORM>), dim3(nwg), dim3(256), lds, st, a);
     if (clkDbg) {
         std::vector<long long> h(8 * (size_t)nwg);
         const bool copied = hipStreamSynchronize(st) == hipSuccess &&
@@ -1626,6 +1747,10 @@ int run_conv(const xl_op &op, hipStream_t st)
         if (!wide) return XL_ERR_UNSUPPORTED;
         if (small) return op.Cin == 512 ? launch_igemm<1, 1, 128, 512, 0, 64, 1>(op, st) : launch_igemm<1, 1, 128, 0, 0, 64, 1>(op, st);
         return op.Cin == 512 ? launch_igemm<1, 1, 128, 512, 0, 128, 1>(op, st) : launch_igemm<1, 1, 128, 0, 0, 128, 1>(op, st);
+    }
+    if (op.ksize == 1 && op.stride == 1 && (op.flags & XL_CONV_NORM_IN)) {   // producer's GroupNorm applied on load
+        if (!wide || small) return XL_ERR_UNSUPPORTED;
+        return op.Cin == 512 ? launch_igemm<1, 1, 128, 512, 0, 128, 0, 1>(op, st) : launch_igemm<1, 1, 128, 0, 0, 128, 0, 1>(op, st);
     }
     if (op.ksize == 1 && op.stride == 1) {
         if (small) {
@@ -1788,9 +1913,11 @@ int run_op(const xl_op &op, hipStream_t st)
             const long long pix = (long long)op.B * op.Hi * op.Wi;
             long long blocks = (pix + 3) / 4;
             if (blocks > 4096) blocks = 4096;
+            if (op.aux2 && !(op.Cin == 512 && op.Cout <= 4)) return XL_ERR_UNSUPPORTED;    // normalise-on-load: 512 -> <=4 form
             hipLaunchKernelGGL(head_kernel<8>, dim3((unsigned)blocks), dim3(256), 0, st, (const float *)op.in,
                                (const float *)op.w, (const float *)op.bias, (const float *)op.aux, (float *)op.out,
-                               op.B, op.Hi * op.Wi, op.Cin, op.ld_in, op.Cout, op.n_task, op.clamp_lo, op.clamp_hi);
+                               op.B, op.Hi * op.Wi, op.Cin, op.ld_in, op.Cout, op.n_task, op.clamp_lo, op.clamp_hi,
+                               (const float *)op.aux2, (op.flags & XL_CONV_NORM_RELU) ? 0.f : -__builtin_huge_valf());
             return XL_OK;
         }
         case XL_OP_DUC_HEAD: {

@@ -30,6 +30,7 @@ XL_OP_DUC_HEAD = 14
 XL_OP_DUC_HEAD_BWD = 15
 XL_OP_WINO_DY, XL_OP_WINO_WFINAL, XL_OP_GNB_FINAL = 16, 17, 18
 CONV_DGRAD, CONV_ACCUMULATE, CONV_SPLIT_BF16 = 1, 2, 64
+CONV_NORM_IN, CONV_NORM_RELU = 128, 256
 
 
 class XlOp(ctypes.Structure):
@@ -340,7 +341,16 @@ class _Plan:
         return t
 
     # -- op emitters; an activation is (tensor, H, W, C, ld, channel_offset)
-    def conv(self, act, conv, out=None, out_ld=None, out_off=0):
+    def norm_on_load_ok(self, act, conv):
+        """The 1x1 forward conv kernel can apply the producer's GroupNorm(+ReLU) to its A operand while loading it (no
+        separate apply pass): 128-row x 128-column tiles, whole 32-channel K-steps, at most two images per tile."""
+        t, H, W, C, ld, off = act
+        cout = conv.out_channels
+        return (conv.kernel_size[0] == 1 and conv.stride[0] == 1 and cout % 128 == 0 and C % 32 == 0 and H * W >= 128
+                and -(-self.B * H * W // 128) * (cout // 128) > 256 and not self.train
+                and not os.environ.get("XL_NO_NORM_ON_LOAD"))
+
+    def conv(self, act, conv, out=None, out_ld=None, out_off=0, norm_in=None):
         t, H, W, C, ld, off = act
         k, s = conv.kernel_size[0], conv.stride[0]
         cout = conv.out_channels
@@ -361,6 +371,9 @@ class _Plan:
         bn = 128 if cout % 128 == 0 else 64
         if -(-self.B * Ho * Wo // 128) * -(-cout // bn) <= 256:
             op.reserved_i = 64
+        if norm_in is not None:                       # the producer's deferred GroupNorm apply, folded into the operand load
+            op.flags |= CONV_NORM_IN | (CONV_NORM_RELU if norm_in.flags & GN_RELU_IN else 0)
+            self.deferred_gn_consumers = getattr(self, "deferred_gn_consumers", []) + [len(self.ops)]
         self.ops.append(op)
         res = (out, Ho, Wo, cout, out_ld, out_off)
         self.tape.append(dict(kind="conv", conv=conv, x=act, raw=res))
@@ -442,7 +455,7 @@ class _Plan:
             return 2 if not (H % 2 or W % 2) and self.B * (H // 2) * (W // 2) * max(C, conv.out_channels) * 4 < 2 ** 31 - 1 else 0
         return self.wino_pick(H, W, max(C, conv.out_channels))
 
-    def conv_wino(self, act, conv, norm, flags, aux, m, deferred=None):
+    def conv_wino(self, act, conv, norm, flags, aux, m, deferred=None, defer=False):
         """conv3x3 + GroupNorm(+epilogue) as F(m x m, 3x3): input transform, (m+2)^2 GEMMs in one batched launch, output
         transform that also emits the GroupNorm partial sums, GN_FINAL, GN_APPLY (in place)."""
         t, H, W, C, ld, off = act
@@ -529,6 +542,12 @@ class _Plan:
             ap.aux = aux[0].data_ptr() + 4 * aux[5]
             ap.ld_aux = aux[4]
         ap.out, ap.ld_out = ap.in_, cout
+        if defer and flags == GN_RELU_IN and aux is None and not os.environ.get("XL_NO_DEFERRED_GN"):
+            # the only consumer applies it while loading its operand (a 1x1 conv: norm_on_load_ok; or a Winograd transform)
+            if not hasattr(self, "pending_gn"):
+                self.pending_gn = {}
+            self.pending_gn[self._act_key(y)] = ap
+            return y
         self.stats_ops.append(len(self.ops))
         self.ops.append(ap)
         return y
@@ -539,15 +558,17 @@ class _Plan:
         GN_APPLY pass (one read + one write of the activation) disappears."""
         pend = getattr(self, "pending_gn", {}).pop(self._act_key(act), None)
         m = self.wino_tile(act, conv)
-        if pend is not None and m not in (4, 6):
+        if pend is not None and m not in (4, 6) and not self.norm_on_load_ok(act, conv):
             self.stats_ops.append(len(self.ops))       # consumer cannot absorb it: materialise now
             self.ops.append(pend)
             pend = None
         if m:
-            return self.conv_wino(act, conv, norm, flags, aux, m, pend)
-        y = self.conv(act, conv)
+            return self.conv_wino(act, conv, norm, flags, aux, m, pend, defer=defer)
+        y = self.conv(act, conv, norm_in=pend)
         bn = 128 if conv.out_channels % 128 == 0 else 64
-        whole_groups = bn % (conv.out_channels // norm.num_groups) == 0       # a conv tile's columns cover whole groups
+        cpg = conv.out_channels // norm.num_groups
+        # a conv tile's columns cover whole groups, and the statistics epilogue sums 2- or 4-channel pieces
+        whole_groups = bn % cpg == 0 and (cpg == 2 or cpg % 4 == 0)
         if not self.train and y[1] * y[2] >= 128 and whole_groups and not self.separate_stats:
             # inference: the conv epilogue produces the GroupNorm statistics, the separate stats pass is dropped
             return self.gn_fused(y, norm, flags, aux, len(self.ops) - 1,
@@ -632,7 +653,7 @@ class _Plan:
 
     def res_block(self, res, block):
         """relu(res + block(res)), networks.py:252-254 / :332-334"""
-        x = self.cgr(res, block[0], block[1])
+        x = self.cgr(res, block[0], block[1], defer=True)
         x2 = self.cgr(x, block[3], block[4], defer=True)
         self.release(x[0])
         x3 = self.cgr(x2, block[6], block[7], GN_RELU_IN | GN_ADD | GN_RELU_OUT, aux=res)
@@ -711,12 +732,12 @@ class _Plan:
         x2 = self.cgr(x, enc.conv2, enc.norm2); self.release(x[0])
         x3 = self.cgr(x2, enc.conv3, enc.norm3); self.release(x2[0])
         res = self.cgr(x3, enc.conv4, enc.norm4); self.release(x3[0])
-        a = self.cgr(res, enc.res1_conv1, enc.res1_norm1)
+        a = self.cgr(res, enc.res1_conv1, enc.res1_norm1, defer=True)
         b = self.cgr(a, enc.res1_conv2, enc.res1_norm2, defer=True); self.release(a[0])
         c = self.cgr(b, enc.res1_conv3, enc.res1_norm3, GN_RELU_IN | GN_ADD | GN_RELU_OUT, aux=res)
         self.release(b[0]); self.release(res[0])
         res = c
-        a = self.cgr(res, enc.res2_conv1, enc.res2_norm1)
+        a = self.cgr(res, enc.res2_conv1, enc.res2_norm1, defer=True)
         b = self.cgr(a, enc.res2_conv2, enc.res2_norm2, defer=True); self.release(a[0])
         c = self.cgr(b, enc.res2_conv3, enc.res2_norm3); self.release(b[0])
         n_add = len(enc.enc_add_res_block_ls)
@@ -763,19 +784,19 @@ class _Plan:
             sk = self.cgr(mlr, net.mlr_skip[0], net.mlr_skip[1], 0)
             mlr = self.gn(mlr, net.mlr_norm, 0)
             f = net.mlr_forward
-            a = self.cgr(mlr, f[0], f[1]); self.release(cat)
+            a = self.cgr(mlr, f[0], f[1], defer=True); self.release(cat)
             b = self.cgr(a, f[3], f[4], defer=True); self.release(a[0])
             res = self.cgr(b, f[6], f[7], GN_RELU_IN | GN_ADD | GN_RELU_OUT, aux=sk)
             self.release(b[0]); self.release(sk[0])
         for block in dec.dec_add_res_block_ls:
             res = self.res_block(res, block)
-        a = self.cgr(res, dec.res3_conv1, dec.res3_norm1)
-        b = self.cgr(a, dec.res3_conv2, dec.res3_norm2); self.release(a[0])
+        a = self.cgr(res, dec.res3_conv1, dec.res3_norm1, defer=True)
+        b = self.cgr(a, dec.res3_conv2, dec.res3_norm2, defer=True); self.release(a[0])
         c = self.cgr(b, dec.res3_conv3, dec.res3_norm3, GN_RELU_IN | GN_ADD | GN_RELU_OUT, aux=res)
         self.release(b[0]); self.release(res[0])
         res = c
-        a = self.cgr(res, dec.fc1, dec.fc1_norm); self.release(res[0])
-        b = self.cgr(a, dec.fc2, dec.fc2_norm); self.release(a[0])
+        a = self.cgr(res, dec.fc1, dec.fc1_norm, defer=True); self.release(res[0])
+        b = self.cgr(a, dec.fc2, dec.fc2_norm, defer=True); self.release(a[0])
         if dec.full_size_output:
             if self.train and (self.H % 8 or self.W % 8):
                 raise NotImplementedError("training the full-size head needs H and W to be multiples of 8 (the backward "
@@ -800,9 +821,18 @@ class _Plan:
             self.out_shape = (self.B, nc, self.H, self.W)
             self.tape.append(dict(kind="duc_head", fc3=dec.fc3, x=d, w3=w3, cout=nc, n_task=op.n_task))
             return
+        pend = getattr(self, "pending_gn", {}).pop(self._act_key(b), None)
         t, H, W, C, ld, off = b
+        nout = dec.num_task_channel + dec.num_pos_channel
+        if pend is not None and not (C == 512 and nout <= 4):
+            self.stats_ops.append(len(self.ops))       # the general head form reads a normalised activation
+            self.ops.append(pend)
+            pend = None
         op = XlOp()
         op.type = XL_OP_HEAD
+        if pend is not None:                           # fc2's GroupNorm + ReLU applied by the head while it loads
+            op.flags = CONV_NORM_RELU if pend.flags & GN_RELU_IN else 0
+            self.deferred_gn_consumers = getattr(self, "deferred_gn_consumers", []) + [len(self.ops)]
         op.B, op.Hi, op.Wi, op.Cin, op.Ho, op.Wo = self.B, H, W, C, H, W
         op.Cout = dec.num_task_channel + dec.num_pos_channel
         op.n_task, op.n_pos, op.ld_in = dec.num_task_channel, dec.num_pos_channel, ld
@@ -1118,7 +1148,9 @@ class _Plan:
         self.op_array[self.out_op_index].out = out.data_ptr()
         stream = torch.cuda.current_stream().cuda_stream
         _check(_bind().xl_cnn_run(self.op_array, len(self.op_array), ctypes.c_void_p(stream)))
-        self.last_image, self.last_out = image, out
+        # (a detached alias: the returned tensor itself becomes the output of the autograd node in training, and a
+        # reference to it from here would keep that graph - and the plan's busy token - alive)
+        self.last_image, self.last_out = image, out.detach()
         return out
 
     def run_backward(self, dout):

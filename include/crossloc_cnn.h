@@ -73,6 +73,10 @@ enum {
 #define XL_CONV_DGRAD 1        /* data gradient: `in` is dY (Hi x Wi x Cin = forward output), result is dX; weights
                                   packed with xl_cnn_pack_conv_weight_dgrad; `stride` is the forward stride */
 #define XL_CONV_ACCUMULATE 2   /* out += result (second writer of a gradient buffer) */
+#define XL_CONV_NORM_IN 128    /* 1x1 forward conv: `in` is the RAW output of the producing convolution and the producer's
+                                  GroupNorm is applied while the operand is loaded (aux2 = {scale, shift} pairs
+                                  [B][Cin][2] written by XL_OP_GN_FINAL): x -> x*scale + shift, no separate apply pass */
+#define XL_CONV_NORM_RELU 256  /* ... followed by ReLU */
 /* extra xl_op.flags for XL_OP_GNB_* */
 #define XL_GN_ACC_AUX 8        /* d(residual) is accumulated into out2 instead of written */
 #define XL_GN_NO_CONV_BIAS 16  /* no conv precedes this GroupNorm: skip the bias gradient */

@@ -67,6 +67,50 @@ def test_igemm_conv_vs_torch(cin, cout, k, s, B, H, W):
     _close(out.cpu().permute(0, 3, 1, 2), ref)
 
 
+@pytest.mark.parametrize("cin,cout,B,H,W,relu", [(512, 512, 3, 12, 16, True), (256, 256, 2, 13, 17, True), (512, 512, 2, 60, 90, True),
+                                                   (1536, 512, 2, 12, 16, False), (512, 512, 1, 16, 8, True)])
+def test_conv1x1_normalise_on_load_with_statistics(cin, cout, B, H, W, relu):
+    """XL_CONV_NORM_IN: the conv consumes the RAW output of its producer and applies the producer's GroupNorm (+ReLU) to
+    the A operand on its way into LDS (per-(image, channel) {scale, shift} pairs).  Tiles straddle image boundaries
+    (H*W is not a multiple of 128), and the launch also emits the GroupNorm statistics of its own output."""
+    g = torch.Generator().manual_seed(cin + cout + B + H)
+    x = torch.randn(B, cin, H, W, generator=g) * 3.0 + 1.0
+    coef = torch.stack([torch.rand(B, cin, generator=g) + 0.5, torch.randn(B, cin, generator=g)], 2)     # [B][C][{scale, shift}]
+    conv = nn.Conv2d(cin, cout, 1)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) * (2.0 / cin) ** 0.5)
+        conv.bias.copy_(torch.randn(cout, generator=g))
+        xn = x.double() * coef[:, :, 0, None, None].double() + coef[:, :, 1, None, None].double()
+        if relu:
+            xn = xn.clamp(min=0)
+        ref = F.conv2d(xn, conv.weight.double(), conv.bias.double())
+    L = networks._bind()
+    xd = _nhwc(x).cuda()
+    wsrc = conv.weight.detach().cuda().contiguous()
+    wd = torch.empty_like(wsrc)
+    networks._check(L.xl_cnn_pack_conv_weight(wsrc.data_ptr(), wd.data_ptr(), cout, cin, 1, None))
+    bd, cd = conv.bias.detach().cuda(), coef.contiguous().cuda()
+    out = torch.full((B, H, W, cout), float("nan"), device="cuda")
+    G, tile = 32, 128
+    nchunks = (H * W + tile - 1) // tile + 1
+    stats = torch.zeros(B * nchunks * G * 2, dtype=torch.float64, device="cuda")
+    op = networks.XlOp()
+    op.type = networks.XL_OP_CONV
+    op.B, op.Hi, op.Wi, op.Cin, op.Ho, op.Wo, op.Cout = B, H, W, cin, H, W, cout
+    op.ksize, op.stride, op.ld_in, op.ld_out = 1, 1, cin, cout
+    op.flags = networks.CONV_NORM_IN | (networks.CONV_NORM_RELU if relu else 0)
+    op.in_, op.w, op.bias, op.out, op.aux2 = xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), out.data_ptr(), cd.data_ptr()
+    op.stats, op.groups, op.nchunks = stats.data_ptr(), G, nchunks
+    _run([op])
+    got = out.cpu().permute(0, 3, 1, 2).double()
+    _close(got, ref)
+    # statistics of the output: per (image, group) sum and sum of squares over all tiles
+    st = stats.cpu().view(B, nchunks, G, 2).sum(1)
+    grp = got.reshape(B, G, -1)
+    assert torch.allclose(st[:, :, 0], grp.sum(2), rtol=1e-5, atol=1e-3)
+    assert torch.allclose(st[:, :, 1], (grp * grp).sum(2), rtol=1e-5)
+
+
 def test_conv_reads_and_writes_channel_slices():
     """ld/offset addressing used by the concat-free MLR fusion."""
     g = torch.Generator().manual_seed(3)

@@ -22,6 +22,8 @@ def main():
     ap.add_argument("--W", type=int, default=90)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--z", type=int, default=1, help="batched GEMMs per launch (16 = the Winograd F(2x2,3x3) GEMMs)")
+    ap.add_argument("--stats", action="store_true", help="fused GroupNorm statistics epilogue (32 groups), as the inference plans run 1x1 layers")
+    ap.add_argument("--norm", action="store_true", help="normalise-on-load form of the 1x1 conv (XL_CONV_NORM_IN + ReLU)")
     a = ap.parse_args()
     L = networks._bind()
     torch.manual_seed(0)
@@ -38,6 +40,13 @@ def main():
     op.in_, op.w, op.bias, op.out = x.data_ptr(), w.data_ptr(), b.data_ptr(), out.data_ptr()
     if a.z > 1:
         op.nchunks2, op.bias = a.z, None
+    if a.norm:
+        coef = torch.stack([torch.rand(a.B, a.cin, device="cuda") + 0.5, torch.randn(a.B, a.cin, device="cuda")], 2).contiguous()
+        op.flags, op.aux2 = networks.CONV_NORM_IN | networks.CONV_NORM_RELU, coef.data_ptr()
+    if a.stats:
+        nch = (Ho * Wo + 127) // 128 + 1
+        st_buf = torch.zeros(a.B * nch * 32 * 2, dtype=torch.float64, device="cuda")
+        op.stats, op.groups, op.nchunks = st_buf.data_ptr(), 32, nch
     arr = (networks.XlOp * 1)(op)
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     for _ in range(3):
