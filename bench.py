@@ -51,6 +51,22 @@ def lookup_traffic(form, frames):
     return None, "no record for %s at %d frames per launch in profiles/traffic.json" % (form, frames)
 
 
+def lookup_solver_counters():
+    """VALU-issue figures of the solver kernels from the committed PMC record (None when there is none)."""
+    try:
+        with open(TRAFFIC_JSON) as f:
+            sv = json.load(f)["solver"]
+    except (OSError, ValueError, KeyError):
+        return None
+    k1 = sv["kernels"].get("xl_dsac_forward_kernel<1>")
+    k2 = sv["kernels"].get("xl_dsac_forward_kernel<2>")
+    if not k1:
+        return None
+    return {"sample_and_score_valu_busy": k1["valu_busy"], "sample_and_score_fp64_share_of_valu": k1["fp64_share_of_valu_instructions"],
+            "sample_and_score_waves_per_simd": k1["mean_waves_per_simd"], "sample_and_score_lds_conflict_share": k1["lds_conflict_share"],
+            "select_and_refine_valu_busy": k2["valu_busy"] if k2 else None, "source": sv["source"]}
+
+
 def gather_and_median(local_err, world, dist=None, group=None):
     """Per-image (t_err [m], r_err [deg]) rows of every rank -> (median cm, median deg, rows gathered).  Equal shards
     (each rank localises batch x steps images), ONE all-gather (RCCL on GPU tensors, gloo on CPU tensors in the test);
@@ -286,6 +302,8 @@ def main():
                        # nHyp*N*12 B + 64 B per image; the stage is LDS-resident and fp64/latency-bound
                        "dsac_algorithmic_GBps": round(B * (NH * 5400 * 12 + 64) / (dsac_ms * 1e-3) / 1e9, 1),
                        "dsac_hbm_roofline_frac": round(B * (NH * 5400 * 12 + 64) / (dsac_ms * 1e-3) / 8e12, 5),
+                       # ... which says little for an LDS-resident fp64 kernel: the VALU-issue fraction from the PMC record
+                       "dsac_pmc": lookup_solver_counters(),
                        # direct-convolution FLOP count of the network over the CNN time; with the Winograd
                        # layers fewer multiplies are executed, so this "algorithmic" rate may exceed the MFMA peak
                        "cnn_fwd_algorithmic_tflops": round((FWD_GFLOP_PER_IMAGE_3ENC if args.mlr else FWD_GFLOP_PER_IMAGE) * B / cnn_ms, 2),

@@ -1114,8 +1114,9 @@ void wino6_in_kernel(const float *__restrict__ in, float *__restrict__ V, int B,
 }
 
 // grid (nchunks, B, C / CB), as wino4_out_kernel: M [64][B*Th*Tw][C] -> out [B,H,W,C] + bias + GroupNorm partial sums.
-// VW channels per thread: with 2 the 6x8 intermediate plus the 8 loads in flight need all 256 VGPRs (one wave per SIMD,
-// 363 us per 512-channel layer at 44 frames); with 1 the kernel keeps 2-4 waves per SIMD and streams.
+// VW channels per thread.  VW = 1: the factored transform on a 6x8 intermediate, one dword per lane and access.
+// VW = 2 (channel counts that are multiples of 512): 8-byte accesses through a buffer descriptor with scalar plane
+// offsets and a column-accumulated row transform - the factored form with two channels needs more than 256 VGPRs.
 template <int VW> struct WinoVec { typedef float type; };
 template <> struct WinoVec<2> { typedef f32x2 type; };
 __device__ __forceinline__ float wino_lane(const float &v, int) { return v; }
@@ -1143,34 +1144,95 @@ void wino6_out_kernel(const float *__restrict__ M, const float *__restrict__ bia
     V bv = V(0.f);
     if (bias) bv = *reinterpret_cast<const V *>(bias + cch);
     V s1 = V(0.f), s2 = V(0.f);
+    const __amdgpu_buffer_rsrc_t srdM = __builtin_amdgcn_make_buffer_rsrc((void *)M, 0, (int)(unsigned)(64 * zs * 4 > 0xffffffffLL ? 0xffffffffLL : 64 * zs * 4), 0x00020000);
     for (int tl = k * tpb + sub; tl < t1; tl += S) {
         const int ty = tl / Tw, tx = tl - ty * Tw;
         const float *m = M + ((long long)n * Timg + tl) * C + cch;
-        V q[6][8];                                   // q[p][j] = (A^T r)[p][j]
+        if constexpr (VW == 1) {
+            V q[6][8];                               // q[p][j] = (A^T r)[p][j]
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            V col[8], o[6];
+            for (int j = 0; j < 8; ++j) {
+                V col[8], o[6];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) col[i] = *reinterpret_cast<const V *>(m + (8 * i + j) * zs);
-            wino6_at(col, o);
+                for (int i = 0; i < 8; ++i) col[i] = *reinterpret_cast<const V *>(m + (8 * i + j) * zs);
+                wino6_at(col, o);
 #pragma unroll
-            for (int pI = 0; pI < 6; ++pI) q[pI][j] = o[pI];
-        }
+                for (int pI = 0; pI < 6; ++pI) q[pI][j] = o[pI];
+            }
 #pragma unroll
-        for (int pI = 0; pI < 6; ++pI) {
-            V y[6];
-            wino6_at(q[pI], y);
-            const int oy = 6 * ty + pI;
-            if (oy >= H) continue;
+            for (int pI = 0; pI < 6; ++pI) {
+                V y[6];
+                wino6_at(q[pI], y);
+                const int oy = 6 * ty + pI;
+                if (oy >= H) continue;
 #pragma unroll
-            for (int qI = 0; qI < 6; ++qI) {
-                const int ox = 6 * tx + qI;
-                if (ox >= W) continue;
-                V v = y[qI] + bv;
-                V *dst = reinterpret_cast<V *>(out + (((long long)n * H + oy) * W + ox) * ldOut + cch);
-                if (accumulate) v += *dst;                     // data gradients: second producer of a gradient tensor
-                *dst = v;
-                s1 += v; s2 += v * v;
+                for (int qI = 0; qI < 6; ++qI) {
+                    const int ox = 6 * tx + qI;
+                    if (ox >= W) continue;
+                    V v = y[qI] + bv;
+                    V *dst = reinterpret_cast<V *>(out + (((long long)n * H + oy) * W + ox) * ldOut + cch);
+                    if (accumulate) v += *dst;                     // data gradients: second producer of a gradient tensor
+                    *dst = v;
+                    s1 += v; s2 += v * v;
+                }
+            }
+        } else {
+            // Two channels per lane: 8-byte accesses (a dword per lane caps the streaming rate of this pass near 4.5 TB/s).
+            // The 6x8 intermediate of the factored form does not fit beside 16-byte-wide columns in flight, so the row
+            // transform is accumulated column by column: y[p][.] += (A^T)[., j] * (A^T col_j)[p]; 36 accumulators, one
+            // column being reduced and one in flight.
+            constexpr float AT[8][6] = { { 1.f, 0.f, 0.f, 0.f, 0.f, 0.f }, { 1.f, 1.f, 1.f, 1.f, 1.f, 1.f },
+                                         { 1.f, -1.f, 1.f, -1.f, 1.f, -1.f }, { 1.f, 2.f, 4.f, 8.f, 16.f, 32.f },
+                                         { 1.f, -2.f, 4.f, -8.f, 16.f, -32.f }, { 32.f, 16.f, 8.f, 4.f, 2.f, 1.f },
+                                         { 32.f, -16.f, 8.f, -4.f, 2.f, -1.f }, { 0.f, 0.f, 0.f, 0.f, 0.f, 1.f } };
+            V y[6][6];
+#pragma unroll
+            for (int pI = 0; pI < 6; ++pI)
+#pragma unroll
+                for (int qI = 0; qI < 6; ++qI) y[pI][qI] = bv;
+            // frequency planes through one buffer descriptor: the lane part of the address is ONE VGPR and the plane
+            // offset a scalar (with flat pointers the compiler keeps 64 loop-invariant 64-bit addresses in registers)
+            const unsigned vo = (unsigned)(((long long)n * Timg + tl) * C + cch) * 4u;
+            const unsigned zsB = (unsigned)(zs * 4);
+            auto ldp = [&](int plane) {
+                typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+                return __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b64(srdM, (int)vo, (int)(plane * zsB), 0));
+            };
+            V colN[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) colN[i] = ldp(8 * i);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                V col[8], o[6];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) col[i] = colN[i];
+                if (j + 1 < 8) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) colN[i] = ldp(8 * i + j + 1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                wino6_at(col, o);
+#pragma unroll
+                for (int pI = 0; pI < 6; ++pI)
+#pragma unroll
+                    for (int qI = 0; qI < 6; ++qI)
+                        if (AT[j][qI] != 0.f) y[pI][qI] += AT[j][qI] * o[pI];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int pI = 0; pI < 6; ++pI) {
+                const int oy = 6 * ty + pI;
+                if (oy >= H) continue;
+#pragma unroll
+                for (int qI = 0; qI < 6; ++qI) {
+                    const int ox = 6 * tx + qI;
+                    if (ox >= W) continue;
+                    V v = y[pI][qI];
+                    V *dst = reinterpret_cast<V *>(out + (((long long)n * H + oy) * W + ox) * ldOut + cch);
+                    if (accumulate) v += *dst;
+                    *dst = v;
+                    s1 += v; s2 += v * v;
+                }
             }
         }
     }
@@ -1836,14 +1898,17 @@ int run_op(const xl_op &op, hipStream_t st)
             // in: M [16][B*Th*Tw][C]; out [B,H,W,C] (Hi x Wi = output size); reserved_i = tiles per block
             if (op.ksize == 6) {
                 const int Th6 = (op.Hi + 5) / 6, Tw6 = (op.Wi + 5) / 6;
-                const int CB = op.Cin < 256 ? op.Cin : 256;
-                if (op.Cin % 2 != 0 || op.Cin % CB != 0 || 256 % CB != 0 || op.ld_out % 2 != 0 || op.reserved_i < 1 ||
+                // two channels per lane where the channel count allows (3.7 -> 3.3 ms per 44-frame step); XL_WINO_OUT_VW=1: one
+                static const int vw = getenv("XL_WINO_OUT_VW") ? atoi(getenv("XL_WINO_OUT_VW")) : 2;
+                const bool two = vw == 2 && op.Cin % 512 == 0 && 64LL * op.B * Th6 * Tw6 * op.Cin * 4 < 0xffffffffLL;
+                const int CB = two ? 512 : (op.Cin < 256 ? op.Cin : 256);
+                if (op.Cin % 2 != 0 || op.Cin % CB != 0 || (256 * (two ? 2 : 1)) % CB != 0 || op.ld_out % 2 != 0 || op.reserved_i < 1 ||
                     op.nchunks != (Th6 * Tw6 + op.reserved_i - 1) / op.reserved_i)
                     return XL_ERR_ARG;
                 if (op.stats && (op.groups < 1 || op.Cin % op.groups != 0 || CB % (op.Cin / op.groups) != 0 ||
                                  CB / (op.Cin / op.groups) > 256))
                     return XL_ERR_ARG;
-                hipLaunchKernelGGL(wino6_out_kernel<1>, dim3(op.nchunks, op.B, op.Cin / CB), dim3(256), 0, st, (const float *)op.in,
+                hipLaunchKernelGGL(two ? wino6_out_kernel<2> : wino6_out_kernel<1>, dim3(op.nchunks, op.B, op.Cin / CB), dim3(256), 0, st, (const float *)op.in,
                                    (const float *)op.bias, (float *)op.out, (double *)op.stats, op.B, op.Hi, op.Wi, op.Cin,
                                    op.ld_out, Th6, Tw6, op.reserved_i, op.groups, op.nchunks,
                                    (op.flags & XL_CONV_ACCUMULATE) ? 1 : 0);

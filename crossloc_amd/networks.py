@@ -497,6 +497,8 @@ class _Plan:
         zblocks = max(1, cout // (256 if m == 6 else 512))          # channel blocks of the output-transform grid
         while tpb > 1 and B * -(-(Th * Tw) // tpb) * zblocks < 1024:
             tpb //= 2                                # small batches: more, shorter workgroups (latency-bound otherwise)
+        if os.environ.get("XL_WINO_OUT_TPB"):
+            tpb = int(os.environ["XL_WINO_OUT_TPB"])
         if self.separate_stats:
             tpb = 4          # batch-invariant plans: the grouping of the partial sums must not depend on the batch size
         nchunks = -(-(Th * Tw) // tpb)

@@ -92,9 +92,10 @@ def _kabsch(Pw, Pc):
     return R, mc - R @ mw
 
 
-def p3p_plus_one(P, uv, f, cx, cy):
+def p3p_plus_one(P, uv, f, cx, cy, all_candidates=None):
     """cv::solvePnP(SOLVEPNP_P3P) call-site contract: the first three correspondences give up to four poses, the
-    fourth picks the one with the smallest reprojection error.  Returns (rvec, tvec) or None."""
+    fourth picks the one with the smallest reprojection error.  Returns (rvec, tvec) or None.
+    all_candidates: optional list that receives (4th-point squared error, R, t) of every admissible solution."""
     m = np.stack([(uv[:3, 0] - cx) / f, (uv[:3, 1] - cy) / f, np.ones(3)], 1)
     fb = m / np.linalg.norm(m, axis=1, keepdims=True)
     ca, cb, cg = fb[1] @ fb[2], fb[0] @ fb[2], fb[0] @ fb[1]
@@ -144,6 +145,8 @@ def p3p_plus_one(P, uv, f, cx, cy):
         R, t = _kabsch(P[:3], Pc)
         Xc = R @ P[3] + t
         e = (cx + f * Xc[0] / Xc[2] - uv[3, 0]) ** 2 + (cy + f * Xc[1] / Xc[2] - uv[3, 1]) ** 2
+        if all_candidates is not None:
+            all_candidates.append((float(e), R, t))
         if best is None or e < best_e:
             best, best_e = (R, t), e
     if best is None:
@@ -291,7 +294,25 @@ def compare_with_oracle(coords, n_hyp, image, gt_pose=None, thr=10.0, focal=480.
     clean = same_cells & ~dup
     order = np.argsort(-rd["scores"])
     dt, dr = synth.pose_error(ref.astype(np.float64), pose.astype(np.float64))
-    rec = dict(image=int(image), n_hyp=int(n_hyp), cells_equal=bool(same_cells.all()),
+    # why do the scores of some non-duplicate hypotheses differ by more than rounding?  Look at the worst one.
+    worst_cause = ""
+    if clean.any() and ds[clean].max() > 1e-6:
+        h = int(np.argmax(np.where(clean, ds, -1.0)))
+        fr = Frame(coords, sub)
+        cells = draw_cells(1305, image, h, int(rd["tries"][h]) - 1, fr.Wo, fr.Ho)
+        P = np.array([[fr.c[0, y, x], fr.c[1, y, x], fr.c[2, y, x]] for x, y in cells], np.float64)
+        uv = np.array([[x * sub + sub // 2, y * sub + sub // 2] for x, y in cells], np.float64)
+        cands = []
+        p3p_plus_one(P, uv, float(focal), float(ppx), float(ppy), all_candidates=cands)
+        errs = sorted(c[0] for c in cands)
+        tri = np.linalg.norm(np.cross(P[1] - P[0], P[2] - P[0])) / (np.linalg.norm(P[1] - P[0]) * np.linalg.norm(P[2] - P[0]))
+        if len(errs) > 1 and errs[1] - errs[0] < 1e-3 * max(errs[1], 1e-12):
+            worst_cause = ("hypothesis %d: two P3P solutions fit the 4th point equally well (squared errors %.3g / %.3g px^2): "
+                           "the selection is decided by rounding" % (h, errs[0], errs[1]))
+        else:
+            worst_cause = ("hypothesis %d: ill-conditioned minimal set (sine of the world triangle's angle %.2g, "
+                           "%d admissible P3P solutions): the two solvers' poses differ by their root precision" % (h, tri, len(errs)))
+    rec = dict(image=int(image), n_hyp=int(n_hyp), cells_equal=bool(same_cells.all()), worst_score_cause=worst_cause,
                n_cell_mismatch=int((~same_cells).sum()), n_duplicate_cell_hyps=int(dup.sum()),
                winner_indep=int(info["winner"]), winner_oracle=int(rd["winner"]),
                score_gap_top2=float(rd["scores"][order[0]] - rd["scores"][order[1]]) if n_hyp > 1 else 0.0,

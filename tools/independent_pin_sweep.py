@@ -39,6 +39,8 @@ def cause(r):
         out.append("refinement path: %d rounds / %d inliers (scipy MINPACK to convergence) vs %d / %d (CvLevMarq state "
                    "machine, <= 20 iterations per round)" % (r["rounds_indep"], r["inliers_indep"], r["rounds_oracle"],
                                                              r["inliers_oracle"]))
+    if r.get("worst_score_cause"):
+        out.append("largest score difference %.3g: %s" % (r["max_dscore_clean"], r["worst_score_cause"]))
     return "; ".join(out)
 
 
@@ -75,6 +77,8 @@ def main():
                                  dpose_deg=r["dpose_deg"], winner=(r["winner_indep"], r["winner_oracle"])))
     out = dict(hypotheses=n_hyp, frames=len(recs), seconds=round(time.time() - t0, 1), workers=workers,
                summary=summary, disagreeing_frames=disagree)
+    with open("/tmp/independent_pin_records.json", "w") as f:
+        json.dump(recs, f)
     path = os.path.join(ROOT, "profiles", "r2_independent_pin.json")
     with open(path, "w") as f:
         json.dump(out, f, indent=1)

@@ -1,7 +1,8 @@
-"""Add / replace one record of profiles/traffic.json (read by bench.py for `roofline.traffic`) from a merged PMC csv
-(tools/merge_pmc.py output): HBM-side bytes per launch = mean FETCH_SIZE [KB] x 2 (gfx950: FETCH_SIZE reports half of
-the bytes of wide coalesced reads, MI355X_MICROARCH.md §HBM) + mean WRITE_SIZE [KB], x 1024.
-    python tools/traffic_record.py <merged_pmc.csv> <form: wino64|wino36|direct> <frames per launch>"""
+"""Write profiles/traffic.json (read by bench.py for `roofline.traffic` and the solver's VALU-issue fraction) from a
+tools/pmc_derive.py table of a bench run under rocprofv3 --pmc:
+    python tools/traffic_record.py <pmc_derived.csv> <frames per launch> <source label>
+HBM-side bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (gfx950: FETCH_SIZE reports half of the bytes of wide coalesced
+reads, MI355X_MICROARCH.md, HBM section).  Every record carries the hash of the kernel source it was measured on."""
 import csv
 import json
 import os
@@ -12,27 +13,30 @@ sys.path.insert(0, ROOT)
 
 
 def main():
-    src, form, frames = sys.argv[1], sys.argv[2], int(sys.argv[3])
+    src, frames, label = sys.argv[1], int(sys.argv[2]), sys.argv[3]
     import bench
-    vals = {}
-    kernel = None
-    for r in csv.DictReader(open(src)):
-        vals.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
-        kernel = r["Kernel_Name"]
-    fetch = sum(vals["FETCH_SIZE"]) / len(vals["FETCH_SIZE"])
-    write = sum(vals["WRITE_SIZE"]) / len(vals["WRITE_SIZE"])
-    rec = dict(form=form, frames_per_launch=frames, kernel=kernel, fetch_size_kb=round(fetch, 1), write_size_kb=round(write, 1),
-               bytes_per_launch=int((2 * fetch + write) * 1024), dispatches=len(vals["FETCH_SIZE"]),
-               source=os.path.relpath(os.path.abspath(src), ROOT), kernel_source_sha256_16=bench.kernel_source_hash())
-    if "TCC_HIT_sum" in vals and "TCC_MISS_sum" in vals:
-        h, m = sum(vals["TCC_HIT_sum"]), sum(vals["TCC_MISS_sum"])
-        rec["l2_hit_rate"] = round(h / (h + m), 4)
-    path = bench.TRAFFIC_JSON
-    data = json.load(open(path)) if os.path.exists(path) else {"records": []}
-    data["records"] = [r for r in data["records"] if not (r["form"] == form and r["frames_per_launch"] == frames)] + [rec]
-    with open(path, "w") as f:
+    rows = list(csv.DictReader(open(src)))
+    recs = []
+    forms = {"wino64": ("igemm_conv_kernel<1,1,128,512,0,128,1,0>", 64), "wino36": ("igemm_conv_kernel<1,1,128,512,0,128,1,0>", 36),
+             "direct": ("igemm_conv_kernel<3,1,128,512,0,128,0,0>", 1)}
+    for form, (kname, z) in forms.items():
+        mtiles = -(-frames * (150 if z == 64 else 345 if z == 36 else 5400) // 128)
+        grid = mtiles * 4 * z * 256
+        for r in rows:
+            if r["kernel"] == kname and int(r["grid_size"]) == grid:
+                recs.append(dict(form=form, frames_per_launch=frames, kernel=kname, bytes_per_launch=int(float(r["hbm_GB"]) * 1e9),
+                                 l2_hit_rate=float(r["l2_hit"]), mfma_busy=float(r["mfma_busy"]), dispatches=int(r["dispatches_per_pass"]),
+                                 profiled_us=float(r["profiled_us"]), source=label, kernel_source_sha256_16=bench.kernel_source_hash()))
+    solver = {}
+    for r in rows:
+        if r["kernel"].startswith("xl_dsac_forward_kernel"):
+            solver[r["kernel"]] = dict(valu_busy=float(r["valu_busy"]), fp64_share_of_valu_instructions=float(r["fp64_valu_share"]),
+                                       mean_waves_per_simd=float(r["mean_waves_per_simd"]), lds_conflict_share=float(r["lds_conflict_share"]),
+                                       profiled_us=float(r["profiled_us"]), hbm_GB=float(r["hbm_GB"]))
+    data = dict(records=recs, solver=dict(kernels=solver, frames_per_launch=frames, source=label))
+    with open(bench.TRAFFIC_JSON, "w") as f:
         json.dump(data, f, indent=1)
-    print(json.dumps(rec))
+    print(json.dumps(data, indent=1)[:1500])
 
 
 if __name__ == "__main__":
