@@ -1,4 +1,4 @@
-"""Reader for the CrossLoc on-disk scene format, evaluation path only.
+"""Reader for the CrossLoc on-disk scene format: evaluation path and training mini-batches.
 
 Reference: dataloader/dataloader.py `CamLocDataset` (:60-586).  Directory layout (:232-247):
     <root>/rgb/*.png            RGB(A) frames
@@ -9,11 +9,18 @@ Reference: dataloader/dataloader.py `CamLocDataset` (:60-586).  Directory layout
     <root>/normal/*.dat         torch-saved [3,Ho,Wo] surface normals                   (normal task)
 Files of one frame share their sorted position in each directory (:310-338).
 
-Covered: mode=1 / sparse labels, augment=False (what utils/evaluation.py:20-78 builds for testing): frames are
-resized to `image_height` when they are not already that tall (PIL bilinear, as torchvision's Resize does on PIL
-images, :189-212) with the focal length scaled accordingly (:314-316); raw_image=True returns un-normalised
-[0,1] RGB, otherwise the urbanscape mean/std normalisation (:193-196).  Training-time augmentation (rotation,
-rescaling, colour jitter, :349-470) is CPU plumbing outside the hot path and is not reproduced.
+Covered: mode=1 / sparse labels.
+  augment=False (what utils/evaluation.py:20-78 builds for testing): frames are resized to `image_height` when they are
+    not already that tall (PIL bilinear, as torchvision's Resize does on PIL images, :189-212) with the focal length
+    scaled accordingly (:314-316); raw_image=True returns un-normalised [0,1] RGB, otherwise the urbanscape mean/std
+    normalisation (:193-196).  Per item on the CPU, like the reference.
+  augment=True, batch=True (what utils/learning.py:177-263 builds for training): `__getitem__` only decodes - it
+    returns the uint8 HWC frame - and `collate_gpu` (the counterpart of `batch_resize`, :512-586, used as the
+    DataLoader's collate_fn) uploads the frames once and runs resize, colour jitter, ToTensor, normalisation and the
+    common scale + rotation of the mini-batch on the GPU (crossloc_amd/data.py, csrc/xl_data.hip).  Random draws follow
+    the reference: one (brightness, contrast) pair per frame, one (scale, angle) pair per mini-batch from `random`.
+Not covered: augment=True with batch=False (per-item scale / rotation with a rotated pose, :349-464: no CrossLoc
+training script uses it), grayscale, dense-depth initialisation (sparse=False), mode 0 / 2.
 """
 import os
 
@@ -31,11 +38,19 @@ def _sorted_files(d):
 
 class CamLocDataset(Dataset):
     def __init__(self, root_dir, mode=1, sparse=True, coord=True, depth=False, normal=False, semantics=False,
-                 augment=False, grayscale=False, batch=True, raw_image=False, image_height=480, **unused):
+                 augment=False, grayscale=False, batch=True, raw_image=False, aug_rotation=30, aug_scale_min=2 / 3,
+                 aug_scale_max=3 / 2, aug_contrast=0.1, aug_brightness=0.1, image_height=480, **unused):
         if mode != 1 or not sparse:
             raise NotImplementedError("only mode=1 with sparse labels is read (the configuration CrossLoc uses)")
-        if augment or grayscale or semantics:
-            raise NotImplementedError("augmentation / grayscale / semantics are outside the evaluation hot path")
+        if grayscale or semantics:
+            raise NotImplementedError("grayscale / semantics labels are not read")
+        if raw_image:
+            augment = False                                # dataloader.py:217-219: raw_image supersedes the rest
+        if augment and not batch:
+            raise NotImplementedError("augment=True needs batch=True (per-item scale / rotation is not reproduced)")
+        self.augment, self.batch = augment, batch
+        self.aug_rotation, self.aug_scale_min, self.aug_scale_max = aug_rotation, aug_scale_min, aug_scale_max
+        self.aug_contrast, self.aug_brightness = aug_contrast, aug_brightness
         if not (coord or depth or normal):
             raise Exception("At least one 3D label should be enabled! Coord: {}, Depth: {}, Normal: {}".format(
                 coord, depth, normal))
@@ -69,12 +84,20 @@ class CamLocDataset(Dataset):
             img = img.convert("RGB")                       # gray -> RGB, RGBA -> RGB (dataloader.py:303-307)
         focal = float(np.loadtxt(self.calibration_files[idx]))
         focal *= self.image_height / img.height            # :314-316
+        if self.augment:
+            # training: decode only; collate_gpu does the rest on the GPU
+            image = torch.from_numpy(np.asarray(img, dtype=np.uint8).copy())
+            return image, *self._labels(idx), focal, self.rgb_files[idx]
         if img.height != self.image_height:
             w = int(round(img.width * self.image_height / img.height))
             img = img.resize((w, self.image_height), Image.BILINEAR)
         image = torch.from_numpy(np.asarray(img, dtype=np.uint8).copy()).permute(2, 0, 1).float() / 255.0
         if not self.raw_image:
             image = (image - torch.tensor(MEAN)[:, None, None]) / torch.tensor(STD)[:, None, None]
+        pose, gt = self._labels(idx)
+        return image, pose, gt, focal, self.rgb_files[idx]
+
+    def _labels(self, idx):
         pose = torch.from_numpy(np.loadtxt(self.pose_files[idx])).float()
         labels = {}
         if self.coord:
@@ -84,7 +107,28 @@ class CamLocDataset(Dataset):
         if self.normal:
             labels["normal"] = torch.load(self.normal_files[idx]).float()
         gt = next(iter(labels.values())) if len(labels) == 1 else labels     # dict for several labels (:560-575)
-        return image, pose, gt, focal, self.rgb_files[idx]
+        return pose, gt
+
+    def collate_gpu(self, batch, device="cuda", output_subsample=8):
+        """Counterpart of `batch_resize` (dataloader.py:512-586) for items produced with augment=True: returns
+        (images [B,3,H',W'] float32, poses [B,4,4], labels tensor or dict, focal lengths float64 [B], file names) with
+        images and labels on `device`.  All frames of a mini-batch must have the same stored size (they are stacked)."""
+        from . import data
+        frames = torch.stack([it[0] for it in batch]).to(device)
+        poses = torch.stack([it[1] for it in batch]).to(device)
+        focals = [it[3] for it in batch]
+        files = [it[4] for it in batch]
+        if isinstance(batch[0][2], dict):
+            labels = {k: torch.stack([it[2][k] for it in batch]).to(device) for k in batch[0][2]}
+        else:
+            labels = torch.stack([it[2] for it in batch]).to(device)
+        jitter = [data.draw_jitter(self.aug_brightness, self.aug_contrast) for _ in batch]
+        images = data.prepare_images(frames, self.image_height, jitter=jitter, normalize=True)
+        import random
+        scale_factor = random.uniform(self.aug_scale_min, self.aug_scale_max)      # :525-526, one draw per mini-batch
+        angle = random.uniform(-self.aug_rotation, self.aug_rotation)
+        images, labels, focals = data.batch_resize(images, labels, focals, scale_factor, angle, output_subsample)
+        return images, poses, labels, torch.tensor(focals, dtype=torch.float64), files
 
 
 def write_synthetic_scene(root, count, seed=2021, noise=0.5, outlier_ratio=0.0):

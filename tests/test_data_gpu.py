@@ -1,0 +1,71 @@
+"""GPU: the frame / label preparation kernels (csrc/xl_data.hip through include/crossloc_data.h) against the oracle
+(oracle/data_oracle.py, itself pinned against Pillow): uint8 stages bit-exact, float stages equal to the torch ops
+they replace."""
+import math
+import random
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+from crossloc_amd import data, dataset          # noqa: E402
+from oracle import data_oracle as do            # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("Hs,Ws,Cs", [(480, 720, 3), (960, 1440, 3), (600, 800, 4), (300, 451, 3), (1080, 1920, 3), (800, 600, 3)])
+@pytest.mark.parametrize("mode", ["raw", "normalized", "jitter"])
+def test_prepare_images_is_bit_exact(Hs, Ws, Cs, mode):
+    rng = np.random.default_rng(Hs + Ws + Cs)
+    frames = rng.integers(0, 256, (2, Hs, Ws, Cs), dtype=np.uint8)
+    jitter = [(0.93, 1.07, 0.0), (1.08, 0.91, 1.0)] if mode == "jitter" else None
+    norm = mode != "raw"
+    got = data.prepare_images(torch.from_numpy(frames).cuda(), 480, jitter=jitter, normalize=norm).cpu().numpy()
+    for b in range(2):
+        ref = do.prepare_image(frames[b], 480, jitter[b] if jitter else None, data.MEAN if norm else None, data.STD if norm else None)
+        assert got[b].shape == ref.shape
+        assert np.array_equal(got[b], ref), "frame %d: max diff %g" % (b, np.abs(got[b] - ref).max())
+
+
+@pytest.mark.parametrize("scale,angle", [(1.0, 0.0), (2 / 3, -30.0), (1.5, 30.0), (1.2345, 12.345), (0.8, -7.0)])
+def test_batch_augment_images_and_labels(scale, angle):
+    g = torch.Generator().manual_seed(int(scale * 100))
+    x = torch.randn(3, 3, 96, 144, generator=g)
+    lab = torch.randn(3, 3, 12, 18, generator=g)
+    lab[:, :, 2, 3] = -1.0
+    oh, ow = math.ceil(96 * scale), math.ceil(144 * scale)
+    got = data.batch_augment(x.cuda(), oh, ow, angle, -1.0, True).cpu()
+    ref = do.batch_resize_images(x, scale, angle)
+    assert got.shape == ref.shape
+    assert torch.equal(got == -1.0, ref == -1.0)                       # same pixels fall outside the rotated frame
+    # bilinear: the interpolation weight is frac(scale * (i + 0.5) - 0.5) in float32; torch's CPU kernel and the HIP kernel
+    # may round that source coordinate differently (fma or not): one ulp of a coordinate up to ~200 (1.5e-5) times the
+    # difference of neighbouring samples (randn: up to ~6)
+    assert torch.allclose(got, ref, rtol=0, atol=1e-4)
+    ch, cw = math.ceil(oh / 8), math.ceil(ow / 8)
+    gl = data.batch_augment(lab.cuda(), ch, cw, angle, -1.0, False).cpu()
+    assert torch.equal(gl, do.batch_resize_labels(lab, ch, cw, angle))  # nearest + nearest: exact
+
+
+def test_collate_gpu_follows_the_reference_draws(tmp_path):
+    """dataset.CamLocDataset(augment=True).collate_gpu against the oracle pipeline driven by the same `random` stream."""
+    root = dataset.write_synthetic_scene(str(tmp_path / "scene"), 3, seed=21)
+    ds = dataset.CamLocDataset(root, augment=True, batch=True)
+    items = [ds[i] for i in range(3)]
+    random.seed(11)
+    images, poses, labels, focals, files = ds.collate_gpu(items)
+    random.seed(11)
+    jit = [data.draw_jitter(0.1, 0.1) for _ in items]
+    scale = random.uniform(2 / 3, 3 / 2)
+    angle = random.uniform(-30, 30)
+    ref = torch.stack([torch.from_numpy(do.prepare_image(items[i][0].numpy(), 480, jit[i], data.MEAN, data.STD)) for i in range(3)])
+    ref = do.batch_resize_images(ref, scale, angle)
+    assert images.shape == ref.shape and images.is_cuda
+    assert torch.allclose(images.cpu(), ref, rtol=0, atol=2e-4)            # (see test_batch_augment_images_and_labels)
+    rl = do.batch_resize_labels(torch.stack([it[2] for it in items]), math.ceil(ref.shape[2] / 8), math.ceil(ref.shape[3] / 8), angle)
+    assert torch.equal(labels.cpu(), rl)
+    assert torch.equal(poses.cpu(), torch.stack([it[1] for it in items]))              # poses untouched in batch mode
+    assert focals.dtype == torch.float64 and np.allclose(focals.numpy(), 480.0 * scale)
+    assert len(files) == 3

@@ -36,8 +36,20 @@ def test_resize_scales_focal_length(tmp_path):
 def test_unsupported_modes_raise(tmp_path):
     root = dataset.write_synthetic_scene(str(tmp_path / "scene"), 1)
     with pytest.raises(NotImplementedError):
-        dataset.CamLocDataset(root, augment=True)
+        dataset.CamLocDataset(root, augment=True, batch=False)
     with pytest.raises(NotImplementedError):
         dataset.CamLocDataset(root, mode=2)
     with pytest.raises(Exception):
         dataset.CamLocDataset(root, coord=False)
+
+
+def test_training_items_are_decoded_frames_only(tmp_path):
+    """augment=True: __getitem__ decodes and hands over the uint8 frame; the transform pipeline runs on the GPU in
+    collate_gpu (tests/test_data_gpu.py)."""
+    root = dataset.write_synthetic_scene(str(tmp_path / "scene"), 2, seed=9)
+    ds = dataset.CamLocDataset(root, augment=True, batch=True)
+    frame, pose, gt, focal, name = ds[0]
+    assert frame.dtype == torch.uint8 and frame.shape == (480, 720, 3)
+    assert pose.shape == (4, 4) and gt.shape == (3, 60, 90) and focal == pytest.approx(480.0)
+    # raw_image supersedes augmentation (dataloader.py:217-219)
+    assert dataset.CamLocDataset(root, augment=True, raw_image=True)[0][0].dtype == torch.float32
