@@ -766,14 +766,20 @@ void head_bwd_kernel(const float *__restrict__ x, const float *__restrict__ w, c
 // DUC activation goes back through the shuffle index map (every input element has exactly one output pixel: plain
 // stores, no atomics); d fc3.weight / d fc3.bias are accumulated per thread, reduced per block in a fixed order and
 // written as one partial vector [C*C + C] per block.
-template <int CMAX>
+// TRIM (H x W differs from the shuffled 8*Hs x 8*Ws grid, networks.py:344-349: F.interpolate(bilinear) trims it): the
+// thread recomputes the interpolated activation of its output pixel for d fc3.weight and writes d(interpolated
+// activation) [B][C][H][W] to `dv`; duc_trim_bwd_kernel gathers that back onto the shuffled grid.
+template <int CMAX, int TRIM>
 __global__ __launch_bounds__(256)
 void duc_head_bwd_kernel(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ dout,
                          const float *__restrict__ fout, float *__restrict__ dx, float *__restrict__ partial,
-                         int B, int Hs, int Ws, int C, int ldX, int ldDx, int nTask, float lo, float hi)
+                         int B, int Hs, int Ws, int C, int ldX, int ldDx, int nTask, float lo, float hi,
+                         int Ho, int Wo, float *__restrict__ dv)
 {
     __shared__ float sRed[4][CMAX * CMAX + CMAX];
-    const int H = 8 * Hs, W = 8 * Ws;
+    const int H = TRIM ? Ho : 8 * Hs, W = TRIM ? Wo : 8 * Ws;
+    const int Hu = 8 * Hs, Wu = 8 * Ws;
+    const float sy = (float)Hu / (float)H, sx = (float)Wu / (float)W;
     const float elo = expf(lo), ehi = expf(hi);
     const long long HW = (long long)H * W, total = (long long)B * HW;
     float aW[CMAX][CMAX], aB[CMAX];
@@ -790,6 +796,21 @@ void duc_head_bwd_kernel(const float *__restrict__ x, const float *__restrict__ 
         const long long pix = (long long)y * W + xx;
         const long long src = (((long long)n * Hs + (y >> 3)) * Ws + (xx >> 3));
         const int sub = (y & 7) * 8 + (xx & 7);
+        // TRIM: the four taps of the forward interpolation (same float arithmetic as duc_head_kernel)
+        long long a00 = 0, a01 = 0, a10 = 0, a11 = 0;
+        float ly0 = 1.f, ly1 = 0.f, lx0 = 1.f, lx1 = 0.f;
+        if (TRIM) {
+            float fy = sy * ((float)y + 0.5f) - 0.5f; if (fy < 0.f) fy = 0.f;
+            float fx = sx * ((float)xx + 0.5f) - 0.5f; if (fx < 0.f) fx = 0.f;
+            const int y0 = (int)fy, x0 = (int)fx;
+            const int y1 = y0 + (y0 < Hu - 1 ? 1 : 0), x1 = x0 + (x0 < Wu - 1 ? 1 : 0);
+            ly1 = fy - (float)y0; lx1 = fx - (float)x0; ly0 = 1.f - ly1; lx0 = 1.f - lx1;
+            const long long img = (long long)n * Hs * Ws * ldX;
+            a00 = img + ((long long)(y0 >> 3) * Ws + (x0 >> 3)) * ldX + (y0 & 7) * 8 + (x0 & 7);
+            a01 = img + ((long long)(y0 >> 3) * Ws + (x1 >> 3)) * ldX + (y0 & 7) * 8 + (x1 & 7);
+            a10 = img + ((long long)(y1 >> 3) * Ws + (x0 >> 3)) * ldX + (y1 & 7) * 8 + (x0 & 7);
+            a11 = img + ((long long)(y1 >> 3) * Ws + (x1 >> 3)) * ldX + (y1 & 7) * 8 + (x1 & 7);
+        }
         float dz[CMAX], v[CMAX];
 #pragma unroll
         for (int o = 0; o < CMAX; ++o) {
@@ -802,7 +823,8 @@ void duc_head_bwd_kernel(const float *__restrict__ x, const float *__restrict__ 
                     g = (fo > elo && fo < ehi) ? g * fo : 0.f;
                 }
                 dz[o] = g;
-                v[o] = x[src * ldX + o * 64 + sub];
+                if (TRIM) v[o] = ly0 * (lx0 * x[a00 + o * 64] + lx1 * x[a01 + o * 64]) + ly1 * (lx0 * x[a10 + o * 64] + lx1 * x[a11 + o * 64]);
+                else v[o] = x[src * ldX + o * 64 + sub];
                 aB[o] += g;
             }
         }
@@ -812,7 +834,8 @@ void duc_head_bwd_kernel(const float *__restrict__ x, const float *__restrict__ 
                 float d = 0.f;
 #pragma unroll
                 for (int o = 0; o < CMAX; ++o) if (o < C) { d = fmaf(w[o * C + c], dz[o], d); aW[o][c] = fmaf(dz[o], v[c], aW[o][c]); }
-                dx[src * ldDx + c * 64 + sub] = d;
+                if (TRIM) dv[((long long)n * C + c) * HW + pix] = d;
+                else dx[src * ldDx + c * 64 + sub] = d;
             }
         }
     }
@@ -837,6 +860,56 @@ void duc_head_bwd_kernel(const float *__restrict__ x, const float *__restrict__ 
         const int i = threadIdx.x;
         const int k2 = (i < C * C) ? (i / C) * CMAX + (i % C) : CMAX * CMAX + (i - C * C);
         partial[(long long)blockIdx.x * len + i] = ((sRed[0][k2] + sRed[1][k2]) + sRed[2][k2]) + sRed[3][k2];
+    }
+}
+
+// Backward of the bilinear trim: one thread per element (n, yy, xx) of the shuffled 8*Hs x 8*Ws grid gathers
+// dv [B][C][H][W] over the output pixels whose interpolation stencil contains it, with the forward weights, in a fixed
+// order (no atomics).  Rows: output rows y with y0(y) == yy or y1(y) == yy lie in a window around yy / scale.
+template <int CMAX>
+__global__ __launch_bounds__(256)
+void duc_trim_bwd_kernel(const float *__restrict__ dv, float *__restrict__ dx, int B, int Hs, int Ws, int C, int ldDx, int H, int W)
+{
+    const int Hu = 8 * Hs, Wu = 8 * Ws;
+    const float sy = (float)Hu / (float)H, sx = (float)Wu / (float)W;
+    const long long total = (long long)B * Hu * Wu;
+    const long long HW = (long long)H * W;
+    for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < total; p += (long long)gridDim.x * 256) {
+        const int xx = (int)(p % Wu);
+        const int yy = (int)((p / Wu) % Hu);
+        const int n = (int)(p / ((long long)Wu * Hu));
+        int ylo = (int)floorf(((float)yy - 1.5f) / sy) - 1, yhi = (int)ceilf(((float)yy + 1.5f) / sy) + 1;
+        int xlo = (int)floorf(((float)xx - 1.5f) / sx) - 1, xhi = (int)ceilf(((float)xx + 1.5f) / sx) + 1;
+        if (ylo < 0) ylo = 0;
+        if (xlo < 0) xlo = 0;
+        if (yhi > H - 1) yhi = H - 1;
+        if (xhi > W - 1) xhi = W - 1;
+        float acc[CMAX];
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c) acc[c] = 0.f;
+        for (int y = ylo; y <= yhi; ++y) {
+            float fy = sy * ((float)y + 0.5f) - 0.5f; if (fy < 0.f) fy = 0.f;
+            const int y0 = (int)fy, y1 = y0 + (y0 < Hu - 1 ? 1 : 0);
+            const float ly1 = fy - (float)y0, ly0 = 1.f - ly1;
+            const float wy = (y0 == yy ? ly0 : 0.f) + (y1 == yy ? ly1 : 0.f);
+            if (wy == 0.f) continue;
+            for (int x = xlo; x <= xhi; ++x) {
+                float fx = sx * ((float)x + 0.5f) - 0.5f; if (fx < 0.f) fx = 0.f;
+                const int x0 = (int)fx, x1 = x0 + (x0 < Wu - 1 ? 1 : 0);
+                const float lx1 = fx - (float)x0, lx0 = 1.f - lx1;
+                const float wx = (x0 == xx ? lx0 : 0.f) + (x1 == xx ? lx1 : 0.f);
+                if (wx == 0.f) continue;
+                const float wgt = wy * wx;
+#pragma unroll
+                for (int c = 0; c < CMAX; ++c)
+                    if (c < C) acc[c] = fmaf(wgt, dv[((long long)n * C + c) * HW + (long long)y * W + x], acc[c]);
+            }
+        }
+        const long long src = (((long long)n * Hs + (yy >> 3)) * Ws + (xx >> 3));
+        const int sub = (yy & 7) * 8 + (xx & 7);
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c)
+            if (c < C) dx[src * ldDx + c * 64 + sub] = acc[c];
     }
 }
 
@@ -1099,16 +1172,28 @@ int xl_run_bwd_op(const xl_op &op, hipStream_t st)
             // in: DUC activation [B,Hi,Wi,Cout*64]; aux: dout, aux2: forward output [B,Cout,8Hi,8Wi]; out: d activation;
             // out2: d fc3.weight [Cout][Cout]; stats: d fc3.bias; stats2: scratch (blocks x (Cout^2 + Cout) floats)
             if (op.Cout < 1 || op.Cout > 8 || op.Cin != op.Cout * 64) return XL_ERR_ARG;
-            if (op.Ho != 8 * op.Hi || op.Wo != 8 * op.Wi) return XL_ERR_UNSUPPORTED;     // bilinear trim: forward only
+            const bool trim = (op.Ho != 8 * op.Hi || op.Wo != 8 * op.Wi);        // networks.py:344-349 bilinear trim
             const long long pix = (long long)op.B * op.Ho * op.Wo;
             long long blocks = (pix + 255) / 256;
             if (blocks > 1024) blocks = 1024;
             const int len = op.Cout * op.Cout + op.Cout;
             float *part = (float *)op.stats2;
-            hipLaunchKernelGGL(duc_head_bwd_kernel<8>, dim3((unsigned)blocks), dim3(256), 0, st, (const float *)op.in,
-                               (const float *)op.w, (const float *)op.aux, (const float *)op.aux2, (float *)op.out, part,
-                               op.B, op.Hi, op.Wi, op.Cout, op.ld_in, op.ld_out, op.n_task, op.clamp_lo, op.clamp_hi);
             float *tot = part + blocks * len;                           // [len]: weights then bias
+            float *dv = tot + len;                                      // trim: [B][Cout][Ho][Wo] behind the partials
+            if (trim) {
+                hipLaunchKernelGGL((duc_head_bwd_kernel<8, 1>), dim3((unsigned)blocks), dim3(256), 0, st, (const float *)op.in,
+                                   (const float *)op.w, (const float *)op.aux, (const float *)op.aux2, (float *)op.out, part,
+                                   op.B, op.Hi, op.Wi, op.Cout, op.ld_in, op.ld_out, op.n_task, op.clamp_lo, op.clamp_hi,
+                                   op.Ho, op.Wo, dv);
+                long long ub = ((long long)op.B * 64 * op.Hi * op.Wi + 255) / 256;
+                if (ub > 65536) ub = 65536;
+                hipLaunchKernelGGL(duc_trim_bwd_kernel<8>, dim3((unsigned)ub), dim3(256), 0, st, (const float *)dv, (float *)op.out,
+                                   op.B, op.Hi, op.Wi, op.Cout, op.ld_out, op.Ho, op.Wo);
+            } else
+                hipLaunchKernelGGL((duc_head_bwd_kernel<8, 0>), dim3((unsigned)blocks), dim3(256), 0, st, (const float *)op.in,
+                                   (const float *)op.w, (const float *)op.aux, (const float *)op.aux2, (float *)op.out, part,
+                                   op.B, op.Hi, op.Wi, op.Cout, op.ld_in, op.ld_out, op.n_task, op.clamp_lo, op.clamp_hi,
+                                   op.Ho, op.Wo, (float *)nullptr);
             hipLaunchKernelGGL(partial_sum_kernel, dim3((len + 31) / 32), dim3(256), 0, st, (const float *)part, tot, (int)blocks, len);
             if (hipMemcpyAsync(op.out2, tot, sizeof(float) * op.Cout * op.Cout, hipMemcpyDeviceToDevice, st) != hipSuccess ||
                 hipMemcpyAsync(op.stats, tot + op.Cout * op.Cout, sizeof(float) * op.Cout, hipMemcpyDeviceToDevice, st) != hipSuccess)

@@ -800,9 +800,6 @@ class _Plan:
         a = self.cgr(res, dec.fc1, dec.fc1_norm, defer=True); self.release(res[0])
         b = self.cgr(a, dec.fc2, dec.fc2_norm, defer=True); self.release(a[0])
         if dec.full_size_output:
-            if self.train and (self.H % 8 or self.W % 8):
-                raise NotImplementedError("training the full-size head needs H and W to be multiples of 8 (the backward "
-                                          "pass of the bilinear trim is not lowered)")
             # networks.py:344-349: DUC conv-GN-ReLU; pixel shuffle, bilinear trim and fc3 fused in one kernel
             d = self.cgr(b, dec.duc_upsample.conv, dec.duc_upsample.norm); self.release(b[0])
             t, H, W, C, ld, off = d
@@ -918,7 +915,8 @@ class _Plan:
                 op.out2 = pgrad(e["fc3"].weight).data_ptr()
                 op.stats = pgrad(e["fc3"].bias).data_ptr()
                 blocks = max(1, min(1024, (B * self.H * self.W + 255) // 256))
-                scratch_f = max(scratch_f, (blocks + 1) * (nc * nc + nc))
+                # (+ d(interpolated activation) [B][nc][H][W] when the bilinear trim is active)
+                scratch_f = max(scratch_f, (blocks + 1) * (nc * nc + nc) + B * nc * self.H * self.W)
                 patch_f.append(len(bops))
                 self.head_bwd_index = len(bops)
                 bops.append(op)

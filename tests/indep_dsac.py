@@ -306,7 +306,17 @@ def compare_with_oracle(coords, n_hyp, image, gt_pose=None, thr=10.0, focal=480.
         p3p_plus_one(P, uv, float(focal), float(ppx), float(ppy), all_candidates=cands)
         errs = sorted(c[0] for c in cands)
         tri = np.linalg.norm(np.cross(P[1] - P[0], P[2] - P[0])) / (np.linalg.norm(P[1] - P[0]) * np.linalg.norm(P[2] - P[0]))
-        if len(errs) > 1 and errs[1] - errs[0] < 1e-3 * max(errs[1], 1e-12):
+        o = xo.p3p(P, uv, float(focal), float(ppx), float(ppy))
+        oerr = None
+        if o is not None:
+            Xc = o[0] @ P[3] + o[1]
+            oerr = float((ppx + focal * Xc[0] / Xc[2] - uv[3, 0]) ** 2 + (ppy + focal * Xc[1] / Xc[2] - uv[3, 1]) ** 2)
+        if oerr is not None and errs and abs(oerr - errs[0]) > 1e-3 * max(oerr, errs[0], 1e-12):
+            worst_cause = ("hypothesis %d: the two quartic solvers do not see the same set of real roots (a near-double root: "
+                           "a complex pair for one, two real roots for the other): 4th-point squared error of the solution "
+                           "kept %.3g px^2 (oracle, closed-form Ferrari) vs %.3g px^2 (np.roots); both pass the acceptance "
+                           "test" % (h, oerr, errs[0]))
+        elif len(errs) > 1 and errs[1] - errs[0] < 1e-3 * max(errs[1], 1e-12):
             worst_cause = ("hypothesis %d: two P3P solutions fit the 4th point equally well (squared errors %.3g / %.3g px^2): "
                            "the selection is decided by rounding" % (h, errs[0], errs[1]))
         else:
