@@ -1084,6 +1084,26 @@ void wino6_in_kernel(const float *__restrict__ in, float *__restrict__ V, int B,
 #pragma unroll
             for (int i = 0; i < 8; ++i) w[i][b] = o[i];
         }
+        if (SPLIT == 2) {
+            // interleaved planes (256 x 256 split GEMM): V[xi][t][c / 16][plane][c % 16] bf16, 2 bf16 per 32-bit word
+            const int c = 2 * c2;
+            unsigned *op = reinterpret_cast<unsigned *>(V) + ((((t * (C >> 4) + (c >> 4)) * 48) + (c & 15)) >> 1);
+            const long long zw = (zs * 3) >> 1;                                           // words per frequency
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                f32x2 o[8];
+                wino6_bt(w[i], o);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    unsigned a1, a2, a3, b1, b2, b3;
+                    bf16_split3(o[j][0], a1, a2, a3);
+                    bf16_split3(o[j][1], b1, b2, b3);
+                    unsigned *q = op + (8 * i + j) * zw;
+                    q[0] = a1 | (b1 << 16); q[8] = a2 | (b2 << 16); q[16] = a3 | (b3 << 16);
+                }
+            }
+            continue;
+        }
         if (SPLIT) {
             unsigned *op = reinterpret_cast<unsigned *>(V) + ((t * C + 2 * c2) >> 1);      // 2 bf16 per 32-bit word
             const long long plane = (64 * zs) >> 1;
@@ -1869,6 +1889,10 @@ int run_op(const xl_op &op, hipStream_t st)
                 auto kin = !op.aux2 ? wino6_in_kernel<0> : (op.flags & XL_GN_RELU_IN) ? wino6_in_kernel<2> : wino6_in_kernel<1>;
                 if (op.flags & XL_CONV_SPLIT_BF16)
                     kin = !op.aux2 ? wino6_in_kernel<0, 1> : (op.flags & XL_GN_RELU_IN) ? wino6_in_kernel<2, 1> : wino6_in_kernel<1, 1>;
+                if ((op.flags & XL_CONV_SPLIT_BF16) && (op.flags & XL_CONV_SPLIT_IL)) {
+                    if (op.Cin % 16 != 0) return XL_ERR_ARG;
+                    kin = !op.aux2 ? wino6_in_kernel<0, 2> : (op.flags & XL_GN_RELU_IN) ? wino6_in_kernel<2, 2> : wino6_in_kernel<1, 2>;
+                }
                 hipLaunchKernelGGL(kin, dim3((unsigned)blocks6), dim3(256), 0, st, (const float *)op.in,
                                    (float *)op.out, op.B, op.Hi, op.Wi, op.Cin, op.ld_in, op.Ho, op.Wo,
                                    (const float *)op.aux2);

@@ -31,6 +31,7 @@ XL_OP_DUC_HEAD_BWD = 15
 XL_OP_WINO_DY, XL_OP_WINO_WFINAL, XL_OP_GNB_FINAL = 16, 17, 18
 CONV_DGRAD, CONV_ACCUMULATE, CONV_SPLIT_BF16 = 1, 2, 64
 CONV_NORM_IN, CONV_NORM_RELU = 128, 256
+CONV_SPLIT_IL = 512
 
 
 class XlOp(ctypes.Structure):
@@ -182,6 +183,8 @@ class _Plan:
                  second op array for the backward pass is lowered from it (data gradients through the same
                  implicit-GEMM kernel, weight gradients, GroupNorm/epilogue backward, head backward)."""
 
+    SPLIT_DEFAULT = "0"            # default of XL_GEMM_SPLIT_BF16 (see conv_wino)
+
     def __init__(self, net, B, H, W, device, train=False):
         self.B, self.H, self.W, self.device, self.train = B, H, W, device, train
         # separate per-image statistics passes instead of the conv-epilogue ones (whose partial sums are grouped by
@@ -266,11 +269,22 @@ class _Plan:
         p2 = (r1 - p1.to(torch.float32)).to(torch.bfloat16)
         return torch.stack([p0, p1, p2]).contiguous().view(torch.int16)
 
-    def pack_conv_wino_split(self, conv, m):
-        """The transformed weights of pack_conv_wino as three bf16 planes (operands of csrc/xl_gemm_split.hip)."""
-        key = (id(conv.weight), "wino%d_split" % m)
+    @staticmethod
+    def split_bf16_interleaved(x, C):
+        """fp32 tensor whose last dimension runs over C channels -> the interleaved-plane operand layout of the 256 x 256
+        split GEMM, [..., C/16, 3, 16] bf16 (as int16 storage): the three planes of a 16-channel chunk next to each other."""
+        planes = _Plan.split_bf16(x.reshape(-1, C // 16, 16)).view(3, -1, C // 16, 16)
+        return planes.permute(1, 2, 0, 3).contiguous()
+
+    def _split_form(self, packed_wino, cin, interleaved):
+        return self.split_bf16_interleaved(packed_wino, cin) if interleaved else self.split_bf16(packed_wino)
+
+    def pack_conv_wino_split(self, conv, m, interleaved=False):
+        """The transformed weights of pack_conv_wino as three bf16 planes (operands of csrc/xl_gemm_split.hip): separate
+        planes, or - `interleaved` - [(m+2)^2][Cout][Cin/16][3][16] for the 256 x 256 kernel."""
+        key = (id(conv.weight), "wino%d_split%s" % (m, "_il" if interleaved else ""))
         if key not in self.packed_split:
-            self.packed_split[key] = self.split_bf16(self.pack_conv_wino(conv, m))
+            self.packed_split[key] = self._split_form(self.pack_conv_wino(conv, m), conv.in_channels, interleaved)
         return self.packed_split[key]
 
     def wino_pick(self, H, W, chan_max, allowed=(6, 4)):
@@ -333,7 +347,9 @@ class _Plan:
         for dst, src, kind in self.packed.values():
             self._pack(dst, src, kind)
         for (wid, kind), planes in self.packed_split.items():
-            planes.copy_(self.split_bf16(self.packed[(wid, kind[:-len("_split")])][0]))
+            il = kind.endswith("_il")
+            base = self.packed[(wid, kind[:kind.index("_split")])][0]
+            planes.copy_(self._split_form(base, planes.shape[-3] * 16 if il else None, il))
 
     def dev(self, p):
         t = p.detach().to(device=self.device, dtype=torch.float32).contiguous()
@@ -464,8 +480,14 @@ class _Plan:
         T = B * Th * Tw
         nf = (m + 2) ** 2
         # opt-in: the GEMMs on the bf16 matrix pipe with every fp32 operand split into three bf16 terms (fp32-accurate)
-        split = (m == 6 and not self.train and bool(os.environ.get("XL_GEMM_SPLIT_BF16")) and C % 32 == 0
-                 and nf * T * max(C, cout) * 6 < 2 ** 31 - 1)           # (xl_gemm_split.hip addresses a plane as a whole)
+        # the GEMMs on the bf16 matrix pipe with every fp32 operand split into three bf16 terms (fp32-accurate).
+        # XL_GEMM_SPLIT_BF16: "il" = interleaved planes + 256 x 256 persistent kernel, "1" = separate planes + 128 x 128
+        # register-staged kernel (the first form), "0" = fp32 MFMA
+        mode = os.environ.get("XL_GEMM_SPLIT_BF16", self.SPLIT_DEFAULT)
+        split = (m == 6 and not self.train and mode not in ("", "0") and C % 32 == 0)
+        split_il = split and mode != "1" and T * max(C * 6, cout * 4) < 2 ** 31 - 1 and C % 16 == 0
+        if split and not split_il:
+            split = nf * T * max(C, cout) * 6 < 2 ** 31 - 1             # (the first form addresses a plane as a whole)
         V = self.alloc(nf * T * C * 3 // 2 if split else nf * T * C)
         op = XlOp()
         op.type = XL_OP_WINO_IN
@@ -473,7 +495,7 @@ class _Plan:
         op.B, op.Hi, op.Wi, op.Cin, op.Ho, op.Wo, op.ld_in = B, H, W, C, Th, Tw, ld
         op.in_, op.out = t.data_ptr() + 4 * off, V.data_ptr()
         if split:
-            op.flags = CONV_SPLIT_BF16
+            op.flags = CONV_SPLIT_BF16 | (CONV_SPLIT_IL if split_il else 0)
         if deferred is not None:                      # the producer's GroupNorm(+ReLU) is applied while gathering
             op.flags |= deferred.flags
             self.deferred_gn_consumers = getattr(self, "deferred_gn_consumers", []) + [len(self.ops)]
@@ -485,7 +507,8 @@ class _Plan:
         op.ksize, op.stride, op.ld_in, op.ld_out, op.nchunks2 = 1, 1, C, cout, nf
         op.in_, op.w, op.out = V.data_ptr(), self.pack_conv_wino(conv, m).data_ptr(), Mb.data_ptr()
         if split:
-            op.flags, op.w = CONV_SPLIT_BF16, self.pack_conv_wino_split(conv, m).data_ptr()
+            op.flags = CONV_SPLIT_BF16 | (CONV_SPLIT_IL if split_il else 0)
+            op.w = self.pack_conv_wino_split(conv, m, split_il).data_ptr()
         if -(-T // 128) * (cout // 128) * nf <= 256:
             op.reserved_i = 64
         self.ops.append(op)

@@ -69,6 +69,8 @@ enum {
  * its operands as three bf16 planes per fp32 value (a = a1 + a2 + a3, exact) and multiplies six term pairs on the bf16
  * matrix pipe with fp32 accumulation; XL_OP_WINO_IN (ksize 6) with the flag writes V in that form. */
 #define XL_CONV_SPLIT_BF16 64
+#define XL_CONV_SPLIT_IL 512   /* with XL_CONV_SPLIT_BF16: the planes of a 16-channel chunk are interleaved,
+                                  operand layout [Z][rows][C/16][3][16] bf16 (csrc/xl_gemm_split.hip, 256 x 256 tiles) */
 /* xl_op.flags for XL_OP_CONV */
 #define XL_CONV_DGRAD 1        /* data gradient: `in` is dY (Hi x Wi x Cin = forward output), result is dX; weights
                                   packed with xl_cnn_pack_conv_weight_dgrad; `stride` is the forward stride */

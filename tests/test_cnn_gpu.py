@@ -488,7 +488,8 @@ def test_winograd_conv_with_statistics_vs_float64(m, cin, cout, B, H, W):
 
 
 @pytest.mark.parametrize("cin,cout,B,H,W", [(512, 512, 2, 12, 18), (256, 512, 1, 10, 14), (512, 512, 2, 60, 90), (1536, 512, 1, 8, 12)])
-def test_winograd_split_bf16_gemm_matches_float64_like_fp32(cin, cout, B, H, W):
+@pytest.mark.parametrize("interleaved", [False, True])
+def test_winograd_split_bf16_gemm_matches_float64_like_fp32(cin, cout, B, H, W, interleaved):
     """Opt-in GEMM path (csrc/xl_gemm_split.hip): V and U as three bf16 planes each (exact 24-bit splits), six bf16 MFMA
     passes with fp32 accumulation.  Same tolerance as the fp32-MFMA F(6x6,3x3) path, and the two paths agree with each
     other far below it: the error is Winograd's, not the GEMM's."""
@@ -504,6 +505,10 @@ def test_winograd_split_bf16_gemm_matches_float64_like_fp32(cin, cout, B, H, W):
     U = _wino_weights(w, m)
     planes = networks._Plan.split_bf16(U)
     assert torch.equal(planes.view(torch.bfloat16).float().sum(0), U)          # the split is exact
+    if interleaved:                               # [64][Cout][Cin/16][3][16]: the operand form of the 256 x 256 kernel
+        planes = networks._Plan.split_bf16_interleaved(U.view(64, cout, cin), cin)
+        assert torch.equal(planes.view(torch.bfloat16).float().sum(-2).reshape(U.shape), U)
+    sflags = networks.CONV_SPLIT_BF16 | (networks.CONV_SPLIT_IL if interleaved else 0)
     outs, Ms, V32 = [], [], None
     for split in (False, True):
         V = torch.zeros(nf * T * cin * (3 if split else 2) // 2, device="cuda")
@@ -519,7 +524,7 @@ def test_winograd_split_bf16_gemm_matches_float64_like_fp32(cin, cout, B, H, W):
         gm.ksize, gm.stride, gm.ld_in, gm.ld_out, gm.nchunks2 = 1, 1, cin, cout, nf
         gm.in_, gm.w, gm.out = V.data_ptr(), (planes if split else U).data_ptr(), Mb.data_ptr()
         if split:
-            a.flags = gm.flags = networks.CONV_SPLIT_BF16
+            a.flags = gm.flags = sflags
         o = networks.XlOp()
         o.type, o.ksize = networks.XL_OP_WINO_OUT, m
         o.B, o.Hi, o.Wi, o.Cin, o.ld_out, o.groups = B, H, W, cout, cout, 1

@@ -26,8 +26,20 @@ def op(split):
 
 
 st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-for split in (0, 1):
-    arr = op(split)
+Vil = networks._Plan.split_bf16_interleaved(V.view(nf, T, C), C)
+Uil = networks._Plan.split_bf16_interleaved(U.view(nf, N, C), C)
+M2 = torch.empty_like(M0)
+
+
+def op_il():
+    g = op(1)[0]
+    g.in_, g.w, g.out = Vil.data_ptr(), Uil.data_ptr(), M2.data_ptr()
+    g.flags = networks.CONV_SPLIT_BF16 | networks.CONV_SPLIT_IL
+    return (networks.XlOp * 1)(g)
+
+
+for split in (0, 1, 2):
+    arr = op_il() if split == 2 else op(split)
     for _ in range(3):
         networks._check(L.xl_cnn_run(arr, 1, st))
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -36,6 +48,8 @@ for split in (0, 1):
         networks._check(L.xl_cnn_run(arr, 1, st))
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 10
-    print("%s: %.3f ms  %.1f TFLOP/s (fp32-equivalent)" % ("split-bf16" if split else "fp32 MFMA ", ms, 2.0 * nf * T * N * C / ms / 1e9))
+    print("%s: %.3f ms  %.1f TFLOP/s (fp32-equivalent)" % (("fp32 MFMA ", "split-bf16", "split 256x256 interleaved")[split], ms, 2.0 * nf * T * N * C / ms / 1e9))
 ref = M0.double()
 print("max |split - fp32| / max|M| = %.2e" % ((M1.double() - ref).abs().max().item() / ref.abs().max().item()))
+print("max |split256 - fp32| / max|M| = %.2e, bitwise equal to the 128x128 split form: %s" % (
+    (M2.double() - ref).abs().max().item() / ref.abs().max().item(), torch.equal(M1, M2)))
