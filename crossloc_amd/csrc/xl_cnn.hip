@@ -1084,11 +1084,18 @@ void wino6_in_kernel(const float *__restrict__ in, float *__restrict__ V, int B,
 #pragma unroll
             for (int i = 0; i < 8; ++i) w[i][b] = o[i];
         }
-        if (SPLIT == 2) {
-            // interleaved planes (256 x 256 split GEMM): V[xi][t][c / 16][plane][c % 16] bf16, 2 bf16 per 32-bit word
+        if constexpr (SPLIT == 2) {
+            // interleaved planes (256 x 256 split GEMM): V[xi][t][c / 16][plane][c % 16] bf16.  The 64 lanes of a wave hold
+            // 128 consecutive channels of one tile = 8 chunks = one contiguous 768-byte piece per frequency, but a lane's
+            // three words (its channel pair in the three planes) lie 32 bytes apart.  They are exchanged through a
+            // wave-private LDS row so that every lane stores 12 contiguous bytes: one dwordx3 store instead of three
+            // scattered dword stores per frequency (C % 128 == 0 and whole waves: checked by the launcher).
+            __shared__ unsigned sX[4][2][192];
+            const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
             const int c = 2 * c2;
-            unsigned *op = reinterpret_cast<unsigned *>(V) + ((((t * (C >> 4) + (c >> 4)) * 48) + (c & 15)) >> 1);
+            unsigned *op = reinterpret_cast<unsigned *>(V) + ((t * (C >> 4) + ((c - 2 * lane) >> 4)) * 48 >> 1) + 3 * lane;
             const long long zw = (zs * 3) >> 1;                                           // words per frequency
+            const int wr = (lane >> 3) * 24 + (lane & 7);                                 // chunk, pair within the chunk
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 f32x2 o[8];
@@ -1098,8 +1105,11 @@ void wino6_in_kernel(const float *__restrict__ in, float *__restrict__ V, int B,
                     unsigned a1, a2, a3, b1, b2, b3;
                     bf16_split3(o[j][0], a1, a2, a3);
                     bf16_split3(o[j][1], b1, b2, b3);
-                    unsigned *q = op + (8 * i + j) * zw;
-                    q[0] = a1 | (b1 << 16); q[8] = a2 | (b2 << 16); q[16] = a3 | (b3 << 16);
+                    unsigned *row = sX[wv][j & 1];
+                    row[wr] = a1 | (b1 << 16); row[wr + 8] = a2 | (b2 << 16); row[wr + 16] = a3 | (b3 << 16);
+                    typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
+                    const u32x3 v3 = u32x3{ row[3 * lane], row[3 * lane + 1], row[3 * lane + 2] };
+                    *reinterpret_cast<u32x3 *>(op + (8 * i + j) * zw) = v3;
                 }
             }
             continue;
@@ -1890,7 +1900,7 @@ int run_op(const xl_op &op, hipStream_t st)
                 if (op.flags & XL_CONV_SPLIT_BF16)
                     kin = !op.aux2 ? wino6_in_kernel<0, 1> : (op.flags & XL_GN_RELU_IN) ? wino6_in_kernel<2, 1> : wino6_in_kernel<1, 1>;
                 if ((op.flags & XL_CONV_SPLIT_BF16) && (op.flags & XL_CONV_SPLIT_IL)) {
-                    if (op.Cin % 16 != 0) return XL_ERR_ARG;
+                    if (op.Cin % 128 != 0) return XL_ERR_ARG;          // a wave = 128 consecutive channels of one tile
                     kin = !op.aux2 ? wino6_in_kernel<0, 2> : (op.flags & XL_GN_RELU_IN) ? wino6_in_kernel<2, 2> : wino6_in_kernel<1, 2>;
                 }
                 hipLaunchKernelGGL(kin, dim3((unsigned)blocks6), dim3(256), 0, st, (const float *)op.in,

@@ -485,7 +485,7 @@ class _Plan:
         # register-staged kernel (the first form), "0" = fp32 MFMA
         mode = os.environ.get("XL_GEMM_SPLIT_BF16", self.SPLIT_DEFAULT)
         split = (m == 6 and not self.train and mode not in ("", "0") and C % 32 == 0)
-        split_il = split and mode != "1" and T * max(C * 6, cout * 4) < 2 ** 31 - 1 and C % 16 == 0
+        split_il = split and mode != "1" and T * max(C * 6, cout * 4) < 2 ** 31 - 1 and C % 128 == 0
         if split and not split_il:
             split = nf * T * max(C, cout) * 6 < 2 ** 31 - 1             # (the first form addresses a plane as a whole)
         V = self.alloc(nf * T * C * 3 // 2 if split else nf * T * C)
