@@ -83,6 +83,7 @@ def gather_and_median(local_err, world, dist=None, group=None):
 
 
 PEAK_F32_MFMA_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md: fp32-input MFMA = vector fp32 peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0      # same guide: dense bf16 MFMA (the 5 PF headline figure includes 2:1 sparsity)
 # HBM-side bytes per launch of the dominant kernel cannot be read from inside the process (PMC counters need
 # rocprofv3): they come from the committed record profiles/traffic.json, written by tools/traffic_record.py from the
 # rocprofv3 PMC passes (FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md §HBM, + WRITE_SIZE), keyed by
@@ -184,6 +185,8 @@ def main():
     # events only around the launches the roofline object reports (the batched Winograd GEMMs; the conv ops when the
     # plan has none), every op with XL_BENCH_VERBOSE: ~100 extra event pairs per step cost 1.5 % of the step
     has_wino = any(op.type == 1 and op.nchunks2 > 1 for op in plan.ops)
+    split_gemm = any(op.type == 1 and op.nchunks2 > 1 and (op.flags & networks.CONV_SPLIT_BF16) for op in plan.ops)
+    split_il = any(op.type == 1 and op.nchunks2 > 1 and (op.flags & networks.CONV_SPLIT_IL) for op in plan.ops)
     if os.environ.get("XL_BENCH_VERBOSE"):
         L.xl_cnn_prof_filter(-1, 0)
     else:
@@ -256,6 +259,10 @@ def main():
     Bl = sub_b[0]                                    # frames per launch (one sub-batch)
     conv_flop = wino * 2.0 * (Bl * wino_tiles) * 512 * 512 if wino else 2.0 * (Bl * 60 * 90) * 512 * (9 * 512)
     conv_tflops = conv_flop / (conv_avg_ms * 1e-3) / 1e12 if conv_ms else float("nan")
+    # split-bf16 GEMMs: every fp32 product is six bf16 MFMA passes; the roofline object counts the bf16 FLOPs the launch
+    # executes against the dense bf16 MFMA peak, and also gives the fp32-equivalent rate
+    mfma_passes = 6 if (wino and split_gemm) else 1
+    peak_tflops = PEAK_BF16_MFMA_TFLOPS if mfma_passes == 6 else PEAK_F32_MFMA_TFLOPS
     cnn_ms = float(np.mean([ev[s][0].elapsed_time(ev[s][1]) for s in range(K)]))
     dsac_ms = float(np.mean([ev[s][2].elapsed_time(ev[s][3]) for s in range(K)]))
 
@@ -279,11 +286,28 @@ def main():
 
     if rank == 0:
         value = total_imgs / elapsed
-        traffic, traffic_source = lookup_traffic("wino%d" % wino if wino else "direct", Bl)
+        traffic, traffic_source = lookup_traffic(("split%d" if mfma_passes == 6 else "wino%d") % wino if wino else "direct", Bl)
+        if mfma_passes == 6:
+            kernel_name = ("split_gemm_persist_kernel (256x256 tiles, interleaved 3xbf16 operand planes)" if split_il else
+                           "split_gemm_kernel (128x128 tiles, separate bf16 planes)") + \
+                          " batched x%d: the Winograd %s GEMMs of a 3x3 512->512 layer @60x90 x%d images per launch, every fp32 " \
+                          "operand as an exact sum of three bf16 terms, six v_mfma_f32_32x32x16_bf16 passes, fp32 accumulation" % (
+                              wino, WINO_NAME.get(wino, "?"), Bl)
+        else:
+            kernel_name = (("igemm_conv_kernel<1,1,128,512,0,128,1> batched x%d: the Winograd %s GEMMs of a 3x3 "
+                            "512->512 layer @60x90" % (wino, WINO_NAME.get(wino, "?")) if wino else
+                            "igemm_conv_kernel<3,1,128,512> (3x3 512->512 @60x90") + " x%d images per launch)" % Bl)
+        alg_bytes = (wino * (2 * Bl * wino_tiles * 512 + 512 * 512) * 4 if wino else 2 * Bl * 5400 * 512 * 4 + 512 * 4608 * 4)
+        if mfma_passes == 6:                         # V and U as 6 bytes per element (three bf16), M written as fp32
+            alg_bytes = wino * ((Bl * wino_tiles * 512 + 512 * 512) * 6 + Bl * wino_tiles * 512 * 4)
         out = {
             "metric": "images/sec localized (480x720, 256 hyps)", "value": round(value, 2), "unit": "images/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(elapsed / K * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": ("f32 (3x3 stride-1 layers: Winograd GEMMs with every fp32 operand as an exact sum of three bf16 terms, six "
+                      "bf16-MFMA passes, fp32 accumulation - fp32-class accuracy, all parity tests at the fp32 tolerances; "
+                      "everything else on fp32 MFMA)" if split_gemm else "f32"),
+            "data": "synthetic",
             "config": {"workload": ("BASELINE configs[4]: CrossLoc 3-encoder (coord+depth+normal) fusion network forward"
                                     if args.mlr else
                                     "BASELINE configs[2]: single-task coord CNN forward (2+2 extra res blocks)")
@@ -309,17 +333,17 @@ def main():
                        "cnn_fwd_algorithmic_tflops": round((FWD_GFLOP_PER_IMAGE_3ENC if args.mlr else FWD_GFLOP_PER_IMAGE) * B / cnn_ms, 2),
                        "conv3x3_s1_algorithm": ("winograd " + WINO_NAME.get(wino, "?")) if wino else "direct implicit GEMM",
                        "median_err_cm": round(med_t_cm, 3), "median_err_deg": round(med_r_deg, 5)},
-            "roofline": {"bound": "mfma",
-                         "kernel": (("igemm_conv_kernel<1,1,128,512,0,128,1> batched x%d: the Winograd %s GEMMs of a 3x3 "
-                                     "512->512 layer @60x90" % (wino, WINO_NAME.get(wino, "?")) if wino else
-                                     "igemm_conv_kernel<3,1,128,512> (3x3 512->512 @60x90") + " x%d images per launch)" % Bl),
-                         "achieved": round(conv_tflops, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(conv_tflops / PEAK_F32_MFMA_TFLOPS, 4),
+            "roofline": {"bound": "mfma", "kernel": kernel_name,
+                         "achieved": round(conv_tflops * mfma_passes, 2), "peak": peak_tflops, "unit": "TFLOP/s",
+                         "frac": round(conv_tflops * mfma_passes / peak_tflops, 4),
+                         "mfma_dtype": "bf16 x bf16 -> f32" if mfma_passes == 6 else "f32",
+                         "fp32_equivalent_tflops": round(conv_tflops, 2),
+                         "fp32_equivalent_vs_f32_mfma_peak": round(conv_tflops / PEAK_F32_MFMA_TFLOPS, 4),
                          "traffic": traffic, "traffic_source": traffic_source,
-                         "algorithmic_bytes_per_launch": (wino * (2 * Bl * wino_tiles * 512 + 512 * 512) * 4 if wino else
-                                                          2 * Bl * 5400 * 512 * 4 + 512 * 4608 * 4),
+                         "algorithmic_bytes_per_launch": alg_bytes,
                          "avg_launch_ms": round(conv_avg_ms, 4), "launches_timed": len(conv_ms),
-                         "algorithmic_gflop_per_launch": round(conv_flop / 1e9, 2)},
+                         "algorithmic_gflop_per_launch": round(conv_flop * mfma_passes / 1e9, 2),
+                         "fp32_equivalent_gflop_per_launch": round(conv_flop / 1e9, 2)},
             "cpu_baseline": cpu,
         }
         out["config"].update(secondary)

@@ -183,7 +183,7 @@ class _Plan:
                  second op array for the backward pass is lowered from it (data gradients through the same
                  implicit-GEMM kernel, weight gradients, GroupNorm/epilogue backward, head backward)."""
 
-    SPLIT_DEFAULT = "0"            # default of XL_GEMM_SPLIT_BF16 (see conv_wino)
+    SPLIT_DEFAULT = "il"           # default of XL_GEMM_SPLIT_BF16 (see conv_wino); "0" = fp32 MFMA everywhere
 
     def __init__(self, net, B, H, W, device, train=False):
         self.B, self.H, self.W, self.device, self.train = B, H, W, device, train

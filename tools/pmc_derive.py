@@ -17,7 +17,7 @@ def main():
             float(r["mean"]), int(r["dispatches"]), float(r["mean_profiled_us"]))
     cols = ["kernel", "grid_size", "vgprs", "lds_bytes", "dispatches_per_pass", "profiled_us", "hbm_GB", "hbm_TBps", "l2_hit",
             "valu_busy", "mfma_busy", "mean_waves_per_simd", "valu_insts", "fp64_valu_share", "fp32_fma_share",
-            "int32_share", "salu_per_valu", "lds_conflict_share", "mfma_GFLOP_f32"]
+            "int32_share", "salu_per_valu", "lds_conflict_share", "mfma_GFLOP_f32", "mfma_GFLOP_bf16"]
     out = []
     for (k, g, vg, lds), c in sorted(by.items()):
         def v(n):
@@ -36,7 +36,8 @@ def main():
                     "%.3f" % (v("SQ_INSTS_VALU_FMA_F32") / max(nv, 1.0)), "%.3f" % (v("SQ_INSTS_VALU_INT32") / max(nv, 1.0)),
                     "%.3f" % (v("SQ_INSTS_SALU") / max(nv, 1.0)),
                     "%.4f" % (v("SQ_LDS_BANK_CONFLICT") / max(v("SQ_LDS_IDX_ACTIVE"), 1.0)),
-                    "%.2f" % (v("SQ_INSTS_VALU_MFMA_MOPS_F32") * 512.0 / 1e9)])
+                    "%.2f" % (v("SQ_INSTS_VALU_MFMA_MOPS_F32") * 512.0 / 1e9),
+                    "%.2f" % (v("SQ_INSTS_VALU_MFMA_MOPS_BF16") * 512.0 / 1e9)])
     with open(dst, "w", newline="") as fh:
         w = csv.writer(fh)
         w.writerow(cols)

@@ -1,10 +1,12 @@
 """Summarise the per-pass rocprofv3 counter_collection.csv files of one `-i <pmc file>` run over bench.py into a compact
 table: one row per (kernel of this library, grid size, counter) with the number of dispatches, the mean / min / max
-counter value and the mean duration of those dispatches in the profiled pass.
+counter value and the mean duration of those dispatches in the profiled pass (persistent kernels: also per duration
+class, appended to the kernel name).
     python tools/pmc_summary.py <rocprof output dir> <out.csv>
 Derived figures (GB/s, VALU busy, ...) are computed by tools/pmc_derive.py from the table."""
 import csv
 import glob
+import math
 import os
 import re
 import sys
@@ -21,10 +23,13 @@ def main():
             m = NAME.search(r["Kernel_Name"][:200])
             if not m or "at::native" in r["Kernel_Name"][:40]:
                 continue
-            key = (m.group(1).replace(" ", ""), int(r["Grid_Size"]), int(r["VGPR_Count"]) + int(r["Accum_VGPR_Count"]),
+            d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+            name = m.group(1).replace(" ", "")
+            if "persist" in name:      # persistent kernels: the grid is the CU count whatever the problem, so the layers
+                name += "@%dus" % (4 ** round(math.log(max(d, 1.0), 4)))  # are told apart by their duration class (power of 4)
+            key = (name, int(r["Grid_Size"]), int(r["VGPR_Count"]) + int(r["Accum_VGPR_Count"]),
                    int(r["LDS_Block_Size"]), r["Counter_Name"])
             v = float(r["Counter_Value"])
-            d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
             a = acc.setdefault(key, [0, 0.0, v, v, 0.0])
             a[0] += 1; a[1] += v; a[2] = min(a[2], v); a[3] = max(a[3], v); a[4] += d
     with open(dst, "w", newline="") as fh:

@@ -17,6 +17,12 @@ def main():
     import bench
     rows = list(csv.DictReader(open(src)))
     recs = []
+
+    def record(form, kname, r):
+        return dict(form=form, frames_per_launch=frames, kernel=kname, bytes_per_launch=int(float(r["hbm_GB"]) * 1e9),
+                    l2_hit_rate=float(r["l2_hit"]), mfma_busy=float(r["mfma_busy"]), dispatches=int(r["dispatches_per_pass"]),
+                    profiled_us=float(r["profiled_us"]), source=label, kernel_source_sha256_16=bench.kernel_source_hash())
+
     forms = {"wino64": ("igemm_conv_kernel<1,1,128,512,0,128,1,0>", 64), "wino36": ("igemm_conv_kernel<1,1,128,512,0,128,1,0>", 36),
              "direct": ("igemm_conv_kernel<3,1,128,512,0,128,0,0>", 1)}
     for form, (kname, z) in forms.items():
@@ -24,9 +30,12 @@ def main():
         grid = mtiles * 4 * z * 256
         for r in rows:
             if r["kernel"] == kname and int(r["grid_size"]) == grid:
-                recs.append(dict(form=form, frames_per_launch=frames, kernel=kname, bytes_per_launch=int(float(r["hbm_GB"]) * 1e9),
-                                 l2_hit_rate=float(r["l2_hit"]), mfma_busy=float(r["mfma_busy"]), dispatches=int(r["dispatches_per_pass"]),
-                                 profiled_us=float(r["profiled_us"]), source=label, kernel_source_sha256_16=bench.kernel_source_hash()))
+                recs.append(record(form, kname, r))
+    # split-bf16 Winograd GEMMs (persistent kernel: grid = CU count): the 512 -> 512 layers are the longest duration class
+    cand = [r for r in rows if r["kernel"].startswith("split_gemm_persist_kernel@")]
+    if cand:
+        r = max(cand, key=lambda r: float(r["profiled_us"]))
+        recs.append(record("split64", r["kernel"], r))
     solver = {}
     for r in rows:
         if r["kernel"].startswith("xl_dsac_forward_kernel"):
