@@ -18,6 +18,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/crossloc_cnn.h"
@@ -381,14 +382,16 @@ void split_gemm_persist_kernel(SplitArgs2 a)
         const __amdgpu_buffer_rsrc_t srdO = __builtin_amdgcn_make_buffer_rsrc((void *)(a.out + (long long)z * a.T * a.N), 0, (int)((long long)a.T * a.N * 4), 0x00020000);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
+            // (exactly 32 stores per wave and tile, counted by the vmcnt arithmetic above: rows past T fall outside the
+            //  descriptor, N is a multiple of 256)
             const int m = m0 + wm * 128 + i * 32 + (lane & 31);
-            const unsigned rowOff = m < a.T ? (unsigned)((long long)m * a.N * 4) : OOB;
+            const unsigned rowOff = (unsigned)((long long)m * a.N * 4);
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int n = n0 + wn * 64 + j * 32 + rhalf + 8 * q;
-                    const unsigned off = (rowOff != OOB && n < a.N) ? rowOff + (unsigned)n * 4u : OOB;
+                    const unsigned off = rowOff + (unsigned)n * 4u;
                     const f32x4 v = f32x4{ acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3] };
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), srdO, (int)off, 0, 0);
                 }
@@ -402,21 +405,476 @@ void split_gemm_persist_kernel(SplitArgs2 a)
 }
 
 
+// ---------------------------------------------------------------------------------------------- 1x1 convolution on the split pipe
+//
+// out[m][n] = bias[n] + sum_c f(in[m][c]) * W[n][c],   m = pixel (B*H*W of them, NHWC), f = identity or the producer's
+// deferred GroupNorm(+ReLU) (XL_CONV_NORM_IN: per-(image, channel) {scale, shift}), plus the GroupNorm partial sums of the
+// OUTPUT (as the fp32 kernel's epilogue, csrc/xl_cnn.hip), so a 1x1 layer stays ONE launch.  The loop is the 256 x 256
+// persistent loop above with a different activation path: the weights W are split once on the host (interleaved planes,
+// LDS-DMA ring of 3 stages) but the activations arrive as fp32, so every thread
+//     loads 8 channels of one row (2 x dwordx4, two K-steps ahead of the multiplies),
+//     normalises, splits them into three bf16 terms (v_cvt_pk_bf16_f32; residuals are exact in fp32) and
+//     writes 3 x 16 bytes into the activation stage of the NEXT K-step (2 stages, same rotated 96-byte rows),
+// between the third and fourth term group of the current step.  60-odd VALU instructions per wave and K-step under 48
+// MFMAs of 8 passes each.
+// LDS (157 KB): weights 3 x 24 KB | activations 2 x 24 KB | 8 KB | fp64 partials 8 KB | coefficient tables 2 x 8 KB |
+// bias 4 KB.  The statistics epilogue stages its per-lane sums in activation stage 1 + the 8 KB behind it: C / 16 is even,
+// so when a tile ends stage 1 has just been multiplied and stage 0 holds the first step of the next tile.
+constexpr int kCvA = 3 * kIOperand;                   // activation stages
+constexpr int kCvStage1 = kCvA + kIOperand;           // statistics staging: 32 KB from here
+constexpr int kCvPart = kCvA + 2 * kIOperand + 8192;  // fp64 partials [32][16][2]
+constexpr int kCvCoef = kCvPart + 8192;               // coefficient tables of two tiles, 8 KB each (C <= 512)
+constexpr int kCvBias = kCvCoef + 16384;              // bias[N <= 1024]
+constexpr int kCvLds = kCvBias + 4096;
+
+struct SplitConvArgs {
+    const float *in; const uint16_t *u; const float *bias; float *out;
+    const float *coef; float normLo;                 // NORM: [B][C][2] {scale, shift}; lower clamp (0 = ReLU, -inf = none)
+    double *stats; int HW, G, nchunks, B;            // statistics of the output (stats == nullptr: none); 16 channels per group
+    int M, C, N, ldIn, ldOut, nbm, nbn;
+};
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pk_bf16(float x, float y)        // {bf16(x), bf16(y)} round to nearest even
+{
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{ x, y }, bf16x2));
+}
+__device__ __forceinline__ float hi_f(unsigned w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
+__device__ __forceinline__ float lo_f(unsigned w) { return __builtin_bit_cast(float, w << 16); }
+// x = t1 + t2 + t3 exactly, for two values at a time (one 32-bit word per term)
+__device__ __forceinline__ void split_pair(float x, float y, unsigned &w1, unsigned &w2, unsigned &w3)
+{
+    w1 = pk_bf16(x, y);
+    const float rx = x - lo_f(w1), ry = y - hi_f(w1);
+    w2 = pk_bf16(rx, ry);
+    w3 = pk_bf16(rx - lo_f(w2), ry - hi_f(w2));
+}
+
+template <bool NORM, int DBG = 0>
+__global__ __launch_bounds__(512)
+void split_conv1x1_kernel(SplitConvArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+    typedef __attribute__((address_space(3))) void lds_void;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+
+    const int total = a.nbm * a.nbn;
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3, nloc = gridDim.x >> 3;
+    const int q8 = total >> 3, r8 = total & 7;
+    const int runStart = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+    const int runLen = q8 + (xcd < r8 ? 1 : 0);
+    const int myCount = runLen > local ? (runLen - local + nloc - 1) / nloc : 0;
+    if (myCount == 0) return;
+    auto tile_at = [&](int i, int &m0, int &n0) {
+        const int t = runStart + local + i * nloc;
+        const int mt = t / a.nbn;
+        m0 = mt * 256; n0 = (t - mt * a.nbn) * 256;
+    };
+
+    constexpr unsigned OOB = 0x80000000u;
+    const long long rowU = (long long)a.C * 6;
+    const int nk = a.C / 16;
+
+    // ---- stream two K-steps ahead of the multiplies: weights by LDS-DMA (3 instructions per wave and step), activations
+    // into registers (row tid >> 1, channels 8 (tid & 1) .. + 7 of the step; two register sets, by the parity of the step)
+    const __amdgpu_buffer_rsrc_t srdU = __builtin_amdgcn_make_buffer_rsrc((void *)a.u, 0, (int)(a.N * rowU), 0x00020000);
+    __amdgpu_buffer_rsrc_t srdIn = __builtin_amdgcn_make_buffer_rsrc((void *)a.in, 0, 0, 0x00020000);
+    const int arow = tid >> 1, ahalf = tid & 1;
+    unsigned gB[3], gA = OOB;
+    int dTile = 0, dK = 0;
+    auto set_dma_tile = [&](int i) {
+        if (i < myCount) {
+            int m0, n0;
+            tile_at(i, m0, n0);
+            const int rows = a.M - m0 < 256 ? a.M - m0 : 256;
+            srdIn = __builtin_amdgcn_make_buffer_rsrc((void *)(a.in + (long long)m0 * a.ldIn), 0, rows * a.ldIn * 4, 0x00020000);
+            gA = (unsigned)(arow * a.ldIn * 4 + ahalf * 32);              // rows past M fall outside the descriptor
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int sl = (wave * 3 + q) * 64 + lane;
+                const int row = sl / 6, phys = sl - row * 6;
+                int logical = phys - ((row >> 3) & 1);
+                if (logical < 0) logical += 6;
+                gB[q] = (unsigned)((long long)(n0 + row) * rowU + logical * 16);
+            }
+        } else {
+            gA = OOB;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) gB[q] = OOB;
+        }
+    };
+    auto dma_instr = [&](int q, int stage) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(srdU, (lds_void *)(dsm + stage * kIOperand + (wave * 3 + q) * 1024), 16,
+                                                 (int)gB[q], dK * kIUnit, 0, 0);
+    };
+    u32x4 rA[2][2];                                                    // [K-step parity][half of my 8 channels]
+    auto load_a = [&](auto parTag) {
+        constexpr int P = decltype(parTag)::value;
+        if constexpr (DBG & 2) {                                      // (diagnostics: opaque values instead of the loads)
+            asm volatile("" : "=v"(rA[P][0]), "=v"(rA[P][1]));
+            return;
+        }
+        rA[P][0] = __builtin_amdgcn_raw_buffer_load_b128(srdIn, (int)gA, dK * 64, 0);
+        rA[P][1] = __builtin_amdgcn_raw_buffer_load_b128(srdIn, (int)(gA + 16u), dK * 64, 0);
+    };
+    auto advance_dma = [&]() {
+        if (++dK == nk) { dK = 0; ++dTile; set_dma_tile(dTile); }
+    };
+
+    // ---- conversion, one K-step ahead of the multiplies
+    unsigned wOff[3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        int ph = 2 * p + ahalf + ((arow >> 3) & 1);
+        if (ph >= 6) ph -= 6;
+        wOff[p] = (unsigned)(kCvA + arow * kIUnit + ph * 16);
+    }
+    int cTile = 0, cK = 0;
+    unsigned cCoef = 0;                                              // LDS offset of my row's {scale, shift} run
+    auto set_conv_tile = [&](int i) {
+        if (NORM && i < myCount) {
+            int m0, n0;
+            tile_at(i, m0, n0);
+            const int nLo = m0 / a.HW;
+            const int split = (nLo + 1) * a.HW - m0;                 // first tile row of the second image
+            cCoef = (unsigned)(kCvCoef + (i & 1) * 8192 + (arow >= split ? a.C * 8 : 0) + ahalf * 64);
+        }
+    };
+    auto convert = [&](auto parTag) {                                  // registers of parity P -> activation stage P
+        constexpr int P = decltype(parTag)::value;
+        constexpr int stage = P;
+        unsigned w[3][4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            f32x4 x = __builtin_bit_cast(f32x4, rA[P][h]);
+            if constexpr (NORM) {
+                const f32x4 c0 = *reinterpret_cast<const f32x4 *>(dsm + cCoef + cK * 128 + h * 32);
+                const f32x4 c1 = *reinterpret_cast<const f32x4 *>(dsm + cCoef + cK * 128 + h * 32 + 16);
+                x[0] = fmaxf(fmaf(x[0], c0[0], c0[1]), a.normLo);
+                x[1] = fmaxf(fmaf(x[1], c0[2], c0[3]), a.normLo);
+                x[2] = fmaxf(fmaf(x[2], c1[0], c1[1]), a.normLo);
+                x[3] = fmaxf(fmaf(x[3], c1[2], c1[3]), a.normLo);
+            }
+            if constexpr (DBG & 1) {
+                for (int p = 0; p < 3; ++p) { w[p][2 * h] = rA[P][h][0] + p; w[p][2 * h + 1] = rA[P][h][2]; }
+                continue;
+            }
+            split_pair(x[0], x[1], w[0][2 * h], w[1][2 * h], w[2][2 * h]);
+            split_pair(x[2], x[3], w[0][2 * h + 1], w[1][2 * h + 1], w[2][2 * h + 1]);
+        }
+        if constexpr (DBG & 4) {                                      // (diagnostics: everything but the LDS writes)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) asm volatile("" :: "v"(w[p][0]), "v"(w[p][1]), "v"(w[p][2]), "v"(w[p][3]));
+            return;
+        }
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+            *reinterpret_cast<u32x4 *>(dsm + stage * kIOperand + wOff[p]) = u32x4{ w[p][0], w[p][1], w[p][2], w[p][3] };
+    };
+    auto advance_conv = [&]() {
+        if (++cK == nk) { cK = 0; ++cTile; set_conv_tile(cTile); }
+    };
+    // coefficient table of tile i: the {scale, shift} pairs of its (at most two) images, 4 C floats, into table i & 1
+    const __amdgpu_buffer_rsrc_t srdCoef = __builtin_amdgcn_make_buffer_rsrc((void *)a.coef, 0, NORM ? a.B * a.C * 8 : 0, 0x00020000);
+    auto load_table = [&](int i) -> u32x4 {
+        unsigned off = OOB;
+        if (i < myCount && tid < a.C) {
+            int m0, n0;
+            tile_at(i, m0, n0);
+            off = (unsigned)(((long long)(m0 / a.HW) * a.C * 2 + tid * 4) * 4);
+        }
+        return __builtin_amdgcn_raw_buffer_load_b128(srdCoef, (int)off, 0, 0);
+    };
+    auto store_table = [&](int i, u32x4 v) {
+        if (tid < a.C) *reinterpret_cast<u32x4 *>(dsm + kCvCoef + (i & 1) * 8192 + tid * 16) = v;
+    };
+
+    // ---- fragments
+    const int fr = lane & 31, kh = lane >> 5;
+    unsigned slotOff[3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        int ph = 2 * p + kh + ((fr >> 3) & 1);
+        if (ph >= 6) ph -= 6;
+        slotOff[p] = (unsigned)(ph * 16);
+    }
+    const unsigned frA = (unsigned)(kCvA + (wm * 128 + fr) * kIUnit), frB = (unsigned)((wn * 64 + fr) * kIUnit);
+    bf16x8 fa[3][4], fb[3][2];
+    bf16x8 faN[4], fbN[2];
+    f32x16 acc[4][2];
+    auto ldA = [&](int stage, int p, int i) { return *reinterpret_cast<const bf16x8 *>(dsm + stage * kIOperand + frA + i * 32 * kIUnit + slotOff[p]); };
+    auto ldB = [&](int stage, int p, int j) { return *reinterpret_cast<const bf16x8 *>(dsm + stage * kIOperand + frB + j * 32 * kIUnit + slotOff[p]); };
+    auto mma_term = [&](int pu, int pv) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[pu][j], fa[pv][i], acc[i][j], 0, 0, 0);
+    };
+    const int rhalf = kh * 4;
+    auto init_acc = [&](int n0) {                                      // accumulators start at the bias
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 b = *reinterpret_cast<const f32x4 *>(dsm + kCvBias + (n0 + wn * 64 + j * 32 + rhalf + 8 * q) * 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[i][j][4 * q + e] = b[e];
+            }
+    };
+
+    // ---- prologue: bias and the first two coefficient tables into LDS, steps 0 and 1 of the stream, step 0 converted
+    for (int i = tid; i < a.nbn * 256; i += 512) reinterpret_cast<float *>(dsm + kCvBias)[i] = i < a.N ? a.bias[i] : 0.f;
+    if constexpr (NORM) {
+        const u32x4 t0 = load_table(0), t1 = load_table(1);
+        store_table(0, t0);
+        store_table(1, t1);
+    }
+    set_dma_tile(0);
+    set_conv_tile(0);
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    load_a(P0{}); dma_instr(0, 0); dma_instr(1, 0); dma_instr(2, 0);
+    advance_dma();
+    __builtin_amdgcn_s_waitcnt(0x0070);                               // everything landed
+    __syncthreads();                                                  // tables and bias visible
+    convert(P0{});
+    advance_conv();
+    load_a(P1{}); dma_instr(0, 1); dma_instr(1, 1); dma_instr(2, 1);  // (the order of a steady-state step)
+    advance_dma();
+    __builtin_amdgcn_s_waitcnt(0x0070 | 5);                           // my writes of step 0; stage 0 of the ring landed before
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int j = 0; j < 2; ++j) fbN[j] = ldB(0, 2, j);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) faN[i] = ldA(0, 0, i);
+    int sc = 0, sd = 2;
+    {
+        int m0, n0;
+        tile_at(0, m0, n0);
+        init_acc(n0);
+    }
+    // one K-step; FIRST: the first step of a tile that follows another one (32 stores of its epilogue are in flight).  The
+    // tile loop is written so that such a step is its own code: the compiler's vmcnt bookkeeping for rA (it assumes the
+    // fewest outstanding operations over all paths into a block) then does not wait for those stores.
+    auto step = [&](auto firstTag, auto parTag) __attribute__((always_inline)) {
+        constexpr int sa = decltype(parTag)::value;                   // parity of the K-step
+        const int next = sc == 2 ? 0 : sc + 1;
+        load_a(parTag);                                               // step kk + 2: two steps until its conversion
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fb[2][j] = fbN[j];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[0][i] = faN[i];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fb[1][j] = ldB(sc, 1, j);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[1][i] = ldA(sa, 1, i);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fb[0][j] = ldB(sc, 0, j);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[2][i] = ldA(sa, 2, i);
+        mma_term(2, 0); dma_instr(0, sd);
+        mma_term(1, 1); dma_instr(1, sd);
+        mma_term(0, 2);
+        mma_term(1, 0);
+        convert(std::integral_constant<int, sa ^ 1>{});           // step kk + 1 (the compiler counts vmcnt for rA)
+        advance_conv();
+        mma_term(0, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        // the weights of step kk + 1 have landed: younger are 2 DMAs and 2 loads of step kk + 2 - and, in the first
+        // step of a tile, the 32 stores of the tile before (vmcnt(36)); lgkmcnt(0): my activation writes are done
+        if constexpr (decltype(firstTag)::value) __builtin_amdgcn_s_waitcnt(0x8070 | 4);
+        else __builtin_amdgcn_s_waitcnt(0x0070 | 4);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fbN[j] = ldB(next, 2, j);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) faN[i] = ldA(sa ^ 1, 0, i);
+        mma_term(0, 0); dma_instr(2, sd);
+        advance_dma();
+        sc = next;
+        sd = sd == 2 ? 0 : sd + 1;
+        __builtin_amdgcn_sched_barrier(0);                            // (the vmcnt arithmetic above assumes this issue order)
+    };
+    auto epilogue = [&](int ti) __attribute__((always_inline)) {
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- tile ti (swapped operands): row = lane & 31, channels (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+        int m0, n0;
+        tile_at(ti, m0, n0);
+        u32x4 tab;
+        if (!(DBG & 8) && a.stats != nullptr) {
+            // GroupNorm partial sums of the output; a tile touches at most two images (HW >= 256): slot 0 = rows before
+            // `split`, slot 1 = the rest.  Fixed order: per lane fp32 over its 4 rows x 8 channels of a group; fp64 over
+            // the 128 lanes holding the group (16 parts of 8 lanes, then the parts); one writer per (image, tile, group).
+            const int nLo = m0 / a.HW;
+            const int split = (nLo + 1) * a.HW - m0;
+            f32x2 *sS = reinterpret_cast<f32x2 *>(dsm + kCvStage1);    // [4 pieces][2 slots][512 threads]
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int gh = 0; gh < 2; ++gh) {
+                    float s[2] = { 0.f, 0.f }, ss[2] = { 0.f, 0.f };
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int row = wm * 128 + i * 32 + fr;
+                        float t = 0.f, tt = 0.f;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float v = acc[i][j][8 * gh + e];
+                            t += v;
+                            tt = fmaf(v, v, tt);
+                        }
+                        const bool live = m0 + row < a.M, hi = row >= split;
+                        s[0] += (live && !hi) ? t : 0.f; ss[0] += (live && !hi) ? tt : 0.f;
+                        s[1] += (live && hi) ? t : 0.f;  ss[1] += (live && hi) ? tt : 0.f;
+                    }
+#pragma unroll
+                    for (int sl = 0; sl < 2; ++sl) sS[((j * 2 + gh) * 2 + sl) * 512 + tid] = f32x2{ s[sl], ss[sl] };
+                }
+            __builtin_amdgcn_s_waitcnt(0x0070 | 0xC00F);               // lgkmcnt(0)
+            __builtin_amdgcn_s_barrier();
+            {
+                const int gs = tid >> 4, part = tid & 15;              // (group of the tile, slot) x 16 parts
+                const int gt = gs >> 1, sl = gs & 1;
+                const int src = ((part >> 3) * 4 + (gt >> 2)) * 64 + (part & 7) * 8;
+                const f32x2 *o = sS + ((gt & 3) * 2 + sl) * 512 + src;
+                double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { s1 += (double)o[e][0]; s2 += (double)o[e][1]; }
+                double *sC = reinterpret_cast<double *>(dsm + kCvPart);
+                sC[tid * 2] = s1; sC[tid * 2 + 1] = s2;
+            }
+            __builtin_amdgcn_s_waitcnt(0x0070 | 0xC00F);
+            __builtin_amdgcn_s_barrier();
+            if (tid < 32) {
+                const int gt = tid >> 1, sl = tid & 1;
+                const int n = nLo + sl;
+                const int firstRow = sl ? split : 0;
+                const int g = (n0 >> 4) + gt;
+                if (n < a.B && m0 + firstRow < a.M && (sl == 0 || split < 256) && g < a.G) {
+                    const double *sC = reinterpret_cast<const double *>(dsm + kCvPart) + tid * 32;
+                    double s1 = 0.0, s2 = 0.0;
+                    for (int e = 0; e < 16; ++e) { s1 += sC[2 * e]; s2 += sC[2 * e + 1]; }
+                    const int k = (m0 >> 8) - (int)(((long long)n * a.HW) >> 8);       // tile index within the image
+                    double *o = a.stats + (((long long)n * a.nchunks + k) * a.G + g) * 2;
+                    o[0] = s1; o[1] = s2;
+                }
+            }
+        }
+        if constexpr (NORM) {                                          // (waits for everything older than the table)
+            tab = load_table(ti + 2);
+            store_table(ti + 2, tab);
+        }
+        // (every wave issues exactly 32 stores per tile - the vmcnt arithmetic of the next step counts them: rows past M
+        //  fall outside the descriptor, N is a multiple of 256)
+        const int rowsLeft = a.M - m0;
+        const __amdgpu_buffer_rsrc_t srdO = __builtin_amdgcn_make_buffer_rsrc((void *)(a.out + (long long)m0 * a.ldOut), 0,
+                                                                              (rowsLeft < 256 ? rowsLeft : 256) * a.ldOut * 4, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned rowOff = (unsigned)((wm * 128 + i * 32 + fr) * a.ldOut * 4);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int n = n0 + wn * 64 + j * 32 + rhalf + 8 * q;
+                    const unsigned off = rowOff + (unsigned)n * 4u;
+                    const f32x4 v = f32x4{ acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3] };
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), srdO, (int)off, 0, 0);
+                }
+        }
+        if (ti + 1 < myCount) {
+            tile_at(ti + 1, m0, n0);
+            init_acc(n0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto tile_steps = [&](auto firstTag) __attribute__((always_inline)) {
+        step(firstTag, P0{});
+        step(std::false_type{}, P1{});
+        for (int kk = 2; kk < nk; kk += 2) {
+            step(std::false_type{}, P0{});
+            step(std::false_type{}, P1{});
+        }
+    };
+    tile_steps(std::false_type{});
+    for (int ti = 1; ti < myCount; ++ti) {
+        epilogue(ti - 1);
+        tile_steps(std::true_type{});
+    }
+    epilogue(myCount - 1);
+    __builtin_amdgcn_s_waitcnt(0x0F70);                             // vmcnt(0)
+}
+
 }  // namespace
 
 // XL_OP_CONV with XL_CONV_SPLIT_BF16: ksize 1, stride 1, nchunks2 = Z batched GEMMs, out fp32 [Z][T][Cout] (ld_out = Cout).
 //   + XL_CONV_SPLIT_IL: in = V [Z][T][Cin/16][3][16] bf16, w = U [Z][Cout][Cin/16][3][16] bf16 (256 x 256 persistent kernel);
 //   else              : in = plane 0 of V ([Z][T][Cin] bf16, planes Z*T*Cin elements apart), w = plane 0 of U
 //                       ([Z][Cout][Cin] bf16, planes Z*Cout*Cin apart) (128 x 128 kernel, the first form).
+// XL_OP_CONV with XL_CONV_SPLIT_BF16 | XL_CONV_SPLIT_IL and nchunks2 <= 1: a 1x1 stride-1 convolution, fp32 NHWC in / out
+// (ld_in / ld_out), w = [Cout][Cin/16][3][16] bf16, bias, optionally XL_CONV_NORM_IN (aux2 = [B][Cin][2] coefficients) and the
+// statistics epilogue (stats / groups / nchunks with 256-row tiles: nchunks >= ceil(HW / 256) + 1, 16 channels per group).
+static int xl_run_split_conv1x1(const xl_op &op, hipStream_t st)
+{
+    const long long M = (long long)op.B * op.Ho * op.Wo;
+    const int HW = op.Ho * op.Wo;
+    const bool norm = (op.flags & XL_CONV_NORM_IN) != 0;
+    if (op.ksize != 1 || op.stride != 1 || op.Cin % 32 != 0 || op.Cout % 256 != 0 || op.Cout > 1024 || op.ld_in < op.Cin ||
+        op.ld_out < op.Cout || (op.ld_in & 3) || (op.ld_out & 3) || !op.bias || (op.flags & XL_CONV_ACCUMULATE) || !op.in ||
+        !op.w || !op.out || (((uintptr_t)op.in | (uintptr_t)op.out | (uintptr_t)op.w) & 15) || M >= 0x7fffffffLL ||
+        (long long)op.Cout * op.Cin * 6 >= 0x7fffffffLL || 256LL * op.ld_in * 4 >= 0x7fffffffLL || 256LL * op.ld_out * 4 >= 0x7fffffffLL)
+        return XL_ERR_ARG;
+    if (norm && (!op.aux2 || op.Cin > 512 || HW < 256)) return XL_ERR_ARG;
+    if (op.stats && (op.groups <= 0 || op.Cout != 16 * op.groups || HW < 256 || op.nchunks < (HW + 255) / 256 + 1)) return XL_ERR_ARG;
+    SplitConvArgs a;
+    a.in = (const float *)op.in; a.u = (const uint16_t *)op.w; a.bias = (const float *)op.bias; a.out = (float *)op.out;
+    a.coef = (const float *)op.aux2;
+    a.normLo = (op.flags & XL_CONV_NORM_RELU) ? 0.f : -__builtin_inff();
+    a.stats = (double *)op.stats; a.HW = HW; a.G = op.groups; a.nchunks = op.nchunks; a.B = op.B;
+    a.M = (int)M; a.C = op.Cin; a.N = op.Cout; a.ldIn = op.ld_in; a.ldOut = op.ld_out;
+    a.nbm = (int)((M + 255) / 256); a.nbn = (op.Cout + 255) / 256;
+    const size_t lds = kCvLds;
+    static XlLdsLimit configured[2];
+    int cfgDev;
+    if (configured[norm].needs(lds, &cfgDev)) {
+        const void *fn = norm ? reinterpret_cast<const void *>(split_conv1x1_kernel<true>) : reinterpret_cast<const void *>(split_conv1x1_kernel<false>);
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return XL_ERR_HIP;
+        configured[norm].done(lds, cfgDev);
+    }
+    const int nwg = a.nbm * a.nbn;
+    int grid = 256;
+    if (grid > ((nwg + 7) & ~7)) grid = (nwg + 7) & ~7;
+    static const int dbg = getenv("XL_SPLIT1X1_DBG") ? atoi(getenv("XL_SPLIT1X1_DBG")) : 0;
+    if (dbg) {
+        auto k = dbg == 1 ? split_conv1x1_kernel<true, 1> : dbg == 2 ? split_conv1x1_kernel<true, 2> : dbg == 3 ? split_conv1x1_kernel<true, 3> :
+                 dbg == 4 ? split_conv1x1_kernel<true, 4> : dbg == 5 ? split_conv1x1_kernel<true, 5> : dbg == 6 ? split_conv1x1_kernel<true, 6> :
+                 dbg == 7 ? split_conv1x1_kernel<true, 7> : split_conv1x1_kernel<true, 8>;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, st, a);
+        return XL_OK;
+    }
+    if (norm) hipLaunchKernelGGL(split_conv1x1_kernel<true>, dim3(grid), dim3(512), lds, st, a);
+    else hipLaunchKernelGGL(split_conv1x1_kernel<false>, dim3(grid), dim3(512), lds, st, a);
+    return XL_OK;
+}
+
 int xl_run_split_gemm(const xl_op &op, hipStream_t st)
 {
+    if ((op.flags & XL_CONV_SPLIT_IL) && op.nchunks2 <= 1) return xl_run_split_conv1x1(op, st);
     const int T = op.B * op.Ho * op.Wo, Z = op.nchunks2;
     if (op.ksize != 1 || op.stride != 1 || Z < 1 || op.Cin % kBK != 0 || op.Cout % 4 != 0 || op.ld_in != op.Cin ||
         op.ld_out != op.Cout || op.bias || op.stats || (op.flags & XL_CONV_ACCUMULATE) || !op.in || !op.w || !op.out)
         return XL_ERR_ARG;
     if (op.flags & XL_CONV_SPLIT_IL) {
         // 32-bit offsets inside one GEMM's operands / result (each z has its own buffer descriptor)
-        if ((long long)T * op.Cin * 6 >= 0x7fffffffLL || (long long)op.Cout * op.Cin * 6 >= 0x7fffffffLL ||
+        if (op.Cout % 256 != 0 || (long long)(T + 256) * op.Cout * 4 >= 0xffffffffLL || (long long)T * op.Cin * 6 >= 0x7fffffffLL || (long long)op.Cout * op.Cin * 6 >= 0x7fffffffLL ||
             (long long)T * op.Cout * 4 >= 0x7fffffffLL) return XL_ERR_ARG;
         SplitArgs2 a;
         a.v = (const uint16_t *)op.in; a.u = (const uint16_t *)op.w; a.out = (float *)op.out;

@@ -192,6 +192,7 @@ class _Plan:
         self.separate_stats = bool(getattr(net, "batch_invariant", False) or os.environ.get("XL_NO_FUSED_STATS"))
         self.ops = []
         self.packed_split = {}
+        self.packed_1x1 = {}
         self.keep = []                      # tensors the op pointers reference
         self.free = {}                      # numel -> [tensor]
         self.packed = {}                    # (id(param), kind) -> packed weight tensor
@@ -350,6 +351,8 @@ class _Plan:
             il = kind.endswith("_il")
             base = self.packed[(wid, kind[:kind.index("_split")])][0]
             planes.copy_(self._split_form(base, planes.shape[-3] * 16 if il else None, il))
+        for planes, src in self.packed_1x1.values():
+            planes.copy_(self.split_bf16_interleaved(src.reshape(src.shape[0], src.shape[1]), src.shape[1]))
 
     def dev(self, p):
         t = p.detach().to(device=self.device, dtype=torch.float32).contiguous()
@@ -366,7 +369,29 @@ class _Plan:
                 and -(-self.B * H * W // 128) * (cout // 128) > 256 and not self.train
                 and not os.environ.get("XL_NO_NORM_ON_LOAD"))
 
-    def conv(self, act, conv, out=None, out_ld=None, out_off=0, norm_in=None):
+    def split_1x1_ok(self, act, conv):
+        """1x1 stride-1 layers of inference plans on the bf16 matrix pipe (csrc/xl_gemm_split.hip, split_conv1x1_kernel):
+        weights split once on the host, activations split by the kernel on their way into LDS - fp32-accurate like the
+        Winograd GEMMs.  The choice depends on the layer only, never on the batch: a frame's result must not change with
+        the batch it is in (a single frame is 44 tiles of 256 x 256: one short round on 44 CUs, about the time the fp32
+        kernel needs for its 340 small tiles)."""
+        t, H, W, C, ld, off = act
+        cout = conv.out_channels
+        return (conv.kernel_size[0] == 1 and conv.stride[0] == 1 and not self.train and C % 32 == 0 and cout % 256 == 0
+                and cout <= 1024 and H * W >= 256 and ld % 4 == 0 and off % 4 == 0
+                and os.environ.get("XL_GEMM_SPLIT_BF16", self.SPLIT_DEFAULT) not in ("", "0", "1")
+                and not os.environ.get("XL_NO_SPLIT_1X1"))
+
+    def pack_conv_1x1_split(self, conv):
+        """[Cout][Cin/16][3][16] bf16: the weight of a 1x1 convolution as interleaved bf16 planes."""
+        w = conv.weight
+        key = id(w)
+        if key not in self.packed_1x1:
+            src = w.detach().to(device=self.device, dtype=torch.float32).contiguous()     # aliases the live parameter
+            self.packed_1x1[key] = (self.split_bf16_interleaved(src.reshape(src.shape[0], src.shape[1]), src.shape[1]), src)
+        return self.packed_1x1[key][0]
+
+    def conv(self, act, conv, out=None, out_ld=None, out_off=0, norm_in=None, split=False):
         t, H, W, C, ld, off = act
         k, s = conv.kernel_size[0], conv.stride[0]
         cout = conv.out_channels
@@ -387,6 +412,10 @@ class _Plan:
         bn = 128 if cout % 128 == 0 else 64
         if -(-self.B * Ho * Wo // 128) * -(-cout // bn) <= 256:
             op.reserved_i = 64
+        if split:
+            op.flags |= CONV_SPLIT_BF16 | CONV_SPLIT_IL
+            op.w = self.pack_conv_1x1_split(conv).data_ptr()
+            op.reserved_i = 256                       # rows per tile (the statistics epilogue writes one entry per tile)
         if norm_in is not None:                       # the producer's deferred GroupNorm apply, folded into the operand load
             op.flags |= CONV_NORM_IN | (CONV_NORM_RELU if norm_in.flags & GN_RELU_IN else 0)
             self.deferred_gn_consumers = getattr(self, "deferred_gn_consumers", []) + [len(self.ops)]
@@ -485,7 +514,7 @@ class _Plan:
         # register-staged kernel (the first form), "0" = fp32 MFMA
         mode = os.environ.get("XL_GEMM_SPLIT_BF16", self.SPLIT_DEFAULT)
         split = (m == 6 and not self.train and mode not in ("", "0") and C % 32 == 0)
-        split_il = split and mode != "1" and T * max(C * 6, cout * 4) < 2 ** 31 - 1 and C % 128 == 0
+        split_il = split and mode != "1" and (T + 256) * max(C * 6, cout * 4) < 2 ** 31 - 1 and C % 128 == 0 and cout % 256 == 0
         if split and not split_il:
             split = nf * T * max(C, cout) * 6 < 2 ** 31 - 1             # (the first form addresses a plane as a whole)
         V = self.alloc(nf * T * C * 3 // 2 if split else nf * T * C)
@@ -589,9 +618,11 @@ class _Plan:
             pend = None
         if m:
             return self.conv_wino(act, conv, norm, flags, aux, m, pend, defer=defer)
-        y = self.conv(act, conv, norm_in=pend)
-        bn = 128 if conv.out_channels % 128 == 0 else 64
         cpg = conv.out_channels // norm.num_groups
+        split = (self.split_1x1_ok(act, conv) and (cpg == 16 or self.separate_stats)
+                 and (pend is None or act[3] <= 512))
+        y = self.conv(act, conv, norm_in=pend, split=split)
+        bn = 128 if conv.out_channels % 128 == 0 else 64
         # a conv tile's columns cover whole groups, and the statistics epilogue sums 2- or 4-channel pieces
         whole_groups = bn % cpg == 0 and (cpg == 2 or cpg % 4 == 0)
         if not self.train and y[1] * y[2] >= 128 and whole_groups and not self.separate_stats:
@@ -625,7 +656,7 @@ class _Plan:
         t, H, W, C, ld, off = act
         G, HW = norm.num_groups, H * W
         cop = self.ops[conv_index]
-        tile = 64 if cop.reserved_i == 64 else 128
+        tile = cop.reserved_i if cop.reserved_i in (64, 256) else 128
         nchunks = (HW + tile - 1) // tile + 1
         self.max_stats = max(self.max_stats, self.B * nchunks * G * 2)
         cop.groups, cop.nchunks = G, nchunks

@@ -111,6 +111,63 @@ def test_conv1x1_normalise_on_load_with_statistics(cin, cout, B, H, W, relu):
     assert torch.allclose(st[:, :, 1], (grp * grp).sum(2), rtol=1e-5)
 
 
+@pytest.mark.parametrize("cin,cout,B,H,W,norm,relu,stats,pad", [
+    (512, 512, 3, 24, 37, True, True, True, 0),        # 888 pixels per image: tiles straddle images, last tile ragged
+    (512, 512, 2, 60, 90, True, False, True, 0),
+    (256, 512, 3, 20, 31, False, False, True, 0),      # the res2 skip layer's shape
+    (512, 512, 5, 16, 16, False, False, False, 32),    # exactly one tile per image; operands inside wider tensors
+    (512, 256, 2, 33, 20, True, True, False, 64),
+    (64, 1024, 1, 40, 52, False, False, False, 0)])
+def test_conv1x1_on_the_split_bf16_pipe(cin, cout, B, H, W, norm, relu, stats, pad):
+    """XL_CONV_SPLIT_BF16 | XL_CONV_SPLIT_IL without batching: a 1x1 convolution whose weights were split into three bf16
+    planes on the host and whose fp32 activations are normalised (optionally) and split by the kernel - same tolerance as
+    the fp32-MFMA kernel, plus the GroupNorm statistics of the output from 256-row tiles."""
+    g = torch.Generator().manual_seed(cin + cout + B + H)
+    x = torch.randn(B, cin, H, W, generator=g) * 3.0 + 1.0
+    coef = torch.stack([torch.rand(B, cin, generator=g) + 0.5, torch.randn(B, cin, generator=g)], 2)
+    conv = nn.Conv2d(cin, cout, 1)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) * (2.0 / cin) ** 0.5)
+        conv.bias.copy_(torch.randn(cout, generator=g))
+        xn = x.double()
+        if norm:
+            xn = xn * coef[:, :, 0, None, None].double() + coef[:, :, 1, None, None].double()
+            if relu:
+                xn = xn.clamp(min=0)
+        ref = F.conv2d(xn, conv.weight.double(), conv.bias.double())
+    wide_in = torch.full((B, H, W, cin + pad), float("nan"))
+    wide_in[..., pad:] = _nhwc(x)
+    xd = wide_in.cuda()
+    wd = networks._Plan.split_bf16_interleaved(conv.weight.detach().reshape(cout, cin).cuda(), cin)
+    bd, cd = conv.bias.detach().cuda(), coef.contiguous().cuda()
+    out = torch.full((B, H, W, cout + pad), float("nan"), device="cuda")
+    G, tile = cout // 16, 256
+    nchunks = (H * W + tile - 1) // tile + 1
+    st = torch.zeros(B * nchunks * G * 2, dtype=torch.float64, device="cuda")
+    op = networks.XlOp()
+    op.type = networks.XL_OP_CONV
+    op.B, op.Hi, op.Wi, op.Cin, op.Ho, op.Wo, op.Cout = B, H, W, cin, H, W, cout
+    op.ksize, op.stride, op.ld_in, op.ld_out = 1, 1, cin + pad, cout + pad
+    op.flags = networks.CONV_SPLIT_BF16 | networks.CONV_SPLIT_IL
+    if norm:
+        op.flags |= networks.CONV_NORM_IN | (networks.CONV_NORM_RELU if relu else 0)
+        op.aux2 = cd.data_ptr()
+    op.in_, op.w, op.bias, op.out = xd.data_ptr() + 4 * pad, wd.data_ptr(), bd.data_ptr(), out.data_ptr()
+    if stats:
+        op.stats, op.groups, op.nchunks = st.data_ptr(), G, nchunks
+    _run([op, op])                                        # twice: the second launch must overwrite, not accumulate
+    got = out.cpu()
+    if pad:
+        assert torch.isnan(got[..., cout:]).all()
+    got = got[..., :cout].permute(0, 3, 1, 2).double()
+    _close(got, ref)
+    if stats:
+        sums = st.cpu().view(B, nchunks, G, 2).sum(1)
+        grp = got.reshape(B, G, -1)
+        assert torch.allclose(sums[:, :, 0], grp.sum(2), rtol=1e-5, atol=1e-3)
+        assert torch.allclose(sums[:, :, 1], (grp * grp).sum(2), rtol=1e-5)
+
+
 def test_conv_reads_and_writes_channel_slices():
     """ld/offset addressing used by the concat-free MLR fusion."""
     g = torch.Generator().manual_seed(3)

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--z", type=int, default=1, help="batched GEMMs per launch (16 = the Winograd F(2x2,3x3) GEMMs)")
     ap.add_argument("--stats", action="store_true", help="fused GroupNorm statistics epilogue (32 groups), as the inference plans run 1x1 layers")
     ap.add_argument("--norm", action="store_true", help="normalise-on-load form of the 1x1 conv (XL_CONV_NORM_IN + ReLU)")
+    ap.add_argument("--split", action="store_true", help="1x1 layer on the bf16 pipe (split_conv1x1_kernel)")
     a = ap.parse_args()
     L = networks._bind()
     torch.manual_seed(0)
@@ -43,8 +44,12 @@ def main():
     if a.norm:
         coef = torch.stack([torch.rand(a.B, a.cin, device="cuda") + 0.5, torch.randn(a.B, a.cin, device="cuda")], 2).contiguous()
         op.flags, op.aux2 = networks.CONV_NORM_IN | networks.CONV_NORM_RELU, coef.data_ptr()
+    if a.split:
+        wsp = networks._Plan.split_bf16_interleaved(w.reshape(a.cout, a.cin), a.cin)
+        op.w = wsp.data_ptr()
+        op.flags |= networks.CONV_SPLIT_BF16 | networks.CONV_SPLIT_IL
     if a.stats:
-        nch = (Ho * Wo + 127) // 128 + 1
+        nch = (Ho * Wo + (255 if a.split else 127)) // (256 if a.split else 128) + 1
         st_buf = torch.zeros(a.B * nch * 32 * 2, dtype=torch.float64, device="cuda")
         op.stats, op.groups, op.nchunks = st_buf.data_ptr(), 32, nch
     arr = (networks.XlOp * 1)(op)
