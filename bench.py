@@ -100,11 +100,10 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=None,
-                    help="images per step per GPU.  44: the batched F(6x6,3x3) GEMM launch has 52 x 4 x 64 = 13312 "
-                         "workgroups = exactly 26 rounds of the 512 resident ones, and the fixed per-launch costs of "
-                         "the ~100 kernels of a forward are amortised over more frames (24: 997, 44: 1006 images/s); "
-                         "47 is the per-launch maximum at 480x720 (32-bit byte offsets).  Default 44; 24 with --mlr 3 "
-                         "(the Winograd buffers of the 1536-channel fusion layer stay below 2 GiB)")
+                    help="images per step per GPU.  The two persistent GEMM kernels walk 256 x 256 tiles with one workgroup "
+                         "per CU, so what matters is how evenly the tiles divide over 256 CUs: 47 frames = 3584 tiles (14.0 "
+                         "rounds) for the 64 batched Winograd GEMMs of a 512-channel layer and 1984 tiles (7.75 rounds) for a "
+                         "1x1 layer (44: 13.0 / 7.26 rounds, 1333 vs 1359 images/s measured).  Default 47; 24 with --mlr 3")
     ap.add_argument("--hyps", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cnn-streams", type=int, default=1,
@@ -119,7 +118,7 @@ def main():
                          "eager, configs[4] 3-encoder network) that N=1 runs report outside the timed region")
     args = ap.parse_args()
     if args.batch is None:
-        args.batch = 24 if args.mlr else 44
+        args.batch = 24 if args.mlr else 47
 
     import torch
     from crossloc_amd import networks, synth, evaluation
@@ -190,7 +189,7 @@ def main():
     if os.environ.get("XL_BENCH_VERBOSE"):
         L.xl_cnn_prof_filter(-1, 0)
     else:
-        L.xl_cnn_prof_filter(1, 2 if has_wino else 0)
+        L.xl_cnn_prof_filter(1, 0)              # every conv launch (30 per forward: the Winograd GEMMs and the 1x1 layers)
     L.xl_cnn_prof_begin(n_ops * K * n_sub)
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True),
@@ -233,9 +232,14 @@ def main():
     ms = (ctypes.c_float * cap)()
     nrec = L.xl_cnn_prof_end(idx, typ, ms, cap)
     conv_ms, by_type, wino, wino_tiles = [], {}, 0, 0
+    pw_ms, pw_split = [], False                                          # the 1x1 512 -> 512 layers
     for i in range(max(nrec, 0)):
         op = plan.op_array[idx[i]]
         by_type[typ[i]] = by_type.get(typ[i], 0.0) + ms[i]
+        if (typ[i] == networks.XL_OP_CONV and op.Cin == 512 and op.Cout == 512 and op.ksize == 1 and op.nchunks2 <= 1
+                and op.Hi == 60):
+            pw_ms.append(ms[i])
+            pw_split = bool(op.flags & networks.CONV_SPLIT_BF16)
         if typ[i] == networks.XL_OP_CONV and op.Cin == 512 and op.Cout == 512 and op.stride == 1 and (
                 (op.ksize == 3 and op.nchunks2 <= 1) or (op.ksize == 1 and op.nchunks2 > 1)):
             conv_ms.append(ms[i])
@@ -304,9 +308,10 @@ def main():
             "metric": "images/sec localized (480x720, 256 hyps)", "value": round(value, 2), "unit": "images/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(elapsed / K * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": ("f32 (3x3 stride-1 layers: Winograd GEMMs with every fp32 operand as an exact sum of three bf16 terms, six "
-                      "bf16-MFMA passes, fp32 accumulation - fp32-class accuracy, all parity tests at the fp32 tolerances; "
-                      "everything else on fp32 MFMA)" if split_gemm else "f32"),
+            "dtype": ("f32 (the GEMMs of the 3x3 stride-1 layers - Winograd F(6x6,3x3) - and of the 1x1 layers run with every fp32 "
+                      "operand as an exact sum of three bf16 terms: six bf16-MFMA passes, fp32 accumulation - fp32-class "
+                      "accuracy, all parity tests at the fp32 tolerances; everything else fp32, the remaining convolutions on "
+                      "fp32 MFMA; XL_GEMM_SPLIT_BF16=0 runs every GEMM on fp32 MFMA)" if split_gemm else "f32"),
             "data": "synthetic",
             "config": {"workload": ("BASELINE configs[4]: CrossLoc 3-encoder (coord+depth+normal) fusion network forward"
                                     if args.mlr else
@@ -332,6 +337,13 @@ def main():
                        # layers fewer multiplies are executed, so this "algorithmic" rate may exceed the MFMA peak
                        "cnn_fwd_algorithmic_tflops": round((FWD_GFLOP_PER_IMAGE_3ENC if args.mlr else FWD_GFLOP_PER_IMAGE) * B / cnn_ms, 2),
                        "conv3x3_s1_algorithm": ("winograd " + WINO_NAME.get(wino, "?")) if wino else "direct implicit GEMM",
+                       # the second GEMM family of the forward: ten 1x1 512 -> 512 layers per frame batch
+                       "conv1x1_512": {"kernel": "split_conv1x1_kernel (bf16 pipe, activations split on load)" if pw_split
+                                                 else "igemm_conv_kernel<1,1,128,512,...> (fp32 MFMA)",
+                                       "avg_launch_ms": round(float(np.mean(pw_ms)), 4) if pw_ms else None,
+                                       "launches_timed": len(pw_ms),
+                                       "fp32_equivalent_tflops": round(2.0 * Bl * 5400 * 512 * 512 / (float(np.mean(pw_ms)) * 1e-3) / 1e12, 2)
+                                       if pw_ms else None},
                        "median_err_cm": round(med_t_cm, 3), "median_err_deg": round(med_r_deg, 5)},
             "roofline": {"bound": "mfma", "kernel": kernel_name,
                          "achieved": round(conv_tflops * mfma_passes, 2), "peak": peak_tflops, "unit": "TFLOP/s",

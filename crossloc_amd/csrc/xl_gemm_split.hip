@@ -415,8 +415,12 @@ void split_gemm_persist_kernel(SplitArgs2 a)
 //     loads 8 channels of one row (2 x dwordx4, two K-steps ahead of the multiplies),
 //     normalises, splits them into three bf16 terms (v_cvt_pk_bf16_f32; residuals are exact in fp32) and
 //     writes 3 x 16 bytes into the activation stage of the NEXT K-step (2 stages, same rotated 96-byte rows),
-// between the third and fourth term group of the current step.  60-odd VALU instructions per wave and K-step under 48
-// MFMAs of 8 passes each.
+// behind the fourth term group of the current step.  60-odd VALU instructions per wave and K-step under 48 MFMAs of 8
+// passes each.  Measured (512 -> 512, 44 frames of 60 x 90, normalise-on-load + statistics): 0.67-0.69 ms stand-alone,
+// 0.62 ms inside the network = 200 TFLOP/s fp32-equivalent; the fp32-MFMA kernel takes 1.0-1.15 ms.  With pieces removed
+// (same launch): no conversion arithmetic 0.69 (the VALU work is free), no activation loads 0.58, no LDS writes 0.60,
+// neither 0.54, nothing but the weight stream and the MFMAs 0.52; no statistics epilogue -0.02.  Giving the loads two
+// K-steps instead of one (second register set) moved 0.69 to 0.68: what the activation path costs is not latency.
 // LDS (157 KB): weights 3 x 24 KB | activations 2 x 24 KB | 8 KB | fp64 partials 8 KB | coefficient tables 2 x 8 KB |
 // bias 4 KB.  The statistics epilogue stages its per-lane sums in activation stage 1 + the 8 KB behind it: C / 16 is even,
 // so when a tile ends stage 1 has just been multiplied and stage 0 holds the first step of the next tile.
@@ -451,7 +455,7 @@ __device__ __forceinline__ void split_pair(float x, float y, unsigned &w1, unsig
     w3 = pk_bf16(rx - lo_f(w2), ry - hi_f(w2));
 }
 
-template <bool NORM, int DBG = 0>
+template <bool NORM>
 __global__ __launch_bounds__(512)
 void split_conv1x1_kernel(SplitConvArgs a)
 {
@@ -513,10 +517,6 @@ void split_conv1x1_kernel(SplitConvArgs a)
     u32x4 rA[2][2];                                                    // [K-step parity][half of my 8 channels]
     auto load_a = [&](auto parTag) {
         constexpr int P = decltype(parTag)::value;
-        if constexpr (DBG & 2) {                                      // (diagnostics: opaque values instead of the loads)
-            asm volatile("" : "=v"(rA[P][0]), "=v"(rA[P][1]));
-            return;
-        }
         rA[P][0] = __builtin_amdgcn_raw_buffer_load_b128(srdIn, (int)gA, dK * 64, 0);
         rA[P][1] = __builtin_amdgcn_raw_buffer_load_b128(srdIn, (int)(gA + 16u), dK * 64, 0);
     };
@@ -558,17 +558,8 @@ void split_conv1x1_kernel(SplitConvArgs a)
                 x[2] = fmaxf(fmaf(x[2], c1[0], c1[1]), a.normLo);
                 x[3] = fmaxf(fmaf(x[3], c1[2], c1[3]), a.normLo);
             }
-            if constexpr (DBG & 1) {
-                for (int p = 0; p < 3; ++p) { w[p][2 * h] = rA[P][h][0] + p; w[p][2 * h + 1] = rA[P][h][2]; }
-                continue;
-            }
             split_pair(x[0], x[1], w[0][2 * h], w[1][2 * h], w[2][2 * h]);
             split_pair(x[2], x[3], w[0][2 * h + 1], w[1][2 * h + 1], w[2][2 * h + 1]);
-        }
-        if constexpr (DBG & 4) {                                      // (diagnostics: everything but the LDS writes)
-#pragma unroll
-            for (int p = 0; p < 3; ++p) asm volatile("" :: "v"(w[p][0]), "v"(w[p][1]), "v"(w[p][2]), "v"(w[p][3]));
-            return;
         }
 #pragma unroll
         for (int p = 0; p < 3; ++p)
@@ -603,7 +594,6 @@ void split_conv1x1_kernel(SplitConvArgs a)
     }
     const unsigned frA = (unsigned)(kCvA + (wm * 128 + fr) * kIUnit), frB = (unsigned)((wn * 64 + fr) * kIUnit);
     bf16x8 fa[3][4], fb[3][2];
-    bf16x8 faN[4], fbN[2];
     f32x16 acc[4][2];
     auto ldA = [&](int stage, int p, int i) { return *reinterpret_cast<const bf16x8 *>(dsm + stage * kIOperand + frA + i * 32 * kIUnit + slotOff[p]); };
     auto ldB = [&](int stage, int p, int j) { return *reinterpret_cast<const bf16x8 *>(dsm + stage * kIOperand + frB + j * 32 * kIUnit + slotOff[p]); };
@@ -649,10 +639,6 @@ void split_conv1x1_kernel(SplitConvArgs a)
     advance_dma();
     __builtin_amdgcn_s_waitcnt(0x0070 | 5);                           // my writes of step 0; stage 0 of the ring landed before
     __builtin_amdgcn_s_barrier();
-#pragma unroll
-    for (int j = 0; j < 2; ++j) fbN[j] = ldB(0, 2, j);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) faN[i] = ldA(0, 0, i);
     int sc = 0, sd = 2;
     {
         int m0, n0;
@@ -667,9 +653,9 @@ void split_conv1x1_kernel(SplitConvArgs a)
         const int next = sc == 2 ? 0 : sc + 1;
         load_a(parTag);                                               // step kk + 2: two steps until its conversion
 #pragma unroll
-        for (int j = 0; j < 2; ++j) fb[2][j] = fbN[j];
+        for (int j = 0; j < 2; ++j) fb[2][j] = ldB(sc, 2, j);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) fa[0][i] = faN[i];
+        for (int i = 0; i < 4; ++i) fa[0][i] = ldA(sa, 0, i);
 #pragma unroll
         for (int j = 0; j < 2; ++j) fb[1][j] = ldB(sc, 1, j);
 #pragma unroll
@@ -680,22 +666,36 @@ void split_conv1x1_kernel(SplitConvArgs a)
         for (int i = 0; i < 4; ++i) fa[2][i] = ldA(sa, 2, i);
         mma_term(2, 0); dma_instr(0, sd);
         mma_term(1, 1); dma_instr(1, sd);
-        mma_term(0, 2);
-        mma_term(1, 0);
-        convert(std::integral_constant<int, sa ^ 1>{});           // step kk + 1 (the compiler counts vmcnt for rA)
-        advance_conv();
-        mma_term(0, 1);
         __builtin_amdgcn_sched_barrier(0);
+        mma_term(0, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        // terms 4 and 5 with the conversion of step kk + 1 threaded through them (the fragments of the terms before are dead
+        // by now: the registers the conversion needs are free): one MFMA (8 passes, 32 cycles of the pipe) covers the issue
+        // of 6 VALU instructions of the same wave.  As a block of its own the conversion cost the wave 800-1400 ticks per
+        // K-step in which it multiplied nothing (clock64 around the phases), and for most of that time the other wave of
+        // the SIMD was converting too.  The LDS writes go out 4 MFMAs before the barrier.
+        mma_term(1, 0);
+        convert(std::integral_constant<int, sa ^ 1>{});           // (the compiler counts vmcnt for rA)
+        mma_term(0, 1);
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            if constexpr (NORM) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // coefficient reads of 4 channels
+#pragma unroll
+            for (int g = 0; g < 6; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+            }
+        }
+        __builtin_amdgcn_sched_group_barrier(0x200, 3, 0);                          // the three LDS writes
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        advance_conv();
         // the weights of step kk + 1 have landed: younger are 2 DMAs and 2 loads of step kk + 2 - and, in the first
         // step of a tile, the 32 stores of the tile before (vmcnt(36)); lgkmcnt(0): my activation writes are done
         if constexpr (decltype(firstTag)::value) __builtin_amdgcn_s_waitcnt(0x8070 | 4);
         else __builtin_amdgcn_s_waitcnt(0x0070 | 4);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) fbN[j] = ldB(next, 2, j);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) faN[i] = ldA(sa ^ 1, 0, i);
         mma_term(0, 0); dma_instr(2, sd);
         advance_dma();
         sc = next;
@@ -708,7 +708,7 @@ void split_conv1x1_kernel(SplitConvArgs a)
         int m0, n0;
         tile_at(ti, m0, n0);
         u32x4 tab;
-        if (!(DBG & 8) && a.stats != nullptr) {
+        if (a.stats != nullptr) {
             // GroupNorm partial sums of the output; a tile touches at most two images (HW >= 256): slot 0 = rows before
             // `split`, slot 1 = the rest.  Fixed order: per lane fp32 over its 4 rows x 8 channels of a group; fp64 over
             // the 128 lanes holding the group (16 parts of 8 lanes, then the parts); one writer per (image, tile, group).
@@ -851,15 +851,6 @@ static int xl_run_split_conv1x1(const xl_op &op, hipStream_t st)
     const int nwg = a.nbm * a.nbn;
     int grid = 256;
     if (grid > ((nwg + 7) & ~7)) grid = (nwg + 7) & ~7;
-    static const int dbg = getenv("XL_SPLIT1X1_DBG") ? atoi(getenv("XL_SPLIT1X1_DBG")) : 0;
-    if (dbg) {
-        auto k = dbg == 1 ? split_conv1x1_kernel<true, 1> : dbg == 2 ? split_conv1x1_kernel<true, 2> : dbg == 3 ? split_conv1x1_kernel<true, 3> :
-                 dbg == 4 ? split_conv1x1_kernel<true, 4> : dbg == 5 ? split_conv1x1_kernel<true, 5> : dbg == 6 ? split_conv1x1_kernel<true, 6> :
-                 dbg == 7 ? split_conv1x1_kernel<true, 7> : split_conv1x1_kernel<true, 8>;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, st, a);
-        return XL_OK;
-    }
     if (norm) hipLaunchKernelGGL(split_conv1x1_kernel<true>, dim3(grid), dim3(512), lds, st, a);
     else hipLaunchKernelGGL(split_conv1x1_kernel<false>, dim3(grid), dim3(512), lds, st, a);
     return XL_OK;

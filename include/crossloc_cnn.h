@@ -70,7 +70,13 @@ enum {
  * matrix pipe with fp32 accumulation; XL_OP_WINO_IN (ksize 6) with the flag writes V in that form. */
 #define XL_CONV_SPLIT_BF16 64
 #define XL_CONV_SPLIT_IL 512   /* with XL_CONV_SPLIT_BF16: the planes of a 16-channel chunk are interleaved,
-                                  operand layout [Z][rows][C/16][3][16] bf16 (csrc/xl_gemm_split.hip, 256 x 256 tiles) */
+                                  operand layout [Z][rows][C/16][3][16] bf16 (csrc/xl_gemm_split.hip, 256 x 256 tiles;
+                                  Cout a multiple of 256).
+                                  nchunks2 <= 1 with both flags: a plain 1x1 stride-1 convolution on the same pipe - only
+                                  `w` is pre-split ([Cout][Cin/16][3][16] bf16), `in` / `out` are fp32 NHWC (ld_in, ld_out),
+                                  `bias` is added, XL_CONV_NORM_IN applies (Cin <= 512) and `stats` receives the GroupNorm
+                                  partial sums of the output per 256-row tile (nchunks >= ceil(Ho*Wo / 256) + 1, 16 channels
+                                  per group, Ho*Wo >= 256); XL_OP_GN_FINAL / XL_OP_GN_APPLY take reserved_i = 256 for them */
 /* xl_op.flags for XL_OP_CONV */
 #define XL_CONV_DGRAD 1        /* data gradient: `in` is dY (Hi x Wi x Cin = forward output), result is dX; weights
                                   packed with xl_cnn_pack_conv_weight_dgrad; `stride` is the forward stride */
