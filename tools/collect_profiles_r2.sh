@@ -1,21 +1,35 @@
-# Round-2 evidence (run with gpurun from the repo root): the bench line, rocprofv3 kernel statistics of the same command,
-# and PMC passes (separate --pmc passes, kernel trace only - no sys/hip/hsa tracing) over a short bench run.
+# Round-2 evidence (run with gpurun from the repo root).  Order matters: the PMC passes come first, their HBM-side bytes
+# go into profiles/traffic.json (keyed by the hash of the kernel sources), and the bench line written afterwards reads
+# `roofline.traffic` from that record.  Counter passes are separate --pmc passes with kernel tracing only.
 set -x
 cd $GRAFT_REPO_ROOT
 OUT=$GRAFT_REPO_ROOT/gpurun_out/r2
-mkdir -p $OUT
-python bench.py > $OUT/bench.json 2> $OUT/bench.err
-tail -c 400 $OUT/bench.json
+rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python $GRAFT_REPO_ROOT/bench.py --no-secondary --no-cpu-baseline > $OUT/kt.log 2>&1
 rocprofv3 -i $GRAFT_REPO_ROOT/tools/pmc_r2.txt --kernel-trace --output-format csv -d $OUT/pmc -- python $GRAFT_REPO_ROOT/bench.py --no-secondary --no-cpu-baseline --steps 2 --warmup 1 > $OUT/pmc.log 2>&1
 cd $GRAFT_REPO_ROOT
 python tools/pmc_summary.py $OUT/pmc $OUT/pmc_summary.csv
 python tools/pmc_derive.py $OUT/pmc_summary.csv $OUT/pmc_derived.csv > /dev/null
-FRAMES=$(python -c "import json;print(json.load(open('$OUT/bench.json'))['config']['batch_per_gpu'])")
-cp profiles/traffic.json $OUT/traffic_before.json 2>/dev/null
+FRAMES=$(grep -o '"batch_per_gpu": [0-9]*' $OUT/pmc.log | head -1 | grep -o '[0-9]*$')
 python tools/traffic_record.py $OUT/pmc_derived.csv $FRAMES "profiles/r2_pmc_summary.csv (rocprofv3 -i tools/pmc_r2.txt over bench.py --steps 2)" > /dev/null
 cp profiles/traffic.json $OUT/traffic.json
-find $OUT -name "*kernel_stats.csv" | head -3
-rm -rf $OUT/pmc/pmc_*/*/*kernel_trace.csv $OUT/pmc/pmc_*/*/*counter_collection.csv   # keep the merged summary only (size)
+rm -rf $OUT/pmc                                                    # keep the merged summary only (size)
+python bench.py > $OUT/bench.json 2> $OUT/bench.err
+tail -c 600 $OUT/bench.json
+XL_GEMM_SPLIT_BF16=0 python bench.py --no-secondary --no-cpu-baseline > $OUT/bench_fp32_mfma.json 2>/dev/null
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python $GRAFT_REPO_ROOT/bench.py --no-secondary --no-cpu-baseline > $OUT/kt.log 2>&1
+cd $GRAFT_REPO_ROOT
+python - <<PY
+import csv, glob, json
+f = glob.glob("$OUT/kt/*/*kernel_trace.csv")[0]
+d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in csv.DictReader(open(f)) if "split_gemm_persist_kernel" in r["Kernel_Name"]]
+big = [x for x in d if x > 0.7]
+json.dump({"kernel": "split_gemm_persist_kernel", "launches": len(d), "launches_of_the_512_channel_layers": len(big),
+           "avg_ms_of_the_512_channel_layers": sum(big) / max(len(big), 1), "command": "rocprofv3 --kernel-trace --stats -- python bench.py --no-secondary --no-cpu-baseline"},
+          open("$OUT/kernel_trace_dominant.json", "w"), indent=1)
+print(open("$OUT/kernel_trace_dominant.json").read())
+PY
+cp $(ls $OUT/kt/*/*kernel_stats.csv | head -1) $OUT/bench_kernel_stats.csv
+rm -rf $OUT/kt
 ls -la $OUT
