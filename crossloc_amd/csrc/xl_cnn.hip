@@ -1339,6 +1339,8 @@ void gn_final_kernel(const double *__restrict__ stats, const float *__restrict__
     int valid = nchunks;
     if (statTile > 0)          // statistics came from a conv epilogue: one entry per conv tile overlapping image n
         valid = (int)((((long long)(n + 1) * HW - 1) / statTile) - (((long long)n * HW) / statTile)) + 1;
+    else if (statTile < 0)     // ... from a conv whose tiles start at image boundaries (batch-invariant plans)
+        valid = (HW - statTile - 1) / -statTile;
     // 8 threads per group each sum a contiguous slice of the chunks, then the 8 slices are added in order
     __shared__ double sP[256 * 2];
     {
@@ -1399,6 +1401,8 @@ void gn_apply_kernel(const float *__restrict__ x, const double *__restrict__ sta
         int valid = nchunks;
         if (statTile > 0)      // statistics came from the conv epilogue: one entry per conv tile overlapping image n
             valid = (int)((((long long)(n + 1) * HW - 1) / statTile) - (((long long)n * HW) / statTile)) + 1;
+        else if (statTile < 0) // ... tiles that start at image boundaries
+            valid = (HW - statTile - 1) / -statTile;
         for (int k = 0; k < valid; ++k) { a += st[(long long)k * G * 2]; b += st[(long long)k * G * 2 + 1]; }
         const double cnt = (double)HW * (double)cpg;
         const double mean = a / cnt;

@@ -436,7 +436,8 @@ struct SplitConvArgs {
     const float *coef; float normLo;                 // NORM: [B][C][2] {scale, shift}; lower clamp (0 = ReLU, -inf = none)
     double *stats; int HW, G, nchunks, B;            // statistics of the output (stats == nullptr: none); 16 channels per group
     int M, C, N, ldIn, ldOut, nbm, nbn;
-};
+    int tpi;                                         // > 0: tiles start at image boundaries, tpi = ceil(HW / 256) per image (the
+};                                                   // grouping of the statistics is then independent of the batch); 0: dense
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -475,7 +476,17 @@ void split_conv1x1_kernel(SplitConvArgs a)
     auto tile_at = [&](int i, int &m0, int &n0) {
         const int t = runStart + local + i * nloc;
         const int mt = t / a.nbn;
-        m0 = mt * 256; n0 = (t - mt * a.nbn) * 256;
+        n0 = (t - mt * a.nbn) * 256;
+        if (a.tpi) {
+            const int n = mt / a.tpi;
+            m0 = n * a.HW + (mt - n * a.tpi) * 256;
+        } else m0 = mt * 256;
+    };
+    // rows of the tile at m0 (per-image tiles end with their image)
+    auto tile_rows = [&](int m0) {
+        int rows = a.M - m0;
+        if (a.tpi) rows = (m0 / a.HW + 1) * a.HW - m0;
+        return rows < 256 ? rows : 256;
     };
 
     constexpr unsigned OOB = 0x80000000u;
@@ -493,7 +504,7 @@ void split_conv1x1_kernel(SplitConvArgs a)
         if (i < myCount) {
             int m0, n0;
             tile_at(i, m0, n0);
-            const int rows = a.M - m0 < 256 ? a.M - m0 : 256;
+            const int rows = tile_rows(m0);
             srdIn = __builtin_amdgcn_make_buffer_rsrc((void *)(a.in + (long long)m0 * a.ldIn), 0, rows * a.ldIn * 4, 0x00020000);
             gA = (unsigned)(arow * a.ldIn * 4 + ahalf * 32);              // rows past M fall outside the descriptor
 #pragma unroll
@@ -730,7 +741,7 @@ void split_conv1x1_kernel(SplitConvArgs a)
                             t += v;
                             tt = fmaf(v, v, tt);
                         }
-                        const bool live = m0 + row < a.M, hi = row >= split;
+                        const bool hi = row >= split, live = m0 + row < a.M && !(a.tpi && hi);
                         s[0] += (live && !hi) ? t : 0.f; ss[0] += (live && !hi) ? tt : 0.f;
                         s[1] += (live && hi) ? t : 0.f;  ss[1] += (live && hi) ? tt : 0.f;
                     }
@@ -757,11 +768,12 @@ void split_conv1x1_kernel(SplitConvArgs a)
                 const int n = nLo + sl;
                 const int firstRow = sl ? split : 0;
                 const int g = (n0 >> 4) + gt;
-                if (n < a.B && m0 + firstRow < a.M && (sl == 0 || split < 256) && g < a.G) {
+                if (n < a.B && m0 + firstRow < a.M && (sl == 0 || (split < 256 && !a.tpi)) && g < a.G) {
                     const double *sC = reinterpret_cast<const double *>(dsm + kCvPart) + tid * 32;
                     double s1 = 0.0, s2 = 0.0;
                     for (int e = 0; e < 16; ++e) { s1 += sC[2 * e]; s2 += sC[2 * e + 1]; }
-                    const int k = (m0 >> 8) - (int)(((long long)n * a.HW) >> 8);       // tile index within the image
+                    const int k = a.tpi ? (m0 - n * a.HW) >> 8                            // tile index within the image
+                                        : (m0 >> 8) - (int)(((long long)n * a.HW) >> 8);
                     double *o = a.stats + (((long long)n * a.nchunks + k) * a.G + g) * 2;
                     o[0] = s1; o[1] = s2;
                 }
@@ -771,11 +783,10 @@ void split_conv1x1_kernel(SplitConvArgs a)
             tab = load_table(ti + 2);
             store_table(ti + 2, tab);
         }
-        // (every wave issues exactly 32 stores per tile - the vmcnt arithmetic of the next step counts them: rows past M
-        //  fall outside the descriptor, N is a multiple of 256)
-        const int rowsLeft = a.M - m0;
+        // (every wave issues exactly 32 stores per tile - the vmcnt arithmetic of the next step counts them: rows past the
+        //  end of the tile fall outside the descriptor, N is a multiple of 256)
         const __amdgpu_buffer_rsrc_t srdO = __builtin_amdgcn_make_buffer_rsrc((void *)(a.out + (long long)m0 * a.ldOut), 0,
-                                                                              (rowsLeft < 256 ? rowsLeft : 256) * a.ldOut * 4, 0x00020000);
+                                                                              tile_rows(m0) * a.ldOut * 4, 0x00020000);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const unsigned rowOff = (unsigned)((wm * 128 + i * 32 + fr) * a.ldOut * 4);
@@ -833,13 +844,17 @@ static int xl_run_split_conv1x1(const xl_op &op, hipStream_t st)
         return XL_ERR_ARG;
     if (norm && (!op.aux2 || op.Cin > 512 || HW < 256)) return XL_ERR_ARG;
     if (op.stats && (op.groups <= 0 || op.Cout != 16 * op.groups || HW < 256 || op.nchunks < (HW + 255) / 256 + 1)) return XL_ERR_ARG;
+    const bool perImage = op.reserved_i < 0;         // tiles start at image boundaries (reserved_i = -256)
+    if (perImage && HW < 256) return XL_ERR_ARG;
     SplitConvArgs a;
     a.in = (const float *)op.in; a.u = (const uint16_t *)op.w; a.bias = (const float *)op.bias; a.out = (float *)op.out;
     a.coef = (const float *)op.aux2;
     a.normLo = (op.flags & XL_CONV_NORM_RELU) ? 0.f : -__builtin_inff();
     a.stats = (double *)op.stats; a.HW = HW; a.G = op.groups; a.nchunks = op.nchunks; a.B = op.B;
     a.M = (int)M; a.C = op.Cin; a.N = op.Cout; a.ldIn = op.ld_in; a.ldOut = op.ld_out;
-    a.nbm = (int)((M + 255) / 256); a.nbn = (op.Cout + 255) / 256;
+    a.tpi = perImage ? (HW + 255) / 256 : 0;
+    a.nbm = perImage ? op.B * a.tpi : (int)((M + 255) / 256);
+    a.nbn = (op.Cout + 255) / 256;
     const size_t lds = kCvLds;
     static XlLdsLimit configured[2];
     int cfgDev;

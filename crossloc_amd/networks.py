@@ -415,7 +415,9 @@ class _Plan:
         if split:
             op.flags |= CONV_SPLIT_BF16 | CONV_SPLIT_IL
             op.w = self.pack_conv_1x1_split(conv).data_ptr()
-            op.reserved_i = 256                       # rows per tile (the statistics epilogue writes one entry per tile)
+            # rows per tile (the statistics epilogue writes one entry per tile); negative: tiles start at image boundaries,
+            # so the grouping of the partial sums does not depend on where a frame sits in the batch (batch-invariant plans)
+            op.reserved_i = -256 if self.separate_stats else 256
         if norm_in is not None:                       # the producer's deferred GroupNorm apply, folded into the operand load
             op.flags |= CONV_NORM_IN | (CONV_NORM_RELU if norm_in.flags & GN_RELU_IN else 0)
             self.deferred_gn_consumers = getattr(self, "deferred_gn_consumers", []) + [len(self.ops)]
@@ -625,7 +627,7 @@ class _Plan:
         bn = 128 if conv.out_channels % 128 == 0 else 64
         # a conv tile's columns cover whole groups, and the statistics epilogue sums 2- or 4-channel pieces
         whole_groups = bn % cpg == 0 and (cpg == 2 or cpg % 4 == 0)
-        if not self.train and y[1] * y[2] >= 128 and whole_groups and not self.separate_stats:
+        if not self.train and y[1] * y[2] >= 128 and whole_groups and (not self.separate_stats or (split and cpg == 16)):
             # inference: the conv epilogue produces the GroupNorm statistics, the separate stats pass is dropped
             return self.gn_fused(y, norm, flags, aux, len(self.ops) - 1,
                                  defer=defer and flags == GN_RELU_IN and aux is None
@@ -656,8 +658,8 @@ class _Plan:
         t, H, W, C, ld, off = act
         G, HW = norm.num_groups, H * W
         cop = self.ops[conv_index]
-        tile = cop.reserved_i if cop.reserved_i in (64, 256) else 128
-        nchunks = (HW + tile - 1) // tile + 1
+        tile = cop.reserved_i if cop.reserved_i in (64, 256, -256) else 128
+        nchunks = (HW + abs(tile) - 1) // abs(tile) + 1
         self.max_stats = max(self.max_stats, self.B * nchunks * G * 2)
         cop.groups, cop.nchunks = G, nchunks
         ap = XlOp()

@@ -111,14 +111,16 @@ def test_conv1x1_normalise_on_load_with_statistics(cin, cout, B, H, W, relu):
     assert torch.allclose(st[:, :, 1], (grp * grp).sum(2), rtol=1e-5)
 
 
-@pytest.mark.parametrize("cin,cout,B,H,W,norm,relu,stats,pad", [
-    (512, 512, 3, 24, 37, True, True, True, 0),        # 888 pixels per image: tiles straddle images, last tile ragged
-    (512, 512, 2, 60, 90, True, False, True, 0),
-    (256, 512, 3, 20, 31, False, False, True, 0),      # the res2 skip layer's shape
-    (512, 512, 5, 16, 16, False, False, False, 32),    # exactly one tile per image; operands inside wider tensors
-    (512, 256, 2, 33, 20, True, True, False, 64),
-    (64, 1024, 1, 40, 52, False, False, False, 0)])
-def test_conv1x1_on_the_split_bf16_pipe(cin, cout, B, H, W, norm, relu, stats, pad):
+@pytest.mark.parametrize("cin,cout,B,H,W,norm,relu,stats,pad,per_image", [
+    (512, 512, 3, 24, 37, True, True, True, 0, False),     # 888 pixels per image: tiles straddle images, last tile ragged
+    (512, 512, 3, 24, 37, True, True, True, 0, True),      # ... tiles that start at image boundaries (batch-invariant plans)
+    (512, 512, 2, 60, 90, True, False, True, 0, False),
+    (512, 512, 2, 60, 90, False, False, True, 0, True),
+    (256, 512, 3, 20, 31, False, False, True, 0, False),   # the res2 skip layer's shape
+    (512, 512, 5, 16, 16, False, False, False, 32, False), # exactly one tile per image; operands inside wider tensors
+    (512, 256, 2, 33, 20, True, True, False, 64, True),
+    (64, 1024, 1, 40, 52, False, False, False, 0, False)])
+def test_conv1x1_on_the_split_bf16_pipe(cin, cout, B, H, W, norm, relu, stats, pad, per_image):
     """XL_CONV_SPLIT_BF16 | XL_CONV_SPLIT_IL without batching: a 1x1 convolution whose weights were split into three bf16
     planes on the host and whose fp32 activations are normalised (optionally) and split by the kernel - same tolerance as
     the fp32-MFMA kernel, plus the GroupNorm statistics of the output from 256-row tiles."""
@@ -155,6 +157,8 @@ def test_conv1x1_on_the_split_bf16_pipe(cin, cout, B, H, W, norm, relu, stats, p
     op.in_, op.w, op.bias, op.out = xd.data_ptr() + 4 * pad, wd.data_ptr(), bd.data_ptr(), out.data_ptr()
     if stats:
         op.stats, op.groups, op.nchunks = st.data_ptr(), G, nchunks
+    if per_image:
+        op.reserved_i = -256
     _run([op, op])                                        # twice: the second launch must overwrite, not accumulate
     got = out.cpu()
     if pad:
@@ -162,7 +166,10 @@ def test_conv1x1_on_the_split_bf16_pipe(cin, cout, B, H, W, norm, relu, stats, p
     got = got[..., :cout].permute(0, 3, 1, 2).double()
     _close(got, ref)
     if stats:
-        sums = st.cpu().view(B, nchunks, G, 2).sum(1)
+        sums = st.cpu().view(B, nchunks, G, 2)
+        if per_image:                                     # one entry per tile of the image's own grid, nothing beyond
+            assert (sums[:, (H * W + 255) // 256:] == 0).all()
+        sums = sums.sum(1)
         grp = got.reshape(B, G, -1)
         assert torch.allclose(sums[:, :, 0], grp.sum(2), rtol=1e-5, atol=1e-3)
         assert torch.allclose(sums[:, :, 1], (grp * grp).sum(2), rtol=1e-5)
