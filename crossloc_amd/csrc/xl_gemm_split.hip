@@ -203,8 +203,13 @@ void split_gemm_kernel(SplitArgs a)
 //     never waits for LDS data right after it.
 // Measured (512 -> 512 layer, 44 frames, 64 GEMMs): 1.05-1.11 ms stand-alone on random data = 200-211 TFLOP/s
 // fp32-equivalent (1.20-1.27 PFLOP/s on the bf16 pipe), 1.03 ms inside the network; fp32-MFMA kernel 1.69 ms.  With every
-// DMA and LDS read removed the same MFMA + barrier stream takes 0.92 ms: under this load the chip clocks near 1.5 GHz
-// (power), so the kernel sits at about 87 % of what the matrix pipe delivers at that clock.
+// DMA and LDS read removed the same MFMA + barrier stream takes 0.92 ms.  What the kernel runs into is the power limit, not
+// a schedule: PMC of the profiled (serialised) launches shows the matrix pipe 64 % busy at an average 1.94 GHz, the
+// back-to-back launches inside the network are 6 % slower again, and changes that remove stalls without removing work
+// leave the time where it is - e.g. issue priorities that fall through a barrier-to-barrier cycle (s_setprio 3 3 2 2 1 1
+// over the six term groups) make the two waves of a SIMD advance in step and cut the older waves' barrier wait from 1800
+// to 700 of a K-step's 4300 ticks (XL_SPLIT_CLK), yet 1.171 vs 1.169 ms.  busy x clock stays near 1.2 GHz-equivalent of the
+// 2.4 GHz the datasheet peak assumes; the lever left is energy per FLOP (fewer LDS reads per MFMA: 128 x 128 per wave).
 constexpr int kIUnit = 96;                              // bytes per row and K-step: 3 planes x 16 bf16
 constexpr int kIOperand = 256 * kIUnit;                 // one operand of one stage: 24 KB
 
