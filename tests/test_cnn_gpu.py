@@ -119,7 +119,10 @@ def test_conv1x1_normalise_on_load_with_statistics(cin, cout, B, H, W, relu):
     (256, 512, 3, 20, 31, False, False, True, 0, False),   # the res2 skip layer's shape
     (512, 512, 5, 16, 16, False, False, False, 32, False), # exactly one tile per image; operands inside wider tensors
     (512, 256, 2, 33, 20, True, True, False, 64, True),
-    (64, 1024, 1, 40, 52, False, False, False, 0, False)])
+    (64, 1024, 1, 40, 52, False, False, False, 0, False),
+    (512, 512, 8, 60, 90, True, True, True, 0, False),     # 338 tiles on 256 workgroups: second tiles (stores in flight)
+    (32, 512, 7, 64, 80, True, True, True, 0, False),      # two K-steps per tile: the operand stream is a tile ahead
+    (96, 256, 9, 48, 70, False, False, True, 0, True)])    # six K-steps; per-image tiles of a 3360-pixel map
 def test_conv1x1_on_the_split_bf16_pipe(cin, cout, B, H, W, norm, relu, stats, pad, per_image):
     """XL_CONV_SPLIT_BF16 | XL_CONV_SPLIT_IL without batching: a 1x1 convolution whose weights were split into three bf16
     planes on the host and whose fp32 activations are normalised (optionally) and split by the kernel - same tolerance as

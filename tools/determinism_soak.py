@@ -1,4 +1,4 @@
-"""Repeat the 44-frame inference forward and one training step N times and compare every result bitwise with the first
+"""Repeat the 47-frame inference forward and one training step N times and compare every result bitwise with the first
 run (fixed-order reductions: any difference is a race).  python tools/determinism_soak.py [N=20]"""
 import os
 import sys
@@ -14,7 +14,7 @@ mean = torch.tensor(synth.SCENE_MEAN, dtype=torch.float32)
 net = networks.TransPoseNet(mean, False, False, 2, 2, 3, 1)
 net.load_state_dict(seeded_state_dict(net, seed=2021))
 net = net.cuda().eval()
-x = torch.rand(44, 3, 480, 720, generator=torch.Generator().manual_seed(3)).cuda()
+x = torch.rand(47, 3, 480, 720, generator=torch.Generator().manual_seed(3)).cuda()
 bad = 0
 with torch.no_grad():
     ref = net(x).clone()
