@@ -31,10 +31,14 @@ if ROOT not in sys.path:
 
 
 def kernel_source_hash():
-    """sha256 (first 16 hex digits) of the conv kernel source: ties a traffic record to the code it was measured on."""
+    """sha256 (first 16 hex digits) of the sources of the GEMM / conv kernels: ties a traffic record to the code it was
+    measured on."""
     import hashlib
-    with open(os.path.join(ROOT, "crossloc_amd", "csrc", "xl_cnn.hip"), "rb") as f:
-        return hashlib.sha256(f.read()).hexdigest()[:16]
+    h = hashlib.sha256()
+    for name in ("xl_cnn.hip", "xl_gemm_split.hip", "xl_common.h"):
+        with open(os.path.join(ROOT, "crossloc_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 def lookup_traffic(form, frames):

@@ -1037,6 +1037,8 @@ __device__ __forceinline__ void bf16_split3(float a, unsigned &h1, unsigned &h2,
 
 // one tile x 2 channels per thread; DEFER as in wino4_in_kernel.  SPLIT: V is written as three bf16 planes
 // ([plane][64][tiles][C], the operand form of csrc/xl_gemm_split.hip) instead of fp32.
+// The interleaved-plane forms are held to 168 VGPRs = three waves per SIMD (the deferred one would take 178 and runs 20 %
+// slower at two waves: 413 vs 346 us per 512-channel launch; at 168 it keeps 5 values in scratch and takes 364).
 template <int DEFER, int SPLIT = 0>
 __global__ __launch_bounds__(256, (SPLIT == 2 ? 3 : 1))
 void wino6_in_kernel(const float *__restrict__ in, float *__restrict__ V, int B, int H, int W, int C, int ldIn, int Th, int Tw,

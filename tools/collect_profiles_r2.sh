@@ -23,10 +23,9 @@ cd $GRAFT_REPO_ROOT
 python - <<PY
 import csv, glob, json
 f = glob.glob("$OUT/kt/*/*kernel_trace.csv")[0]
-d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in csv.DictReader(open(f)) if "split_gemm_persist_kernel" in r["Kernel_Name"]]
-big = [x for x in d if x > 0.7]
-json.dump({"kernel": "split_gemm_persist_kernel", "launches": len(d), "launches_of_the_512_channel_layers": len(big),
-           "avg_ms_of_the_512_channel_layers": sum(big) / max(len(big), 1), "command": "rocprofv3 --kernel-trace --stats -- python bench.py --no-secondary --no-cpu-baseline"},
+d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in csv.DictReader(open(f)) if "split_gemm_persist_kernel<512>" in r["Kernel_Name"].replace(" ", "")]
+big = d
+json.dump({"kernel": "split_gemm_persist_kernel<512>", "launches": len(d), "avg_ms": sum(big) / max(len(big), 1), "command": "rocprofv3 --kernel-trace --stats -- python bench.py --no-secondary --no-cpu-baseline"},
           open("$OUT/kernel_trace_dominant.json", "w"), indent=1)
 print(open("$OUT/kernel_trace_dominant.json").read())
 PY

@@ -31,8 +31,8 @@ def main():
         for r in rows:
             if r["kernel"] == kname and int(r["grid_size"]) == grid:
                 recs.append(record(form, kname, r))
-    # split-bf16 Winograd GEMMs (persistent kernel: grid = CU count): the 512 -> 512 layers are the longest duration class
-    cand = [r for r in rows if r["kernel"].startswith("split_gemm_persist_kernel@")]
+    # split-bf16 Winograd GEMMs (persistent kernel: grid = CU count): the 512-channel layers have their own instantiation
+    cand = [r for r in rows if r["kernel"].startswith("split_gemm_persist_kernel<512>")]
     if cand:
         r = max(cand, key=lambda r: float(r["profiled_us"]))
         recs.append(record("split64", r["kernel"], r))
