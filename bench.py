@@ -296,7 +296,7 @@ def main():
         value = total_imgs / elapsed
         traffic, traffic_source = lookup_traffic(("split%d" if mfma_passes == 6 else "wino%d") % wino if wino else "direct", Bl)
         if mfma_passes == 6:
-            kernel_name = ("split_gemm_persist_kernel (256x256 tiles, interleaved 3xbf16 operand planes)" if split_il else
+            kernel_name = ("split_gemm_persist_kernel<512> (256x256 tiles, interleaved 3xbf16 operand planes)" if split_il else
                            "split_gemm_kernel (128x128 tiles, separate bf16 planes)") + \
                           " batched x%d: the Winograd %s GEMMs of a 3x3 512->512 layer @60x90 x%d images per launch, every fp32 " \
                           "operand as an exact sum of three bf16 terms, six v_mfma_f32_32x32x16_bf16 passes, fp32 accumulation" % (
