@@ -206,6 +206,168 @@ void conv1_fused_kernel(const float *__restrict__ in, const float *__restrict__ 
     }
 }
 
+// ---------------------------------------------------------------------------------------------- conv1 on the matrix pipe
+//
+// The same two evaluations (statistics only / normalise + ReLU + write) with the multiplies on the bf16 matrix pipe instead
+// of 432 packed VALU FMAs per pixel: every fp32 value - image and weights - is an exact sum of three bf16 terms, six term
+// pairs per product, fp32 accumulation (as csrc/xl_gemm_split.hip).  A workgroup owns 16 x 64 output pixels: the 18 x 66
+// halo of the image is split ONCE while it is staged into LDS (each value is used by nine patches), one 8-byte word
+// {R, G, B, 0} per pixel and plane.  The K dimension is laid out so that a K-step of v_mfma_f32_32x32x16_bf16 is one row of
+// the 3 x 3 window: 16 slots = 4 pixels (x-1, x, x+1 and a fourth with zero weights) x {R, G, B, 0}; a lane's 8 values are
+// two neighbouring pixel words = one ds_read2_b64, no gather.  32 pixels of a row x 32 channels = 3 K-steps x 6 term
+// pairs = 18 MFMAs; the weight fragments (9 x 4 registers) are built once per wave.
+typedef __bf16 c1_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int c1_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int c1_u32x2 __attribute__((ext_vector_type(2)));
+constexpr int kC1TH = 16, kC1TW = 64, kC1HH = kC1TH + 2, kC1HW = kC1TW + 4;   // 66 halo columns + 2 of zeros (slot dx = 3 of the last pixels)
+constexpr int kC1Halo = 3 * kC1HH * kC1HW * 8;                 // bytes: [plane][row][col] of 8-byte pixel words
+
+__device__ __forceinline__ unsigned c1_bf16_rn(float x)
+{
+    unsigned u = __builtin_bit_cast(unsigned, x);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+__device__ __forceinline__ void c1_split3(float a, unsigned &h1, unsigned &h2, unsigned &h3)
+{
+    h1 = c1_bf16_rn(a);
+    const float r1 = a - __builtin_bit_cast(float, h1 << 16);
+    h2 = c1_bf16_rn(r1);
+    h3 = c1_bf16_rn(r1 - __builtin_bit_cast(float, h2 << 16));
+}
+
+template <int PASS>
+__global__ __launch_bounds__(256)
+void conv1_mfma_kernel(const float *__restrict__ in, const c1_u32x4 *__restrict__ wfrag, const float *__restrict__ bias,
+                       const float *__restrict__ coeff, float *__restrict__ out, double *__restrict__ stats,
+                       int H, int W, int tilesX, int relu)
+{
+    constexpr int CO = 32;
+    constexpr int kSm = PASS == 0 ? (kC1Halo > 256 * 32 * 4 ? kC1Halo : 256 * 32 * 4) : kC1Halo + 4 * 32 * kC1Pitch * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[kSm];
+    const int n = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int ty = blockIdx.x / tilesX, tx = blockIdx.x - ty * tilesX;
+    const int y0 = ty * kC1TH, x0 = tx * kC1TW;
+    const long long HW = (long long)H * W;
+    const float *img = in + (long long)n * 3 * HW;
+
+    // ---- halo -> LDS, split
+    c1_u32x2 *sH = reinterpret_cast<c1_u32x2 *>(smem);
+    for (int i = tid; i < kC1HH * kC1HW; i += 256) {
+        const int r = i / kC1HW, c = i - r * kC1HW;
+        const int y = y0 - 1 + r, x = x0 - 1 + c;
+        const bool inb = ((unsigned)y < (unsigned)H) & ((unsigned)x < (unsigned)W) & (c < kC1TW + 2);
+        const long long off = (long long)(inb ? y : 0) * W + (inb ? x : 0);
+        unsigned h[3][3];
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            const float v = inb ? img[ch * HW + off] : 0.f;
+            c1_split3(v, h[0][ch], h[1][ch], h[2][ch]);
+        }
+#pragma unroll
+        for (int p = 0; p < 3; ++p) sH[p * (kC1HH * kC1HW) + i] = c1_u32x2{ h[p][0] | (h[p][1] << 16), h[p][2] };
+    }
+    // ---- weight fragments: lane -> (channel lane & 31, K half lane >> 5); slot j of a K-step = (dx = j >> 2, c = j & 3),
+    // zero for c = 3 and dx = 3.  Split and packed once per plan on the host side: wfrag[plane][dy][lane], 16 bytes each.
+    const int kh = lane >> 5;
+    c1_bf16x8 wf[3][3];                                              // [plane][dy]
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) wf[p][dy] = __builtin_bit_cast(c1_bf16x8, wfrag[(p * 3 + dy) * 64 + lane]);
+    // accumulator element r of a lane: pixel lane & 31, channel 8 (r >> 2) + 4 kh + (r & 3)
+    float b16[16], sc[16], sh[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int c = 8 * (r >> 2) + 4 * kh + (r & 3);
+        b16[r] = bias[c];
+        if (PASS == 1) { sc[r] = coeff[((long long)n * CO + c) * 2]; sh[r] = coeff[((long long)n * CO + c) * 2 + 1]; }
+    }
+    float s[16], q[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s[r] = 0.f; q[r] = 0.f; }
+    __syncthreads();
+
+    const int px = lane & 31;
+#pragma unroll 1
+    for (int blk = 0; blk < 8; ++blk) {
+        const int ly = wv * 4 + (blk >> 1), lx = (blk & 1) * 32 + px;   // pixel of this lane inside the tile
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = b16[r];
+        c1_bf16x8 pf[3][3];                                          // [plane][dy]
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                const c1_u32x2 *src = sH + p * (kC1HH * kC1HW) + (ly + dy) * kC1HW + lx + 2 * kh;
+                const c1_u32x2 a = src[0], b = src[1];
+                pf[p][dy] = __builtin_bit_cast(c1_bf16x8, c1_u32x4{ a[0], a[1], b[0], b[1] });
+            }
+        constexpr int PW[6] = { 2, 1, 0, 1, 0, 0 }, PP[6] = { 0, 1, 2, 0, 1, 0 };   // smallest terms first
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[PW[t]][dy], pf[PP[t]][dy], acc, 0, 0, 0);
+        const int y = y0 + ly, xb = x0 + (blk & 1) * 32;               // first pixel of the block
+        if (PASS == 0) {
+            const bool live = (y < H) & (xb + px < W);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float a = live ? acc[r] : 0.f;
+                s[r] += a;
+                q[r] = fmaf(a, a, q[r]);
+            }
+        } else {
+            // the block is one contiguous 4 KB span of the NHWC output: transposed through a wave-private LDS area so that
+            // every store instruction writes 1 KB of consecutive addresses
+            float *row = reinterpret_cast<float *>(smem + kC1Halo) + wv * (32 * kC1Pitch);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float t = acc[4 * g + e] * sc[4 * g + e] + sh[4 * g + e];
+                    if (relu) t = fmaxf(t, 0.f);
+                    v[e] = t;
+                }
+                *reinterpret_cast<f32x4 *>(row + px * kC1Pitch + 8 * g + 4 * kh) = v;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (y < H) {
+                float *o = out + (((long long)n * H + y) * W + xb) * CO;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int qd = c * 64 + lane;                       // 16-byte piece of the span
+                    const int pp = qd >> 3, part = qd & 7;
+                    const f32x4 v = *reinterpret_cast<const f32x4 *>(row + pp * kC1Pitch + part * 4);
+                    if (xb + pp < W) *reinterpret_cast<f32x4 *>(o + (long long)qd * 4) = v;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    if (PASS == 0) {
+        // per-lane fp32 partials (8 pixels each) -> fp64 over the 128 lanes that hold a channel, fixed order
+        float *sRed = reinterpret_cast<float *>(smem);
+        __syncthreads();                                             // every wave is done with the halo
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sRed[tid * 32 + r] = s[r]; sRed[tid * 32 + 16 + r] = q[r]; }
+        __syncthreads();
+        if (tid < 64) {
+            const int c = tid & 31, half = tid >> 5;
+            const int khc = (c >> 2) & 1, r = ((c >> 3) << 2) | (c & 3);
+            double a = 0.0;
+            for (int wq = 0; wq < 4; ++wq)
+                for (int l = 0; l < 32; ++l) a += (double)sRed[(wq * 64 + khc * 32 + l) * 32 + half * 16 + r];
+            stats[(((long long)n * gridDim.x + blockIdx.x) * CO + c) * 2 + half] = a;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- igemm conv
 
 constexpr int kWaitVm0 = 0x0F70;                   // s_waitcnt vmcnt(0) (expcnt / lgkmcnt fields left at their maxima)
@@ -1869,6 +2031,21 @@ int run_op(const xl_op &op, hipStream_t st)
             if (op.stats || op.aux2) {
                 // inference form: statistics-only pass (stats, nchunks workgroups per image, reserved_i pixels/256 each)
                 // or conv + deferred GroupNorm (aux2 = {scale, shift} pairs) + ReLU (flags & XL_GN_RELU_IN)
+                if (op.Cin == 3 && op.Cout == 32 && op.ld_out == 32 && op.reserved_i == 0) {
+                    // matrix-pipe form: one workgroup per 16 x 64 output tile, nchunks = tiles per image; `w` = the weight
+                    // fragments [3 planes][3 rows of the window][64 lanes][8] bf16 (crossloc_amd/networks.py, pack_conv1_split)
+                    const int tilesX = (op.Wi + kC1TW - 1) / kC1TW, tilesY = (op.Hi + kC1TH - 1) / kC1TH;
+                    if (op.nchunks != tilesX * tilesY || (op.stats && op.groups != 32)) return XL_ERR_ARG;
+                    if (op.stats)
+                        hipLaunchKernelGGL(conv1_mfma_kernel<0>, dim3(op.nchunks, op.B), dim3(256), 0, st, (const float *)op.in,
+                                           (const c1_u32x4 *)op.w, (const float *)op.bias, (const float *)nullptr, (float *)nullptr,
+                                           (double *)op.stats, op.Hi, op.Wi, tilesX, 0);
+                    else
+                        hipLaunchKernelGGL(conv1_mfma_kernel<1>, dim3(op.nchunks, op.B), dim3(256), 0, st, (const float *)op.in,
+                                           (const c1_u32x4 *)op.w, (const float *)op.bias, (const float *)op.aux2, (float *)op.out,
+                                           (double *)nullptr, op.Hi, op.Wi, tilesX, (op.flags & XL_GN_RELU_IN) ? 1 : 0);
+                    return XL_OK;
+                }
                 if (op.Cin != 3 || op.Cout != 32 || op.ld_out != 32 || op.reserved_i < 1 ||
                     (long long)op.nchunks * op.reserved_i * 256 < (long long)op.Hi * op.Wi || (op.stats && op.groups != 32))
                     return XL_ERR_ARG;

@@ -193,6 +193,7 @@ class _Plan:
         self.ops = []
         self.packed_split = {}
         self.packed_1x1 = {}
+        self.packed_c1 = {}
         self.keep = []                      # tensors the op pointers reference
         self.free = {}                      # numel -> [tensor]
         self.packed = {}                    # (id(param), kind) -> packed weight tensor
@@ -353,6 +354,8 @@ class _Plan:
             planes.copy_(self._split_form(base, planes.shape[-3] * 16 if il else None, il))
         for planes, src in self.packed_1x1.values():
             planes.copy_(self.split_bf16_interleaved(src.reshape(src.shape[0], src.shape[1]), src.shape[1]))
+        for planes, src in self.packed_c1.values():
+            planes.copy_(self.conv1_fragments(src))
 
     def dev(self, p):
         t = p.detach().to(device=self.device, dtype=torch.float32).contiguous()
@@ -390,6 +393,27 @@ class _Plan:
             src = w.detach().to(device=self.device, dtype=torch.float32).contiguous()     # aliases the live parameter
             self.packed_1x1[key] = (self.split_bf16_interleaved(src.reshape(src.shape[0], src.shape[1]), src.shape[1]), src)
         return self.packed_1x1[key][0]
+
+    @staticmethod
+    def conv1_fragments(weight):
+        """[3 planes][3 window rows][64 lanes][8] bf16 (int16 storage): the MFMA weight fragments of conv1_mfma_kernel.  Lane =
+        32 * K-half + output channel; slot i of a lane = (dx = 2 * K-half + i // 4, c = i % 4), zero for c = 3 and dx = 3."""
+        w = weight.detach().to(torch.float32)                                    # [32][3][ky][kx]
+        f = torch.zeros(3, 2, 32, 8, dtype=torch.float32, device=w.device)       # [dy][K-half][channel][slot]
+        for kh in range(2):
+            for i in range(8):
+                dx, c = 2 * kh + i // 4, i % 4
+                if c < 3 and dx < 3:
+                    f[:, kh, :, i] = w[:, c, :, dx].t()
+        planes = _Plan.split_bf16(f.reshape(3, 64, 8))                           # [3 planes][3 dy][64][8]
+        return planes.contiguous()
+
+    def pack_conv1_split(self, conv):
+        key = id(conv.weight)
+        if key not in self.packed_c1:
+            src = conv.weight.detach().to(device=self.device, dtype=torch.float32).contiguous()   # aliases the live parameter
+            self.packed_c1[key] = (self.conv1_fragments(src), src)
+        return self.packed_c1[key][0]
 
     def conv(self, act, conv, out=None, out_ld=None, out_off=0, norm_in=None, split=False):
         t, H, W, C, ld, off = act
@@ -762,6 +786,9 @@ class _Plan:
         c1, G, ppt = enc.conv1.out_channels, enc.norm1.num_groups, 5
         nchunks = -(-(H * W) // (256 * ppt))
         w, bias = self.pack_conv(enc.conv1), self.dev(enc.conv1.bias)
+        if not os.environ.get("XL_CONV1_VALU"):       # matrix-pipe form: one workgroup per 16 x 64 output tile
+            ppt, nchunks = 0, -(-H // 16) * -(-W // 64)
+            w = self.pack_conv1_split(enc.conv1)
         gamma, beta = self.dev(enc.norm1.weight), self.dev(enc.norm1.bias)
 
         def conv1_op():

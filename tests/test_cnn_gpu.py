@@ -225,11 +225,13 @@ def test_conv1_vs_torch(cin):
     _close(out.cpu().permute(0, 3, 1, 2), ref, 1e-5)
 
 
-@pytest.mark.parametrize("B,H,W,ppt", [(2, 24, 40, 5), (3, 37, 53, 2), (1, 64, 96, 1)])
+@pytest.mark.parametrize("B,H,W,ppt", [(2, 24, 40, 5), (3, 37, 53, 2), (1, 64, 96, 1),
+                                       (2, 24, 40, 0), (3, 37, 53, 0), (1, 64, 96, 0), (2, 100, 203, 0), (1, 480, 720, 0)])
 def test_conv1_inference_form_vs_torch(B, H, W, ppt):
     """XL_OP_CONV1 with `stats` (statistics-only evaluation), GN_FINAL, XL_OP_CONV1 with aux2 (second evaluation that
     writes relu(groupnorm(conv))) against torch conv2d -> group_norm(32 groups) -> relu; 37x53 leaves a ragged last
-    workgroup."""
+    workgroup.  ppt = 0: the matrix-pipe form (conv1_mfma_kernel, exact three-term bf16 splits of image and weights), one
+    workgroup per 16 x 64 output tile; ppt > 0: the packed-VALU form."""
     g = torch.Generator().manual_seed(B * 100 + H)
     x = torch.rand(B, 3, H, W, generator=g)
     conv = nn.Conv2d(3, 32, 3, 1, 1)
@@ -240,7 +242,7 @@ def test_conv1_inference_form_vs_torch(B, H, W, ppt):
         ref = torch.relu(F.group_norm(raw, 32, gamma.double(), beta.double(), 1e-5))
     wd = conv.weight.detach().permute(2, 3, 1, 0).contiguous().cuda()
     bd, xd, gd, btd = conv.bias.detach().cuda(), x.cuda(), gamma.cuda(), beta.cuda()
-    nch = -(-(H * W) // (256 * ppt))
+    nch = -(-(H * W) // (256 * ppt)) if ppt else -(-H // 16) * -(-W // 64)
     stats = torch.full((B, nch, 32, 2), float("nan"), dtype=torch.float64, device="cuda")
     coeff = torch.full((B, 32, 2), float("nan"), device="cuda")
     out = torch.full((B, H, W, 32), float("nan"), device="cuda")
@@ -250,8 +252,9 @@ def test_conv1_inference_form_vs_torch(B, H, W, ppt):
         op.type = networks.XL_OP_CONV1
         op.B, op.Hi, op.Wi, op.Cin, op.Ho, op.Wo, op.Cout, op.ld_out = B, H, W, 3, H, W, 32, 32
         op.groups, op.nchunks, op.reserved_i = 32, nch, ppt
-        op.in_, op.w, op.bias = xd.data_ptr(), wd.data_ptr(), bd.data_ptr()
+        op.in_, op.w, op.bias = xd.data_ptr(), (wd if ppt else wfr).data_ptr(), bd.data_ptr()
         return op
+    wfr = networks._Plan.conv1_fragments(conv.weight.detach().cuda())
     a = conv1()
     a.stats = stats.data_ptr()
     f = networks.XlOp()
