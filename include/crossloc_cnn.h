@@ -25,7 +25,10 @@ enum {
     XL_OP_CONV1 = 0,     /* 3x3 s1 p1 conv, Cin in {1,3} NCHW input -> NHWC, + bias (networks.py:186-189).  Inference form
                             (Cin 3, Cout 32, 32 groups): with `stats` the op only emits the GroupNorm partial sums of its
                             output (nchunks workgroups per image x reserved_i*256 pixels each); with aux2 = {scale, shift}
-                            pairs it writes relu(conv*scale+shift) - the raw output never exists in memory */
+                            pairs it writes relu(conv*scale+shift) - the raw output never exists in memory.
+                            reserved_i = 0 selects the matrix-pipe form of the same two passes: one workgroup per 16 x 64
+                            output tile (nchunks = ceil(Hi/16) * ceil(Wi/64)), `w` = the weight fragments
+                            [3 planes][3 window rows][64 lanes][8] bf16 (networks.py, _Plan.conv1_fragments) */
     XL_OP_CONV = 1,      /* 3x3 (pad 1) or 1x1 conv, stride 1 or 2, NHWC, implicit GEMM on fp32 MFMA, + bias.
                             With stats != NULL and groups > 0 the epilogue also emits the GroupNorm partial sums of
                             its output ([B][nchunks][groups][2], one entry per 128-row tile overlapping an image;
