@@ -168,6 +168,27 @@ def test_conv1x1_on_the_split_bf16_pipe(cin, cout, B, H, W, norm, relu, stats, p
         assert torch.isnan(got[..., cout:]).all()
     got = got[..., :cout].permute(0, 3, 1, 2).double()
     _close(got, ref)
+    # fp32-class: the same layer through the fp32-MFMA kernel (operand normalised on the host, no statistics), both against
+    # the float64 result - the split path must be within a small factor of the fp32 kernel's own rounding error
+    with torch.no_grad():
+        xin = xn.float() if norm else x
+    xf = torch.zeros((B, H, W, cin + pad))
+    xf[..., pad:] = _nhwc(xin)
+    xfd = xf.cuda()
+    wsrc = conv.weight.detach().cuda().contiguous()
+    wpk = torch.empty_like(wsrc)
+    networks._check(networks._bind().xl_cnn_pack_conv_weight(wsrc.data_ptr(), wpk.data_ptr(), cout, cin, 1, None))
+    out32 = torch.full((B, H, W, cout), float("nan"), device="cuda")
+    o32 = networks.XlOp()
+    o32.type = networks.XL_OP_CONV
+    o32.B, o32.Hi, o32.Wi, o32.Cin, o32.Ho, o32.Wo, o32.Cout = B, H, W, cin, H, W, cout
+    o32.ksize, o32.stride, o32.ld_in, o32.ld_out = 1, 1, cin + pad, cout
+    o32.in_, o32.w, o32.bias, o32.out = xfd.data_ptr() + 4 * pad, wpk.data_ptr(), bd.data_ptr(), out32.data_ptr()
+    _run([o32])
+    scale = ref.abs().max().item()
+    e32 = (out32.cpu().permute(0, 3, 1, 2).double() - ref).abs().max().item() / scale
+    esp = (got - ref).abs().max().item() / scale
+    assert esp < 2e-6 and esp < 4 * e32 + 2e-7, (esp, e32)
     if stats:
         sums = st.cpu().view(B, nchunks, G, 2)
         if per_image:                                     # one entry per tile of the image's own grid, nothing beyond
