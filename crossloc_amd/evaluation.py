@@ -161,9 +161,9 @@ def gather_errors(local_vals, num_images, rank, world_size, group=None):
     D = local_vals.shape[1]
     pad = torch.full((per, D), float("nan"), dtype=local_vals.dtype, device=local_vals.device)
     pad[:local_vals.shape[0]] = local_vals
-    if world_size == 1:
+    if world_size == 1 and group is None:
         gathered = [pad]
-    else:
+    else:                                                    # (a one-rank group passed explicitly still runs the collective)
         import torch.distributed as dist
         gathered = [torch.empty_like(pad) for _ in range(world_size)]
         dist.all_gather(gathered, pad, group=group)

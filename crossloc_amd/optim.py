@@ -107,8 +107,10 @@ class Adam(torch.optim.Optimizer):
 
 
 def allreduce_gradients(params, world_size, group=None):
-    """Average `.grad` over the ranks with one flat all-reduce (NCCL=RCCL on GPUs, gloo on CPU tensors)."""
-    if world_size <= 1:
+    """Average `.grad` over the ranks with one flat all-reduce (NCCL=RCCL on GPUs, gloo on CPU tensors).  A single rank
+    returns at once unless a process group is passed explicitly (then the collective runs: a one-rank RCCL group is how
+    the path is exercised on a one-GPU box)."""
+    if world_size <= 1 and group is None:
         return
     import torch.distributed as dist
     grads = [p.grad for p in params if p.grad is not None]

@@ -133,3 +133,36 @@ def test_second_training_forward_before_backward_keeps_the_first_graph_intact():
         net(xa)
     with torch.no_grad():
         net(xa)
+
+
+def test_rccl_collectives_on_a_one_rank_group():
+    """The two data-path collectives of the N > 1 runs - the flat gradient all-reduce (optim.allreduce_gradients) and the
+    NaN-padded all-gather of per-image errors (evaluation.gather_errors) - through the `nccl` backend, which is RCCL on
+    ROCm, on device tensors.  A one-GPU box cannot host two ranks (RCCL refuses two ranks on one device), so the group has
+    one rank: what is checked is that the RCCL path runs on these tensors and leaves the values it must leave."""
+    import os
+    import socket
+    import torch.distributed as dist
+    from crossloc_amd import evaluation, optim
+    if dist.is_initialized():
+        pytest.skip("a default process group already exists in this process")
+    with socket.socket() as sck:
+        sck.bind(("127.0.0.1", 0))
+        port = sck.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        assert dist.get_backend() == "nccl"
+        g = dist.group.WORLD
+        params = [torch.nn.Parameter(torch.randn(n, device="cuda")) for n in (7, 1024, 3 * 3 * 512)]
+        for p in params:
+            p.grad = torch.randn_like(p)
+        before = [p.grad.clone() for p in params]
+        optim.allreduce_gradients(params, 1, group=g)
+        torch.cuda.synchronize()
+        assert all(torch.equal(a, p.grad) for a, p in zip(before, params))
+        vals = torch.rand(5, 2, device="cuda")
+        out = evaluation.gather_errors(vals, 5, 0, 1, group=g)
+        assert torch.equal(out, vals)
+    finally:
+        dist.destroy_process_group()
