@@ -3,18 +3,23 @@
 480x720 frames, 256 RANSAC hypotheses; median pose error in cm / deg).
 
 A step = one batch of synthetic frames through the whole path on one GPU:
-    single-task scene-coordinate CNN forward (fp32 MFMA kernels)  ->  HIP dsacstar, 256 hypotheses per image.
+    single-task scene-coordinate CNN forward  ->  HIP dsacstar, 256 hypotheses per image.
+The CNN computes in fp32: its GEMMs (Winograd F(6x6,3x3) for the 3x3 stride-1 layers, the 1x1 layers, the stride-2 stem) run on
+the bf16 matrix pipe with every fp32 operand as an exact sum of three bf16 terms (six MFMA passes, fp32 accumulation).
 No trained weights or datasets exist offline: the CNN runs seeded random weights on uniform-random images and
 the solver consumes synthetic scene-coordinate maps (ray-cast terrain, 0.5 m noise, 30 % outliers) that are
 resident in HBM before the timed region; both stages execute in full for every image of every step.
-Multi-GPU (driver: torch.distributed.run, one rank per GPU): images shard as independent batches (weak
-scaling, no data-path collective); one RCCL all-gather of the per-image errors for the median.
+Multi-GPU: images shard as independent batches (weak scaling, no data-path collective); one RCCL all-gather of the
+per-image errors for the median.  One rank per GPU under torch.distributed.run (the driver's launch line); a plain
+`python bench.py --gpus N` re-executes itself under torch.distributed.run with N ranks on 127.0.0.1.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) including
-    roofline     — the dominant kernel (3x3 512->512 implicit-GEMM conv, 78 % of forward FLOPs) timed with HIP
-                   events on its launch stream inside the timed region, against the fp32 MFMA peak;
-    cpu_baseline — the CPU oracle (restated reference path: OpenMP C solver + PyTorch-CPU network) on a bounded
-                   sample, rank 0 at N=1 only.
+    roofline         - the dominant kernel (the 64 batched Winograd GEMMs of a 3x3 512->512 layer) timed with HIP events on
+                       its launch stream inside the timed region: executed bf16-MFMA FLOP against the dense bf16 MFMA peak;
+    roofline_forward - the whole CNN forward: executed MFMA FLOP per step / CNN time against the same peak, and the
+                       algorithmic HBM bytes per step / CNN time against the HBM peak;
+    cpu_baseline     - the CPU oracle (restated reference path: OpenMP C solver + PyTorch-CPU network) on a bounded
+                       sample, rank 0 at N=1 only.
 """
 import argparse
 import ctypes
@@ -98,6 +103,105 @@ FWD_GFLOP_PER_IMAGE = 295.41        # SURVEY.md §8(d), single-task net, 480x720
 FWD_GFLOP_PER_IMAGE_3ENC = 755.96   # SURVEY.md §8(d), CrossLoc 3-encoder net
 
 
+def respawn_under_torchrun(n, argv):
+    """`python bench.py --gpus N` started without a launcher (WORLD_SIZE unset): re-execute the same command line under
+    torch.distributed.run with N ranks on this node - what the driver's own launch line does.  Returns the exit status."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL across processes needs it on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
+def init_ranks(gpus, backend="nccl"):
+    """RANK / LOCAL_RANK / WORLD_SIZE from the launcher -> (rank, local_rank, world, dist module or None, ranks in the
+    group).  `nccl` IS RCCL on ROCm; one rank per GPU.  A rank without a GPU of its own stops here with a clear message
+    (after the spawn, so `--gpus 2` on a one-GPU box says what is missing instead of hanging in the rendezvous)."""
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != gpus:
+        raise SystemExit("bench.py --gpus %d launched with WORLD_SIZE=%d" % (gpus, world))
+    if backend == "nccl":
+        have = torch.cuda.device_count()
+        if have < world:
+            raise SystemExit("bench.py --gpus %d needs %d GPUs on this node (one rank per GPU over RCCL); torch sees %d"
+                             % (gpus, world, have))
+    if world == 1:
+        return rank, local_rank, 1, None, 1
+    import torch.distributed as dist
+    if backend == "nccl":
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        probe = torch.ones(1, device=torch.device("cuda", local_rank))
+    else:
+        dist.init_process_group(backend)
+        probe = torch.ones(1)
+    ranks = dist.get_world_size()
+    assert dist.get_backend() == backend and ranks == world, (dist.get_backend(), ranks, world)
+    dist.all_reduce(probe)                                                    # one collective before the timed region
+    assert int(probe.item()) == world, "all-reduce over %d ranks returned %s" % (world, probe.item())
+    return rank, local_rank, world, dist, ranks
+
+
+def timed_steps(dist, sync, run_steps):
+    """The contract's timed region: barrier + synchronize, EXACTLY the K steps, synchronize + barrier, MAX over ranks."""
+    import torch
+    if dist is not None:
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    run_steps()
+    sync()
+    if dist is not None:
+        dist.barrier()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    return elapsed
+
+
+def run_stub(args, rank, world, dist):
+    """XL_BENCH_STUB=1 (tests/test_distributed_cpu.py): bench.py's launcher, rank, barrier, max-over-ranks and all-gather
+    code on CPU ranks (gloo) around a stand-in localiser that returns the ground-truth pose moved by a known amount per
+    global image index.  Not a measurement: the line says so and carries no roofline."""
+    import torch
+    B, K = args.batch, args.steps
+    rows = []
+
+    def run_steps():
+        for s in range(K):
+            image0 = (s * world + rank) * B                                   # same global image index as the real step
+            idx = torch.arange(image0, image0 + B, dtype=torch.float64)
+            rows.append(torch.stack([0.01 * (1.0 + idx % 7), 0.001 * (1.0 + idx % 5)], 1))
+    elapsed = timed_steps(dist, lambda: None, run_steps)
+    local = torch.cat(rows, 0)
+    med_t_cm, med_r_deg, n_rows = gather_and_median(local, world, dist)
+    assert n_rows == world * B * K
+    if rank == 0:
+        print(json.dumps({"metric": "images/sec localized (480x720, 256 hyps)", "value": round(n_rows / max(elapsed, 1e-9), 2),
+                          "unit": "images/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
+                          "ms_per_step": round(elapsed / K * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "none", "data": "STUB localiser on CPU ranks (plumbing test, not a measurement)",
+                          "config": {"workload": "stub", "backend": dist.get_backend() if dist is not None else None,
+                                     "ranks": world, "rows_gathered": n_rows, "median_err_cm": med_t_cm,
+                                     "median_err_deg": med_r_deg}}))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -124,29 +228,18 @@ def main():
     if args.batch is None:
         args.batch = 24 if args.mlr else 47
 
+    stub = bool(os.environ.get("XL_BENCH_STUB"))       # tests only: the rank / collective / timing plumbing on CPU (gloo)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: become the launcher (one rank per GPU, rendezvous on 127.0.0.1)
+        raise SystemExit(respawn_under_torchrun(args.gpus, sys.argv[1:]))
+
     import torch
+    rank, local_rank, world, dist, rccl_ranks = init_ranks(args.gpus, "gloo" if stub else "nccl")
+    if stub:
+        return run_stub(args, rank, world, dist)
     from crossloc_amd import networks, synth, evaluation
     from crossloc_amd.weights import seeded_state_dict
     import dsacstar
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
-    rccl_ranks = 1
-    if world > 1:
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))       # "nccl" IS RCCL on ROCm
-        rccl_ranks = dist.get_world_size()
-        assert dist.get_backend() == "nccl" and rccl_ranks == world, (dist.get_backend(), rccl_ranks, world)
-        if world != args.gpus:
-            raise SystemExit("bench.py --gpus %d launched with WORLD_SIZE=%d" % (args.gpus, world))
-        probe = torch.ones(1, device=torch.device("cuda", local_rank))
-        dist.all_reduce(probe)                                                # one RCCL collective before the timed region
-        assert int(probe.item()) == world, "RCCL all-reduce over %d ranks returned %s" % (world, probe.item())
-    elif args.gpus != 1:
-        raise SystemExit("bench.py --gpus %d needs torch.distributed.run with %d ranks (WORLD_SIZE is 1)" % (args.gpus, args.gpus))
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
@@ -199,35 +292,25 @@ def main():
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True),
            torch.cuda.Event(enable_timing=True)) for _ in range(K)]
     all_poses = []
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for s in range(K):
-        ev[s][0].record(pipe.cnn[0])
-        pred, done = pipe.forward_cnn(images, plant=coords)
-        ev[s][1].record(pipe.cnn[0])                                     # stream 0 joins the others before the concat
-        poses = torch.zeros((B, 4, 4), dtype=torch.float32, device=dev)
-        for e in done:
-            pipe.side.wait_event(e)                                      # solver(s) after CNN(s)
-        pipe.side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(pipe.side):
-            ev[s][2].record()
-            dsacstar.forward_rgb_batch(pred[:, :3], poses, NH, 10.0, synth.FOCAL, IMW / 2.0, H / 2.0, 100.0, 100.0, 8,
-                                       image0=(s * world + rank) * B)
-            ev[s][3].record()
-        pred.record_stream(pipe.side)
-        all_poses.append(poses)
-    pipe.finish()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+
+    def run_steps():
+        for s in range(K):
+            ev[s][0].record(pipe.cnn[0])
+            pred, done = pipe.forward_cnn(images, plant=coords)
+            ev[s][1].record(pipe.cnn[0])                                 # stream 0 joins the others before the concat
+            poses = torch.zeros((B, 4, 4), dtype=torch.float32, device=dev)
+            for e in done:
+                pipe.side.wait_event(e)                                  # solver(s) after CNN(s)
+            pipe.side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(pipe.side):
+                ev[s][2].record()
+                dsacstar.forward_rgb_batch(pred[:, :3], poses, NH, 10.0, synth.FOCAL, IMW / 2.0, H / 2.0, 100.0, 100.0, 8,
+                                           image0=(s * world + rank) * B)
+                ev[s][3].record()
+            pred.record_stream(pipe.side)
+            all_poses.append(poses)
+        pipe.finish()
+    elapsed = timed_steps(dist, torch.cuda.synchronize, run_steps)
 
     # ---- per-kernel durations from the HIP events recorded inside the timed region
     cap = n_ops * K * n_sub
@@ -533,36 +616,69 @@ def secondary_configs(dev, n_hyp, train_batch=16, mlr_batch=24, steps=5):
     return out
 
 
-def cpu_baseline(net, images, coords_np, n_hyp, num_mlr=0):
-    """The restated reference CPU path on this box's host cores: PyTorch-CPU fp32 network + OpenMP C solver.
-    Bounded sample (a few frames) so the default run stays within minutes."""
+def host_cpu_info():
+    """(model string, hardware threads this process may use, physical cores among them) from /proc/cpuinfo + affinity."""
+    allowed = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+    model, cores, cur = "unknown", set(), {}
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f.read().split("\n") + [""]:
+                if ":" in line:
+                    k, v = [t.strip() for t in line.split(":", 1)]
+                    cur[k] = v
+                elif cur:
+                    if "model name" in cur and model == "unknown":
+                        model = cur["model name"]
+                    if int(cur.get("processor", "-1")) in allowed:
+                        cores.add((cur.get("physical id", "0"), cur.get("core id", cur.get("processor", "0"))))
+                    cur = {}
+    except (OSError, ValueError):
+        pass
+    return model, len(allowed), max(1, len(cores))
+
+
+def cpu_baseline(net, images, coords_np, n_hyp, num_mlr=0, frames=5):
+    """The restated reference CPU path on this box's host cores: PyTorch-CPU fp32 network with all
+    physical cores + the C/OpenMP solver at OMP_NUM_THREADS = 1 and = the physical cores; the same synthetic frames and
+    seeds as the GPU run, `frames` frames each after a warm-up, MEDIAN per-frame time.  Bounded (well under a minute)."""
     import torch
     from oracle import cnn_oracle, dsac_oracle
     dsac_oracle.build()
-    # all hardware threads of a 2-socket host oversubscribe both OpenMP runtimes badly (measured 22 s per
-    # frame at 256 threads); use up to 64 and report that number as `cores`
-    cores = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 64)
+    model, threads, phys = host_cpu_info()
+    # more threads than physical cores (or than 64) oversubscribe both OpenMP runtimes badly on a 2-socket host
+    # (measured 22 s per frame at 256 threads): physical cores, at most 64, reported as `cores`
+    cores = max(1, min(phys, 64))
     torch.set_num_threads(cores)
-    dsac_oracle.set_num_threads(cores)
     sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
-    x = images[:1].detach().cpu()
-    cnn_oracle.transposenet_forward(sd, x, num_mlr, 2, 2)                # warm-up
-    n_cnn = 3
-    t0 = time.perf_counter()
-    for _ in range(n_cnn):
+    frames = min(frames, images.shape[0], coords_np.shape[0])
+    xs = [images[b:b + 1].detach().cpu() for b in range(frames)]
+    cnn_oracle.transposenet_forward(sd, xs[0], num_mlr, 2, 2)            # warm-up
+    t_cnn = []
+    for x in xs:
+        t0 = time.perf_counter()
         cnn_oracle.transposenet_forward(sd, x, num_mlr, 2, 2)
-    t_cnn = (time.perf_counter() - t0) / n_cnn
-    n_dsac = min(16, coords_np.shape[0])
-    dsac_oracle.forward_rgb(coords_np[0], n_hyp, 10.0, 480.0, 360.0, 240.0, 100.0, 100.0, 8)   # warm-up
-    t0 = time.perf_counter()
-    for b in range(n_dsac):
-        dsac_oracle.forward_rgb(coords_np[b], n_hyp, 10.0, 480.0, 360.0, 240.0, 100.0, 100.0, 8, image=b)
-    t_dsac = (time.perf_counter() - t0) / n_dsac
-    return {"value": round(1.0 / (t_cnn + t_dsac), 3), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": "%d frames CNN forward (PyTorch CPU fp32, batch 1) + %d frames oracle dsacstar %d hyps "
-                      "(C/OpenMP, %d threads); reference binary unbuildable (needs OpenCV)" % (
-                          n_cnn, n_dsac, n_hyp, dsac_oracle.num_threads()),
-            "cnn_s_per_image": round(t_cnn, 4), "dsac_s_per_image": round(t_dsac, 5)}
+        t_cnn.append(time.perf_counter() - t0)
+
+    def solver(nthreads):
+        dsac_oracle.set_num_threads(nthreads)
+        dsac_oracle.forward_rgb(coords_np[0], n_hyp, 10.0, 480.0, 360.0, 240.0, 100.0, 100.0, 8)   # warm-up
+        ts = []
+        for b in range(frames):
+            t0 = time.perf_counter()
+            dsac_oracle.forward_rgb(coords_np[b], n_hyp, 10.0, 480.0, 360.0, 240.0, 100.0, 100.0, 8, image=b)
+            ts.append(time.perf_counter() - t0)
+        return float(np.median(ts))
+    t_dsac_1 = solver(1)
+    t_dsac_n = solver(cores)
+    t_cnn = float(np.median(t_cnn))
+    return {"value": round(1.0 / (t_cnn + t_dsac_n), 3), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": "median of %d frames each, after one warm-up frame: CNN forward (PyTorch CPU fp32, batch 1, %d threads) + "
+                      "oracle dsacstar %d hyps (C/OpenMP, %d threads); reference binary unbuildable (needs OpenCV)" % (
+                          frames, cores, n_hyp, cores),
+            "cpu_model": model, "hardware_threads": threads, "physical_cores": phys,
+            "cnn_s_per_image": round(t_cnn, 4), "dsac_s_per_image": round(t_dsac_n, 5),
+            "dsac_s_per_image_omp1": round(t_dsac_1, 5),
+            "value_omp1_solver": round(1.0 / (t_cnn + t_dsac_1), 3)}
 
 
 if __name__ == "__main__":

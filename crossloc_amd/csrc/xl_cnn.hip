@@ -1057,7 +1057,7 @@ void wino4_in_kernel(const float *__restrict__ in, float *__restrict__ V, int B,
                 for (int a = 0; a < 6; ++a) {
                     const int y = 4 * ty - 1 + a;
                     const bool inb = ((unsigned)y < (unsigned)H) & ((unsigned)x < (unsigned)W);
-                    float v0 = col[a][0] * ss[0] + ss[1], v1 = col[a][1] * ss[2] + ss[3];
+                    float v0 = fmaf(col[a][0], ss[0], ss[1]), v1 = fmaf(col[a][1], ss[2], ss[3]);   // one rounding, as every apply site
                     if (DEFER == 2) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
                     col[a] = f32x2{ inb ? v0 : 0.f, inb ? v1 : 0.f };
                 }
@@ -1239,7 +1239,7 @@ void wino6_in_kernel(const float *__restrict__ in, float *__restrict__ V, int B,
                 for (int a = 0; a < 8; ++a) {
                     const int y = 6 * ty - 1 + a;
                     const bool inb = ((unsigned)y < (unsigned)H) & ((unsigned)x < (unsigned)W);
-                    float v0 = col[a][0] * ss[0] + ss[1], v1 = col[a][1] * ss[2] + ss[3];
+                    float v0 = fmaf(col[a][0], ss[0], ss[1]), v1 = fmaf(col[a][1], ss[2], ss[3]);   // one rounding, as every apply site
                     if (DEFER == 2) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
                     col[a] = f32x2{ inb ? v0 : 0.f, inb ? v1 : 0.f };
                 }
@@ -1595,7 +1595,8 @@ void gn_apply_kernel(const float *__restrict__ x, const double *__restrict__ sta
         const f32x4 sh = *reinterpret_cast<const f32x4 *>(sSS + C + c);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            float t = v[j] * sc[j] + sh[j];
+            float t = fmaf(v[j], sc[j], sh[j]);       // one rounding - the same arithmetic as the consumers that apply a
+                                                      // deferred GroupNorm while loading (a frame must not depend on which form ran)
             if (reluIn) t = fmaxf(t, 0.f);
             v[j] = t;
         }

@@ -176,9 +176,12 @@ def gather_errors(local_vals, num_images, rank, world_size, group=None):
 def _focal_args(focal, n):
     """focal: one number for the whole batch, or one per frame (sequence / tensor: the dataset computes it per frame from
     calibration/*.txt scaled by the stored image height, dataloader/dataloader.py:263-266).  -> (scalar, focals kwarg)."""
-    if isinstance(focal, (int, float)):
+    import numbers
+    if isinstance(focal, (numbers.Real, np.generic)):              # Python and numpy scalars alike
         return float(focal), None
     f = torch.as_tensor(focal, dtype=torch.float32).reshape(-1)
+    if f.numel() == 1:                                             # 0-dim / one-element tensor or sequence: one focal for all
+        return float(f[0]), None
     if f.numel() != n:
         raise RuntimeError("expected %d focal lengths, got %d" % (n, f.numel()))
     return float(f[0]), f

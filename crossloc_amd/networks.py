@@ -368,9 +368,12 @@ class _Plan:
         separate apply pass): 128-row x 128-column tiles, whole 32-channel K-steps, at most two images per tile."""
         t, H, W, C, ld, off = act
         cout = conv.out_channels
+        # (the tile-count term - small launches run the 64-row form, which has no operand normalisation - depends on the
+        #  batch: batch-invariant plans make the choice from the layer alone, see split_1x1_ok; and every apply site, fused
+        #  or not, computes fmaf(x, scale, shift), so the two forms agree to the bit anyway)
+        fills = self.separate_stats or -(-self.B * H * W // 128) * (cout // 128) > 256
         return (conv.kernel_size[0] == 1 and conv.stride[0] == 1 and cout % 128 == 0 and C % 32 == 0 and H * W >= 128
-                and -(-self.B * H * W // 128) * (cout // 128) > 256 and not self.train
-                and not os.environ.get("XL_NO_NORM_ON_LOAD"))
+                and fills and not self.train and not os.environ.get("XL_NO_NORM_ON_LOAD"))
 
     def split_1x1_ok(self, act, conv):
         """1x1 stride-1 layers of inference plans on the bf16 matrix pipe (csrc/xl_gemm_split.hip, split_conv1x1_kernel):
@@ -434,8 +437,8 @@ class _Plan:
         op.out = out.data_ptr() + 4 * out_off
         # 64-row tiles when 128-row tiles would not even fill one wave of workgroups over the 256 CUs
         bn = 128 if cout % 128 == 0 else 64
-        if -(-self.B * Ho * Wo // 128) * -(-cout // bn) <= 256:
-            op.reserved_i = 64
+        if -(-self.B * Ho * Wo // 128) * -(-cout // bn) <= 256 and norm_in is None:
+            op.reserved_i = 64                        # (the normalise-on-load form exists with 128-row tiles only)
         if split:
             op.flags |= CONV_SPLIT_BF16 | CONV_SPLIT_IL
             op.w = self.pack_conv_1x1_split(conv).data_ptr()

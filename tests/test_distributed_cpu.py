@@ -134,3 +134,52 @@ def test_bench_gather_and_median_two_ranks(tmp_path):
     want = bench.gather_and_median(rows, 1)
     assert np.array_equal(r0, r1) and np.allclose(r0, want) and int(r0[2]) == 12
     assert abs(want[0] - 100.0 * float(torch.median(rows[:, 0]))) < 1e-12
+
+
+def _run_bench(args, extra_env):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    env.update(extra_env)
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=env, capture_output=True, text=True,
+                          timeout=600)
+
+
+def test_bench_self_spawns_two_ranks_without_a_launcher():
+    """`python bench.py --gpus 2` with no WORLD_SIZE: bench.py re-executes itself under torch.distributed.run (2 ranks on
+    127.0.0.1) and its own init / barrier / max-over-ranks / all-gather code runs - here on CPU ranks (gloo) around the
+    stand-in localiser of XL_BENCH_STUB, whose per-image errors are a known function of the global image index."""
+    import json
+    r = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "4"], {"XL_BENCH_STUB": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                           # ONE JSON line, from rank 0
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["config"]["backend"] == "gloo"
+    assert out["config"]["ranks"] == 2 and out["config"]["rows_gathered"] == 2 * 3 * 4
+    idx = np.arange(24, dtype=np.float64)                            # image indices 0..23 are covered exactly once
+    assert out["config"]["median_err_cm"] == pytest.approx(100.0 * np.sort(0.01 * (1.0 + idx % 7))[(24 - 1) // 2])
+    assert "STUB" in out["data"] and "roofline" not in out
+
+
+def test_bench_two_gpus_on_a_box_without_them_fails_after_the_spawn_with_a_clear_message():
+    """The real (RCCL) path on a node with fewer GPUs than ranks: every spawned rank stops with `needs 2 GPUs`, the
+    launcher reports the failure - no hang in the rendezvous, no SystemExit before the spawn."""
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        pytest.skip("this node has two GPUs")
+    r = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0"], {})
+    assert r.returncode != 0
+    assert "needs 2 GPUs on this node" in (r.stderr + r.stdout)
+    assert "torch.distributed" in r.stderr or "ChildFailedError" in r.stderr      # it did go through the launcher
+
+
+def test_focal_argument_forms():
+    """One focal length for the batch may arrive as a Python number, a numpy scalar or a 0-dim / one-element tensor."""
+    for f in (480.0, 480, np.float32(480.0), np.float64(480.0), torch.tensor(480.0), torch.tensor([480.0]), [480.0]):
+        assert evaluation._focal_args(f, 3) == (480.0, None)
+    f0, per = evaluation._focal_args([470.0, 480.0, 490.0], 3)
+    assert f0 == 470.0 and per.tolist() == [470.0, 480.0, 490.0]
+    with pytest.raises(RuntimeError):
+        evaluation._focal_args([470.0, 480.0], 3)

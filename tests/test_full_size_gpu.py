@@ -85,3 +85,23 @@ def test_batch16_training_step_at_full_size(monkeypatch):
     assert (y_w[:, :3] - y_d[:, :3]).abs().max().item() < 5e-4
     worst = max(rel(g_w[n], g_d[n]) for n in g_d)
     assert worst < 5e-2, worst
+
+
+def test_batch_invariant_single_frame_equals_the_frame_inside_a_batch_at_full_size():
+    """batch_invariant plans at 480x720: a frame that runs alone (the tail batch of test_single_task) is BITWISE the frame
+    inside a larger batch.  At this size the form of a deferred GroupNorm used to depend on the batch (applied on load by
+    the consuming 1x1 layer for B >= 2, as a pass of its own for B = 1, with different rounding): the choice is now made
+    from the layer alone and every apply site computes fmaf(x, scale, shift)."""
+    net = networks.TransPoseNet(MEAN, False, False, 2, 2, 3, 1)
+    net.load_state_dict(seeded_state_dict(net, seed=13))
+    net.batch_invariant = True
+    net = net.cuda().eval()
+    x = _images(5, 3).cuda()
+    with torch.no_grad():
+        y5 = net(x)
+        y1 = net(x[3:4])
+        y2 = net(x[3:5])
+    assert torch.equal(y1[0], y5[3]) and torch.equal(y2[0], y5[3]) and torch.equal(y2[1], y5[4])
+    # the two plans lowered the same op types in the same order (layer-only choices)
+    ops = {B: [(op.type, op.flags, op.ksize, op.Cin, op.Cout) for op in p.ops] for (B, *_), p in net._plans.items()}
+    assert ops[1] == ops[2] == ops[5]
