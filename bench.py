@@ -103,6 +103,52 @@ FWD_GFLOP_PER_IMAGE = 295.41        # SURVEY.md §8(d), single-task net, 480x720
 FWD_GFLOP_PER_IMAGE_3ENC = 755.96   # SURVEY.md §8(d), CrossLoc 3-encoder net
 
 
+def plan_work(plan, networks):
+    """What one forward of an inference plan executes, from its op list: MFMA FLOP by pipe (a split-bf16 GEMM = six bf16
+    passes per fp32 product; useful K only, no tile padding) and the HBM bytes the plan's own tensors imply (every op reads its
+    inputs and writes its outputs once; weights once; V / M of the Winograd layers included) - to be set against the
+    algorithmic bytes of SURVEY.md 8(d)."""
+    bf16 = f32 = 0.0
+    byts = 0.0
+    for op in plan.ops:
+        t = op.type
+        if t == networks.XL_OP_CONV:
+            Z = max(1, op.nchunks2)
+            M = op.B * op.Ho * op.Wo
+            K = op.ksize * op.ksize * op.Cin
+            fl = 2.0 * Z * M * op.Cout * K
+            split = bool(op.flags & networks.CONV_SPLIT_BF16)
+            if split:
+                bf16 += 6 * fl
+            else:
+                f32 += fl
+            act_in = Z * op.B * op.Hi * op.Wi * op.Cin
+            if split and Z > 1 and not (op.flags & getattr(networks, "CONV_SPLIT_ACT", 0)):
+                byts += act_in * 6                               # V as three bf16 planes
+            else:
+                byts += act_in * 4
+            byts += Z * M * op.Cout * 4 + Z * op.Cout * K * (6 if split else 4)
+        elif t == networks.XL_OP_CONV1:
+            px = op.B * op.Hi * op.Wi
+            if op.reserved_i == 0 and (op.stats or op.aux2):     # matrix-pipe form, one evaluation per launch
+                bf16 += 6 * 2.0 * px * op.Cout * 27
+            byts += px * 3 * 4 + (px * op.Cout * 4 if op.out else 0)
+        elif t == networks.XL_OP_WINO_IN:
+            nf = (op.ksize + 2) ** 2
+            split = bool(op.flags & networks.CONV_SPLIT_BF16)
+            byts += op.B * op.Hi * op.Wi * op.Cin * 4 + nf * op.B * op.Ho * op.Wo * op.Cin * (6 if split else 4)
+        elif t == networks.XL_OP_WINO_OUT:
+            nf = (op.ksize + 2) ** 2
+            Th, Tw = -(-op.Hi // op.ksize), -(-op.Wi // op.ksize)
+            byts += nf * op.B * Th * Tw * op.Cin * 4 + op.B * op.Hi * op.Wi * op.Cin * 4
+        elif t in (networks.XL_OP_GN_STATS, networks.XL_OP_GN_APPLY):
+            n = op.B * op.Hi * op.Wi * op.Cin * 4
+            byts += n * (1 if t == networks.XL_OP_GN_STATS else 2 + (1 if op.flags & networks.GN_ADD else 0))
+        elif t == networks.XL_OP_HEAD:
+            byts += op.B * op.Hi * op.Wi * (op.Cin + op.Cout) * 4
+    return {"bf16_flop": bf16, "f32_flop": f32, "bytes": byts}
+
+
 def respawn_under_torchrun(n, argv):
     """`python bench.py --gpus N` started without a launcher (WORLD_SIZE unset): re-execute the same command line under
     torch.distributed.run with N ranks on this node - what the driver's own launch line does.  Returns the exit status."""
@@ -355,6 +401,8 @@ def main():
     mfma_passes = 6 if (wino and split_gemm) else 1
     peak_tflops = PEAK_BF16_MFMA_TFLOPS if mfma_passes == 6 else PEAK_F32_MFMA_TFLOPS
     cnn_ms = float(np.mean([ev[s][0].elapsed_time(ev[s][1]) for s in range(K)]))
+    work = plan_work(plan, networks)                 # one sub-batch; the sub-batches of a step have the same ops
+    work = {k: v * n_sub for k, v in work.items()}
     dsac_ms = float(np.mean([ev[s][2].elapsed_time(ev[s][3]) for s in range(K)]))
 
     # ---- pose errors: every image of every step, gathered over ranks with one all-gather
@@ -443,6 +491,26 @@ def main():
                          "avg_launch_ms": round(conv_avg_ms, 4), "launches_timed": len(conv_ms),
                          "algorithmic_gflop_per_launch": round(conv_flop * mfma_passes / 1e9, 2),
                          "fp32_equivalent_gflop_per_launch": round(conv_flop / 1e9, 2)},
+            # the whole CNN forward of a step (north_star: ">= 50 % MFMA roofline on the coord-regression forward"): the MFMA
+            # FLOP the plan executes (useful K, no tile padding; a split-bf16 product = six bf16 passes) over the CNN time of a
+            # step, by pipe; `frac` = the time both pipes would need at their dense peaks / the CNN time.  HBM side: the
+            # algorithmic bytes of SURVEY.md 8(d) (668 MB per image + 107 MB of weights) and the bytes the plan's own tensors
+            # imply (V and M of the Winograd layers, every remaining GroupNorm pass), both over the same time
+            "roofline_forward": {
+                "bound": "mfma", "cnn_ms_per_step": round(cnn_ms, 3), "frames_per_step": B,
+                "mfma_bf16_tflop_per_step": round(work["bf16_flop"] / 1e12, 3),
+                "mfma_f32_tflop_per_step": round(work["f32_flop"] / 1e12, 4),
+                "achieved": round(work["bf16_flop"] / (cnn_ms * 1e-3) / 1e12, 1), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac_bf16_pipe": round(work["bf16_flop"] / (cnn_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
+                "frac": round((work["bf16_flop"] / PEAK_BF16_MFMA_TFLOPS + work["f32_flop"] / PEAK_F32_MFMA_TFLOPS) / 1e12
+                              / (cnn_ms * 1e-3), 4),
+                "fp32_equivalent_tflops": round((work["bf16_flop"] / 6 + work["f32_flop"]) / (cnn_ms * 1e-3) / 1e12, 1),
+                "hbm": {"algorithmic_bytes_per_step": int((668e6 if not args.mlr else 0) * B + 107e6) if not args.mlr else None,
+                        "algorithmic_TBps": round((668e6 * B + 107e6) / (cnn_ms * 1e-3) / 1e12, 3) if not args.mlr else None,
+                        "plan_bytes_per_step": int(work["bytes"]),
+                        "plan_TBps": round(work["bytes"] / (cnn_ms * 1e-3) / 1e12, 3),
+                        "plan_over_algorithmic": round(work["bytes"] / (668e6 * B + 107e6), 2) if not args.mlr else None,
+                        "peak_TBps": 8.0}},
             "cpu_baseline": cpu,
         }
         out["config"].update(secondary)

@@ -1201,11 +1201,19 @@ __device__ __forceinline__ void bf16_split3(float a, unsigned &h1, unsigned &h2,
 // ([plane][64][tiles][C], the operand form of csrc/xl_gemm_split.hip) instead of fp32.
 // The interleaved-plane forms are held to 168 VGPRs = three waves per SIMD (the deferred one would take 178 and runs 20 %
 // slower at two waves: 413 vs 346 us per 512-channel launch; at 168 it keeps 5 values in scratch and takes 364).
-template <int DEFER, int SPLIT = 0>
+// FOLD (with DEFER = 1): `in` is the RAW output of a convolution whose GroupNorm(+ReLU, +residual, +ReLU) apply pass was not
+// run: every in-image pixel becomes v = relu_out(relu_in(fmaf(x, scale, shift)) + res) on load (the arithmetic of
+// gn_apply_kernel, flags as XL_GN_*), and the thread that owns a pixel - the tile whose 6 x 6 output footprint contains it -
+// also writes v to `side`: the activation is materialised for its other consumers (the residual branch) by the pass that had
+// to read it anyway.  `side` must not alias `in` or `res` (other tiles read their halo pixels from those).
+struct WinoFold { const float *res; float *side; int ldRes, ldSide, flags; };
+
+template <int DEFER, int SPLIT = 0, int FOLD = 0>
 __global__ __launch_bounds__(256, (SPLIT == 2 ? 3 : 1))
 void wino6_in_kernel(const float *__restrict__ in, float *__restrict__ V, int B, int H, int W, int C, int ldIn, int Th, int Tw,
-                     const float *__restrict__ coeff)
+                     const float *__restrict__ coeff, WinoFold fold)
 {
+    static_assert(!FOLD || DEFER == 1, "the fold form takes its ReLU / residual flags at run time");
     const int C2 = C >> 1;
     const long long T = (long long)B * Th * Tw;
     const long long items = T * C2;
@@ -1235,12 +1243,29 @@ void wino6_in_kernel(const float *__restrict__ in, float *__restrict__ V, int B,
                     col[a] = f32x2{ 0.f, 0.f };
             }
             if (DEFER) {
+                f32x2 rcol[8];
+                if constexpr (FOLD != 0) {
+                    if (fold.res) {
+#pragma unroll
+                        for (int a = 0; a < 8; ++a) {
+                            const int yc = min(max(6 * ty - 1 + a, 0), H - 1), xc = min(max(x, 0), W - 1);
+                            rcol[a] = *reinterpret_cast<const f32x2 *>(fold.res + (((long long)n * H + yc) * W + xc) * fold.ldRes + 2 * c2);
+                        }
+                    }
+                }
 #pragma unroll
                 for (int a = 0; a < 8; ++a) {
                     const int y = 6 * ty - 1 + a;
                     const bool inb = ((unsigned)y < (unsigned)H) & ((unsigned)x < (unsigned)W);
                     float v0 = fmaf(col[a][0], ss[0], ss[1]), v1 = fmaf(col[a][1], ss[2], ss[3]);   // one rounding, as every apply site
                     if (DEFER == 2) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+                    if constexpr (FOLD != 0) {
+                        if (fold.flags & XL_GN_RELU_IN) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+                        if (fold.res) { v0 += rcol[a][0]; v1 += rcol[a][1]; }
+                        if (fold.flags & XL_GN_RELU_OUT) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+                        if (inb && a >= 1 && a <= 6 && b >= 1 && b <= 6)
+                            *reinterpret_cast<f32x2 *>(fold.side + (((long long)n * H + y) * W + x) * fold.ldSide + 2 * c2) = f32x2{ v0, v1 };
+                    }
                     col[a] = f32x2{ inb ? v0 : 0.f, inb ? v1 : 0.f };
                 }
             }
@@ -1431,13 +1456,28 @@ void wino6_out_kernel(const float *__restrict__ M, const float *__restrict__ bia
         }
     }
     if (!stats) return;
+    const int cpg = C / G;
+    const int lpg = cpg / VW;                          // lanes that hold one group
+    if (S == 1 && lpg >= 1 && lpg <= 64 && (lpg & (lpg - 1)) == 0 && cpg == lpg * VW) {
+        // every channel of the block lives in exactly one thread and a group in lpg neighbouring lanes of one wave: fp64
+        // butterfly over those lanes (fixed order), one writer per (image, chunk, group) - no LDS, no barrier.  (The LDS
+        // form below reads 16 doubles per group at a 256-byte lane stride: 32-way bank conflicts at the tail of every block.)
+        double a = 0.0, b = 0.0;
+#pragma unroll
+        for (int e = 0; e < VW; ++e) { a += (double)wino_lane(s1, e); b += (double)wino_lane(s2, e); }
+        for (int off = 1; off < lpg; off <<= 1) { a += __shfl_xor(a, off, 64); b += __shfl_xor(b, off, 64); }
+        if ((tid & (lpg - 1)) == 0) {
+            double *o = stats + (((long long)n * nchunks + k) * G + cch / cpg) * 2;
+            o[0] = a; o[1] = b;
+        }
+        return;
+    }
 #pragma unroll
     for (int e = 0; e < VW; ++e) {
         sS[(tid * VW + e) * 2] = (double)wino_lane(s1, e);
         sS[(tid * VW + e) * 2 + 1] = (double)wino_lane(s2, e);
     }
     __syncthreads();
-    const int cpg = C / G;
     const int gPerBlock = CB / cpg;                    // groups whose channels all live in this block
     if (tid < gPerBlock) {
         double a = 0.0, b = 0.0;
@@ -2087,9 +2127,24 @@ int run_op(const xl_op &op, hipStream_t st)
                     if (op.Cin % 128 != 0) return XL_ERR_ARG;          // a wave = 128 consecutive channels of one tile
                     kin = !op.aux2 ? wino6_in_kernel<0, 2> : (op.flags & XL_GN_RELU_IN) ? wino6_in_kernel<2, 2> : wino6_in_kernel<1, 2>;
                 }
+                WinoFold fold = { nullptr, nullptr, 0, 0, 0 };
+                if (op.out2) {
+                    // fold form: aux2 = coefficients, out2 = the materialised activation (pixel stride ld_out), aux = residual
+                    // (pixel stride ld_aux) when XL_GN_ADD is set; flags & (XL_GN_RELU_IN | XL_GN_ADD | XL_GN_RELU_OUT)
+                    if (!op.aux2 || op.ld_out % 2 != 0 || ((op.flags & XL_GN_ADD) && (!op.aux || op.ld_aux % 2 != 0)) ||
+                        op.out2 == op.in || op.out2 == op.aux) return XL_ERR_ARG;
+                    fold.res = (op.flags & XL_GN_ADD) ? (const float *)op.aux : nullptr;
+                    fold.side = (float *)op.out2; fold.ldRes = op.ld_aux; fold.ldSide = op.ld_out;
+                    fold.flags = op.flags & (XL_GN_RELU_IN | XL_GN_RELU_OUT);
+                    kin = wino6_in_kernel<1, 0, 1>;
+                    if (op.flags & XL_CONV_SPLIT_BF16) {
+                        if (!(op.flags & XL_CONV_SPLIT_IL)) return XL_ERR_UNSUPPORTED;
+                        kin = wino6_in_kernel<1, 2, 1>;
+                    }
+                }
                 hipLaunchKernelGGL(kin, dim3((unsigned)blocks6), dim3(256), 0, st, (const float *)op.in,
                                    (float *)op.out, op.B, op.Hi, op.Wi, op.Cin, op.ld_in, op.Ho, op.Wo,
-                                   (const float *)op.aux2);
+                                   (const float *)op.aux2, fold);
                 return XL_OK;
             }
             if (op.ksize == 4) {                    // F(4x4,3x3): Ho x Wo tiles of 4x4 outputs, partial tiles allowed

@@ -443,7 +443,9 @@ struct SplitConvArgs {
     double *stats; int HW, G, nchunks, B;            // statistics of the output (stats == nullptr: none); 16 channels per group
     int M, C, N, ldIn, ldOut, nbm, nbn;
     int tpi;                                         // > 0: tiles start at image boundaries, tpi = ceil(HW / 256) per image (the
-};                                                   // grouping of the statistics is then independent of the batch); 0: dense
+                                                     // grouping of the statistics is then independent of the batch); 0: dense
+    int Z; long long zIn, zOut;                      // Z > 1: Z independent products in one launch (the frequencies of a Winograd
+};                                                   // layer: in / out advance by zIn / zOut floats, the weights by N rows; no bias)
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -472,15 +474,18 @@ void split_conv1x1_kernel(SplitConvArgs a)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
 
-    const int total = a.nbm * a.nbn;
+    const int total = a.nbm * a.nbn * a.Z;
     const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3, nloc = gridDim.x >> 3;
     const int q8 = total >> 3, r8 = total & 7;
     const int runStart = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
     const int runLen = q8 + (xcd < r8 ? 1 : 0);
     const int myCount = runLen > local ? (runLen - local + nloc - 1) / nloc : 0;
     if (myCount == 0) return;
+    // (z, m-tile, n-tile) order: the workgroups of an XCD walk neighbouring tiles of one product, whose weights stay in its L2
+    auto tile_z = [&](int i) { return (runStart + local + i * nloc) / (a.nbm * a.nbn); };
     auto tile_at = [&](int i, int &m0, int &n0) {
-        const int t = runStart + local + i * nloc;
+        int t = runStart + local + i * nloc;
+        t -= (t / (a.nbm * a.nbn)) * (a.nbm * a.nbn);
         const int mt = t / a.nbn;
         n0 = (t - mt * a.nbn) * 256;
         if (a.tpi) {
@@ -501,7 +506,7 @@ void split_conv1x1_kernel(SplitConvArgs a)
 
     // ---- stream two K-steps ahead of the multiplies: weights by LDS-DMA (3 instructions per wave and step), activations
     // into registers (row tid >> 1, channels 8 (tid & 1) .. + 7 of the step; two register sets, by the parity of the step)
-    const __amdgpu_buffer_rsrc_t srdU = __builtin_amdgcn_make_buffer_rsrc((void *)a.u, 0, (int)(a.N * rowU), 0x00020000);
+    __amdgpu_buffer_rsrc_t srdU = __builtin_amdgcn_make_buffer_rsrc((void *)a.u, 0, (int)(a.N * rowU), 0x00020000);
     __amdgpu_buffer_rsrc_t srdIn = __builtin_amdgcn_make_buffer_rsrc((void *)a.in, 0, 0, 0x00020000);
     const int arow = tid >> 1, ahalf = tid & 1;
     unsigned gB[3], gA = OOB;
@@ -511,7 +516,9 @@ void split_conv1x1_kernel(SplitConvArgs a)
             int m0, n0;
             tile_at(i, m0, n0);
             const int rows = tile_rows(m0);
-            srdIn = __builtin_amdgcn_make_buffer_rsrc((void *)(a.in + (long long)m0 * a.ldIn), 0, rows * a.ldIn * 4, 0x00020000);
+            const int z = tile_z(i);
+            srdIn = __builtin_amdgcn_make_buffer_rsrc((void *)(a.in + z * a.zIn + (long long)m0 * a.ldIn), 0, rows * a.ldIn * 4, 0x00020000);
+            if (a.Z > 1) srdU = __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)a.u + z * (a.N * rowU)), 0, (int)(a.N * rowU), 0x00020000);
             gA = (unsigned)(arow * a.ldIn * 4 + ahalf * 32);              // rows past M fall outside the descriptor
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
@@ -636,7 +643,7 @@ void split_conv1x1_kernel(SplitConvArgs a)
     };
 
     // ---- prologue: bias and the first two coefficient tables into LDS, steps 0 and 1 of the stream, step 0 converted
-    for (int i = tid; i < a.nbn * 256; i += 512) reinterpret_cast<float *>(dsm + kCvBias)[i] = i < a.N ? a.bias[i] : 0.f;
+    for (int i = tid; i < a.nbn * 256; i += 512) reinterpret_cast<float *>(dsm + kCvBias)[i] = (a.bias && i < a.N) ? a.bias[i] : 0.f;
     if constexpr (NORM) {
         const u32x4 t0 = load_table(0), t1 = load_table(1);
         store_table(0, t0);
@@ -791,7 +798,7 @@ void split_conv1x1_kernel(SplitConvArgs a)
         }
         // (every wave issues exactly 32 stores per tile - the vmcnt arithmetic of the next step counts them: rows past the
         //  end of the tile fall outside the descriptor, N is a multiple of 256)
-        const __amdgpu_buffer_rsrc_t srdO = __builtin_amdgcn_make_buffer_rsrc((void *)(a.out + (long long)m0 * a.ldOut), 0,
+        const __amdgpu_buffer_rsrc_t srdO = __builtin_amdgcn_make_buffer_rsrc((void *)(a.out + tile_z(ti) * a.zOut + (long long)m0 * a.ldOut), 0,
                                                                               tile_rows(m0) * a.ldOut * 4, 0x00020000);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -843,8 +850,10 @@ static int xl_run_split_conv1x1(const xl_op &op, hipStream_t st)
     const long long M = (long long)op.B * op.Ho * op.Wo;
     const int HW = op.Ho * op.Wo;
     const bool norm = (op.flags & XL_CONV_NORM_IN) != 0;
+    const int Z = op.nchunks2 > 1 ? op.nchunks2 : 1;            // Z > 1: XL_CONV_SPLIT_ACT, the batched GEMMs of a Winograd layer
+    if (Z > 1 && (op.bias || op.stats || norm || op.reserved_i < 0 || op.ld_in != op.Cin || op.ld_out != op.Cout)) return XL_ERR_ARG;
     if (op.ksize != 1 || op.stride != 1 || op.Cin % 32 != 0 || op.Cout % 256 != 0 || op.Cout > 1024 || op.ld_in < op.Cin ||
-        op.ld_out < op.Cout || (op.ld_in & 3) || (op.ld_out & 3) || !op.bias || (op.flags & XL_CONV_ACCUMULATE) || !op.in ||
+        op.ld_out < op.Cout || (op.ld_in & 3) || (op.ld_out & 3) || (!op.bias && Z == 1) || (op.flags & XL_CONV_ACCUMULATE) || !op.in ||
         !op.w || !op.out || (((uintptr_t)op.in | (uintptr_t)op.out | (uintptr_t)op.w) & 15) || M >= 0x7fffffffLL ||
         (long long)op.Cout * op.Cin * 6 >= 0x7fffffffLL || 256LL * op.ld_in * 4 >= 0x7fffffffLL || 256LL * op.ld_out * 4 >= 0x7fffffffLL)
         return XL_ERR_ARG;
@@ -861,6 +870,7 @@ static int xl_run_split_conv1x1(const xl_op &op, hipStream_t st)
     a.tpi = perImage ? (HW + 255) / 256 : 0;
     a.nbm = perImage ? op.B * a.tpi : (int)((M + 255) / 256);
     a.nbn = (op.Cout + 255) / 256;
+    a.Z = Z; a.zIn = M * op.ld_in; a.zOut = M * op.ld_out;
     const size_t lds = kCvLds;
     static XlLdsLimit configured[2];
     int cfgDev;
@@ -869,7 +879,7 @@ static int xl_run_split_conv1x1(const xl_op &op, hipStream_t st)
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return XL_ERR_HIP;
         configured[norm].done(lds, cfgDev);
     }
-    const int nwg = a.nbm * a.nbn;
+    const int nwg = a.nbm * a.nbn * Z;
     int grid = 256;
     if (grid > ((nwg + 7) & ~7)) grid = (nwg + 7) & ~7;
     if (norm) hipLaunchKernelGGL(split_conv1x1_kernel<true>, dim3(grid), dim3(512), lds, st, a);
@@ -879,7 +889,7 @@ static int xl_run_split_conv1x1(const xl_op &op, hipStream_t st)
 
 int xl_run_split_gemm(const xl_op &op, hipStream_t st)
 {
-    if ((op.flags & XL_CONV_SPLIT_IL) && op.nchunks2 <= 1) return xl_run_split_conv1x1(op, st);
+    if ((op.flags & XL_CONV_SPLIT_IL) && (op.nchunks2 <= 1 || (op.flags & XL_CONV_SPLIT_ACT))) return xl_run_split_conv1x1(op, st);
     const int T = op.B * op.Ho * op.Wo, Z = op.nchunks2;
     if (op.ksize != 1 || op.stride != 1 || Z < 1 || op.Cin % kBK != 0 || op.Cout % 4 != 0 || op.ld_in != op.Cin ||
         op.ld_out != op.Cout || op.bias || op.stats || (op.flags & XL_CONV_ACCUMULATE) || !op.in || !op.w || !op.out)

@@ -32,6 +32,7 @@ XL_OP_WINO_DY, XL_OP_WINO_WFINAL, XL_OP_GNB_FINAL = 16, 17, 18
 CONV_DGRAD, CONV_ACCUMULATE, CONV_SPLIT_BF16 = 1, 2, 64
 CONV_NORM_IN, CONV_NORM_RELU = 128, 256
 CONV_SPLIT_IL = 512
+CONV_SPLIT_ACT = 1024
 
 
 class XlOp(ctypes.Structure):
@@ -546,13 +547,17 @@ class _Plan:
         split_il = split and mode != "1" and (T + 256) * max(C * 6, cout * 4) < 2 ** 31 - 1 and C % 128 == 0 and cout % 256 == 0
         if split and not split_il:
             split = nf * T * max(C, cout) * 6 < 2 ** 31 - 1             # (the first form addresses a plane as a whole)
-        V = self.alloc(nf * T * C * 3 // 2 if split else nf * T * C)
+        # round 3: V stays fp32 in HBM (4 bytes per element instead of 6, written once and read once) and the GEMM kernel
+        # splits it on its way into LDS, like the activations of a 1x1 layer (XL_CONV_SPLIT_ACT); XL_WINO_V_SPLIT=1: the
+        # round-2 form, V written as interleaved bf16 planes by the input transform
+        split_act = split_il and cout <= 1024 and not os.environ.get("XL_WINO_V_SPLIT")
+        V = self.alloc(nf * T * C * 3 // 2 if (split and not split_act) else nf * T * C)
         op = XlOp()
         op.type = XL_OP_WINO_IN
         op.ksize = m
         op.B, op.Hi, op.Wi, op.Cin, op.Ho, op.Wo, op.ld_in = B, H, W, C, Th, Tw, ld
         op.in_, op.out = t.data_ptr() + 4 * off, V.data_ptr()
-        if split:
+        if split and not split_act:
             op.flags = CONV_SPLIT_BF16 | (CONV_SPLIT_IL if split_il else 0)
         if deferred is not None:                      # the producer's GroupNorm(+ReLU) is applied while gathering
             op.flags |= deferred.flags
@@ -565,7 +570,7 @@ class _Plan:
         op.ksize, op.stride, op.ld_in, op.ld_out, op.nchunks2 = 1, 1, C, cout, nf
         op.in_, op.w, op.out = V.data_ptr(), self.pack_conv_wino(conv, m).data_ptr(), Mb.data_ptr()
         if split:
-            op.flags = CONV_SPLIT_BF16 | (CONV_SPLIT_IL if split_il else 0)
+            op.flags = CONV_SPLIT_BF16 | (CONV_SPLIT_IL if split_il else 0) | (CONV_SPLIT_ACT if split_act else 0)
             op.w = self.pack_conv_wino_split(conv, m, split_il).data_ptr()
         if -(-T // 128) * (cout // 128) * nf <= 256:
             op.reserved_i = 64

@@ -80,6 +80,11 @@ enum {
                                   `bias` is added, XL_CONV_NORM_IN applies (Cin <= 512) and `stats` receives the GroupNorm
                                   partial sums of the output per 256-row tile (nchunks >= ceil(Ho*Wo / 256) + 1, 16 channels
                                   per group, Ho*Wo >= 256); XL_OP_GN_FINAL / XL_OP_GN_APPLY take reserved_i = 256 for them */
+#define XL_CONV_SPLIT_ACT 1024 /* with both flags above and nchunks2 = Z > 1: the Z batched GEMMs of a Winograd layer whose
+                                  activation operand V arrives as plain fp32 [Z][rows][Cin] (XL_OP_WINO_IN without the split
+                                  flags) and is split into its three bf16 terms inside the GEMM kernel on its way into LDS, like
+                                  the activations of a 1x1 layer: V costs 4 bytes per element in HBM (written once, read
+                                  once) instead of 6; only `w` is pre-split ([Z][Cout][Cin/16][3][16] bf16) */
 /* xl_op.flags for XL_OP_CONV */
 #define XL_CONV_DGRAD 1        /* data gradient: `in` is dY (Hi x Wi x Cin = forward output), result is dX; weights
                                   packed with xl_cnn_pack_conv_weight_dgrad; `stride` is the forward stride */

@@ -664,7 +664,9 @@ def test_winograd_input_transform_applies_deferred_groupnorm(relu, m):
         _run([a])
         return V.cpu()
 
-    y = x * co[:, None, None, :, 0] + co[:, None, None, :, 1]
+    # the apply is one fused multiply-add (every apply site, fused or not, rounds once): the product of two floats is exact
+    # in float64 and the sum rounds to float like fmaf does
+    y = (x.double() * co[:, None, None, :, 0].double() + co[:, None, None, :, 1].double()).float()
     if relu:
         y = torch.relu(y)
     ref = transform(y.cuda().contiguous(), None)
