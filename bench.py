@@ -137,6 +137,8 @@ def plan_work(plan, networks):
             nf = (op.ksize + 2) ** 2
             split = bool(op.flags & networks.CONV_SPLIT_BF16)
             byts += op.B * op.Hi * op.Wi * op.Cin * 4 + nf * op.B * op.Ho * op.Wo * op.Cin * (6 if split else 4)
+            if op.out2:                                          # fold: + residual read, + the materialised activation
+                byts += op.B * op.Hi * op.Wi * op.Cin * 4 * (2 if op.flags & networks.GN_ADD else 1)
         elif t == networks.XL_OP_WINO_OUT:
             nf = (op.ksize + 2) ** 2
             Th, Tw = -(-op.Hi // op.ksize), -(-op.Wi // op.ksize)

@@ -2136,11 +2136,8 @@ int run_op(const xl_op &op, hipStream_t st)
                     fold.res = (op.flags & XL_GN_ADD) ? (const float *)op.aux : nullptr;
                     fold.side = (float *)op.out2; fold.ldRes = op.ld_aux; fold.ldSide = op.ld_out;
                     fold.flags = op.flags & (XL_GN_RELU_IN | XL_GN_RELU_OUT);
+                    if (op.flags & XL_CONV_SPLIT_BF16) return XL_ERR_UNSUPPORTED;     // the fold form writes V as fp32
                     kin = wino6_in_kernel<1, 0, 1>;
-                    if (op.flags & XL_CONV_SPLIT_BF16) {
-                        if (!(op.flags & XL_CONV_SPLIT_IL)) return XL_ERR_UNSUPPORTED;
-                        kin = wino6_in_kernel<1, 2, 1>;
-                    }
                 }
                 hipLaunchKernelGGL(kin, dim3((unsigned)blocks6), dim3(256), 0, st, (const float *)op.in,
                                    (float *)op.out, op.B, op.Hi, op.Wi, op.Cin, op.ld_in, op.Ho, op.Wo,

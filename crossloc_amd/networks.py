@@ -220,6 +220,7 @@ class _Plan:
         for i in getattr(self, "deferred_gn_consumers", []):
             self.op_array[i].aux2 = self.coeff.data_ptr()
         assert not getattr(self, "pending_gn", None), "a deferred GroupNorm was never consumed"
+        assert not getattr(self, "pending_fold", None), "a folded GroupNorm apply was never consumed"
         if train:
             self._lower_backward()
 
@@ -233,8 +234,44 @@ class _Plan:
         return t
 
     def release(self, t):
-        if not self.train:                  # training keeps every forward tensor for the backward pass
-            self.free.setdefault(t.numel(), []).append(t)
+        if self.train:                      # training keeps every forward tensor for the backward pass
+            return
+        held = getattr(self, "held", {}).get(id(t))
+        if held is not None:                # an input of a GroupNorm apply that a later op performs (fold): free it then
+            held[1] = True
+            return
+        self.free.setdefault(t.numel(), []).append(t)
+
+    # -- folded GroupNorm applies (inference plans).  A GroupNorm(+ReLU, +residual, +ReLU) whose result has SEVERAL consumers
+    # - the first convolution of the next block and, later, a residual branch - used to be a pass of its own (read the raw
+    # conv output and the residual, write the activation).  With `share` the pass is left to the first consumer when that is
+    # an F(6x6,3x3) layer: its input transform reads the raw tensor and the residual anyway, applies the normalisation on load
+    # and writes the activation (to a buffer of its own) for the consumers that follow.  Same arithmetic, same bits.
+    def _fold_begin(self, ap, raw, aux):
+        t, H, W, C, ld, off = raw
+        mat = self.alloc(self.B * H * W * C)
+        res = (mat, H, W, C, C, 0)
+        if not hasattr(self, "pending_fold"):
+            self.pending_fold, self.held = {}, {}
+        tensors = [raw[0]] + ([aux[0]] if aux is not None else [])
+        for x in tensors:
+            self.held[id(x)] = [x, x is raw[0]]           # the raw conv output has no other owner: released with the fold
+        self.pending_fold[self._act_key(res)] = dict(ap=ap, raw=raw, tensors=tensors)
+        return res
+
+    def _fold_end(self, fold):
+        for x in fold["tensors"]:
+            entry = self.held.pop(id(x))
+            if entry[1]:
+                self.release(x)
+
+    def _fold_materialise(self, fold, act):
+        """The first consumer cannot apply it on load: run the GroupNorm apply as a pass (raw -> the activation's buffer)."""
+        ap = fold["ap"]
+        ap.out, ap.ld_out = act[0].data_ptr() + 4 * act[5], act[4]
+        self.stats_ops.append(len(self.ops))
+        self.ops.append(ap)
+        self._fold_end(fold)
 
     def release_grad(self, t):
         self.free.setdefault(t.numel(), []).append(t)
@@ -530,7 +567,22 @@ class _Plan:
             return 2 if not (H % 2 or W % 2) and self.B * (H // 2) * (W // 2) * max(C, conv.out_channels) * 4 < 2 ** 31 - 1 else 0
         return self.wino_pick(H, W, max(C, conv.out_channels))
 
-    def conv_wino(self, act, conv, norm, flags, aux, m, deferred=None, defer=False):
+    def wino_gemm_form(self, C, cout, m, T):
+        """(split, split_il, split_act) of the GEMMs of an F(m x m,3x3) layer with T tiles.  XL_GEMM_SPLIT_BF16: "il" =
+        interleaved planes + 256 x 256 persistent kernels, "1" = separate planes + 128 x 128 register-staged kernel (the
+        first form), "0" = fp32 MFMA.  split_act (round 3): V stays fp32 in HBM (4 bytes per element instead of 6, written
+        once and read once) and the GEMM kernel splits it on its way into LDS, like the activations of a 1x1 layer
+        (XL_CONV_SPLIT_ACT); XL_WINO_V_SPLIT=1: the round-2 form, V written as interleaved bf16 planes by the input transform."""
+        nf = (m + 2) ** 2
+        mode = os.environ.get("XL_GEMM_SPLIT_BF16", self.SPLIT_DEFAULT)
+        split = (m == 6 and not self.train and mode not in ("", "0") and C % 32 == 0)
+        split_il = split and mode != "1" and (T + 256) * max(C * 6, cout * 4) < 2 ** 31 - 1 and C % 128 == 0 and cout % 256 == 0
+        if split and not split_il:
+            split = nf * T * max(C, cout) * 6 < 2 ** 31 - 1             # (the first form addresses a plane as a whole)
+        split_act = split_il and cout <= 1024 and not os.environ.get("XL_WINO_V_SPLIT")
+        return split, split_il, split_act
+
+    def conv_wino(self, act, conv, norm, flags, aux, m, deferred=None, defer=False, fold=None, share=False):
         """conv3x3 + GroupNorm(+epilogue) as F(m x m, 3x3): input transform, (m+2)^2 GEMMs in one batched launch, output
         transform that also emits the GroupNorm partial sums, GN_FINAL, GN_APPLY (in place)."""
         t, H, W, C, ld, off = act
@@ -542,15 +594,8 @@ class _Plan:
         # the GEMMs on the bf16 matrix pipe with every fp32 operand split into three bf16 terms (fp32-accurate).
         # XL_GEMM_SPLIT_BF16: "il" = interleaved planes + 256 x 256 persistent kernel, "1" = separate planes + 128 x 128
         # register-staged kernel (the first form), "0" = fp32 MFMA
-        mode = os.environ.get("XL_GEMM_SPLIT_BF16", self.SPLIT_DEFAULT)
-        split = (m == 6 and not self.train and mode not in ("", "0") and C % 32 == 0)
-        split_il = split and mode != "1" and (T + 256) * max(C * 6, cout * 4) < 2 ** 31 - 1 and C % 128 == 0 and cout % 256 == 0
-        if split and not split_il:
-            split = nf * T * max(C, cout) * 6 < 2 ** 31 - 1             # (the first form addresses a plane as a whole)
-        # round 3: V stays fp32 in HBM (4 bytes per element instead of 6, written once and read once) and the GEMM kernel
-        # splits it on its way into LDS, like the activations of a 1x1 layer (XL_CONV_SPLIT_ACT); XL_WINO_V_SPLIT=1: the
-        # round-2 form, V written as interleaved bf16 planes by the input transform
-        split_act = split_il and cout <= 1024 and not os.environ.get("XL_WINO_V_SPLIT")
+        split, split_il, split_act = self.wino_gemm_form(C, cout, m, T)
+        assert fold is None or not split or split_act
         V = self.alloc(nf * T * C * 3 // 2 if (split and not split_act) else nf * T * C)
         op = XlOp()
         op.type = XL_OP_WINO_IN
@@ -562,7 +607,17 @@ class _Plan:
         if deferred is not None:                      # the producer's GroupNorm(+ReLU) is applied while gathering
             op.flags |= deferred.flags
             self.deferred_gn_consumers = getattr(self, "deferred_gn_consumers", []) + [len(self.ops)]
+        if fold is not None:                          # ... and, fold: the activation `act` is written by this transform
+            fap, raw = fold["ap"], fold["raw"]
+            op.in_, op.ld_in = raw[0].data_ptr() + 4 * raw[5], raw[4]
+            op.flags |= fap.flags & (GN_RELU_IN | GN_ADD | GN_RELU_OUT)
+            op.out2, op.ld_out = t.data_ptr() + 4 * off, ld
+            if fap.flags & GN_ADD:
+                op.aux, op.ld_aux = fap.aux, fap.ld_aux
+            self.deferred_gn_consumers = getattr(self, "deferred_gn_consumers", []) + [len(self.ops)]
         self.ops.append(op)
+        if fold is not None:
+            self._fold_end(fold)
         Mb = self.alloc(nf * T * cout)
         op = XlOp()
         op.type = XL_OP_CONV
@@ -636,22 +691,34 @@ class _Plan:
                 self.pending_gn = {}
             self.pending_gn[self._act_key(y)] = ap
             return y
+        if share and self.fold_ok():
+            return self._fold_begin(ap, y, aux)
         self.stats_ops.append(len(self.ops))
         self.ops.append(ap)
         return y
 
-    def cgr(self, act, conv, norm, flags=GN_RELU_IN, aux=None, defer=False):
+    def fold_ok(self):
+        return not self.train and not os.environ.get("XL_NO_DEFERRED_GN") and not os.environ.get("XL_NO_FOLD_GN")
+
+    def cgr(self, act, conv, norm, flags=GN_RELU_IN, aux=None, defer=False, share=False):
         """conv -> GroupNorm -> epilogue.  `defer`: the caller promises that the next cgr() is the only consumer of the
         result; when that consumer is an F(4x4,3x3) layer its input transform applies the normalisation and the separate
         GN_APPLY pass (one read + one write of the activation) disappears."""
         pend = getattr(self, "pending_gn", {}).pop(self._act_key(act), None)
+        fold = getattr(self, "pending_fold", {}).pop(self._act_key(act), None)
         m = self.wino_tile(act, conv)
         if pend is not None and m not in (4, 6) and not self.norm_on_load_ok(act, conv):
             self.stats_ops.append(len(self.ops))       # consumer cannot absorb it: materialise now
             self.ops.append(pend)
             pend = None
+        if fold is not None:
+            # the fold form of the input transform writes V as fp32 (F(6x6,3x3) layers whose GEMMs read fp32 activations)
+            sp, _, sp_act = self.wino_gemm_form(act[3], conv.out_channels, m, self.B * -(-act[1] // 6) * -(-act[2] // 6)) if m == 6 else (0, 0, 0)
+            if m != 6 or (sp and not sp_act):
+                self._fold_materialise(fold, act)
+                fold = None
         if m:
-            return self.conv_wino(act, conv, norm, flags, aux, m, pend, defer=defer)
+            return self.conv_wino(act, conv, norm, flags, aux, m, pend, defer=defer, fold=fold, share=share)
         cpg = conv.out_channels // norm.num_groups
         split = (self.split_1x1_ok(act, conv) and (cpg == 16 or self.separate_stats)
                  and (pend is None or act[3] <= 512))
@@ -663,7 +730,7 @@ class _Plan:
             # inference: the conv epilogue produces the GroupNorm statistics, the separate stats pass is dropped
             return self.gn_fused(y, norm, flags, aux, len(self.ops) - 1,
                                  defer=defer and flags == GN_RELU_IN and aux is None
-                                 and not os.environ.get("XL_NO_DEFERRED_GN"))
+                                 and not os.environ.get("XL_NO_DEFERRED_GN"), share=share)
         if (self.train and y[1] * y[2] >= 128 and whole_groups and not self.separate_stats
                 and self.ops[-1].type == XL_OP_CONV):
             # training: same epilogue statistics, written to a buffer of the layer's own (they are inputs of the
@@ -685,7 +752,7 @@ class _Plan:
     def _act_key(act):
         return (act[0].data_ptr(), act[5], act[3])
 
-    def gn_fused(self, act, norm, flags, aux, conv_index, out=None, defer=False):
+    def gn_fused(self, act, norm, flags, aux, conv_index, out=None, defer=False, share=False):
         """GroupNorm apply (in place) consuming statistics emitted by the epilogue of the conv op `conv_index`."""
         t, H, W, C, ld, off = act
         G, HW = norm.num_groups, H * W
@@ -718,6 +785,8 @@ class _Plan:
                 self.pending_gn = {}
             self.pending_gn[self._act_key(res)] = ap
             return res
+        if share and out is None and self.fold_ok():
+            return self._fold_begin(ap, act, aux)
         self.stats_ops.append(len(self.ops))
         self.ops.append(ap)
         return res
@@ -746,7 +815,7 @@ class _Plan:
         x = self.cgr(res, block[0], block[1], defer=True)
         x2 = self.cgr(x, block[3], block[4], defer=True)
         self.release(x[0])
-        x3 = self.cgr(x2, block[6], block[7], GN_RELU_IN | GN_ADD | GN_RELU_OUT, aux=res)
+        x3 = self.cgr(x2, block[6], block[7], GN_RELU_IN | GN_ADD | GN_RELU_OUT, aux=res, share=True)
         self.release(x2[0])
         self.release(res[0])
         return x3
@@ -824,10 +893,10 @@ class _Plan:
     def _encoder_tail(self, enc, x, out=None):
         x2 = self.cgr(x, enc.conv2, enc.norm2); self.release(x[0])
         x3 = self.cgr(x2, enc.conv3, enc.norm3); self.release(x2[0])
-        res = self.cgr(x3, enc.conv4, enc.norm4); self.release(x3[0])
+        res = self.cgr(x3, enc.conv4, enc.norm4, share=True); self.release(x3[0])
         a = self.cgr(res, enc.res1_conv1, enc.res1_norm1, defer=True)
         b = self.cgr(a, enc.res1_conv2, enc.res1_norm2, defer=True); self.release(a[0])
-        c = self.cgr(b, enc.res1_conv3, enc.res1_norm3, GN_RELU_IN | GN_ADD | GN_RELU_OUT, aux=res)
+        c = self.cgr(b, enc.res1_conv3, enc.res1_norm3, GN_RELU_IN | GN_ADD | GN_RELU_OUT, aux=res, share=True)
         self.release(b[0]); self.release(res[0])
         res = c
         a = self.cgr(res, enc.res2_conv1, enc.res2_norm1, defer=True)
@@ -837,7 +906,7 @@ class _Plan:
         last_out = out if n_add == 0 else None
         if last_out is None:                        # conv -> GroupNorm with the statistics out of the conv epilogue
             skip_in = res
-            res = self.cgr(skip_in, enc.res2_skip, enc.res2_skip_norm, GN_ADD | GN_RELU_OUT, aux=c)
+            res = self.cgr(skip_in, enc.res2_skip, enc.res2_skip_norm, GN_ADD | GN_RELU_OUT, aux=c, share=True)
             self.release(skip_in[0]); self.release(c[0])
         else:
             sk = self.conv(res, enc.res2_skip)
@@ -879,7 +948,7 @@ class _Plan:
             f = net.mlr_forward
             a = self.cgr(mlr, f[0], f[1], defer=True); self.release(cat)
             b = self.cgr(a, f[3], f[4], defer=True); self.release(a[0])
-            res = self.cgr(b, f[6], f[7], GN_RELU_IN | GN_ADD | GN_RELU_OUT, aux=sk)
+            res = self.cgr(b, f[6], f[7], GN_RELU_IN | GN_ADD | GN_RELU_OUT, aux=sk, share=True)
             self.release(b[0]); self.release(sk[0])
         for block in dec.dec_add_res_block_ls:
             res = self.res_block(res, block)

@@ -746,3 +746,39 @@ def test_winograd_weight_gradient_vs_autograd(m, cin, cout, B, H, W):
     f.in_, f.out = dU.data_ptr(), dw.data_ptr()
     _run([a, d, wg, f])
     _close(dw.cpu().double(), ref, 1e-4)
+
+
+def test_folded_groupnorm_apply_is_bitwise_the_separate_pass(monkeypatch):
+    """Inference plans leave the GroupNorm(+ReLU, +residual, +ReLU) apply of a block's last layer to the F(6x6,3x3) input
+    transform of the next block, which also writes the activation for the residual branch (XL_OP_WINO_IN with out2).  Same
+    arithmetic in the same order as gn_apply_kernel: the network output must not change by a bit."""
+    net = networks.TransPoseNet(MEAN, False, False, 2, 2, 3, 1)
+    net.load_state_dict(seeded_state_dict(net, seed=9))
+    net = net.cuda().eval()
+    x = torch.rand(3, 3, 192, 288, generator=torch.Generator().manual_seed(8)).cuda()    # 24 x 36 grid: 6 divides both
+    with torch.no_grad():
+        y = net(x)
+    plan = list(net._plans.values())[0]
+    folds = [op for op in plan.ops if op.type == networks.XL_OP_WINO_IN and op.out2]
+    assert len(folds) >= 5, len(folds)                 # conv4, res1, res2 skip, and the blocks that feed another block
+    assert any(op.flags & networks.GN_ADD for op in folds) and any(not (op.flags & networks.GN_ADD) for op in folds)
+    n_apply = sum(op.type == networks.XL_OP_GN_APPLY for op in plan.ops)
+    monkeypatch.setenv("XL_NO_FOLD_GN", "1")
+    net.invalidate()
+    with torch.no_grad():
+        y0 = net(x)
+    plan0 = list(net._plans.values())[0]
+    assert not any(op.type == networks.XL_OP_WINO_IN and op.out2 for op in plan0.ops)
+    assert sum(op.type == networks.XL_OP_GN_APPLY for op in plan0.ops) == n_apply + len(folds)
+    assert torch.equal(y, y0)
+    # ragged 6x6 tiles (a 16 x 24 grid): the owner of a pixel is the tile whose footprint holds it, also at the edges
+    monkeypatch.delenv("XL_NO_FOLD_GN")
+    net.invalidate()
+    x2 = torch.rand(2, 3, 128, 192, generator=torch.Generator().manual_seed(9)).cuda()
+    with torch.no_grad():
+        ya = net(x2)
+    monkeypatch.setenv("XL_NO_FOLD_GN", "1")
+    net.invalidate()
+    with torch.no_grad():
+        yb = net(x2)
+    assert torch.equal(ya, yb)
