@@ -640,7 +640,20 @@ def secondary_configs(dev, n_hyp, train_batch=16, mlr_batch=24, steps=5):
     out["train16_fwd_bwd_algorithmic_tflops"] = round(885.64 * B / ms, 1)     # 885.64 GFLOP per image
     sd = {k: v.detach().clone().requires_grad_(v.dtype.is_floating_point and not k.endswith("mean"))
           for k, v in net.state_dict().items()}
-    del net
+    # the training step as the reference runs it (train_single_task.py:298-300, utils/learning.py:390-396): forward + MLE
+    # coordinate loss + backward + optimizer.step() (fused Adam, one launch), and - because the weights changed - the re-pack
+    # of every convolution operand before the next forward (Winograd transforms in float64 + the bf16 splits: HIP kernels,
+    # csrc/xl_pack.hip).  Consecutive steps, so each timed step contains one of everything.
+    from crossloc_amd import optim as xl_optim
+    opt = xl_optim.Adam(net.parameters(), lr=1e-4)
+
+    def full_step():
+        loss, _ = xl_optim.train_step(net, opt, images, poses_t, gt_t, grid, cam)
+        return loss
+    fms, floss = timed(full_step)
+    out["train16_full_step_ms"] = round(fms, 2)
+    out["train16_full_step_loss_after_%d_steps" % (steps + 2)] = round(float(floss.item()), 4)
+    del net, opt
     torch.cuda.empty_cache()
 
     def eager_step():

@@ -34,6 +34,7 @@
 
 int xl_run_bwd_op(const xl_op &op, hipStream_t st);   // xl_cnn_bwd.hip
 int xl_run_split_gemm(const xl_op &op, hipStream_t st);   // xl_gemm_split.hip
+int xl_run_split_stem(const xl_op &op, hipStream_t st);   // xl_stem_split.hip
 
 namespace {
 
@@ -243,7 +244,11 @@ void conv1_mfma_kernel(const float *__restrict__ in, const c1_u32x4 *__restrict_
                        int H, int W, int tilesX, int relu)
 {
     constexpr int CO = 32;
-    constexpr int kSm = PASS == 0 ? (kC1Halo > 256 * 32 * 4 ? kC1Halo : 256 * 32 * 4) : kC1Halo + 4 * 32 * kC1Pitch * 4;
+    // PASS 0: statistics only; 1: conv * scale + shift (+ReLU) written; 2 (round 3): the RAW convolution written AND its
+    // statistics, one evaluation - the consumer (conv2 on the split pipe) applies the GroupNorm while it loads its operand
+    constexpr bool kStats = PASS != 1, kWrite = PASS != 0;
+    constexpr int kSmW = kC1Halo + 4 * 32 * kC1Pitch * 4, kSmS = kC1Halo > 256 * 32 * 4 ? kC1Halo : 256 * 32 * 4;
+    constexpr int kSm = !kWrite ? kSmS : (kStats && kSmS > kSmW ? kSmS : kSmW);
     __shared__ __attribute__((aligned(16))) unsigned char smem[kSm];
     const int n = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int ty = blockIdx.x / tilesX, tx = blockIdx.x - ty * tilesX;
@@ -311,7 +316,7 @@ void conv1_mfma_kernel(const float *__restrict__ in, const c1_u32x4 *__restrict_
             for (int dy = 0; dy < 3; ++dy)
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[PW[t]][dy], pf[PP[t]][dy], acc, 0, 0, 0);
         const int y = y0 + ly, xb = x0 + (blk & 1) * 32;               // first pixel of the block
-        if (PASS == 0) {
+        if (kStats) {
             const bool live = (y < H) & (xb + px < W);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -319,7 +324,8 @@ void conv1_mfma_kernel(const float *__restrict__ in, const c1_u32x4 *__restrict_
                 s[r] += a;
                 q[r] = fmaf(a, a, q[r]);
             }
-        } else {
+        }
+        if (kWrite) {
             // the block is one contiguous 4 KB span of the NHWC output: transposed through a wave-private LDS area so that
             // every store instruction writes 1 KB of consecutive addresses
             float *row = reinterpret_cast<float *>(smem + kC1Halo) + wv * (32 * kC1Pitch);
@@ -328,8 +334,11 @@ void conv1_mfma_kernel(const float *__restrict__ in, const c1_u32x4 *__restrict_
                 f32x4 v;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float t = acc[4 * g + e] * sc[4 * g + e] + sh[4 * g + e];
-                    if (relu) t = fmaxf(t, 0.f);
+                    float t = acc[4 * g + e];
+                    if (PASS == 1) {
+                        t = t * sc[4 * g + e] + sh[4 * g + e];
+                        if (relu) t = fmaxf(t, 0.f);
+                    }
                     v[e] = t;
                 }
                 *reinterpret_cast<f32x4 *>(row + px * kC1Pitch + 8 * g + 4 * kh) = v;
@@ -350,7 +359,7 @@ void conv1_mfma_kernel(const float *__restrict__ in, const c1_u32x4 *__restrict_
             __builtin_amdgcn_wave_barrier();
         }
     }
-    if (PASS == 0) {
+    if (kStats) {
         // per-lane fp32 partials (8 pixels each) -> fp64 over the 128 lanes that hold a channel, fixed order
         float *sRed = reinterpret_cast<float *>(smem);
         __syncthreads();                                             // every wave is done with the halo
@@ -1493,6 +1502,119 @@ void wino6_out_kernel(const float *__restrict__ M, const float *__restrict__ bia
     }
 }
 
+// F(6x6,3x3) output transform with the product M staged through LDS by DMA (round 3).  The register form above keeps one
+// column of the 8 x 8 frequency block in flight per lane (8 loads of 8 bytes): ~32 KB per CU, and the pass runs at 4.8 TB/s.
+// Here every WAVE is an independent unit - one (image, chunk of `tpb` tiles, 128-channel slice) - that owns a 32 KB ring
+// in LDS: the 8 columns of a tile's frequency block, 8 planes x 512 bytes each, fetched by `buffer_load ... lds` (4
+// instructions per column: lanes 0-31 one plane, lanes 32-63 the next), the column of the NEXT tile refilling a slot as
+// soon as the current one has been reduced: 28-32 KB in flight per wave whatever the register pressure.  A lane reads its two
+// channels of a plane with one ds_read_b64 (consecutive lanes, consecutive words).  In-order vmcnt bookkeeping: younger
+// than the column being waited for are the other 7 columns (28 instructions) and, from the second tile on, the 36 stores
+// of the tile before - every tile issues exactly 36, out-of-image pixels fall outside the buffer descriptor.
+// GroupNorm partial sums: fp64 butterfly over the lanes of a group, one writer per (image, chunk, group).
+__global__ __launch_bounds__(256, 1)
+void wino6_out_dma_kernel(const float *__restrict__ M, const float *__restrict__ bias, float *__restrict__ out,
+                          double *__restrict__ stats, int B, int H, int W, int C, int ldOut, int Th, int Tw, int tpb,
+                          int G, int nchunks, long long units)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char dsmW[];
+    typedef __attribute__((address_space(3))) void lds_void;
+    constexpr unsigned OOB = 0x80000000u;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long long unit = (long long)blockIdx.x * 4 + wave;            // (image, chunk, slice), slice fastest
+    if (unit >= units) return;
+    const int nsl = C >> 7;
+    const int slice = (int)(unit % nsl);
+    const int k = (int)((unit / nsl) % nchunks);
+    const int n = (int)(unit / ((long long)nsl * nchunks));
+    unsigned char *ring = dsmW + wave * 32768;
+    const int Timg = Th * Tw;
+    const long long T = (long long)B * Timg;
+    const unsigned zsB = (unsigned)(T * C * 4);                          // bytes per frequency plane (host: 64 planes < 4 GiB)
+    const int t0 = k * tpb;
+    int t1 = t0 + tpb; if (t1 > Timg) t1 = Timg;
+    const int cch = slice * 128 + 2 * lane;                              // first of this lane's two channels
+    const __amdgpu_buffer_rsrc_t srdM = __builtin_amdgcn_make_buffer_rsrc((void *)M, 0, (int)(unsigned)(64ull * zsB), 0x00020000);
+    // lane part of a DMA address: plane parity (lane >> 5) -> +8 planes... see dma_col: planes 8 (2h + (lane >> 5)) + j
+    const unsigned laneOff = (unsigned)(lane >> 5) * 8u * zsB + (unsigned)(lane & 31) * 16u + (unsigned)slice * 512u;
+    auto dma_col = [&](int tl, int j) {                                  // column j of tile tl (of this image) -> ring slot j
+        const unsigned vo = tl < t1 ? (unsigned)(((long long)n * Timg + tl) * C * 4) + laneOff : OOB;
+#pragma unroll
+        for (int h = 0; h < 4; ++h)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srdM, (lds_void *)(ring + j * 4096 + h * 1024), 16, (int)vo,
+                                                     (int)((unsigned)(16 * h + j) * zsB), 0, 0);
+    };
+    f32x2 bv = f32x2{ 0.f, 0.f };
+    if (bias) bv = *reinterpret_cast<const f32x2 *>(bias + cch);
+    f32x2 s1 = f32x2{ 0.f, 0.f }, s2 = f32x2{ 0.f, 0.f };
+    constexpr float AT[8][6] = { { 1.f, 0.f, 0.f, 0.f, 0.f, 0.f }, { 1.f, 1.f, 1.f, 1.f, 1.f, 1.f },
+                                 { 1.f, -1.f, 1.f, -1.f, 1.f, -1.f }, { 1.f, 2.f, 4.f, 8.f, 16.f, 32.f },
+                                 { 1.f, -2.f, 4.f, -8.f, 16.f, -32.f }, { 32.f, 16.f, 8.f, 4.f, 2.f, 1.f },
+                                 { 32.f, -16.f, 8.f, -4.f, 2.f, -1.f }, { 0.f, 0.f, 0.f, 0.f, 0.f, 1.f } };
+    const long long outBytes = ((long long)B * H * W - 1) * ldOut * 4 + (long long)C * 4;
+    const __amdgpu_buffer_rsrc_t srdO = __builtin_amdgcn_make_buffer_rsrc((void *)out, 0, (int)(unsigned)outBytes, 0x00020000);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dma_col(t0, j);
+    for (int tl = t0; tl < t1; ++tl) {
+        const int ty = tl / Tw, tx = tl - ty * Tw;
+        f32x2 y[6][6];
+#pragma unroll
+        for (int pI = 0; pI < 6; ++pI)
+#pragma unroll
+            for (int qI = 0; qI < 6; ++qI) y[pI][qI] = bv;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            // column j has landed when at most the 28 column fetches behind it (+ the 36 stores of the tile before) remain
+            if (tl == t0) __builtin_amdgcn_s_waitcnt(0x0F70 | (28 & 15) | ((28 >> 4) << 14));
+            else __builtin_amdgcn_s_waitcnt(0x0F70 | (63 & 15) | ((63 >> 4) << 14));
+            __builtin_amdgcn_sched_barrier(0);
+            f32x2 col[8], o[6];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) col[i] = *reinterpret_cast<const f32x2 *>(ring + j * 4096 + i * 512 + lane * 8);
+            wino6_at(col, o);
+#pragma unroll
+            for (int pI = 0; pI < 6; ++pI)
+#pragma unroll
+                for (int qI = 0; qI < 6; ++qI)
+                    if (AT[j][qI] != 0.f) y[pI][qI] += AT[j][qI] * o[pI];
+            // (the reads above have returned - their values were consumed - before the slot is refilled)
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_waitcnt(0xC07F);                          // lgkmcnt(0)
+            dma_col(tl + 1, j);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int pI = 0; pI < 6; ++pI) {
+            const int oy = 6 * ty + pI;
+#pragma unroll
+            for (int qI = 0; qI < 6; ++qI) {
+                const int ox = 6 * tx + qI;
+                const bool live = (oy < H) & (ox < W);
+                const f32x2 v = y[pI][qI];
+                const unsigned off = live ? (unsigned)(((((long long)n * H + oy) * W + ox) * ldOut + cch) * 4) : OOB;
+                typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), srdO, (int)off, 0, 0);
+                if (live) { s1 += v; s2 += v * v; }
+            }
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);                                  // vmcnt(0): the dummy fetches behind the last tile
+    if (!stats) return;
+    const int cpg = C / G, lpg = cpg >> 1;                               // lanes per group (host: a power of two, 1 .. 64)
+    double a = (double)s1[0] + (double)s1[1], b = (double)s2[0] + (double)s2[1];
+    if (lpg == 0) {                                                      // one channel per group (never with 32 groups of >= 128 channels)
+        double *o = stats + (((long long)n * nchunks + k) * G + cch) * 2;
+        o[0] = (double)s1[0]; o[1] = (double)s2[0]; o[2] = (double)s1[1]; o[3] = (double)s2[1];
+        return;
+    }
+    for (int off = 1; off < lpg; off <<= 1) { a += __shfl_xor(a, off, 64); b += __shfl_xor(b, off, 64); }
+    if ((lane & (lpg - 1)) == 0) {
+        double *o = stats + (((long long)n * nchunks + k) * G + cch / cpg) * 2;
+        o[0] = a; o[1] = b;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- GroupNorm
 
 // grid (nchunks, B); T threads with T % (C/4) == 0.  stats[((n*nchunks + chunk)*G + g)*2 + {0,1}] = sum, sumsq
@@ -2040,6 +2162,7 @@ int run_conv(const xl_op &op, hipStream_t st)
         return wide ? XL_FWD(3, 1, 128, 0, 128) : XL_FWD(3, 1, 64, 0, 128);
     }
     if (op.ksize == 3 && op.stride == 2) {
+        if (op.flags & XL_CONV_SPLIT_BF16) return xl_run_split_stem(op, st);
         if (small) return wide ? XL_FWD(3, 2, 128, 0, 64) : XL_FWD(3, 2, 64, 0, 64);
         return wide ? XL_FWD(3, 2, 128, 0, 128) : XL_FWD(3, 2, 64, 0, 128);
     }
@@ -2077,7 +2200,11 @@ int run_op(const xl_op &op, hipStream_t st)
                     // fragments [3 planes][3 rows of the window][64 lanes][8] bf16 (crossloc_amd/networks.py, pack_conv1_split)
                     const int tilesX = (op.Wi + kC1TW - 1) / kC1TW, tilesY = (op.Hi + kC1TH - 1) / kC1TH;
                     if (op.nchunks != tilesX * tilesY || (op.stats && op.groups != 32)) return XL_ERR_ARG;
-                    if (op.stats)
+                    if (op.stats && op.out)
+                        hipLaunchKernelGGL(conv1_mfma_kernel<2>, dim3(op.nchunks, op.B), dim3(256), 0, st, (const float *)op.in,
+                                           (const c1_u32x4 *)op.w, (const float *)op.bias, (const float *)nullptr, (float *)op.out,
+                                           (double *)op.stats, op.Hi, op.Wi, tilesX, 0);
+                    else if (op.stats)
                         hipLaunchKernelGGL(conv1_mfma_kernel<0>, dim3(op.nchunks, op.B), dim3(256), 0, st, (const float *)op.in,
                                            (const c1_u32x4 *)op.w, (const float *)op.bias, (const float *)nullptr, (float *)nullptr,
                                            (double *)op.stats, op.Hi, op.Wi, tilesX, 0);
@@ -2178,6 +2305,25 @@ int run_op(const xl_op &op, hipStream_t st)
                 if (op.stats && (op.groups < 1 || op.Cin % op.groups != 0 || CB % (op.Cin / op.groups) != 0 ||
                                  CB / (op.Cin / op.groups) > 256))
                     return XL_ERR_ARG;
+                // round 3: M staged through LDS by DMA, one wave per (image, chunk, 128-channel slice)
+                static const bool noDma = getenv("XL_WINO_OUT_NO_DMA") != nullptr;
+                const int cpg6 = op.groups > 0 ? op.Cin / op.groups : 2;
+                const long long outB = ((long long)op.B * op.Hi * op.Wi - 1) * op.ld_out * 4 + (long long)op.Cin * 4;
+                if (!noDma && !(op.flags & XL_CONV_ACCUMULATE) && op.Cin % 128 == 0 && 64LL * op.B * Th6 * Tw6 * op.Cin * 4 < 0x7fffffffLL &&
+                    outB < 0x7fffffffLL && (!op.stats || (cpg6 >= 2 && cpg6 <= 128 && (cpg6 & (cpg6 - 1)) == 0 && op.Cin % op.groups == 0))) {
+                    static XlLdsLimit configuredDma;
+                    int cfgDev;
+                    if (configuredDma.needs(131072, &cfgDev)) {
+                        if (hipFuncSetAttribute(reinterpret_cast<const void *>(wino6_out_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                131072) != hipSuccess) return XL_ERR_HIP;
+                        configuredDma.done(131072, cfgDev);
+                    }
+                    const long long units = (long long)op.B * op.nchunks * (op.Cin / 128);
+                    hipLaunchKernelGGL(wino6_out_dma_kernel, dim3((unsigned)((units + 3) / 4)), dim3(256), 131072, st, (const float *)op.in,
+                                       (const float *)op.bias, (float *)op.out, (double *)op.stats, op.B, op.Hi, op.Wi, op.Cin,
+                                       op.ld_out, Th6, Tw6, op.reserved_i, op.groups, op.nchunks, units);
+                    return XL_OK;
+                }
                 hipLaunchKernelGGL(two ? wino6_out_kernel<2> : wino6_out_kernel<1>, dim3(op.nchunks, op.B, op.Cin / CB), dim3(256), 0, st, (const float *)op.in,
                                    (const float *)op.bias, (float *)op.out, (double *)op.stats, op.B, op.Hi, op.Wi, op.Cin,
                                    op.ld_out, Th6, Tw6, op.reserved_i, op.groups, op.nchunks,

@@ -1,0 +1,428 @@
+// crossloc_hip: the stride-2 3x3 stem convolutions (conv2 32->64, conv3 64->128, conv4 128->256; networks.py:191-201 of
+// the reference) of inference plans on the bf16 matrix pipe, fp32-accurate (operands as exact sums of three bf16 terms, six
+// term pairs, fp32 accumulation - csrc/xl_gemm_split.hip explains the arithmetic).
+//
+//   out[m][n] = bias[n] + sum_{tap, c} f(in[pix(m, tap)][c]) * W[n][tap][c]        m = output pixel (B*Ho*Wo of them, NHWC)
+//
+// f = the producer's deferred GroupNorm + ReLU (per-(image, channel) {scale, shift}, applied to in-image pixels only: the
+// zero padding of the convolution stays zero) or the identity.  The loop is split_conv1x1_kernel's: persistent workgroups
+// walk tiles of 256 (128) output pixels x all Cout channels; the weights - split once per plan, interleaved
+// planes [Cout][9 Cin / 16][3][16] bf16, K ordered tap-major - stream by LDS-DMA through a ring of three stages, two K-steps
+// ahead of the multiplies; the activations arrive as fp32: every thread gathers 8 channels of ONE source pixel of its row
+// (row = tid >> 1; the pixel moves with the tap: (2 oy + dy - 1, 2 ox + dx - 1), out of the image -> an out-of-range buffer
+// offset, which reads as zero), two K-steps ahead, and normalises, splits and writes them into the activation stage of the
+// next K-step under the MFMAs of the current one.  A K-step = 16 channels of one tap = one k-depth of
+// v_mfma_f32_32x32x16_bf16.  Workgroups: Cout 256: 8 waves (2 x 4 of 128 x 64) on tiles of 256 pixels, one per CU;
+// Cout 128: 4 waves (2 x 2 of 64 x 64) on tiles of 128 pixels, two per CU; Cout 64: 4 waves (4 x 1 of 32 x 64) on tiles of 128
+// pixels, three per CU - a K-step of the narrow layers has few MFMAs per wave (24 / 12) under the same fixed costs
+// (conversion, LDS traffic, the barrier), so several independent workgroups per CU fill each other's gaps.
+// The weight stage of a K-step is Cout x 96 bytes = 24 / 12 / 6 DMA instructions: waves 0 .. Cout/32 - 1 issue three each,
+// and the counted vmcnt waits differ between the waves that stream weights and those that do not (a wave-uniform branch).
+// The GroupNorm statistics of the output are NOT produced here (XL_OP_GN_STATS follows: one read of the output tensor).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <type_traits>
+
+#include "../../include/crossloc_cnn.h"
+#include "../../include/crossloc_dsac.h"   // status codes
+#include "xl_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kUnit = 96;                               // bytes per row and K-step: 3 planes x 16 bf16
+
+__device__ __forceinline__ unsigned pk_bf16(float x, float y)        // {bf16(x), bf16(y)} round to nearest even
+{
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{ x, y }, bf16x2));
+}
+__device__ __forceinline__ float hi_f(unsigned w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
+__device__ __forceinline__ float lo_f(unsigned w) { return __builtin_bit_cast(float, w << 16); }
+__device__ __forceinline__ void split_pair(float x, float y, unsigned &w1, unsigned &w2, unsigned &w3)
+{
+    w1 = pk_bf16(x, y);
+    const float rx = x - lo_f(w1), ry = y - hi_f(w1);
+    w2 = pk_bf16(rx, ry);
+    w3 = pk_bf16(rx - lo_f(w2), ry - hi_f(w2));
+}
+
+struct StemArgs {
+    const float *in; const uint16_t *u; const float *bias; float *out;
+    const float *coef; float normLo;                 // NORM: [B][Cin][2] {scale, shift}; lower clamp (0 = ReLU, -inf = none)
+    int B, Hi, Wi, Cin, Ho, Wo, ldIn, ldOut, M, nbm;
+};
+
+template <int NT, bool NORM, int NW>                                  // Cout; normalise on load; waves per workgroup
+__global__ __launch_bounds__(64 * NW, (NT == 64 ? 3 : 2))           // waves per SIMD: 3 workgroups of 4 waves per CU / 2 of 4 / 1 of 8
+void split_conv3x3s2_kernel(StemArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+    typedef __attribute__((address_space(3))) void lds_void;
+    constexpr int NTH = 64 * NW, BM = NTH / 2;                        // threads; rows per tile (a thread = 8 channels of one row)
+    constexpr int kAStage = BM * kUnit;                               // one activation stage
+    constexpr int WN = NT / 64, WM = NW / WN, RI = BM / WM / 32;      // waves across columns / rows; 32-row blocks per wave
+    static_assert(WN * WM == NW && RI >= 1 && RI * WM * 32 == BM, "tile shape");
+    constexpr int kW = NT * kUnit;                                    // one weight stage
+    constexpr int kA = 3 * kW;                                        // activation stages
+    constexpr int kCoef = kA + 2 * kAStage;                           // coefficient tables of two tiles, 2 KB each (Cin <= 128)
+    constexpr int kBias = kCoef + 4096;
+    constexpr int NDMA = NT * kUnit / 1024;                           // DMA instructions per weight stage
+    constexpr int NS = 8 * RI;                                        // stores per wave and tile
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const bool dmaWave = wave * 3 < NDMA;
+
+    const int total = a.nbm;
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3, nloc = gridDim.x >> 3;
+    const int q8 = total >> 3, r8 = total & 7;
+    const int runStart = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+    const int runLen = q8 + (xcd < r8 ? 1 : 0);
+    const int myCount = runLen > local ? (runLen - local + nloc - 1) / nloc : 0;
+    if (myCount == 0) return;
+    auto tile_m0 = [&](int i) { return (runStart + local + i * nloc) * BM; };
+    auto tile_rows = [&](int m0) { const int rows = a.M - m0; return rows < BM ? rows : BM; };
+
+    constexpr unsigned OOB = 0x80000000u;
+    const int HWo = a.Ho * a.Wo;
+    const int nch = a.Cin >> 4;                                       // 16-channel chunks per tap
+    const int nk = 9 * nch;
+    const long long rowU = (long long)9 * a.Cin * 6;                  // bytes per weight row
+    const long long imgIn = (long long)a.Hi * a.Wi * a.ldIn;          // floats per input image
+
+    // ---- stream two K-steps ahead of the multiplies
+    const __amdgpu_buffer_rsrc_t srdU = __builtin_amdgcn_make_buffer_rsrc((void *)a.u, 0, (int)(NT * rowU), 0x00020000);
+    __amdgpu_buffer_rsrc_t srdIn = __builtin_amdgcn_make_buffer_rsrc((void *)a.in, 0, 0, 0x00020000);
+    const int arow = tid >> 1, ahalf = tid & 1;
+    unsigned gB[3];
+    int dTile = 0, dK = 0, dChunk = 0, dDy = 0, dDx = 0;
+    int pY = 0, pX = 0;                                               // 2 oy - 1, 2 ox - 1 of my row in the stream's tile
+    unsigned pBase = OOB;                                             // byte offset of my row's image inside srdIn (OOB: no row)
+    unsigned gTap = OOB;                                              // ... of the source pixel of the stream's tap (+ my half)
+    auto set_tap = [&]() {
+        const int iy = pY + dDy, ix = pX + dDx;
+        const bool inb = (pBase != OOB) & ((unsigned)iy < (unsigned)a.Hi) & ((unsigned)ix < (unsigned)a.Wi);
+        gTap = inb ? pBase + (unsigned)((iy * a.Wi + ix) * a.ldIn * 4 + ahalf * 32) : OOB;
+    };
+    auto set_dma_tile = [&](int i) {
+        pBase = OOB;
+        if (i < myCount) {
+            const int m0 = tile_m0(i);
+            const int nLo = m0 / HWo;
+            const int left = a.B - nLo < 2 ? a.B - nLo : 2;           // a tile touches at most two images (Ho*Wo >= 256)
+            srdIn = __builtin_amdgcn_make_buffer_rsrc((void *)(a.in + nLo * imgIn), 0, (int)(left * imgIn * 4), 0x00020000);
+            const int m = m0 + arow;
+            if (m < a.M) {
+                const int n = m / HWo, p = m - n * HWo;
+                const int oy = p / a.Wo, ox = p - oy * a.Wo;
+                pY = 2 * oy - 1; pX = 2 * ox - 1;
+                pBase = (unsigned)((n - nLo) * imgIn * 4);
+            }
+        }
+        if (dmaWave) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int sl = (wave * 3 + q) * 64 + lane;
+                const int row = sl / 6, phys = sl - row * 6;
+                int logical = phys - ((row >> 3) & 1);
+                if (logical < 0) logical += 6;
+                gB[q] = i < myCount ? (unsigned)((long long)row * rowU + logical * 16) : OOB;
+            }
+        }
+        dDy = 0; dDx = 0; dChunk = 0;
+        set_tap();
+    };
+    auto dma_instr = [&](int q, int stage) {                           // (waves that stream weights only)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(srdU, (lds_void *)(dsm + stage * kW + (wave * 3 + q) * 1024), 16,
+                                                 (int)gB[q], dK * kUnit, 0, 0);
+    };
+    u32x4 rA[2][2];                                                    // [K-step parity][half of my 8 channels]
+    unsigned mOK[2] = { 0u, 0u };                                      // [K-step parity] my source pixel is inside the image
+    auto load_a = [&](auto parTag) {
+        constexpr int P = decltype(parTag)::value;
+        rA[P][0] = __builtin_amdgcn_raw_buffer_load_b128(srdIn, (int)gTap, dChunk * 64, 0);
+        rA[P][1] = __builtin_amdgcn_raw_buffer_load_b128(srdIn, (int)(gTap + 16u), dChunk * 64, 0);
+        mOK[P] = gTap != OOB ? 0xffffffffu : 0u;
+    };
+    auto advance_dma = [&]() {
+        if (++dK == nk) { dK = 0; ++dTile; set_dma_tile(dTile); return; }
+        if (++dChunk == nch) {
+            dChunk = 0;
+            if (++dDx == 3) { dDx = 0; ++dDy; }
+            set_tap();
+        }
+    };
+
+    // ---- conversion, one K-step ahead of the multiplies
+    unsigned wOff[3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        int ph = 2 * p + ahalf + ((arow >> 3) & 1);
+        if (ph >= 6) ph -= 6;
+        wOff[p] = (unsigned)(kA + arow * kUnit + ph * 16);
+    }
+    int cTile = 0, cK = 0, cChunk = 0;
+    unsigned cCoef = 0;                                              // LDS offset of my row's {scale, shift} run
+    auto set_conv_tile = [&](int i) {
+        if (NORM && i < myCount) {
+            const int m0 = tile_m0(i);
+            const int nLo = m0 / HWo;
+            const int split = (nLo + 1) * HWo - m0;                  // first tile row of the second image
+            cCoef = (unsigned)(kCoef + (i & 1) * 2048 + (arow >= split ? a.Cin * 8 : 0) + ahalf * 64);
+        }
+    };
+    auto convert = [&](auto parTag) {                                  // registers of parity P -> activation stage P
+        constexpr int P = decltype(parTag)::value;
+        unsigned w[3][4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            f32x4 x = __builtin_bit_cast(f32x4, rA[P][h]);
+            if constexpr (NORM) {
+                const f32x4 c0 = *reinterpret_cast<const f32x4 *>(dsm + cCoef + cChunk * 128 + h * 32);
+                const f32x4 c1 = *reinterpret_cast<const f32x4 *>(dsm + cCoef + cChunk * 128 + h * 32 + 16);
+                const bool ok = mOK[P] != 0u;                        // the zero padding stays zero
+                x[0] = ok ? fmaxf(fmaf(x[0], c0[0], c0[1]), a.normLo) : 0.f;
+                x[1] = ok ? fmaxf(fmaf(x[1], c0[2], c0[3]), a.normLo) : 0.f;
+                x[2] = ok ? fmaxf(fmaf(x[2], c1[0], c1[1]), a.normLo) : 0.f;
+                x[3] = ok ? fmaxf(fmaf(x[3], c1[2], c1[3]), a.normLo) : 0.f;
+            }
+            split_pair(x[0], x[1], w[0][2 * h], w[1][2 * h], w[2][2 * h]);
+            split_pair(x[2], x[3], w[0][2 * h + 1], w[1][2 * h + 1], w[2][2 * h + 1]);
+        }
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+            *reinterpret_cast<u32x4 *>(dsm + P * kAStage + wOff[p]) = u32x4{ w[p][0], w[p][1], w[p][2], w[p][3] };
+    };
+    auto advance_conv = [&]() {
+        if (++cK == nk) { cK = 0; cChunk = 0; ++cTile; set_conv_tile(cTile); return; }
+        if (++cChunk == nch) cChunk = 0;
+    };
+    // coefficient table of tile i: the {scale, shift} pairs of its (at most two) images, 4 Cin floats, into table i & 1
+    const __amdgpu_buffer_rsrc_t srdCoef = __builtin_amdgcn_make_buffer_rsrc((void *)a.coef, 0, NORM ? a.B * a.Cin * 8 : 0, 0x00020000);
+    auto load_table = [&](int i) -> u32x4 {
+        unsigned off = OOB;
+        if (i < myCount && tid < a.Cin) off = (unsigned)(((long long)(tile_m0(i) / HWo) * a.Cin * 2 + tid * 4) * 4);
+        return __builtin_amdgcn_raw_buffer_load_b128(srdCoef, (int)off, 0, 0);
+    };
+    auto store_table = [&](int i, u32x4 v) {
+        if (tid < a.Cin) *reinterpret_cast<u32x4 *>(dsm + kCoef + (i & 1) * 2048 + tid * 16) = v;
+    };
+
+    // ---- fragments
+    const int fr = lane & 31, kh = lane >> 5;
+    unsigned slotOff[3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        int ph = 2 * p + kh + ((fr >> 3) & 1);
+        if (ph >= 6) ph -= 6;
+        slotOff[p] = (unsigned)(ph * 16);
+    }
+    const unsigned frA = (unsigned)(kA + (wm * (32 * RI) + fr) * kUnit), frB = (unsigned)((wn * 64 + fr) * kUnit);
+    bf16x8 fa[3][RI], fb[3][2];
+    f32x16 acc[RI][2];
+    auto ldA = [&](int stage, int p, int i) { return *reinterpret_cast<const bf16x8 *>(dsm + stage * kAStage + frA + i * 32 * kUnit + slotOff[p]); };
+    auto ldB = [&](int stage, int p, int j) { return *reinterpret_cast<const bf16x8 *>(dsm + stage * kW + frB + j * 32 * kUnit + slotOff[p]); };
+    auto mma_term = [&](int pu, int pv) {
+#pragma unroll
+        for (int i = 0; i < RI; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[pu][j], fa[pv][i], acc[i][j], 0, 0, 0);
+    };
+    const int rhalf = kh * 4;
+    auto init_acc = [&]() {                                            // accumulators start at the bias
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 b = *reinterpret_cast<const f32x4 *>(dsm + kBias + (wn * 64 + j * 32 + rhalf + 8 * q) * 4);
+#pragma unroll
+                for (int i = 0; i < RI; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[i][j][4 * q + e] = b[e];
+            }
+    };
+
+    // ---- prologue: bias and the first two coefficient tables into LDS, steps 0 and 1 of the stream, step 0 converted
+    for (int i = tid; i < NT; i += NTH) reinterpret_cast<float *>(dsm + kBias)[i] = a.bias[i];
+    if constexpr (NORM) {
+        const u32x4 t0 = load_table(0), t1 = load_table(1);
+        store_table(0, t0);
+        store_table(1, t1);
+    }
+    set_dma_tile(0);
+    set_conv_tile(0);
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    load_a(P0{});
+    if (dmaWave) { dma_instr(0, 0); dma_instr(1, 0); dma_instr(2, 0); }
+    advance_dma();
+    __builtin_amdgcn_s_waitcnt(0x0070);                               // everything landed
+    __syncthreads();                                                  // tables and bias visible
+    convert(P0{});
+    advance_conv();
+    load_a(P1{});
+    if (dmaWave) { dma_instr(0, 1); dma_instr(1, 1); dma_instr(2, 1); }
+    advance_dma();
+    __builtin_amdgcn_s_waitcnt(0x0070 | 5);                           // my writes of step 0; stage 0 of the ring landed before
+    __builtin_amdgcn_s_barrier();
+    int sc = 0, sd = 2;
+    init_acc();
+    // one K-step; FIRST: the first step of a tile that follows another one (NS stores of its epilogue are in flight)
+    auto step = [&](auto firstTag, auto parTag) __attribute__((always_inline)) {
+        constexpr int sa = decltype(parTag)::value;                   // parity of the K-step
+        const int next = sc == 2 ? 0 : sc + 1;
+        load_a(parTag);                                               // step kk + 2: two steps until its conversion
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fb[2][j] = ldB(sc, 2, j);
+#pragma unroll
+        for (int i = 0; i < RI; ++i) fa[0][i] = ldA(sa, 0, i);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fb[1][j] = ldB(sc, 1, j);
+#pragma unroll
+        for (int i = 0; i < RI; ++i) fa[1][i] = ldA(sa, 1, i);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fb[0][j] = ldB(sc, 0, j);
+#pragma unroll
+        for (int i = 0; i < RI; ++i) fa[2][i] = ldA(sa, 2, i);
+        mma_term(2, 0); if (dmaWave) dma_instr(0, sd);
+        mma_term(1, 1); if (dmaWave) dma_instr(1, sd);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_term(0, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        // terms 4 and 5 with the conversion of step kk + 1 threaded through them
+        mma_term(1, 0);
+        convert(std::integral_constant<int, sa ^ 1>{});           // (the compiler counts vmcnt for rA)
+        mma_term(0, 1);
+        {
+            constexpr int nM = 4 * RI;                                // MFMAs of the two terms
+            constexpr int groups = nM < 12 ? nM : 12;
+            constexpr int valu = (NORM ? 84 : 60) / groups;
+#pragma unroll
+            for (int g = 0; g < groups; ++g) {
+                if constexpr (NORM) { if (g == 0 || g == groups / 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); }
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, valu, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x200, 3, 0);                      // the three LDS writes
+            if constexpr (nM > groups) __builtin_amdgcn_sched_group_barrier(0x008, nM - groups, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        advance_conv();
+        // the weights of step kk + 1 have landed: younger are 2 DMAs and 2 loads of step kk + 2 (2 loads in the waves that do
+        // not stream weights) - and, in the first step of a tile, the NS stores of the tile before; lgkmcnt(0): my
+        // activation writes are done
+        if (dmaWave) {
+            if constexpr (decltype(firstTag)::value) __builtin_amdgcn_s_waitcnt(0x0070 | ((4 + NS) & 15) | (((4 + NS) >> 4) << 14));
+            else __builtin_amdgcn_s_waitcnt(0x0070 | 4);
+        } else {
+            if constexpr (decltype(firstTag)::value) __builtin_amdgcn_s_waitcnt(0x0070 | ((2 + NS) & 15) | (((2 + NS) >> 4) << 14));
+            else __builtin_amdgcn_s_waitcnt(0x0070 | 2);
+        }
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        mma_term(0, 0); if (dmaWave) dma_instr(2, sd);
+        advance_dma();
+        sc = next;
+        sd = sd == 2 ? 0 : sd + 1;
+        __builtin_amdgcn_sched_barrier(0);                            // (the vmcnt arithmetic above assumes this issue order)
+    };
+    auto epilogue = [&](int ti) __attribute__((always_inline)) {
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- tile ti (swapped operands): row = lane & 31, channels (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+        const int m0 = tile_m0(ti);
+        if constexpr (NORM) {                                          // (waits for everything older than the table)
+            const u32x4 tab = load_table(ti + 2);
+            store_table(ti + 2, tab);
+        }
+        // (every wave issues exactly NS stores per tile - the vmcnt arithmetic of the next step counts them: rows past the
+        //  end of the tile fall outside the descriptor)
+        const __amdgpu_buffer_rsrc_t srdO = __builtin_amdgcn_make_buffer_rsrc((void *)(a.out + (long long)m0 * a.ldOut), 0,
+                                                                              tile_rows(m0) * a.ldOut * 4, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < RI; ++i) {
+            const unsigned rowOff = (unsigned)((wm * (32 * RI) + i * 32 + fr) * a.ldOut * 4);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int n = wn * 64 + j * 32 + rhalf + 8 * q;
+                    const unsigned off = rowOff + (unsigned)n * 4u;
+                    const f32x4 v = f32x4{ acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3] };
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), srdO, (int)off, 0, 0);
+                }
+        }
+        if (ti + 1 < myCount) init_acc();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto tile_steps = [&](auto firstTag) __attribute__((always_inline)) {
+        step(firstTag, P0{});
+        step(std::false_type{}, P1{});
+        for (int kk = 2; kk < nk; kk += 2) {
+            step(std::false_type{}, P0{});
+            step(std::false_type{}, P1{});
+        }
+    };
+    tile_steps(std::false_type{});
+    for (int ti = 1; ti < myCount; ++ti) {
+        epilogue(ti - 1);
+        tile_steps(std::true_type{});
+    }
+    epilogue(myCount - 1);
+    __builtin_amdgcn_s_waitcnt(0x0F70);                             // vmcnt(0)
+}
+
+template <int NT, int NW, int PER_CU>
+int launch_stem(StemArgs a, bool norm, hipStream_t st)
+{
+    constexpr int BM = 32 * NW;
+    const size_t lds = 3 * NT * kUnit + 2 * BM * kUnit + 4096 + NT * 4;
+    static XlLdsLimit configured[2];
+    int cfgDev;
+    const void *fn = norm ? reinterpret_cast<const void *>(split_conv3x3s2_kernel<NT, true, NW>)
+                          : reinterpret_cast<const void *>(split_conv3x3s2_kernel<NT, false, NW>);
+    if (configured[norm].needs(lds, &cfgDev)) {
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return XL_ERR_HIP;
+        configured[norm].done(lds, cfgDev);
+    }
+    a.nbm = (a.M + BM - 1) / BM;
+    int grid = 256 * PER_CU;                                          // persistent: PER_CU workgroups per CU (LDS- and register-bound)
+    if (grid > ((a.nbm + 7) & ~7)) grid = (a.nbm + 7) & ~7;
+    if (norm) hipLaunchKernelGGL((split_conv3x3s2_kernel<NT, true, NW>), dim3(grid), dim3(64 * NW), lds, st, a);
+    else hipLaunchKernelGGL((split_conv3x3s2_kernel<NT, false, NW>), dim3(grid), dim3(64 * NW), lds, st, a);
+    return XL_OK;
+}
+
+}  // namespace
+
+// XL_OP_CONV with ksize 3, stride 2 and XL_CONV_SPLIT_BF16 | XL_CONV_SPLIT_IL: in fp32 NHWC [B,Hi,Wi,Cin] (ld_in), out fp32 NHWC
+// [B,Ho,Wo,Cout] (ld_out), w = [Cout][9 Cin / 16][3][16] bf16 (K = tap * Cin + c, tap = 3 ky + kx), bias; optionally
+// XL_CONV_NORM_IN (aux2 = [B][Cin][2] coefficients, XL_CONV_NORM_RELU).  Cin in {32, 64, 128}, Cout in {64, 128, 256},
+// Ho*Wo >= 256.  No statistics epilogue (stats must be null).
+int xl_run_split_stem(const xl_op &op, hipStream_t st)
+{
+    const long long M = (long long)op.B * op.Ho * op.Wo;
+    const bool norm = (op.flags & XL_CONV_NORM_IN) != 0;
+    if (op.ksize != 3 || op.stride != 2 || (op.Cin != 32 && op.Cin != 64 && op.Cin != 128) ||
+        (op.Cout != 64 && op.Cout != 128 && op.Cout != 256) || op.Ho != (op.Hi - 1) / 2 + 1 || op.Wo != (op.Wi - 1) / 2 + 1 ||
+        op.Ho * op.Wo < 256 || op.ld_in < op.Cin || op.ld_out < op.Cout || (op.ld_in & 3) || (op.ld_out & 3) || !op.bias ||
+        op.stats || (op.flags & (XL_CONV_ACCUMULATE | XL_CONV_DGRAD)) || !op.in || !op.w || !op.out ||
+        (((uintptr_t)op.in | (uintptr_t)op.out | (uintptr_t)op.w) & 15) || M >= 0x7fffffffLL - 256 ||
+        2LL * op.Hi * op.Wi * op.ld_in * 4 >= 0x7fffffffLL || 256LL * op.ld_out * 4 >= 0x7fffffffLL || (norm && !op.aux2))
+        return XL_ERR_ARG;
+    StemArgs a;
+    a.in = (const float *)op.in; a.u = (const uint16_t *)op.w; a.bias = (const float *)op.bias; a.out = (float *)op.out;
+    a.coef = (const float *)op.aux2;
+    a.normLo = (op.flags & XL_CONV_NORM_RELU) ? 0.f : -__builtin_inff();
+    a.B = op.B; a.Hi = op.Hi; a.Wi = op.Wi; a.Cin = op.Cin; a.Ho = op.Ho; a.Wo = op.Wo;
+    a.ldIn = op.ld_in; a.ldOut = op.ld_out; a.M = (int)M; a.nbm = 0;
+    if (op.Cout == 64) return launch_stem<64, 4, 3>(a, norm, st);
+    if (op.Cout == 128) return launch_stem<128, 4, 2>(a, norm, st);
+    return launch_stem<256, 8, 1>(a, norm, st);
+}

@@ -54,6 +54,10 @@ def _bind():
                                               ctypes.c_int, ctypes.c_void_p]
         L.xl_cnn_pack_conv_weight_dgrad.restype = ctypes.c_int
         L.xl_cnn_pack_conv_weight_dgrad.argtypes = L.xl_cnn_pack_conv_weight.argtypes
+        L.xl_cnn_pack_wino_weight.restype = ctypes.c_int
+        L.xl_cnn_pack_wino_weight.argtypes = [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 5 + [ctypes.c_void_p]
+        L.xl_cnn_split_weight.restype = ctypes.c_int
+        L.xl_cnn_split_weight.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
         L.xl_cnn_last_error.restype = ctypes.c_char_p
         if L.xl_cnn_op_size() != ctypes.sizeof(XlOp):
             raise _lib.XlError("xl_op layout mismatch: C %d vs ctypes %d" % (L.xl_cnn_op_size(), ctypes.sizeof(XlOp)))
@@ -316,16 +320,29 @@ class _Plan:
         planes = _Plan.split_bf16(x.reshape(-1, C // 16, 16)).view(3, -1, C // 16, 16)
         return planes.permute(1, 2, 0, 3).contiguous()
 
-    def _split_form(self, packed_wino, cin, interleaved):
-        return self.split_bf16_interleaved(packed_wino, cin) if interleaved else self.split_bf16(packed_wino)
-
-    def pack_conv_wino_split(self, conv, m, interleaved=False):
+    def pack_conv_wino_split(self, conv, m, interleaved=False, dgrad=False):
         """The transformed weights of pack_conv_wino as three bf16 planes (operands of csrc/xl_gemm_split.hip): separate
         planes, or - `interleaved` - [(m+2)^2][Cout][Cin/16][3][16] for the 256 x 256 kernel."""
-        key = (id(conv.weight), "wino%d_split%s" % (m, "_il" if interleaved else ""))
+        key = (id(conv.weight), "wino%d%s_split%s" % (m, "d" if dgrad else "", "_il" if interleaved else ""))
         if key not in self.packed_split:
-            self.packed_split[key] = self._split_form(self.pack_conv_wino(conv, m), conv.in_channels, interleaved)
-        return self.packed_split[key]
+            src = conv.weight.detach().to(device=self.device, dtype=torch.float32).contiguous()   # aliases the live parameter
+            planes = torch.empty(3 * (m + 2) ** 2 * src.shape[0] * src.shape[1], dtype=torch.int16, device=self.device)
+            self.packed_split[key] = (planes, src, m, interleaved, dgrad)
+            self._pack_wino_split(*self.packed_split[key])
+        return self.packed_split[key][0]
+
+    def _pack_wino_split(self, planes, src, m, interleaved, dgrad=False):
+        """U = G g G^T (float64 inside) and its exact three-term bf16 split in one HIP launch (csrc/xl_pack.hip); dgrad: the
+        data-gradient operand [(m+2)^2][Cin][Cout] (flipped kernel, channel roles swapped)."""
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        _check(_bind().xl_cnn_pack_wino_weight(src.data_ptr(), planes.data_ptr(), src.shape[0], src.shape[1], m,
+                                               1 if dgrad else 0, 2 if interleaved else 1, stream))
+
+    def _split_weight(self, planes, src):
+        """fp32 [rows][K] (1x1) or OIHW 3x3 (K tap-major) -> interleaved bf16 planes, one HIP launch."""
+        taps = 9 if (src.dim() == 4 and src.shape[2] == 3) else 1
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        _check(_bind().xl_cnn_split_weight(src.data_ptr(), planes.data_ptr(), src.shape[0], src.shape[1] * taps, taps, stream))
 
     def wino_pick(self, H, W, chan_max, allowed=(6, 4)):
         """Output tile m of F(m x m, 3x3) for an H x W map: the allowed size (capped by XL_WINOGRAD) with the fewest
@@ -366,14 +383,9 @@ class _Plan:
         L = _bind()
         cout, cin, k, _ = src.shape
         stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-        if kind.startswith("wino"):
-            m = int(kind[4])
-            G = torch.tensor(self._WINO_G[m], dtype=torch.float64, device=self.device)
-            g = src.to(torch.float64)
-            if kind.endswith("d"):
-                g = g.flip(2, 3).permute(1, 0, 2, 3)                                    # [Cin, Cout, 3, 3]
-            U = torch.einsum("ia,ocab,jb->ijoc", G, g, G)                               # fp64, rounded once
-            dst.view(m + 2, m + 2, g.shape[0], g.shape[1]).copy_(U)
+        if kind.startswith("wino"):                  # U = G g G^T in float64, rounded once: one HIP launch (csrc/xl_pack.hip)
+            _check(L.xl_cnn_pack_wino_weight(src.data_ptr(), dst.data_ptr(), cout, cin, int(kind[4]),
+                                             1 if kind.endswith("d") else 0, 0, stream))
         elif kind == "conv1":                     # [(ky*3+kx)*Cin + c][Cout]
             dst.view(k, k, cin, cout).copy_(src.permute(2, 3, 1, 0))
         elif kind == "dgrad":
@@ -386,12 +398,10 @@ class _Plan:
         GroupNorm affine parameters and fc3 are read through pointers to the live parameters."""
         for dst, src, kind in self.packed.values():
             self._pack(dst, src, kind)
-        for (wid, kind), planes in self.packed_split.items():
-            il = kind.endswith("_il")
-            base = self.packed[(wid, kind[:kind.index("_split")])][0]
-            planes.copy_(self._split_form(base, planes.shape[-3] * 16 if il else None, il))
+        for entry in self.packed_split.values():
+            self._pack_wino_split(*entry)
         for planes, src in self.packed_1x1.values():
-            planes.copy_(self.split_bf16_interleaved(src.reshape(src.shape[0], src.shape[1]), src.shape[1]))
+            self._split_weight(planes, src)
         for planes, src in self.packed_c1.values():
             planes.copy_(self.conv1_fragments(src))
 
@@ -421,10 +431,42 @@ class _Plan:
         kernel needs for its 340 small tiles)."""
         t, H, W, C, ld, off = act
         cout = conv.out_channels
-        return (conv.kernel_size[0] == 1 and conv.stride[0] == 1 and not self.train and C % 32 == 0 and cout % 256 == 0
+        return (conv.kernel_size[0] == 1 and conv.stride[0] == 1 and self.split_train_ok() and C % 32 == 0 and cout % 256 == 0
                 and cout <= 1024 and H * W >= 256 and ld % 4 == 0 and off % 4 == 0
                 and os.environ.get("XL_GEMM_SPLIT_BF16", self.SPLIT_DEFAULT) not in ("", "0", "1")
                 and not os.environ.get("XL_NO_SPLIT_1X1"))
+
+    def split_train_ok(self):
+        """Training plans run their forward GEMMs (and the Winograd data gradients) on the split pipe too (round 3);
+        XL_NO_SPLIT_TRAIN=1: fp32 MFMA throughout, the round-2 training plans."""
+        return not self.train or not os.environ.get("XL_NO_SPLIT_TRAIN")
+
+    def stem_split_ok(self, act, conv):
+        """The stride-2 3x3 stem layers of inference plans on the bf16 matrix pipe (csrc/xl_stem_split.hip): a choice by
+        layer, never by batch."""
+        t, H, W, C, ld, off = act
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        return (conv.kernel_size[0] == 3 and conv.stride[0] == 2 and self.split_train_ok() and C in (32, 64, 128)
+                and conv.out_channels in (64, 128, 256) and Ho * Wo >= 256 and ld % 4 == 0 and off % 4 == 0
+                and 2 * H * W * ld * 4 < 2 ** 31 - 1
+                and os.environ.get("XL_GEMM_SPLIT_BF16", self.SPLIT_DEFAULT) not in ("", "0", "1")
+                and not os.environ.get("XL_NO_SPLIT_STEM"))
+
+    def pack_conv_stem_split(self, conv):
+        """[Cout][9 Cin / 16][3][16] bf16: the weight of a 3x3 convolution with K ordered tap-major (K = (3 ky + kx) Cin + c)
+        as interleaved bf16 planes."""
+        w = conv.weight
+        key = id(w)
+        if key not in self.packed_1x1:
+            src = w.detach().to(device=self.device, dtype=torch.float32).contiguous()     # aliases the live parameter
+            planes = torch.empty(3 * src.numel(), dtype=torch.int16, device=self.device)
+            self.packed_1x1[key] = (planes, src)
+            self._split_weight(planes, src)
+        return self.packed_1x1[key][0]
+
+    @staticmethod
+    def _stem_rows(src):
+        return src.permute(0, 2, 3, 1).reshape(src.shape[0], -1) if src.dim() == 4 and src.shape[2] == 3 else src.reshape(src.shape[0], src.shape[1])
 
     def pack_conv_1x1_split(self, conv):
         """[Cout][Cin/16][3][16] bf16: the weight of a 1x1 convolution as interleaved bf16 planes."""
@@ -432,7 +474,9 @@ class _Plan:
         key = id(w)
         if key not in self.packed_1x1:
             src = w.detach().to(device=self.device, dtype=torch.float32).contiguous()     # aliases the live parameter
-            self.packed_1x1[key] = (self.split_bf16_interleaved(src.reshape(src.shape[0], src.shape[1]), src.shape[1]), src)
+            planes = torch.empty(3 * src.numel(), dtype=torch.int16, device=self.device)
+            self.packed_1x1[key] = (planes, src)
+            self._split_weight(planes, src)
         return self.packed_1x1[key][0]
 
     @staticmethod
@@ -470,14 +514,19 @@ class _Plan:
         op.B, op.Hi, op.Wi, op.Cin, op.Ho, op.Wo, op.Cout = self.B, H, W, C, Ho, Wo, cout
         op.ksize, op.stride, op.ld_in, op.ld_out = k, s, ld, out_ld
         op.in_ = t.data_ptr() + 4 * off
-        op.w = self.pack_conv(conv).data_ptr()
+        if not split:
+            op.w = self.pack_conv(conv).data_ptr()
         op.bias = self.dev(conv.bias).data_ptr()
         op.out = out.data_ptr() + 4 * out_off
         # 64-row tiles when 128-row tiles would not even fill one wave of workgroups over the 256 CUs
         bn = 128 if cout % 128 == 0 else 64
         if -(-self.B * Ho * Wo // 128) * -(-cout // bn) <= 256 and norm_in is None:
             op.reserved_i = 64                        # (the normalise-on-load form exists with 128-row tiles only)
-        if split:
+        if split and k == 3:                          # stride-2 stem layer on the split pipe (no statistics epilogue)
+            op.flags |= CONV_SPLIT_BF16 | CONV_SPLIT_IL
+            op.w = self.pack_conv_stem_split(conv).data_ptr()
+            op.reserved_i = 0
+        elif split:
             op.flags |= CONV_SPLIT_BF16 | CONV_SPLIT_IL
             op.w = self.pack_conv_1x1_split(conv).data_ptr()
             # rows per tile (the statistics epilogue writes one entry per tile); negative: tiles start at image boundaries,
@@ -491,7 +540,7 @@ class _Plan:
         self.tape.append(dict(kind="conv", conv=conv, x=act, raw=res))
         return res
 
-    def gn(self, act, norm, flags, aux=None, out=None, pre_stats=None, stat_tile=0):
+    def gn(self, act, norm, flags, aux=None, out=None, pre_stats=None, stat_tile=0, defer=False, share=False):
         """GroupNorm (+fused epilogue) of `act`; in place unless `out` (tensor, ld, off) is given or training.
         pre_stats = (stats tensor, nchunks): the partial sums were already produced (Winograd output transform or conv
         epilogue of a training plan; stat_tile = rows per conv tile in the latter case), no statistics pass is emitted.
@@ -544,6 +593,14 @@ class _Plan:
             ot, old, ooff = out
             ap.out, ap.ld_out = ot.data_ptr() + 4 * ooff, old
             res = (ot, H, W, C, old, ooff)
+        if not self.train and res is act:
+            if defer:                                 # the only consumer applies it while loading its operand
+                if not hasattr(self, "pending_gn"):
+                    self.pending_gn = {}
+                self.pending_gn[self._act_key(res)] = ap
+                return res
+            if share and self.fold_ok():              # ... or the first of several consumers does, and materialises it
+                return self._fold_begin(ap, act, aux)
         self.ops.append(ap)
         self.tape.append(dict(kind="gn", norm=norm, raw=act, out=res, aux=aux, flags=flags, table=table,
                               gamma=gamma, beta=beta))
@@ -575,11 +632,16 @@ class _Plan:
         (XL_CONV_SPLIT_ACT); XL_WINO_V_SPLIT=1: the round-2 form, V written as interleaved bf16 planes by the input transform."""
         nf = (m + 2) ** 2
         mode = os.environ.get("XL_GEMM_SPLIT_BF16", self.SPLIT_DEFAULT)
-        split = (m == 6 and not self.train and mode not in ("", "0") and C % 32 == 0)
+        split = (mode not in ("", "0") and C % 32 == 0 and self.split_train_ok())
         split_il = split and mode != "1" and (T + 256) * max(C * 6, cout * 4) < 2 ** 31 - 1 and C % 128 == 0 and cout % 256 == 0
+        split_act = split_il and cout <= 1024 and not os.environ.get("XL_WINO_V_SPLIT")
+        if m != 6 or self.train:
+            # the forms that read V as bf16 planes exist for F(6x6,3x3) inference layers only (wino6_in_kernel writes them);
+            # the form that splits an fp32 V inside the GEMM does not care about the tile size, and leaves V as the weight
+            # gradient of a training plan wants it
+            split = split_il = split_act
         if split and not split_il:
             split = nf * T * max(C, cout) * 6 < 2 ** 31 - 1             # (the first form addresses a plane as a whole)
-        split_act = split_il and cout <= 1024 and not os.environ.get("XL_WINO_V_SPLIT")
         return split, split_il, split_act
 
     def conv_wino(self, act, conv, norm, flags, aux, m, deferred=None, defer=False, fold=None, share=False):
@@ -623,10 +685,12 @@ class _Plan:
         op.type = XL_OP_CONV
         op.B, op.Hi, op.Wi, op.Cin, op.Ho, op.Wo, op.Cout = B, Th, Tw, C, Th, Tw, cout
         op.ksize, op.stride, op.ld_in, op.ld_out, op.nchunks2 = 1, 1, C, cout, nf
-        op.in_, op.w, op.out = V.data_ptr(), self.pack_conv_wino(conv, m).data_ptr(), Mb.data_ptr()
+        op.in_, op.out = V.data_ptr(), Mb.data_ptr()
         if split:
             op.flags = CONV_SPLIT_BF16 | (CONV_SPLIT_IL if split_il else 0) | (CONV_SPLIT_ACT if split_act else 0)
             op.w = self.pack_conv_wino_split(conv, m, split_il).data_ptr()
+        else:
+            op.w = self.pack_conv_wino(conv, m).data_ptr()
         if -(-T // 128) * (cout // 128) * nf <= 256:
             op.reserved_i = 64
         self.ops.append(op)
@@ -707,7 +771,8 @@ class _Plan:
         pend = getattr(self, "pending_gn", {}).pop(self._act_key(act), None)
         fold = getattr(self, "pending_fold", {}).pop(self._act_key(act), None)
         m = self.wino_tile(act, conv)
-        if pend is not None and m not in (4, 6) and not self.norm_on_load_ok(act, conv):
+        stem = self.stem_split_ok(act, conv)
+        if pend is not None and m not in (4, 6) and not self.norm_on_load_ok(act, conv) and not stem:
             self.stats_ops.append(len(self.ops))       # consumer cannot absorb it: materialise now
             self.ops.append(pend)
             pend = None
@@ -720,6 +785,12 @@ class _Plan:
         if m:
             return self.conv_wino(act, conv, norm, flags, aux, m, pend, defer=defer, fold=fold, share=share)
         cpg = conv.out_channels // norm.num_groups
+        if stem:
+            # conv on the split pipe with the producer's GroupNorm applied on load; statistics pass; the apply is left to the
+            # consumer (the next stem layer, or - conv4 - the input transform of res1_conv1)
+            y = self.conv(act, conv, norm_in=pend, split=True)
+            return self.gn(y, norm, flags, aux, defer=defer and flags == GN_RELU_IN and aux is None
+                           and not os.environ.get("XL_NO_DEFERRED_GN"), share=share)
         split = (self.split_1x1_ok(act, conv) and (cpg == 16 or self.separate_stats)
                  and (pend is None or act[3] <= 512))
         y = self.conv(act, conv, norm_in=pend, split=split)
@@ -736,7 +807,7 @@ class _Plan:
             # training: same epilogue statistics, written to a buffer of the layer's own (they are inputs of the
             # backward pass).  Slots a conv tile never touches stay zero, so the consumers may sum all of them.
             cop = self.ops[-1]
-            tile = 64 if cop.reserved_i == 64 else 128
+            tile = 64 if cop.reserved_i == 64 else (256 if split else 128)
             G = norm.num_groups
             nchunks = (y[1] * y[2] + tile - 1) // tile + 1
             stats_t = torch.zeros(self.B * nchunks * G * 2, dtype=torch.float64, device=self.device)
@@ -877,6 +948,27 @@ class _Plan:
             return op
         st = conv1_op()
         self.max_stats = max(self.max_stats, B * nchunks * G * 2)
+        act1 = (t1, H, W, c1, c1, 0)
+        if (ppt == 0 and self.stem_split_ok(act1, enc.conv2) and not os.environ.get("XL_NO_DEFERRED_GN")
+                and not os.environ.get("XL_CONV1_TWO_PASS")):
+            # round 3: ONE evaluation - the raw convolution is written together with its statistics, and conv2 (on the split
+            # pipe) applies GroupNorm + ReLU while it gathers its operand: the statistics-only evaluation disappears
+            st.out = t1.data_ptr()
+            self.stats_ops.append(len(self.ops))
+            self.image_op_indices.append(len(self.ops))
+            self.ops.append(st)
+            ap = XlOp()                                # the apply pass, left to the consumer (materialised only if it cannot)
+            ap.type = XL_OP_GN_APPLY
+            ap.B, ap.Hi, ap.Wi, ap.Cin, ap.groups, ap.nchunks, ap.ld_in = B, H, W, c1, G, nchunks, c1
+            ap.flags, ap.eps = GN_RELU_IN, enc.norm1.eps
+            ap.in_ = ap.out = t1.data_ptr()
+            ap.ld_out = c1
+            ap.w, ap.bias = gamma.data_ptr(), beta.data_ptr()
+            self._emit_final(ap, gamma, beta, 0)
+            if not hasattr(self, "pending_gn"):
+                self.pending_gn = {}
+            self.pending_gn[self._act_key(act1)] = ap
+            return act1
         self.stats_ops.append(len(self.ops))
         self.image_op_indices.append(len(self.ops))
         self.ops.append(st)
@@ -891,8 +983,8 @@ class _Plan:
         return (t1, H, W, c1, c1, 0)
 
     def _encoder_tail(self, enc, x, out=None):
-        x2 = self.cgr(x, enc.conv2, enc.norm2); self.release(x[0])
-        x3 = self.cgr(x2, enc.conv3, enc.norm3); self.release(x2[0])
+        x2 = self.cgr(x, enc.conv2, enc.norm2, defer=True); self.release(x[0])
+        x3 = self.cgr(x2, enc.conv3, enc.norm3, defer=True); self.release(x2[0])
         res = self.cgr(x3, enc.conv4, enc.norm4, share=True); self.release(x3[0])
         a = self.cgr(res, enc.res1_conv1, enc.res1_norm1, defer=True)
         b = self.cgr(a, enc.res1_conv2, enc.res1_norm2, defer=True); self.release(a[0])
@@ -1249,9 +1341,14 @@ class _Plan:
                     gm.type = XL_OP_CONV
                     gm.B, gm.Hi, gm.Wi, gm.Cin, gm.Ho, gm.Wo, gm.Cout = B, Th, Tw, Cout, Th, Tw, C
                     gm.ksize, gm.stride, gm.ld_in, gm.ld_out, gm.nchunks2 = 1, 1, Cout, C, nf
-                    gm.in_, gm.w, gm.out = Vb.data_ptr(), self.pack_conv_wino(conv, m, dgrad=True).data_ptr(), Mb.data_ptr()
-                    if -(-T // 128) * (C // 128) * nf <= 256:
-                        gm.reserved_i = 64
+                    gm.in_, gm.out = Vb.data_ptr(), Mb.data_ptr()
+                    if self.wino_gemm_form(Cout, C, m, T)[2]:       # on the split pipe, V(dY) split inside the GEMM kernel
+                        gm.flags = CONV_SPLIT_BF16 | CONV_SPLIT_IL | CONV_SPLIT_ACT
+                        gm.w = self.pack_conv_wino_split(conv, m, True, dgrad=True).data_ptr()
+                    else:
+                        gm.w = self.pack_conv_wino(conv, m, dgrad=True).data_ptr()
+                        if -(-T // 128) * (C // 128) * nf <= 256:
+                            gm.reserved_i = 64
                     bops.append(gm)
                     wo = XlOp()
                     wo.type, wo.ksize = XL_OP_WINO_OUT, m

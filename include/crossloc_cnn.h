@@ -148,6 +148,21 @@ int xl_cnn_pack_conv_weight(const float *w_oihw_dev, float *w_ohwi_dev, int Cout
  * same implicit GEMM; taps are NOT flipped, the kernel mirrors the offsets).  Cout % 32 == 0. */
 int xl_cnn_pack_conv_weight_dgrad(const float *w_oihw_dev, float *w_dgrad_dev, int Cout, int Cin, int k, void *stream);
 
+/* Winograd weight transform U = G g G^T of a 3x3 convolution for F(m x m, 3x3), m in {2, 4, 6}, evaluated in float64 per
+ * (output, input) channel pair and rounded once (Lavin & Gray 2016; the F(6x6) matrices carry the scaling of wincnn).  What
+ * a training step re-runs after every optimizer step (train_single_task.py:298-300: the weights change in place).
+ *   dgrad = 0: rows = output channels, K = input channels: U[xi][o][c];
+ *   dgrad = 1: the data-gradient operand - the flipped kernel with the channel roles swapped: U[xi][c][o].
+ *   form 0: fp32 [(m+2)^2][rows][K];
+ *   form 1: three bf16 planes, each [(m+2)^2][rows][K] (the exact split u = u1 + u2 + u3), planes (m+2)^2*rows*K apart;
+ *   form 2: interleaved planes [(m+2)^2][rows][K/16][3][16] bf16 (K % 16 == 0). */
+int xl_cnn_pack_wino_weight(const float *w_oihw_dev, void *dst_dev, int Cout, int Cin, int m, int dgrad, int form, void *stream);
+
+/* fp32 weight matrix -> interleaved bf16 planes [rows][K/16][3][16] of the split-pipe kernels (K % 16 == 0):
+ *   taps = 1: src = [rows][K] (a 1x1 convolution's [Cout][Cin]);
+ *   taps = 9: src = OIHW [rows][K/9][3][3], K ordered tap-major: k = (3 ky + kx) * Cin + c (csrc/xl_stem_split.hip). */
+int xl_cnn_split_weight(const float *src_dev, void *dst_dev, int rows, int K, int taps, void *stream);
+
 /* Per-op HIP-event timing for measurement (bench.py): between prof_begin and prof_end every op launched by
  * xl_cnn_run is bracketed by two events on its own stream (up to max_records ops).  prof_end waits for the
  * recorded events, writes (index in the op list, op type, elapsed ms) per record and returns the record count

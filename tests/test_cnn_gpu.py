@@ -553,7 +553,8 @@ def _wino_conv(x_nhwc, U, bias, m, B, H, W, cin, cout, out, ld_out, stats=None, 
 @pytest.mark.parametrize("m,cin,cout,B,H,W", [(4, 256, 256, 2, 8, 12), (4, 512, 512, 1, 10, 14), (4, 256, 512, 2, 9, 13),
                                               (4, 1536, 512, 1, 8, 12), (2, 256, 256, 2, 8, 12), (2, 512, 128, 1, 10, 14),
                                               (6, 256, 256, 2, 12, 18), (6, 512, 512, 1, 10, 14), (6, 256, 512, 2, 9, 13),
-                                              (6, 1536, 512, 1, 8, 12), (6, 512, 512, 2, 60, 90)])
+                                              (6, 1536, 512, 1, 8, 12), (6, 512, 512, 2, 60, 90),
+                                              (6, 128, 128, 3, 13, 20), (6, 256, 1024, 1, 12, 12), (6, 512, 512, 5, 25, 31)])
 def test_winograd_conv_with_statistics_vs_float64(m, cin, cout, B, H, W):
     """Input transform + batched GEMMs + output transform (bias, GroupNorm partial sums) against a float64 convolution;
     9x13 and 10x14 exercise the partial tiles of F(4x4,3x3) and F(6x6,3x3); 60x90 is the BASELINE feature map."""
@@ -782,3 +783,118 @@ def test_folded_groupnorm_apply_is_bitwise_the_separate_pass(monkeypatch):
     with torch.no_grad():
         yb = net(x2)
     assert torch.equal(ya, yb)
+
+
+@pytest.mark.parametrize("cin,cout,B,H,W,norm,relu,pad", [
+    (32, 64, 2, 40, 56, False, False, 0),       # conv2's shape class: plain input (conv1 writes it normalised)
+    (32, 64, 3, 37, 61, True, True, 0),         # odd sizes: the far-edge taps fall on the padding; tiles straddle images
+    (64, 128, 3, 33, 47, True, True, 0),        # conv3
+    (128, 256, 2, 35, 49, True, True, 32),      # conv4, operands inside wider tensors
+    (128, 256, 5, 120, 180, True, False, 0),    # conv4 at its real size: 106 tiles per... 27000 rows, several tiles per CU later
+    (64, 128, 9, 96, 120, True, True, 0),       # 102 tiles on <= 256 workgroups with second tiles (stores in flight)
+    (32, 64, 40, 80, 96, True, True, 0)])       # 300 tiles: every workgroup past its first tile
+def test_stride2_stem_conv_on_the_split_bf16_pipe(cin, cout, B, H, W, norm, relu, pad):
+    """XL_OP_CONV 3x3 stride 2 with XL_CONV_SPLIT_BF16 | XL_CONV_SPLIT_IL (csrc/xl_stem_split.hip): weights split on the host
+    (K tap-major), fp32 activations gathered per tap, optionally normalised (the producer's GroupNorm + ReLU applied to
+    in-image pixels only: the zero padding stays zero - the shift is non-zero here) and split by the kernel.  Against a
+    float64 convolution, and within a small factor of the fp32-MFMA kernel's own rounding error."""
+    g = torch.Generator().manual_seed(cin + cout + B + H)
+    x = torch.randn(B, cin, H, W, generator=g) * 3.0 + 1.0
+    coef = torch.stack([torch.rand(B, cin, generator=g) + 0.5, torch.randn(B, cin, generator=g) + 0.7], 2)
+    conv = nn.Conv2d(cin, cout, 3, 2, 1)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) * (2.0 / (9 * cin)) ** 0.5)
+        conv.bias.copy_(torch.randn(cout, generator=g))
+        xn = x.double()
+        if norm:
+            xn = xn * coef[:, :, 0, None, None].double() + coef[:, :, 1, None, None].double()
+            if relu:
+                xn = xn.clamp(min=0)
+        ref = F.conv2d(xn, conv.weight.double(), conv.bias.double(), stride=2, padding=1)
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    wide_in = torch.full((B, H, W, cin + pad), float("nan"))
+    wide_in[..., pad:] = _nhwc(x)
+    xd = wide_in.cuda()
+    wd = networks._Plan.split_bf16_interleaved(networks._Plan._stem_rows(conv.weight.detach().cuda()), 9 * cin)
+    bd, cd = conv.bias.detach().cuda(), coef.contiguous().cuda()
+    out = torch.full((B, Ho, Wo, cout + pad), float("nan"), device="cuda")
+    op = networks.XlOp()
+    op.type = networks.XL_OP_CONV
+    op.B, op.Hi, op.Wi, op.Cin, op.Ho, op.Wo, op.Cout = B, H, W, cin, Ho, Wo, cout
+    op.ksize, op.stride, op.ld_in, op.ld_out = 3, 2, cin + pad, cout + pad
+    op.flags = networks.CONV_SPLIT_BF16 | networks.CONV_SPLIT_IL
+    if norm:
+        op.flags |= networks.CONV_NORM_IN | (networks.CONV_NORM_RELU if relu else 0)
+        op.aux2 = cd.data_ptr()
+    op.in_, op.w, op.bias, op.out = xd.data_ptr() + 4 * pad, wd.data_ptr(), bd.data_ptr(), out.data_ptr()
+    _run([op, op])                                        # twice: the second launch must overwrite, not accumulate
+    got = out.cpu()
+    if pad:
+        assert torch.isnan(got[..., cout:]).all()
+    got = got[..., :cout].permute(0, 3, 1, 2).double()
+    _close(got, ref)
+    # the same layer through the fp32-MFMA kernel (operand normalised on the host)
+    xfd = _nhwc(xn.float()).cuda()
+    wsrc = conv.weight.detach().cuda().contiguous()
+    wpk = torch.empty_like(wsrc)
+    networks._check(networks._bind().xl_cnn_pack_conv_weight(wsrc.data_ptr(), wpk.data_ptr(), cout, cin, 3, None))
+    out32 = torch.full((B, Ho, Wo, cout), float("nan"), device="cuda")
+    o32 = networks.XlOp()
+    o32.type = networks.XL_OP_CONV
+    o32.B, o32.Hi, o32.Wi, o32.Cin, o32.Ho, o32.Wo, o32.Cout = B, H, W, cin, Ho, Wo, cout
+    o32.ksize, o32.stride, o32.ld_in, o32.ld_out = 3, 2, cin, cout
+    o32.in_, o32.w, o32.bias, o32.out = xfd.data_ptr(), wpk.data_ptr(), bd.data_ptr(), out32.data_ptr()
+    _run([o32])
+    scale = ref.abs().max().item()
+    e32 = (out32.cpu().permute(0, 3, 1, 2).double() - ref).abs().max().item() / scale
+    esp = (got - ref).abs().max().item() / scale
+    assert esp < 2e-6 and esp < 4 * e32 + 2e-7, (esp, e32)
+
+
+@pytest.mark.parametrize("m", [2, 4, 6])
+@pytest.mark.parametrize("dgrad", [0, 1])
+def test_winograd_weight_transform_kernel_vs_float64_einsum(m, dgrad):
+    """xl_cnn_pack_wino_weight (csrc/xl_pack.hip): U = G g G^T per channel pair in float64, rounded once - against torch's
+    float64 einsum (what the plans ran before round 3), in the fp32 form and in both split forms (whose three planes must
+    add up to the fp32 value exactly)."""
+    import ctypes
+    L = networks._bind()
+    cout, cin = 96, 64
+    w = torch.randn(cout, cin, 3, 3, generator=torch.Generator().manual_seed(m + dgrad)).cuda()
+    G = torch.tensor(networks._Plan._WINO_G[m], dtype=torch.float64, device="cuda")
+    g = w.double()
+    if dgrad:
+        g = g.flip(2, 3).permute(1, 0, 2, 3)
+    ref = torch.einsum("ia,ocab,jb->ijoc", G, g, G)                              # [m+2][m+2][rows][K]
+    rows, K, nf = g.shape[0], g.shape[1], (m + 2) ** 2
+    u32 = torch.full((nf, rows, K), float("nan"), device="cuda")
+    networks._check(L.xl_cnn_pack_wino_weight(w.data_ptr(), u32.data_ptr(), cout, cin, m, dgrad, 0, None))
+    torch.cuda.synchronize()
+    want = ref.reshape(nf, rows, K)
+    # rounded once: every element within half an fp32 ulp of the float64 value (plus float64 noise).  Not "== want.float()":
+    # exact ties are common (the sum of three fp32 weights divisible by 3, times 1/24, is a 25-bit number) and an ulp of
+    # float64 decides them
+    half_ulp = 2.0 ** -24 * want.abs().clamp(min=2.0 ** -126)                # half an ulp is at most 2^-24 |x|
+    assert ((u32.double() - want).abs() <= half_ulp * (1 + 1e-6)).all()
+    assert (u32 == want.float()).float().mean().item() > 0.98
+    p1 = torch.zeros(3, nf, rows, K, dtype=torch.int16, device="cuda")
+    networks._check(L.xl_cnn_pack_wino_weight(w.data_ptr(), p1.data_ptr(), cout, cin, m, dgrad, 1, None))
+    assert torch.equal(p1, networks._Plan.split_bf16(u32))
+    p2 = torch.zeros(nf, rows, K // 16, 3, 16, dtype=torch.int16, device="cuda")
+    networks._check(L.xl_cnn_pack_wino_weight(w.data_ptr(), p2.data_ptr(), cout, cin, m, dgrad, 2, None))
+    assert torch.equal(p2.reshape(-1), networks._Plan.split_bf16_interleaved(u32, K).reshape(-1))
+    back = p2.view(torch.bfloat16).float().sum(3).reshape(nf, rows, K)     # the three planes add up exactly
+    assert torch.equal(back, u32)
+
+
+def test_split_weight_kernel_is_the_exact_three_term_split():
+    L = networks._bind()
+    w1 = torch.randn(256, 96, generator=torch.Generator().manual_seed(1)).cuda()
+    p = torch.zeros(3 * w1.numel(), dtype=torch.int16, device="cuda")
+    networks._check(L.xl_cnn_split_weight(w1.data_ptr(), p.data_ptr(), 256, 96, 1, None))
+    assert torch.equal(p, networks._Plan.split_bf16_interleaved(w1, 96).reshape(-1))
+    w3 = torch.randn(64, 32, 3, 3, generator=torch.Generator().manual_seed(2)).cuda()
+    p = torch.zeros(3 * w3.numel(), dtype=torch.int16, device="cuda")
+    networks._check(L.xl_cnn_split_weight(w3.data_ptr(), p.data_ptr(), 64, 288, 9, None))
+    assert torch.equal(p, networks._Plan.split_bf16_interleaved(networks._Plan._stem_rows(w3), 288).reshape(-1))
+    assert L.xl_cnn_split_weight(w3.data_ptr(), p.data_ptr(), 64, 280, 9, None) != 0      # K % 16
