@@ -2305,11 +2305,15 @@ int run_op(const xl_op &op, hipStream_t st)
                 if (op.stats && (op.groups < 1 || op.Cin % op.groups != 0 || CB % (op.Cin / op.groups) != 0 ||
                                  CB / (op.Cin / op.groups) > 256))
                     return XL_ERR_ARG;
-                // round 3: M staged through LDS by DMA, one wave per (image, chunk, 128-channel slice)
+                // round 3: M staged through LDS by DMA, one wave per (image, chunk, 128-channel slice).  Measured at 47 frames:
+                // 256 channels 0.155 vs 0.174 ms for the register form with one channel per lane; 512 channels 0.29 vs 0.28 ms
+                // for the two-channels-per-lane register form (both ~5.1 TB/s: bytes in flight were not what limits this
+                // pass) - so the DMA form takes the layers the 8-byte register form does not cover.  XL_WINO_OUT_DMA=1: all.
                 static const bool noDma = getenv("XL_WINO_OUT_NO_DMA") != nullptr;
+                static const bool allDma = getenv("XL_WINO_OUT_DMA") != nullptr;
                 const int cpg6 = op.groups > 0 ? op.Cin / op.groups : 2;
                 const long long outB = ((long long)op.B * op.Hi * op.Wi - 1) * op.ld_out * 4 + (long long)op.Cin * 4;
-                if (!noDma && !(op.flags & XL_CONV_ACCUMULATE) && op.Cin % 128 == 0 && 64LL * op.B * Th6 * Tw6 * op.Cin * 4 < 0x7fffffffLL &&
+                if (!noDma && (allDma || !two) && !(op.flags & XL_CONV_ACCUMULATE) && op.Cin % 128 == 0 && 64LL * op.B * Th6 * Tw6 * op.Cin * 4 < 0x7fffffffLL &&
                     outB < 0x7fffffffLL && (!op.stats || (cpg6 >= 2 && cpg6 <= 128 && (cpg6 & (cpg6 - 1)) == 0 && op.Cin % op.groups == 0))) {
                     static XlLdsLimit configuredDma;
                     int cfgDev;

@@ -18,6 +18,8 @@
 #include "../../include/crossloc_cnn.h"
 #include "../../include/crossloc_dsac.h"
 
+int xl_run_wgrad_split(const xl_op &op, hipStream_t st);   // xl_wgrad_split.hip
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -1085,6 +1087,16 @@ int xl_run_bwd_op(const xl_op &op, hipStream_t st)
     switch (op.type) {
         case XL_OP_WGRAD: {
             if (op.nchunks2 < 1 || op.ld_in % 4 != 0 || op.ld_aux % 4 != 0) return XL_ERR_ARG;
+            if (op.flags & XL_CONV_SPLIT_BF16) {                      // 1x1 / batched Winograd products on the bf16 pipe
+                const int rc = xl_run_wgrad_split(op, st);
+                if (rc != XL_OK) return rc;
+                const long long total = (long long)op.Cout * op.Cin;
+                long long blocks = (total + 255) / 256;
+                if (blocks > 2048) blocks = 2048;
+                hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks, op.groups > 1 ? op.groups : 1), dim3(256), 0, st,
+                                   (const float *)op.stats2, (float *)op.out, op.nchunks2, 1, op.Cout, op.Cin);
+                return XL_OK;
+            }
             if (op.Cout % 128 == 0 && op.Cin % 128 == 0) return launch_wgrad<128, 128, 2, 2>(op, st);
             if (op.Cout % 128 == 0 && op.Cin % 64 == 0) return launch_wgrad<128, 64, 2, 2>(op, st);
             if (op.Cout % 64 == 0 && op.Cin % 32 == 0) return launch_wgrad<64, 32, 2, 1>(op, st);

@@ -146,20 +146,30 @@ __device__ __forceinline__ int blend_u8(int degenerate, int v, float alpha, bool
 __device__ __forceinline__ int luma(int r, int g, int b) { return (r * 19595 + g * 38470 + b * 7471 + 0x8000) >> 16; }
 
 struct Jitter { float brightness, contrast; int contrastFirst, active; };
+// the per-frame jitter records of one call travel as a by-value kernel argument (1 KB for 64 frames): no device table to
+// fill, no host synchronisation - the call stays asynchronous on its stream.  Larger mini-batches run in chunks of 64.
+constexpr int kJitMax = 64;
+struct JitterPack { Jitter j[kJitMax]; };
 
 // per-image sum of the 'L' conversion of the image the contrast step sees (the brightened one when brightness runs first)
 __global__ __launch_bounds__(256)
-void gray_sum_kernel(const uint8_t *__restrict__ img, int Cs, long long pixels, const Jitter *__restrict__ jit,
-                     unsigned long long *__restrict__ sums)
+void gray_sum_kernel(const uint8_t *__restrict__ img, int Cs, long long pixels, JitterPack jit,
+                     unsigned long long *__restrict__ sums, int gray)
 {
     const int b = blockIdx.y;
-    const Jitter j = jit[b];
+    const Jitter j = jit.j[b];
     if (!j.active) return;
     const bool bInterp = j.brightness >= 0.f && j.brightness <= 1.f;
     unsigned long long acc = 0;
     for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < pixels; p += (long long)gridDim.x * 256) {
         const uint8_t *s = img + ((long long)b * pixels + p) * Cs;
         int r = s[0], g = s[1], bl = s[2];
+        if (gray) {                                   // Grayscale() runs before ColorJitter: the image IS its 'L' conversion
+            int l = luma(r, g, bl);
+            if (!j.contrastFirst) l = blend_u8(0, l, j.brightness, bInterp);
+            acc += (unsigned long long)l;
+            continue;
+        }
         if (!j.contrastFirst) {
             r = blend_u8(0, r, j.brightness, bInterp); g = blend_u8(0, g, j.brightness, bInterp); bl = blend_u8(0, bl, j.brightness, bInterp);
         }
@@ -170,18 +180,29 @@ void gray_sum_kernel(const uint8_t *__restrict__ img, int Cs, long long pixels, 
 }
 
 __global__ __launch_bounds__(256)
-void jitter_to_tensor_kernel(const uint8_t *__restrict__ img, int Cs, long long pixels, const Jitter *__restrict__ jit,
+void jitter_to_tensor_kernel(const uint8_t *__restrict__ img, int Cs, long long pixels, JitterPack jit,
                              const unsigned long long *__restrict__ sums, float m0, float m1, float m2, float s0, float s1,
-                             float s2, int normalize, float *__restrict__ out)
+                             float s2, int normalize, float *__restrict__ out, int gray)
 {
     const int b = blockIdx.y;
-    const Jitter j = jit[b];
+    const Jitter j = jit.j[b];
     int mean = 0;
     if (j.active) mean = (int)((double)sums[b] / (double)pixels + 0.5);       // int(ImageStat mean + 0.5)
     const bool bInterp = j.brightness >= 0.f && j.brightness <= 1.f, cInterp = j.contrast >= 0.f && j.contrast <= 1.f;
     for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < pixels; p += (long long)gridDim.x * 256) {
         const uint8_t *s = img + ((long long)b * pixels + p) * Cs;
         int v[3] = { s[0], s[1], s[2] };
+        if (gray) {                                   // transforms.Grayscale(): one channel, (x - mean[0]) / std[0]
+            int l = luma(v[0], v[1], v[2]);
+            if (j.active) {
+                if (j.contrastFirst) l = blend_u8(0, blend_u8(mean, l, j.contrast, cInterp), j.brightness, bInterp);
+                else l = blend_u8(mean, blend_u8(0, l, j.brightness, bInterp), j.contrast, cInterp);
+            }
+            float f = (float)l / 255.f;
+            if (normalize) f = (f - m0) / s0;
+            out[(long long)b * pixels + p] = f;
+            continue;
+        }
         if (j.active) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
@@ -277,9 +298,9 @@ long long xl_data_prepare_workspace_bytes(int B, int Hs, int Ws, int H, int W)
            al((long long)B * sizeof(unsigned long long));
 }
 
-int xl_data_prepare_images(const uint8_t *src, int B, int Hs, int Ws, int Cs, int image_height,
-                           const float *jitter_host, const float *mean_host, const float *std_host,
-                           float *out, void *workspace, void *stream)
+static int prepare_images(const uint8_t *src, int B, int Hs, int Ws, int Cs, int image_height,
+                          const float *jitter_host, const float *mean_host, const float *std_host,
+                          float *out, void *workspace, void *stream, int gray)
 {
     if (!src || !out || !workspace || B < 1 || (Cs != 3 && Cs != 4) || (mean_host == nullptr) != (std_host == nullptr)) return XL_ERR_ARG;
     int H = 0, W = 0;
@@ -309,30 +330,48 @@ int xl_data_prepare_images(const uint8_t *src, int B, int Hs, int Ws, int Cs, in
                            H, t.bounds, t.coef, t.ksize);
         cur = res; curC = 3;
     }
-    std::vector<Jitter> hj((size_t)B);
-    for (int b = 0; b < B; ++b) {
-        hj[b].active = jitter_host ? 1 : 0;
-        hj[b].brightness = jitter_host ? jitter_host[3 * b] : 1.f;
-        hj[b].contrast = jitter_host ? jitter_host[3 * b + 1] : 1.f;
-        hj[b].contrastFirst = jitter_host ? (jitter_host[3 * b + 2] != 0.f) : 0;
-    }
-    // (pageable source: the copy is staged before the call returns, the vector may die afterwards)
-    if (hipMemcpyAsync(jit, hj.data(), sizeof(Jitter) * B, hipMemcpyHostToDevice, st) != hipSuccess) return XL_ERR_HIP;
-    if (hipStreamSynchronize(st) != hipSuccess) return XL_ERR_HIP;
+    (void)jit;
     const long long pixels = (long long)H * W;
-    if (jitter_host) {
-        if (hipMemsetAsync(sums, 0, sizeof(unsigned long long) * B, st) != hipSuccess) return XL_ERR_HIP;
+    const int nm = gray ? 1 : 3;                                       // entries of mean_host / std_host
+    const float m0 = mean_host ? mean_host[0] : 0.f, m1 = (mean_host && nm > 1) ? mean_host[1] : 0.f, m2 = (mean_host && nm > 2) ? mean_host[2] : 0.f;
+    const float s0 = std_host ? std_host[0] : 1.f, s1 = (std_host && nm > 1) ? std_host[1] : 1.f, s2 = (std_host && nm > 2) ? std_host[2] : 1.f;
+    if (jitter_host && hipMemsetAsync(sums, 0, sizeof(unsigned long long) * B, st) != hipSuccess) return XL_ERR_HIP;
+    for (int b0 = 0; b0 < B; b0 += kJitMax) {                          // the jitter records ride in the kernel arguments
+        const int nb = B - b0 < kJitMax ? B - b0 : kJitMax;
+        JitterPack pack;
+        for (int b = 0; b < kJitMax; ++b) {
+            const bool on = jitter_host && b < nb;
+            pack.j[b].active = on ? 1 : 0;
+            pack.j[b].brightness = on ? jitter_host[3 * (b0 + b)] : 1.f;
+            pack.j[b].contrast = on ? jitter_host[3 * (b0 + b) + 1] : 1.f;
+            pack.j[b].contrastFirst = on ? (jitter_host[3 * (b0 + b) + 2] != 0.f) : 0;
+        }
+        const uint8_t *img = cur + (long long)b0 * pixels * curC;
+        if (jitter_host) {
+            unsigned gx = grid_for(pixels);
+            if (gx > 1024) gx = 1024;
+            hipLaunchKernelGGL(gray_sum_kernel, dim3(gx, nb), dim3(256), 0, st, img, curC, pixels, pack, sums + b0, gray);
+        }
         unsigned gx = grid_for(pixels);
-        if (gx > 1024) gx = 1024;
-        hipLaunchKernelGGL(gray_sum_kernel, dim3(gx, B), dim3(256), 0, st, cur, curC, pixels, jit, sums);
+        if (gx > 4096) gx = 4096;
+        hipLaunchKernelGGL(jitter_to_tensor_kernel, dim3(gx, nb), dim3(256), 0, st, img, curC, pixels, pack, sums + b0, m0, m1, m2,
+                           s0, s1, s2, mean_host ? 1 : 0, out + (long long)b0 * (gray ? 1 : 3) * pixels, gray);
     }
-    const float m0 = mean_host ? mean_host[0] : 0.f, m1 = mean_host ? mean_host[1] : 0.f, m2 = mean_host ? mean_host[2] : 0.f;
-    const float s0 = std_host ? std_host[0] : 1.f, s1 = std_host ? std_host[1] : 1.f, s2 = std_host ? std_host[2] : 1.f;
-    unsigned gx = grid_for(pixels);
-    if (gx > 4096) gx = 4096;
-    hipLaunchKernelGGL(jitter_to_tensor_kernel, dim3(gx, B), dim3(256), 0, st, cur, curC, pixels, jit, sums, m0, m1, m2, s0, s1,
-                       s2, mean_host ? 1 : 0, out);
     return hipGetLastError() == hipSuccess ? XL_OK : XL_ERR_HIP;
+}
+
+int xl_data_prepare_images(const uint8_t *src, int B, int Hs, int Ws, int Cs, int image_height,
+                           const float *jitter_host, const float *mean_host, const float *std_host,
+                           float *out, void *workspace, void *stream)
+{
+    return prepare_images(src, B, Hs, Ws, Cs, image_height, jitter_host, mean_host, std_host, out, workspace, stream, 0);
+}
+
+int xl_data_prepare_images_gray(const uint8_t *src, int B, int Hs, int Ws, int Cs, int image_height,
+                                const float *jitter_host, const float *mean_host, const float *std_host,
+                                float *out, void *workspace, void *stream)
+{
+    return prepare_images(src, B, Hs, Ws, Cs, image_height, jitter_host, mean_host, std_host, out, workspace, stream, 1);
 }
 
 int xl_data_batch_augment(const float *in, float *out, int B, int C, int H, int W, int oh, int ow,

@@ -430,12 +430,10 @@ void split_gemm_persist_kernel(SplitArgs2 a)
 // LDS (157 KB): weights 3 x 24 KB | activations 2 x 24 KB | 8 KB | fp64 partials 8 KB | coefficient tables 2 x 8 KB |
 // bias 4 KB.  The statistics epilogue stages its per-lane sums in activation stage 1 + the 8 KB behind it: C / 16 is even,
 // so when a tile ends stage 1 has just been multiplied and stage 0 holds the first step of the next tile.
-constexpr int kCvA = 3 * kIOperand;                   // activation stages
-constexpr int kCvStage1 = kCvA + kIOperand;           // statistics staging: 32 KB from here
-constexpr int kCvPart = kCvA + 2 * kIOperand + 8192;  // fp64 partials [32][16][2]
-constexpr int kCvCoef = kCvPart + 8192;               // coefficient tables of two tiles, 8 KB each (C <= 512)
-constexpr int kCvBias = kCvCoef + 16384;              // bias[N <= 1024]
-constexpr int kCvLds = kCvBias + 4096;
+constexpr int split_conv_lds(int NW)                  // bytes of LDS of split_conv1x1_kernel<., ., NW>
+{
+    return 3 * (NW == 8 ? 256 : 128) * kIUnit + 2 * (32 * NW) * kIUnit + 2 * 16 * (64 * NW) + 16384 + 4096;
+}
 
 struct SplitConvArgs {
     const float *in; const uint16_t *u; const float *bias; float *out;
@@ -464,15 +462,27 @@ __device__ __forceinline__ void split_pair(float x, float y, unsigned &w1, unsig
     w3 = pk_bf16(rx - lo_f(w2), ry - hi_f(w2));
 }
 
-template <bool NORM>
-__global__ __launch_bounds__(512)
+// NW = waves per workgroup: 8 -> tiles of 256 x 256 (2 x 4 waves of 128 x 64), the throughput form; 4 -> tiles of 128 x 128
+// (2 x 2 waves of 64 x 64) for launches whose 256 x 256 tiles would leave most of the 256 CUs idle (a single frame: 44 tiles).
+// Every output element accumulates its K-steps and term pairs in the same order in both forms: bitwise the same result.
+template <bool NORM, bool ACC = false, int NW = 8>  // ACC: out += result (a data gradient with a second producer, training plans)
+__global__ __launch_bounds__(64 * NW)
 void split_conv1x1_kernel(SplitConvArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
     typedef __attribute__((address_space(3))) void lds_void;
+    constexpr int NTH = 64 * NW, BM = NTH / 2, BN = NW == 8 ? 256 : 128;      // threads; tile rows (a thread = 8 channels of a row); columns
+    constexpr int WN = BN / 64, WM = NW / WN, RI = BM / WM / 32;              // waves across columns / rows; 32-row blocks per wave
+    static_assert(WM == 2 && RI * WM * 32 == BM, "tile shape");
+    constexpr int kW = BN * kIUnit, kAS = BM * kIUnit;                         // one weight stage / one activation stage
+    constexpr int kCvA = 3 * kW, kCvStage1 = kCvA + kAS;                       // activation stages; statistics staging: 64 NTH bytes
+    constexpr int kCvPart = kCvA + 2 * kAS + 16 * NTH;                         // fp64 partials [NTH / 16][16][2]
+    constexpr int kCvCoef = kCvPart + 16 * NTH;                                // coefficient tables of two tiles, 8 KB each (C <= 512)
+    constexpr int kCvBias = kCvCoef + 16384;                                   // bias[N <= 1024]
+    constexpr int NS = 8 * RI;                                                 // stores per wave and tile
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
+    const int wm = wave / WN, wn = wave % WN;
 
     const int total = a.nbm * a.nbn * a.Z;
     const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3, nloc = gridDim.x >> 3;
@@ -487,17 +497,17 @@ void split_conv1x1_kernel(SplitConvArgs a)
         int t = runStart + local + i * nloc;
         t -= (t / (a.nbm * a.nbn)) * (a.nbm * a.nbn);
         const int mt = t / a.nbn;
-        n0 = (t - mt * a.nbn) * 256;
+        n0 = (t - mt * a.nbn) * BN;
         if (a.tpi) {
             const int n = mt / a.tpi;
-            m0 = n * a.HW + (mt - n * a.tpi) * 256;
-        } else m0 = mt * 256;
+            m0 = n * a.HW + (mt - n * a.tpi) * BM;
+        } else m0 = mt * BM;
     };
     // rows of the tile at m0 (per-image tiles end with their image)
     auto tile_rows = [&](int m0) {
         int rows = a.M - m0;
         if (a.tpi) rows = (m0 / a.HW + 1) * a.HW - m0;
-        return rows < 256 ? rows : 256;
+        return rows < BM ? rows : BM;
     };
 
     constexpr unsigned OOB = 0x80000000u;
@@ -535,7 +545,7 @@ void split_conv1x1_kernel(SplitConvArgs a)
         }
     };
     auto dma_instr = [&](int q, int stage) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(srdU, (lds_void *)(dsm + stage * kIOperand + (wave * 3 + q) * 1024), 16,
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(srdU, (lds_void *)(dsm + stage * kW + (wave * 3 + q) * 1024), 16,
                                                  (int)gB[q], dK * kIUnit, 0, 0);
     };
     u32x4 rA[2][2];                                                    // [K-step parity][half of my 8 channels]
@@ -587,24 +597,36 @@ void split_conv1x1_kernel(SplitConvArgs a)
         }
 #pragma unroll
         for (int p = 0; p < 3; ++p)
-            *reinterpret_cast<u32x4 *>(dsm + stage * kIOperand + wOff[p]) = u32x4{ w[p][0], w[p][1], w[p][2], w[p][3] };
+            *reinterpret_cast<u32x4 *>(dsm + stage * kAS + wOff[p]) = u32x4{ w[p][0], w[p][1], w[p][2], w[p][3] };
     };
     auto advance_conv = [&]() {
         if (++cK == nk) { cK = 0; ++cTile; set_conv_tile(cTile); }
     };
     // coefficient table of tile i: the {scale, shift} pairs of its (at most two) images, 4 C floats, into table i & 1
     const __amdgpu_buffer_rsrc_t srdCoef = __builtin_amdgcn_make_buffer_rsrc((void *)a.coef, 0, NORM ? a.B * a.C * 8 : 0, 0x00020000);
-    auto load_table = [&](int i) -> u32x4 {
-        unsigned off = OOB;
-        if (i < myCount && tid < a.C) {
-            int m0, n0;
-            tile_at(i, m0, n0);
-            off = (unsigned)(((long long)(m0 / a.HW) * a.C * 2 + tid * 4) * 4);
+    constexpr int TPT = 512 / NTH;                                     // 16-byte table entries per thread (C <= 512)
+    struct Tab { u32x4 v[TPT]; };
+    auto load_table = [&](int i) -> Tab {
+        Tab t;
+#pragma unroll
+        for (int e = 0; e < TPT; ++e) {
+            const int idx = tid + e * NTH;
+            unsigned off = OOB;
+            if (i < myCount && idx < a.C) {
+                int m0, n0;
+                tile_at(i, m0, n0);
+                off = (unsigned)(((long long)(m0 / a.HW) * a.C * 2 + idx * 4) * 4);
+            }
+            t.v[e] = __builtin_amdgcn_raw_buffer_load_b128(srdCoef, (int)off, 0, 0);
         }
-        return __builtin_amdgcn_raw_buffer_load_b128(srdCoef, (int)off, 0, 0);
+        return t;
     };
-    auto store_table = [&](int i, u32x4 v) {
-        if (tid < a.C) *reinterpret_cast<u32x4 *>(dsm + kCvCoef + (i & 1) * 8192 + tid * 16) = v;
+    auto store_table = [&](int i, const Tab &t) {
+#pragma unroll
+        for (int e = 0; e < TPT; ++e) {
+            const int idx = tid + e * NTH;
+            if (idx < a.C) *reinterpret_cast<u32x4 *>(dsm + kCvCoef + (i & 1) * 8192 + idx * 16) = t.v[e];
+        }
     };
 
     // ---- fragments
@@ -616,14 +638,14 @@ void split_conv1x1_kernel(SplitConvArgs a)
         if (ph >= 6) ph -= 6;
         slotOff[p] = (unsigned)(ph * 16);
     }
-    const unsigned frA = (unsigned)(kCvA + (wm * 128 + fr) * kIUnit), frB = (unsigned)((wn * 64 + fr) * kIUnit);
-    bf16x8 fa[3][4], fb[3][2];
-    f32x16 acc[4][2];
-    auto ldA = [&](int stage, int p, int i) { return *reinterpret_cast<const bf16x8 *>(dsm + stage * kIOperand + frA + i * 32 * kIUnit + slotOff[p]); };
-    auto ldB = [&](int stage, int p, int j) { return *reinterpret_cast<const bf16x8 *>(dsm + stage * kIOperand + frB + j * 32 * kIUnit + slotOff[p]); };
+    const unsigned frA = (unsigned)(kCvA + (wm * (32 * RI) + fr) * kIUnit), frB = (unsigned)((wn * 64 + fr) * kIUnit);
+    bf16x8 fa[3][RI], fb[3][2];
+    f32x16 acc[RI][2];
+    auto ldA = [&](int stage, int p, int i) { return *reinterpret_cast<const bf16x8 *>(dsm + stage * kAS + frA + i * 32 * kIUnit + slotOff[p]); };
+    auto ldB = [&](int stage, int p, int j) { return *reinterpret_cast<const bf16x8 *>(dsm + stage * kW + frB + j * 32 * kIUnit + slotOff[p]); };
     auto mma_term = [&](int pu, int pv) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < RI; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[pu][j], fa[pv][i], acc[i][j], 0, 0, 0);
@@ -636,16 +658,16 @@ void split_conv1x1_kernel(SplitConvArgs a)
             for (int q = 0; q < 4; ++q) {
                 const f32x4 b = *reinterpret_cast<const f32x4 *>(dsm + kCvBias + (n0 + wn * 64 + j * 32 + rhalf + 8 * q) * 4);
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < RI; ++i)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) acc[i][j][4 * q + e] = b[e];
             }
     };
 
     // ---- prologue: bias and the first two coefficient tables into LDS, steps 0 and 1 of the stream, step 0 converted
-    for (int i = tid; i < a.nbn * 256; i += 512) reinterpret_cast<float *>(dsm + kCvBias)[i] = (a.bias && i < a.N) ? a.bias[i] : 0.f;
+    for (int i = tid; i < a.nbn * BN; i += NTH) reinterpret_cast<float *>(dsm + kCvBias)[i] = (a.bias && i < a.N) ? a.bias[i] : 0.f;
     if constexpr (NORM) {
-        const u32x4 t0 = load_table(0), t1 = load_table(1);
+        const Tab t0 = load_table(0), t1 = load_table(1);
         store_table(0, t0);
         store_table(1, t1);
     }
@@ -679,16 +701,19 @@ void split_conv1x1_kernel(SplitConvArgs a)
 #pragma unroll
         for (int j = 0; j < 2; ++j) fb[2][j] = ldB(sc, 2, j);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) fa[0][i] = ldA(sa, 0, i);
+        for (int i = 0; i < RI; ++i) fa[0][i] = ldA(sa, 0, i);
 #pragma unroll
         for (int j = 0; j < 2; ++j) fb[1][j] = ldB(sc, 1, j);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) fa[1][i] = ldA(sa, 1, i);
+        for (int i = 0; i < RI; ++i) fa[1][i] = ldA(sa, 1, i);
 #pragma unroll
         for (int j = 0; j < 2; ++j) fb[0][j] = ldB(sc, 0, j);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) fa[2][i] = ldA(sa, 2, i);
         mma_term(2, 0); dma_instr(0, sd);
+        // (the third plane of the activations is first used by term 3: read it here, into the registers the first term's
+        //  weight fragments have just left - all 18 fragment reads up front cost 16 more live registers and spilled)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < RI; ++i) fa[2][i] = ldA(sa, 2, i);
         mma_term(1, 1); dma_instr(1, sd);
         __builtin_amdgcn_sched_barrier(0);
         mma_term(0, 2);
@@ -701,22 +726,22 @@ void split_conv1x1_kernel(SplitConvArgs a)
         mma_term(1, 0);
         convert(std::integral_constant<int, sa ^ 1>{});           // (the compiler counts vmcnt for rA)
         mma_term(0, 1);
+        {
+            constexpr int nM = 4 * RI, groups = nM < 12 ? nM : 12, valu = 72 / groups;    // MFMAs of the two terms; 12 x 6 / 8 x 9 VALU
 #pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-            if constexpr (NORM) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // coefficient reads of 4 channels
-#pragma unroll
-            for (int g = 0; g < 6; ++g) {
+            for (int g = 0; g < groups; ++g) {
+                if constexpr (NORM) { if (g == 0 || g == groups / 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); }  // coefficient reads of 4 channels
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, valu, 0);
             }
+            __builtin_amdgcn_sched_group_barrier(0x200, 3, 0);                      // the three LDS writes
+            if constexpr (nM > groups) __builtin_amdgcn_sched_group_barrier(0x008, nM - groups, 0);
         }
-        __builtin_amdgcn_sched_group_barrier(0x200, 3, 0);                          // the three LDS writes
-        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
         __builtin_amdgcn_sched_barrier(0);
         advance_conv();
         // the weights of step kk + 1 have landed: younger are 2 DMAs and 2 loads of step kk + 2 - and, in the first
         // step of a tile, the 32 stores of the tile before (vmcnt(36)); lgkmcnt(0): my activation writes are done
-        if constexpr (decltype(firstTag)::value) __builtin_amdgcn_s_waitcnt(0x8070 | 4);
+        if constexpr (decltype(firstTag)::value) __builtin_amdgcn_s_waitcnt(0x0070 | ((4 + NS) & 15) | (((4 + NS) >> 4) << 14));
         else __builtin_amdgcn_s_waitcnt(0x0070 | 4);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
@@ -731,22 +756,21 @@ void split_conv1x1_kernel(SplitConvArgs a)
         // ---- tile ti (swapped operands): row = lane & 31, channels (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
         int m0, n0;
         tile_at(ti, m0, n0);
-        u32x4 tab;
         if (a.stats != nullptr) {
             // GroupNorm partial sums of the output; a tile touches at most two images (HW >= 256): slot 0 = rows before
             // `split`, slot 1 = the rest.  Fixed order: per lane fp32 over its 4 rows x 8 channels of a group; fp64 over
             // the 128 lanes holding the group (16 parts of 8 lanes, then the parts); one writer per (image, tile, group).
             const int nLo = m0 / a.HW;
             const int split = (nLo + 1) * a.HW - m0;
-            f32x2 *sS = reinterpret_cast<f32x2 *>(dsm + kCvStage1);    // [4 pieces][2 slots][512 threads]
+            f32x2 *sS = reinterpret_cast<f32x2 *>(dsm + kCvStage1);    // [4 pieces][2 slots][NTH threads]
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int gh = 0; gh < 2; ++gh) {
                     float s[2] = { 0.f, 0.f }, ss[2] = { 0.f, 0.f };
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int row = wm * 128 + i * 32 + fr;
+                    for (int i = 0; i < RI; ++i) {
+                        const int row = wm * (32 * RI) + i * 32 + fr;
                         float t = 0.f, tt = 0.f;
 #pragma unroll
                         for (int e = 0; e < 8; ++e) {
@@ -759,15 +783,15 @@ void split_conv1x1_kernel(SplitConvArgs a)
                         s[1] += (live && hi) ? t : 0.f;  ss[1] += (live && hi) ? tt : 0.f;
                     }
 #pragma unroll
-                    for (int sl = 0; sl < 2; ++sl) sS[((j * 2 + gh) * 2 + sl) * 512 + tid] = f32x2{ s[sl], ss[sl] };
+                    for (int sl = 0; sl < 2; ++sl) sS[((j * 2 + gh) * 2 + sl) * NTH + tid] = f32x2{ s[sl], ss[sl] };
                 }
             __builtin_amdgcn_s_waitcnt(0x0070 | 0xC00F);               // lgkmcnt(0)
             __builtin_amdgcn_s_barrier();
             {
                 const int gs = tid >> 4, part = tid & 15;              // (group of the tile, slot) x 16 parts
                 const int gt = gs >> 1, sl = gs & 1;
-                const int src = ((part >> 3) * 4 + (gt >> 2)) * 64 + (part & 7) * 8;
-                const f32x2 *o = sS + ((gt & 3) * 2 + sl) * 512 + src;
+                const int src = ((part >> 3) * WN + (gt >> 2)) * 64 + (part & 7) * 8;
+                const f32x2 *o = sS + ((gt & 3) * 2 + sl) * NTH + src;
                 double s1 = 0.0, s2 = 0.0;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { s1 += (double)o[e][0]; s2 += (double)o[e][1]; }
@@ -776,24 +800,24 @@ void split_conv1x1_kernel(SplitConvArgs a)
             }
             __builtin_amdgcn_s_waitcnt(0x0070 | 0xC00F);
             __builtin_amdgcn_s_barrier();
-            if (tid < 32) {
+            if (tid < NTH / 16) {
                 const int gt = tid >> 1, sl = tid & 1;
                 const int n = nLo + sl;
                 const int firstRow = sl ? split : 0;
                 const int g = (n0 >> 4) + gt;
-                if (n < a.B && m0 + firstRow < a.M && (sl == 0 || (split < 256 && !a.tpi)) && g < a.G) {
+                if (n < a.B && m0 + firstRow < a.M && (sl == 0 || (split < BM && !a.tpi)) && g < a.G) {
                     const double *sC = reinterpret_cast<const double *>(dsm + kCvPart) + tid * 32;
                     double s1 = 0.0, s2 = 0.0;
                     for (int e = 0; e < 16; ++e) { s1 += sC[2 * e]; s2 += sC[2 * e + 1]; }
-                    const int k = a.tpi ? (m0 - n * a.HW) >> 8                            // tile index within the image
-                                        : (m0 >> 8) - (int)(((long long)n * a.HW) >> 8);
+                    const int k = a.tpi ? (m0 - n * a.HW) / BM                            // tile index within the image
+                                        : m0 / BM - (int)(((long long)n * a.HW) / BM);
                     double *o = a.stats + (((long long)n * a.nchunks + k) * a.G + g) * 2;
                     o[0] = s1; o[1] = s2;
                 }
             }
         }
         if constexpr (NORM) {                                          // (waits for everything older than the table)
-            tab = load_table(ti + 2);
+            const Tab tab = load_table(ti + 2);
             store_table(ti + 2, tab);
         }
         // (every wave issues exactly 32 stores per tile - the vmcnt arithmetic of the next step counts them: rows past the
@@ -801,15 +825,25 @@ void split_conv1x1_kernel(SplitConvArgs a)
         const __amdgpu_buffer_rsrc_t srdO = __builtin_amdgcn_make_buffer_rsrc((void *)(a.out + tile_z(ti) * a.zOut + (long long)m0 * a.ldOut), 0,
                                                                               tile_rows(m0) * a.ldOut * 4, 0x00020000);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const unsigned rowOff = (unsigned)((wm * 128 + i * 32 + fr) * a.ldOut * 4);
+        for (int i = 0; i < RI; ++i) {
+            const unsigned rowOff = (unsigned)((wm * (32 * RI) + i * 32 + fr) * a.ldOut * 4);
+            f32x4 old[2][4];
+            if constexpr (ACC) {                                       // (8 loads in flight per 32-row block; rows past the tile read 0)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        old[j][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                            srdO, (int)(rowOff + (unsigned)(n0 + wn * 64 + j * 32 + rhalf + 8 * q) * 4u), 0, 0));
+            }
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int n = n0 + wn * 64 + j * 32 + rhalf + 8 * q;
                     const unsigned off = rowOff + (unsigned)n * 4u;
-                    const f32x4 v = f32x4{ acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3] };
+                    f32x4 v = f32x4{ acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3] };
+                    if constexpr (ACC) v += old[j][q];
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), srdO, (int)off, 0, 0);
                 }
         }
@@ -845,46 +879,65 @@ void split_conv1x1_kernel(SplitConvArgs a)
 // XL_OP_CONV with XL_CONV_SPLIT_BF16 | XL_CONV_SPLIT_IL and nchunks2 <= 1: a 1x1 stride-1 convolution, fp32 NHWC in / out
 // (ld_in / ld_out), w = [Cout][Cin/16][3][16] bf16, bias, optionally XL_CONV_NORM_IN (aux2 = [B][Cin][2] coefficients) and the
 // statistics epilogue (stats / groups / nchunks with 256-row tiles: nchunks >= ceil(HW / 256) + 1, 16 channels per group).
+template <int NW>
+static int launch_split_conv1x1(const xl_op &op, SplitConvArgs a, bool norm, int Z, hipStream_t st)
+{
+    constexpr int BM = 32 * NW, BN = NW == 8 ? 256 : 128;
+    const long long M = a.M;
+    const bool perImage = op.reserved_i < 0;         // tiles start at image boundaries (reserved_i = -256 / -128)
+    a.tpi = perImage ? (a.HW + BM - 1) / BM : 0;
+    a.nbm = perImage ? op.B * a.tpi : (int)((M + BM - 1) / BM);
+    a.nbn = (op.Cout + BN - 1) / BN;
+    const size_t lds = split_conv_lds(NW);
+    const bool accumulate = (op.flags & XL_CONV_ACCUMULATE) != 0;
+    const void *fn = accumulate ? reinterpret_cast<const void *>(split_conv1x1_kernel<false, true, NW>)
+                   : norm ? reinterpret_cast<const void *>(split_conv1x1_kernel<true, false, NW>)
+                          : reinterpret_cast<const void *>(split_conv1x1_kernel<false, false, NW>);
+    static XlLdsLimit configured[3];
+    int cfgDev;
+    const int slot = accumulate ? 2 : (norm ? 1 : 0);
+    if (configured[slot].needs(lds, &cfgDev)) {
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return XL_ERR_HIP;
+        configured[slot].done(lds, cfgDev);
+    }
+    const int nwg = a.nbm * a.nbn * Z;
+    int grid = 256;                                   // persistent: one workgroup per CU
+    if (grid > ((nwg + 7) & ~7)) grid = (nwg + 7) & ~7;
+    if (accumulate) hipLaunchKernelGGL((split_conv1x1_kernel<false, true, NW>), dim3(grid), dim3(64 * NW), lds, st, a);
+    else if (norm) hipLaunchKernelGGL((split_conv1x1_kernel<true, false, NW>), dim3(grid), dim3(64 * NW), lds, st, a);
+    else hipLaunchKernelGGL((split_conv1x1_kernel<false, false, NW>), dim3(grid), dim3(64 * NW), lds, st, a);
+    return XL_OK;
+}
+
+// reserved_i selects the tile form: +-256 (or 0 / 64, what the fp32 path passes): 256 x 256 tiles; +-128: 128 x 128 tiles (the
+// statistics epilogue then writes one entry per 128-row tile: nchunks >= ceil(HW / 128) + 1, GN_FINAL / GN_APPLY take 128);
+// negative: tiles start at image boundaries.
 static int xl_run_split_conv1x1(const xl_op &op, hipStream_t st)
 {
     const long long M = (long long)op.B * op.Ho * op.Wo;
     const int HW = op.Ho * op.Wo;
     const bool norm = (op.flags & XL_CONV_NORM_IN) != 0;
+    const bool small = op.reserved_i == 128 || op.reserved_i == -128;
+    const int BM = small ? 128 : 256;
     const int Z = op.nchunks2 > 1 ? op.nchunks2 : 1;            // Z > 1: XL_CONV_SPLIT_ACT, the batched GEMMs of a Winograd layer
     if (Z > 1 && (op.bias || op.stats || norm || op.reserved_i < 0 || op.ld_in != op.Cin || op.ld_out != op.Cout)) return XL_ERR_ARG;
     if (op.ksize != 1 || op.stride != 1 || op.Cin % 32 != 0 || op.Cout % 256 != 0 || op.Cout > 1024 || op.ld_in < op.Cin ||
-        op.ld_out < op.Cout || (op.ld_in & 3) || (op.ld_out & 3) || (!op.bias && Z == 1) || (op.flags & XL_CONV_ACCUMULATE) || !op.in ||
+        op.ld_out < op.Cout || (op.ld_in & 3) || (op.ld_out & 3) || ((op.flags & XL_CONV_ACCUMULATE) && (norm || Z > 1 || op.stats)) || !op.in ||
         !op.w || !op.out || (((uintptr_t)op.in | (uintptr_t)op.out | (uintptr_t)op.w) & 15) || M >= 0x7fffffffLL ||
         (long long)op.Cout * op.Cin * 6 >= 0x7fffffffLL || 256LL * op.ld_in * 4 >= 0x7fffffffLL || 256LL * op.ld_out * 4 >= 0x7fffffffLL)
         return XL_ERR_ARG;
-    if (norm && (!op.aux2 || op.Cin > 512 || HW < 256)) return XL_ERR_ARG;
-    if (op.stats && (op.groups <= 0 || op.Cout != 16 * op.groups || HW < 256 || op.nchunks < (HW + 255) / 256 + 1)) return XL_ERR_ARG;
-    const bool perImage = op.reserved_i < 0;         // tiles start at image boundaries (reserved_i = -256)
-    if (perImage && HW < 256) return XL_ERR_ARG;
+    if (norm && (!op.aux2 || op.Cin > 512 || HW < BM)) return XL_ERR_ARG;
+    if (op.stats && (op.groups <= 0 || op.Cout != 16 * op.groups || HW < BM || op.nchunks < (HW + BM - 1) / BM + 1)) return XL_ERR_ARG;
+    if (op.reserved_i < 0 && HW < BM) return XL_ERR_ARG;
     SplitConvArgs a;
     a.in = (const float *)op.in; a.u = (const uint16_t *)op.w; a.bias = (const float *)op.bias; a.out = (float *)op.out;
     a.coef = (const float *)op.aux2;
     a.normLo = (op.flags & XL_CONV_NORM_RELU) ? 0.f : -__builtin_inff();
     a.stats = (double *)op.stats; a.HW = HW; a.G = op.groups; a.nchunks = op.nchunks; a.B = op.B;
     a.M = (int)M; a.C = op.Cin; a.N = op.Cout; a.ldIn = op.ld_in; a.ldOut = op.ld_out;
-    a.tpi = perImage ? (HW + 255) / 256 : 0;
-    a.nbm = perImage ? op.B * a.tpi : (int)((M + 255) / 256);
-    a.nbn = (op.Cout + 255) / 256;
     a.Z = Z; a.zIn = M * op.ld_in; a.zOut = M * op.ld_out;
-    const size_t lds = kCvLds;
-    static XlLdsLimit configured[2];
-    int cfgDev;
-    if (configured[norm].needs(lds, &cfgDev)) {
-        const void *fn = norm ? reinterpret_cast<const void *>(split_conv1x1_kernel<true>) : reinterpret_cast<const void *>(split_conv1x1_kernel<false>);
-        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return XL_ERR_HIP;
-        configured[norm].done(lds, cfgDev);
-    }
-    const int nwg = a.nbm * a.nbn * Z;
-    int grid = 256;
-    if (grid > ((nwg + 7) & ~7)) grid = (nwg + 7) & ~7;
-    if (norm) hipLaunchKernelGGL(split_conv1x1_kernel<true>, dim3(grid), dim3(512), lds, st, a);
-    else hipLaunchKernelGGL(split_conv1x1_kernel<false>, dim3(grid), dim3(512), lds, st, a);
-    return XL_OK;
+    a.tpi = 0; a.nbm = 0; a.nbn = 0;
+    return small ? launch_split_conv1x1<4>(op, a, norm, Z, st) : launch_split_conv1x1<8>(op, a, norm, Z, st);
 }
 
 int xl_run_split_gemm(const xl_op &op, hipStream_t st)

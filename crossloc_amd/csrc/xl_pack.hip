@@ -81,11 +81,12 @@ __global__ __launch_bounds__(256)
 void split_weight_kernel(const float *__restrict__ src, uint16_t *__restrict__ dst, int rows, int K, int taps)
 {
     const long long total = (long long)rows * K;
-    const int Cin = K / taps;
+    const int Cin = taps > 0 ? K / taps : K;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const int r = (int)(i / K), k = (int)(i - (long long)r * K);
         float v;
         if (taps == 1) v = src[i];
+        else if (taps == 0) v = src[(long long)k * rows + r];                      // transposed source [K][rows]
         else { const int tap = k / Cin, c = k - tap * Cin; v = src[((long long)r * Cin + c) * taps + tap]; }
         unsigned h1, h2, h3;
         split3(v, h1, h2, h3);
@@ -115,7 +116,7 @@ int xl_cnn_pack_wino_weight(const float *w, void *dst, int Cout, int Cin, int m,
 
 int xl_cnn_split_weight(const float *src, void *dst, int rows, int K, int taps, void *stream)
 {
-    if (!src || !dst || rows < 1 || K < 16 || K % 16 != 0 || (taps != 1 && taps != 9) || K % taps != 0) return XL_ERR_ARG;
+    if (!src || !dst || rows < 1 || K < 16 || K % 16 != 0 || (taps != 0 && taps != 1 && taps != 9) || (taps > 0 && K % taps != 0)) return XL_ERR_ARG;
     const long long total = (long long)rows * K;
     long long blocks = (total + 255) / 256;
     if (blocks > 8192) blocks = 8192;

@@ -289,9 +289,12 @@ void split_conv3x3s2_kernel(StemArgs a)
         for (int i = 0; i < RI; ++i) fa[1][i] = ldA(sa, 1, i);
 #pragma unroll
         for (int j = 0; j < 2; ++j) fb[0][j] = ldB(sc, 0, j);
+        mma_term(2, 0); if (dmaWave) dma_instr(0, sd);
+        // (the third plane of the activations is first used by term 3: read it here, into the registers the first term's
+        //  weight fragments have just left - all 18 fragment reads up front cost 16 more live registers and spilled)
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < RI; ++i) fa[2][i] = ldA(sa, 2, i);
-        mma_term(2, 0); if (dmaWave) dma_instr(0, sd);
         mma_term(1, 1); if (dmaWave) dma_instr(1, sd);
         __builtin_amdgcn_sched_barrier(0);
         mma_term(0, 2);

@@ -1,0 +1,236 @@
+// crossloc_hip: weight gradients of training plans on the bf16 matrix pipe, fp32-accurate (operands as exact sums of three bf16
+// terms, six term pairs, fp32 accumulation - csrc/xl_gemm_split.hip explains the arithmetic).
+//
+//   P_z,s[o][c] = sum_{t in split s} dY_z[t][o] * X_z[t][c]            ("pixels as the GEMM K dimension")
+//
+// for a 1x1 layer (Z = 1, t = the B*H*W pixels, split-K over `splits` workgroups per tile) and for the batched products of a
+// Winograd layer (Z = (m+2)^2 frequencies, t = the tiles, dY = dM = A dY A^T, X = V = B^T x B); the fixed-order reduce over the
+// splits and the layout / transform of the result stay with wgrad_reduce_kernel / XL_OP_WINO_WFINAL (csrc/xl_cnn_bwd.hip).
+//
+// Both operands arrive as fp32 with the K dimension (t) OUTERMOST in memory - rows of channels.  The MFMA wants 8
+// consecutive k per lane and row, so a thread owns ONE channel (row of the operand tile) and 8 consecutive t: 8 dword loads
+// whose lanes run along the channels (256 contiguous bytes per wave-load), converted to the three bf16 planes in registers
+// and written as 3 x 16 bytes into the same rotated 96-byte LDS rows as the other split kernels - the transpose costs
+// nothing.  Tile 256 (o) x 256 (c), 8 waves of 128 x 64, K-step = 16 t; one register set per operand, loaded a step ahead,
+// converted under the MFMAs of terms 4 and 5; two LDS stages, one barrier per step.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/crossloc_cnn.h"
+#include "../../include/crossloc_dsac.h"   // status codes
+#include "xl_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kUnit = 96;                               // bytes per row and K-step: 3 planes x 16 bf16
+constexpr int kOperand = 256 * kUnit;                   // one operand of one stage: 24 KB
+
+__device__ __forceinline__ unsigned pk_bf16(float x, float y)
+{
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{ x, y }, bf16x2));
+}
+__device__ __forceinline__ float hi_f(unsigned w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
+__device__ __forceinline__ float lo_f(unsigned w) { return __builtin_bit_cast(float, w << 16); }
+__device__ __forceinline__ void split_pair(float x, float y, unsigned &w1, unsigned &w2, unsigned &w3)
+{
+    w1 = pk_bf16(x, y);
+    const float rx = x - lo_f(w1), ry = y - hi_f(w1);
+    w2 = pk_bf16(rx, ry);
+    w3 = pk_bf16(rx - lo_f(w2), ry - hi_f(w2));
+}
+
+struct WgSplitArgs {
+    const float *x, *dy; float *partial;
+    int M, Cin, Cout, ldX, ldY, splits, mPerSplit, zCount, nbo, nbc;
+    long long zX, zY;
+    unsigned xBytes, dyBytes;
+};
+
+__global__ __launch_bounds__(512)
+void wgrad_split_kernel(WgSplitArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+    constexpr int kStage = 2 * kOperand;                              // dY side (rows = o) then x side (rows = c)
+    constexpr unsigned OOB = 0x80000000u;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;                          // 2 x 4 waves of 128 (o) x 64 (c)
+
+    // block -> (z, o-tile, c-tile, split); the splits of a tile are neighbours (their operand columns share cache lines)
+    int b = blockIdx.x;
+    const int s = b % a.splits; b /= a.splits;
+    const int ct = b % a.nbc; b /= a.nbc;
+    const int ot = b % a.nbo;
+    const int z = b / a.nbo;
+    const int o0 = ot * 256, c0 = ct * 256;
+    const int mBeg = s * a.mPerSplit;
+    int mEnd = mBeg + a.mPerSplit; if (mEnd > a.M) mEnd = a.M;
+    const int nk = mEnd > mBeg ? (mEnd - mBeg + 15) >> 4 : 0;
+
+    const __amdgpu_buffer_rsrc_t srdY = __builtin_amdgcn_make_buffer_rsrc((void *)(a.dy + z * a.zY), 0, (int)a.dyBytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srdX = __builtin_amdgcn_make_buffer_rsrc((void *)(a.x + z * a.zX), 0, (int)a.xBytes, 0x00020000);
+    const int row = tid & 255, th = tid >> 8;                         // my channel of both tiles; my half of the 16 t of a step
+    const bool okO = o0 + row < a.Cout, okC = c0 + row < a.Cin;
+    float ra[8], rb[8];
+    auto load_regs = [&](int kk) {                                    // K-step kk -> registers
+        const int t0 = mBeg + 16 * kk + 8 * th;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int t = t0 + e;
+            const bool live = t < mEnd;
+            const unsigned va = (live && okO) ? (unsigned)(((long long)t * a.ldY + o0 + row) * 4) : OOB;
+            const unsigned vb = (live && okC) ? (unsigned)(((long long)t * a.ldX + c0 + row) * 4) : OOB;
+            ra[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srdY, (int)va, 0, 0));
+            rb[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srdX, (int)vb, 0, 0));
+        }
+    };
+    unsigned wOff[3];                                                 // my 16-byte slot of plane p in a row (rotated rows)
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        int ph = 2 * p + th + ((row >> 3) & 1);
+        if (ph >= 6) ph -= 6;
+        wOff[p] = (unsigned)(row * kUnit + ph * 16);
+    }
+    auto convert = [&](int stage) {                                   // registers -> stage (both operands)
+        unsigned char *sb = dsm + stage * kStage;
+        unsigned w[3][4];
+#pragma unroll
+        for (int h = 0; h < 4; ++h) split_pair(ra[2 * h], ra[2 * h + 1], w[0][h], w[1][h], w[2][h]);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4 *>(sb + wOff[p]) = u32x4{ w[p][0], w[p][1], w[p][2], w[p][3] };
+#pragma unroll
+        for (int h = 0; h < 4; ++h) split_pair(rb[2 * h], rb[2 * h + 1], w[0][h], w[1][h], w[2][h]);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4 *>(sb + kOperand + wOff[p]) = u32x4{ w[p][0], w[p][1], w[p][2], w[p][3] };
+    };
+
+    const int fr = lane & 31, kh = lane >> 5;
+    unsigned slotOff[3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        int ph = 2 * p + kh + ((fr >> 3) & 1);
+        if (ph >= 6) ph -= 6;
+        slotOff[p] = (unsigned)(ph * 16);
+    }
+    const unsigned frA = (unsigned)((wm * 128 + fr) * kUnit), frB = (unsigned)(kOperand + (wn * 64 + fr) * kUnit);
+    bf16x8 fa[3][4], fb[3][2];
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    auto ldA = [&](int stage, int p, int i) { return *reinterpret_cast<const bf16x8 *>(dsm + stage * kStage + frA + i * 32 * kUnit + slotOff[p]); };
+    auto ldB = [&](int stage, int p, int j) { return *reinterpret_cast<const bf16x8 *>(dsm + stage * kStage + frB + j * 32 * kUnit + slotOff[p]); };
+    auto mma_term = [&](int pu, int pv) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[pu][j], fa[pv][i], acc[i][j], 0, 0, 0);
+    };
+
+    if (nk > 0) {
+        load_regs(0);
+        convert(0);
+        if (nk > 1) load_regs(1);
+        __syncthreads();
+        for (int kk = 0; kk < nk; ++kk) {
+            const int st = kk & 1;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[2][j] = ldB(st, 2, j);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[0][i] = ldA(st, 0, i);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[1][j] = ldB(st, 1, j);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[1][i] = ldA(st, 1, i);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[0][j] = ldB(st, 0, j);
+            mma_term(2, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[2][i] = ldA(st, 2, i);
+            mma_term(1, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_term(0, 2);
+            __builtin_amdgcn_sched_barrier(0);
+            // terms 4 and 5 with the conversion of step kk + 1 threaded through them (the other stage: every wave finished
+            // reading it before the barrier that ended step kk - 1)
+            mma_term(1, 0);
+            if (kk + 1 < nk) convert(st ^ 1);
+            mma_term(0, 1);
+#pragma unroll
+            for (int g = 0; g < 12; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+                if (g == 5 || g == 11) __builtin_amdgcn_sched_group_barrier(0x200, 3, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kk + 2 < nk) load_regs(kk + 2);                        // (the registers are free again)
+            __syncthreads();
+            mma_term(0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    // ---- store the partial tile: row o = lane & 31 (+ 32 i), 4 consecutive c per quad
+    float *P = a.partial + ((long long)z * a.splits + s) * (long long)a.Cout * a.Cin;
+    const int rhalf = kh * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int o = o0 + wm * 128 + i * 32 + fr;
+        if (o >= a.Cout) continue;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c = c0 + wn * 64 + j * 32 + rhalf + 8 * q;
+                if (c < a.Cin)
+                    *reinterpret_cast<f32x4 *>(P + (long long)o * a.Cin + c) =
+                        f32x4{ acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3] };
+            }
+    }
+}
+
+}  // namespace
+
+// XL_OP_WGRAD with ksize 1 and XL_CONV_SPLIT_BF16: the same operands and scratch layout as the fp32 kernel - in = x [M][Cin]
+// (ld_in), aux = dY [M][Cout] (ld_aux), stats2 = partial [z][splits][Cout][Cin], groups = Z batched GEMMs (dense operands),
+// nchunks2 = splits.  Cin % 4 == 0.  The caller runs wgrad_reduce_kernel afterwards.
+int xl_run_wgrad_split(const xl_op &op, hipStream_t st)
+{
+    if (op.ksize != 1 || op.stride != 1 || op.nchunks2 < 1 || op.ld_in % 4 != 0 || op.ld_aux % 4 != 0 || op.Cin % 4 != 0 ||
+        !op.in || !op.aux || !op.stats2) return XL_ERR_ARG;
+    WgSplitArgs a;
+    a.x = (const float *)op.in; a.dy = (const float *)op.aux; a.partial = (float *)op.stats2;
+    a.M = op.B * op.Ho * op.Wo; a.Cin = op.Cin; a.Cout = op.Cout; a.ldX = op.ld_in; a.ldY = op.ld_aux;
+    a.splits = op.nchunks2;
+    a.mPerSplit = ((a.M + a.splits - 1) / a.splits + 15) / 16 * 16;
+    a.nbo = (op.Cout + 255) / 256; a.nbc = (op.Cin + 255) / 256;
+    a.zCount = op.groups > 1 ? op.groups : 1;
+    if (a.zCount > 1 && (op.ld_in != op.Cin || op.ld_aux != op.Cout)) return XL_ERR_ARG;
+    a.zX = (long long)a.M * op.Cin; a.zY = (long long)a.M * op.Cout;
+    const long long xb = (((long long)a.M - 1) * op.ld_in + op.Cin) * 4, yb = (((long long)a.M - 1) * op.ld_aux + op.Cout) * 4;
+    if (xb >= 0x7fffffffLL || yb >= 0x7fffffffLL) return XL_ERR_ARG;
+    a.xBytes = (unsigned)xb; a.dyBytes = (unsigned)yb;
+    const size_t lds = 4 * (size_t)kOperand;                          // two stages of two operands: 96 KB
+    static XlLdsLimit configured;
+    int cfgDev;
+    if (configured.needs(lds, &cfgDev)) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(wgrad_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess) return XL_ERR_HIP;
+        configured.done(lds, cfgDev);
+    }
+    hipLaunchKernelGGL(wgrad_split_kernel, dim3(a.zCount * a.nbo * a.nbc * a.splits), dim3(512), lds, st, a);
+    return XL_OK;
+}

@@ -12,6 +12,8 @@ from . import _lib
 
 MEAN = (0.4245, 0.4375, 0.3836)        # urbanscape statistics, dataloader/dataloader.py:193-196
 STD = (0.1823, 0.1701, 0.1854)
+MEAN_GRAY = (0.4308,)                  # dataloader/dataloader.py:178-180 (grayscale pipeline)
+STD_GRAY = (0.1724,)
 
 
 def _bind():
@@ -24,6 +26,8 @@ def _bind():
         L.xl_data_prepare_workspace_bytes.argtypes = [ci] * 5
         L.xl_data_prepare_images.restype = ci
         L.xl_data_prepare_images.argtypes = [vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp]
+        L.xl_data_prepare_images_gray.restype = ci
+        L.xl_data_prepare_images_gray.argtypes = [vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp]
         L.xl_data_batch_augment.restype = ci
         L.xl_data_batch_augment.argtypes = [vp, vp, ci, ci, ci, ci, ci, ci, ctypes.c_double, cf, ci, vp]
         L._data_bound = True
@@ -46,11 +50,12 @@ def draw_jitter(aug_brightness=0.1, aug_contrast=0.1, rng=random):
     return b, c, 1.0 if rng.random() < 0.5 else 0.0
 
 
-def prepare_images(frames_u8, image_height=480, jitter=None, normalize=True):
+def prepare_images(frames_u8, image_height=480, jitter=None, normalize=True, grayscale=False):
     """frames_u8: uint8 GPU tensor [B,Hs,Ws,3|4] (decoded frames, HWC) -> float32 [B,3,H,W] network input: PIL-exact
     resize so that the smaller edge is `image_height`, optional colour jitter (list of B (brightness, contrast,
     contrast_first) triples, see draw_jitter), ToTensor, urbanscape normalisation (`normalize`; False = raw [0,1],
-    what evaluation uses: utils/evaluation.py:72)."""
+    what evaluation uses: utils/evaluation.py:72).  `grayscale`: the one-channel pipeline of dataloader.py:171-187 /
+    :359-373 (Pillow's 'L' conversion after the resize, jitter on it, its own mean / std) -> [B,1,H,W]."""
     if not isinstance(frames_u8, torch.Tensor) or frames_u8.dtype != torch.uint8 or frames_u8.dim() != 4:
         raise RuntimeError("prepare_images expects a uint8 tensor [B,H,W,C]")
     if not frames_u8.is_cuda:
@@ -61,19 +66,21 @@ def prepare_images(frames_u8, image_height=480, jitter=None, normalize=True):
         raise RuntimeError("expected RGB or RGBA frames, got %d channels" % Cs)
     L = _bind()
     H, W = resized_shape(Hs, Ws, image_height)
-    out = torch.empty((B, 3, H, W), dtype=torch.float32, device=x.device)
+    out = torch.empty((B, 1 if grayscale else 3, H, W), dtype=torch.float32, device=x.device)
     ws = torch.empty(L.xl_data_prepare_workspace_bytes(B, Hs, Ws, H, W), dtype=torch.uint8, device=x.device)
     jit = None
     if jitter is not None:
         if len(jitter) != B:
             raise RuntimeError("expected %d jitter triples, got %d" % (B, len(jitter)))
         jit = (ctypes.c_float * (3 * B))(*[float(v) for t in jitter for v in t])
-    mean = (ctypes.c_float * 3)(*MEAN) if normalize else None
-    std = (ctypes.c_float * 3)(*STD) if normalize else None
+    m, sd = (MEAN_GRAY, STD_GRAY) if grayscale else (MEAN, STD)
+    mean = (ctypes.c_float * len(m))(*m) if normalize else None
+    std = (ctypes.c_float * len(sd))(*sd) if normalize else None
+    fn = L.xl_data_prepare_images_gray if grayscale else L.xl_data_prepare_images
     with torch.cuda.device(x.device):
         st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-        _lib.check(L.xl_data_prepare_images(ctypes.c_void_p(x.data_ptr()), B, Hs, Ws, Cs, int(image_height), jit, mean, std,
-                                            ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(ws.data_ptr()), st))
+        _lib.check(fn(ctypes.c_void_p(x.data_ptr()), B, Hs, Ws, Cs, int(image_height), jit, mean, std,
+                      ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(ws.data_ptr()), st))
     ws.record_stream(torch.cuda.current_stream())
     return out
 

@@ -193,6 +193,18 @@ class CrossEntropyLoss2d(torch.nn.Module):
             raise NotImplementedError("only CrossEntropyLoss2d() as constructed by train_single_task.py:215")
 
 
+def trim_semantic_label(raw_labels):
+    """loss/semantics.py:21-41: raw class ids of the urbanscape / naturescape label maps -> the 6 training classes
+    (0 sky, 1 unclassified + ground, 2 low vegetation, 3 buildings, 4 water, 5 bridge deck).  numpy in, numpy out."""
+    import numpy as np
+    raw_labels = np.asarray(raw_labels)
+    out = raw_labels.copy()
+    for old, new in zip((0, 1, 2, 3, 6, 9, 17), (0, 1, 1, 2, 3, 4, 5)):
+        out[raw_labels == old] = new
+    assert out.min() >= 0 and out.max() <= 5, "semantic label outside the 7 known raw classes"
+    return out
+
+
 def semantics_classification_loss(uncertainty, semantic_logits, uncertainty_map, gt_labels, criterion, reduction):
     """loss/semantics.py:44-91: cross entropy over the C class logits [B,C,H,W] against gt_labels [B,1,H,W];
     returns (loss, share of correctly classified pixels).  One fused kernel computes the loss, the arg-max accuracy

@@ -338,11 +338,15 @@ class _Plan:
         _check(_bind().xl_cnn_pack_wino_weight(src.data_ptr(), planes.data_ptr(), src.shape[0], src.shape[1], m,
                                                1 if dgrad else 0, 2 if interleaved else 1, stream))
 
-    def _split_weight(self, planes, src):
-        """fp32 [rows][K] (1x1) or OIHW 3x3 (K tap-major) -> interleaved bf16 planes, one HIP launch."""
+    def _split_weight(self, planes, src, transposed=False):
+        """fp32 [rows][K] (1x1; `transposed`: rows and K swapped) or OIHW 3x3 (K tap-major) -> interleaved bf16 planes, one
+        HIP launch."""
         taps = 9 if (src.dim() == 4 and src.shape[2] == 3) else 1
         stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-        _check(_bind().xl_cnn_split_weight(src.data_ptr(), planes.data_ptr(), src.shape[0], src.shape[1] * taps, taps, stream))
+        if transposed:
+            _check(_bind().xl_cnn_split_weight(src.data_ptr(), planes.data_ptr(), src.shape[1], src.shape[0], 0, stream))
+        else:
+            _check(_bind().xl_cnn_split_weight(src.data_ptr(), planes.data_ptr(), src.shape[0], src.shape[1] * taps, taps, stream))
 
     def wino_pick(self, H, W, chan_max, allowed=(6, 4)):
         """Output tile m of F(m x m, 3x3) for an H x W map: the allowed size (capped by XL_WINOGRAD) with the fewest
@@ -400,8 +404,8 @@ class _Plan:
             self._pack(dst, src, kind)
         for entry in self.packed_split.values():
             self._pack_wino_split(*entry)
-        for planes, src in self.packed_1x1.values():
-            self._split_weight(planes, src)
+        for entry in self.packed_1x1.values():
+            self._split_weight(*entry)
         for planes, src in self.packed_c1.values():
             planes.copy_(self.conv1_fragments(src))
 
@@ -436,6 +440,17 @@ class _Plan:
                 and os.environ.get("XL_GEMM_SPLIT_BF16", self.SPLIT_DEFAULT) not in ("", "0", "1")
                 and not os.environ.get("XL_NO_SPLIT_1X1"))
 
+    def wgrad_split_ok(self, C, Cout):
+        """Weight gradients of 1x1 layers and of the batched Winograd products on the split pipe (256 x 256 tiles)."""
+        return (C % 256 == 0 and Cout % 256 == 0 and self.split_train_ok()
+                and os.environ.get("XL_GEMM_SPLIT_BF16", self.SPLIT_DEFAULT) not in ("", "0", "1")
+                and not os.environ.get("XL_NO_SPLIT_WGRAD"))
+
+    @staticmethod
+    def wgrad_splits(tiles, K):
+        """Split-K factor of the split-pipe weight gradient: fill the 256 CUs once, at least 256 rows of K per split."""
+        return max(1, min(256 // max(tiles, 1), K // 256))
+
     def split_train_ok(self):
         """Training plans run their forward GEMMs (and the Winograd data gradients) on the split pipe too (round 3);
         XL_NO_SPLIT_TRAIN=1: fp32 MFMA throughout, the round-2 training plans."""
@@ -460,7 +475,7 @@ class _Plan:
         if key not in self.packed_1x1:
             src = w.detach().to(device=self.device, dtype=torch.float32).contiguous()     # aliases the live parameter
             planes = torch.empty(3 * src.numel(), dtype=torch.int16, device=self.device)
-            self.packed_1x1[key] = (planes, src)
+            self.packed_1x1[key] = (planes, src, False)
             self._split_weight(planes, src)
         return self.packed_1x1[key][0]
 
@@ -468,15 +483,16 @@ class _Plan:
     def _stem_rows(src):
         return src.permute(0, 2, 3, 1).reshape(src.shape[0], -1) if src.dim() == 4 and src.shape[2] == 3 else src.reshape(src.shape[0], src.shape[1])
 
-    def pack_conv_1x1_split(self, conv):
-        """[Cout][Cin/16][3][16] bf16: the weight of a 1x1 convolution as interleaved bf16 planes."""
+    def pack_conv_1x1_split(self, conv, transposed=False):
+        """[Cout][Cin/16][3][16] bf16: the weight of a 1x1 convolution as interleaved bf16 planes; `transposed`:
+        [Cin][Cout/16][3][16], the operand of its data gradient."""
         w = conv.weight
-        key = id(w)
+        key = (id(w), "t") if transposed else id(w)
         if key not in self.packed_1x1:
             src = w.detach().to(device=self.device, dtype=torch.float32).contiguous()     # aliases the live parameter
             planes = torch.empty(3 * src.numel(), dtype=torch.int16, device=self.device)
-            self.packed_1x1[key] = (planes, src)
-            self._split_weight(planes, src)
+            self.packed_1x1[key] = (planes, src, transposed)
+            self._split_weight(planes, src, transposed)
         return self.packed_1x1[key][0]
 
     @staticmethod
@@ -532,6 +548,13 @@ class _Plan:
             # rows per tile (the statistics epilogue writes one entry per tile); negative: tiles start at image boundaries,
             # so the grouping of the partial sums does not depend on where a frame sits in the batch (batch-invariant plans)
             op.reserved_i = -256 if self.separate_stats else 256
+            # latency form: when the 256 x 256 tiles would leave most of the chip idle and 128 x 128 tiles fit in ONE round
+            # of the 256 CUs (a single 60 x 90 frame: 44 tiles vs 172), the 4-wave kernel - same bits, a tile has a quarter
+            # of the MFMAs behind the same number of K-steps.  A choice by the layer's M = B*H*W; batch-invariant plans keep
+            # the 256-row tiles (their statistics entries are per tile).
+            if (not self.separate_stats and not self.train and not os.environ.get("XL_NO_SMALL_TILES")
+                    and -(-self.B * Ho * Wo // 128) * (cout // 128) <= 256 and Ho * Wo >= 128):
+                op.reserved_i = 128
         if norm_in is not None:                       # the producer's deferred GroupNorm apply, folded into the operand load
             op.flags |= CONV_NORM_IN | (CONV_NORM_RELU if norm_in.flags & GN_RELU_IN else 0)
             self.deferred_gn_consumers = getattr(self, "deferred_gn_consumers", []) + [len(self.ops)]
@@ -772,7 +795,12 @@ class _Plan:
         fold = getattr(self, "pending_fold", {}).pop(self._act_key(act), None)
         m = self.wino_tile(act, conv)
         stem = self.stem_split_ok(act, conv)
-        if pend is not None and m not in (4, 6) and not self.norm_on_load_ok(act, conv) and not stem:
+        cpg = conv.out_channels // norm.num_groups
+        # a 1x1 layer on the split pipe applies a pending GroupNorm on load at ANY batch size (the tile-count condition of
+        # norm_on_load_ok belongs to the fp32 kernel's 64-row form)
+        split_1x1 = self.split_1x1_ok(act, conv) and (cpg == 16 or self.separate_stats)
+        absorbs = (split_1x1 and act[3] <= 512 and act[1] * act[2] >= 256 and not os.environ.get("XL_NO_NORM_ON_LOAD"))
+        if pend is not None and m not in (4, 6) and not self.norm_on_load_ok(act, conv) and not stem and not absorbs:
             self.stats_ops.append(len(self.ops))       # consumer cannot absorb it: materialise now
             self.ops.append(pend)
             pend = None
@@ -784,15 +812,13 @@ class _Plan:
                 fold = None
         if m:
             return self.conv_wino(act, conv, norm, flags, aux, m, pend, defer=defer, fold=fold, share=share)
-        cpg = conv.out_channels // norm.num_groups
         if stem:
             # conv on the split pipe with the producer's GroupNorm applied on load; statistics pass; the apply is left to the
             # consumer (the next stem layer, or - conv4 - the input transform of res1_conv1)
             y = self.conv(act, conv, norm_in=pend, split=True)
             return self.gn(y, norm, flags, aux, defer=defer and flags == GN_RELU_IN and aux is None
                            and not os.environ.get("XL_NO_DEFERRED_GN"), share=share)
-        split = (self.split_1x1_ok(act, conv) and (cpg == 16 or self.separate_stats)
-                 and (pend is None or act[3] <= 512))
+        split = split_1x1 and (pend is None or absorbs)
         y = self.conv(act, conv, norm_in=pend, split=split)
         bn = 128 if conv.out_channels % 128 == 0 else 64
         # a conv tile's columns cover whole groups, and the statistics epilogue sums 2- or 4-channel pieces
@@ -1277,6 +1303,10 @@ class _Plan:
                     wg = XlOp()
                     wg.type = XL_OP_WGRAD
                     wg.B, wg.Hi, wg.Wi, wg.Cin, wg.Ho, wg.Wo, wg.Cout = 1, Tw4, 1, C, Tw4, 1, Cout
+                    if self.wgrad_split_ok(C, Cout):
+                        # on the split pipe (csrc/xl_wgrad_split.hip): 256 x 256 tiles, one workgroup per CU
+                        wg.flags = CONV_SPLIT_BF16
+                        splits = self.wgrad_splits(nfw * (Cout // 256) * (C // 256), Tw4)
                     wg.ksize, wg.stride, wg.ld_in, wg.ld_aux, wg.groups, wg.nchunks2 = 1, 1, C, Cout, nfw, splits
                     wg.in_, wg.aux, wg.out = Vb.data_ptr(), dMb.data_ptr(), dU.data_ptr()
                     scratch_f = max(scratch_f, nfw * splits * Cout * C)
@@ -1308,6 +1338,9 @@ class _Plan:
                     cost = rounds * (-(-steps_total // cand) + 8) + (cand + 1) * tiles * bo * bc * 4 / 4e12 / 1.8e-6
                     if best is None or cost < best - 1e-9:
                         best, splits = cost, cand
+                if k == 1 and s == 1 and not wino_w and self.wgrad_split_ok(C, Cout) and ld % 4 == 0 and off % 4 == 0:
+                    op.flags = CONV_SPLIT_BF16
+                    splits = self.wgrad_splits((Cout // 256) * (C // 256), M)
                 op.nchunks2 = splits
                 op.in_, op.aux = t.data_ptr() + 4 * off, dy.data_ptr()
                 if not wino_w:
@@ -1366,7 +1399,17 @@ class _Plan:
                 op.B, op.Hi, op.Wi, op.Cin, op.Ho, op.Wo, op.Cout = B, Ho, Wo, Cout, H, W, C
                 op.ksize, op.stride, op.ld_in, op.ld_out = k, s, Cout, gx[1]
                 op.in_, op.out = dy.data_ptr(), gx[0].data_ptr() + 4 * gx[2]
-                op.w = self.pack_conv(conv, dgrad=True).data_ptr()
+                if (k == 1 and s == 1 and Cout % 32 == 0 and C % 256 == 0 and C <= 1024 and H * W >= 256
+                        and gx[1] % 4 == 0 and gx[2] % 4 == 0 and self.split_train_ok()
+                        and os.environ.get("XL_GEMM_SPLIT_BF16", self.SPLIT_DEFAULT) not in ("", "0", "1")
+                        and not os.environ.get("XL_NO_SPLIT_1X1")):
+                    # dX = dY W on the split pipe: a plain 1x1 "convolution" of dY with the transposed weight matrix, split
+                    # once per weight version; a second producer of the gradient accumulates in the epilogue
+                    op.flags = CONV_SPLIT_BF16 | CONV_SPLIT_IL | (op.flags & CONV_ACCUMULATE)
+                    op.w = self.pack_conv_1x1_split(conv, transposed=True).data_ptr()
+                    op.reserved_i = 256
+                else:
+                    op.w = self.pack_conv(conv, dgrad=True).data_ptr()
                 bops.append(op)      # 32 result channels (conv2): the kernel masks the padded half of its 64-wide tile
                 self.release_grad(dy)
             elif kind == "conv1":

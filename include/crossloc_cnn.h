@@ -160,7 +160,8 @@ int xl_cnn_pack_wino_weight(const float *w_oihw_dev, void *dst_dev, int Cout, in
 
 /* fp32 weight matrix -> interleaved bf16 planes [rows][K/16][3][16] of the split-pipe kernels (K % 16 == 0):
  *   taps = 1: src = [rows][K] (a 1x1 convolution's [Cout][Cin]);
- *   taps = 9: src = OIHW [rows][K/9][3][3], K ordered tap-major: k = (3 ky + kx) * Cin + c (csrc/xl_stem_split.hip). */
+ *   taps = 9: src = OIHW [rows][K/9][3][3], K ordered tap-major: k = (3 ky + kx) * Cin + c (csrc/xl_stem_split.hip);
+ *   taps = 0: src = [K][rows], i.e. the transpose - the operand of a 1x1 layer's data gradient, dX = dY W. */
 int xl_cnn_split_weight(const float *src_dev, void *dst_dev, int rows, int K, int taps, void *stream);
 
 /* Per-op HIP-event timing for measurement (bench.py): between prof_begin and prof_end every op launched by

@@ -18,7 +18,8 @@
  *   batch aug   images: bilinear resize (align_corners = false, like F.interpolate) to (oh, ow) composed with the
  *               nearest-neighbour rotation of torchvision's tensor `rotate` about the image centre, `fill` outside;
  *               labels: nearest resize (F.interpolate 'nearest') composed with the same rotation
- * All pointers are device pointers unless stated; calls are asynchronous on `stream` and return 0 or a negative xl
+ * All pointers are device pointers unless stated; calls are asynchronous on `stream` (the per-frame jitter records
+ * travel as kernel arguments: the host arrays may be freed when a call returns) and return 0 or a negative xl
  * status (crossloc_dsac.h).  Frames of one call share their size (the reference's collate stacks them, :563).
  */
 #ifndef CROSSLOC_DATA_H
@@ -41,6 +42,13 @@ long long xl_data_prepare_workspace_bytes(int B, int Hs, int Ws, int H, int W);
 int xl_data_prepare_images(const uint8_t *src, int B, int Hs, int Ws, int Cs, int image_height,
                            const float *jitter_host, const float *mean_host, const float *std_host,
                            float *out, void *workspace, void *stream);
+
+/* The grayscale pipeline (dataloader.py:171-187, 359-373: ... Resize -> Grayscale -> [ColorJitter] -> ToTensor ->
+ * Normalize(mean[1], std[1])): Pillow's 'L' conversion (R*19595 + G*38470 + B*7471 + 0x8000) >> 16 of the resized frame,
+ * the jitter on that one channel; out: float32 [B][1][H][W]; mean_host / std_host: one float each (or NULL). */
+int xl_data_prepare_images_gray(const uint8_t *src, int B, int Hs, int Ws, int Cs, int image_height,
+                                const float *jitter_host, const float *mean_host, const float *std_host,
+                                float *out, void *workspace, void *stream);
 
 /* in: float32 [B][C][H][W] -> out [B][C][oh][ow]: resize (bilinear = 1: images; 0: nearest, labels) + rotation by
  * angle_deg (counter-clockwise, nearest, `fill` outside the rotated frame). */

@@ -132,11 +132,33 @@ def to_tensor_normalize(img_u8, mean=None, std=None):
     return x
 
 
-def prepare_image(img_u8, image_height, jitter=None, mean=None, std=None):
-    """One frame through the reference's transform pipeline.  jitter = (brightness, contrast, contrast_first) or None."""
+def to_gray_u8(img):
+    """transforms.Grayscale() on a PIL RGB image = convert('L'): (R*19595 + G*38470 + B*7471 + 0x8000) >> 16, uint8 [H,W]."""
+    r, g, b = (img[..., c].astype(np.int64) for c in range(3))
+    return ((r * 19595 + g * 38470 + b * 7471 + 0x8000) >> 16).astype(np.uint8)
+
+
+def color_jitter_gray_u8(img, brightness, contrast, contrast_first):
+    """ColorJitter on an 'L' image: the same blends on one channel; the contrast mean is int(mean of the image + 0.5)."""
+    def bright(x):
+        return _blend_u8(np.zeros_like(x), x, brightness)
+
+    def contr(x):
+        return _blend_u8(np.full_like(x, int(x.astype(np.int64).sum() / x.size + 0.5)), x, contrast)
+    return bright(contr(img)) if contrast_first else contr(bright(img))
+
+
+def prepare_image(img_u8, image_height, jitter=None, mean=None, std=None, grayscale=False):
+    """One frame through the reference's transform pipeline.  jitter = (brightness, contrast, contrast_first) or None.
+    grayscale: the one-channel pipeline (dataloader.py:171-187, 359-373), mean / std with one entry -> [1,H,W]."""
     img = np.asarray(img_u8, np.uint8)[..., :3]
     oh, ow = resize_target(img.shape[0], img.shape[1], image_height)
     img = pil_resize_bilinear(img, oh, ow)
+    if grayscale:
+        img = to_gray_u8(img)
+        if jitter is not None:
+            img = color_jitter_gray_u8(img, *jitter)
+        return to_tensor_normalize(img[..., None], mean, std)
     if jitter is not None:
         img = color_jitter_u8(img, *jitter)
     return to_tensor_normalize(img, mean, std)

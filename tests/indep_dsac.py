@@ -227,6 +227,7 @@ def draw_argmax(probs):
 def refine(fr, hyp, errs, thr, f, cx, cy, max_reproj):
     """refineHyp (dsacstar_util.h:522-597).  Returns (hyp, rounds accepted, final inlier count)."""
     best, rounds, final = 4, 0, 0
+    refine.last_inliers = None                           # inlierMap of the last accepted re-fit (dsacstar_util.h:583)
     for _ in range(MAX_REF_STEPS):
         inl = errs < np.float32(thr)
         n = int(inl.sum())
@@ -244,6 +245,7 @@ def refine(fr, hyp, errs, thr, f, cx, cy, max_reproj):
             break
         hyp = (sol.x[:3], sol.x[3:])
         rounds, final = rounds + 1, n
+        refine.last_inliers = inl.copy()
         errs = fr.errors(hyp, f, cx, cy, max_reproj)
     return hyp, rounds, final
 
@@ -274,6 +276,235 @@ def forward_rgb(coords, n_hyp, thr, focal, ppx, ppy, alpha, max_reproj, sub, see
     return pose2trans(hyp), dict(cells=np.array(cells, np.int32), tries=np.array(tries, np.int32),
                                  scores=np.array(scores), winner=win, rounds=rounds, inliers=inliers,
                                  pose0=pose2trans(hyp0))
+
+
+# ------------------------------------------------------------------------------------------ backward_rgb, independently
+#
+# dsacstar_rgb_backward (dsacstar.cpp:200-483) defines the gradient of the expected pose loss through a chain of Jacobians
+# that the reference evaluates ANALYTICALLY (cv::projectPoints' Jacobian, dProjectdObj dsacstar_derivative.h:50-107, dLoss
+# dsacstar_loss.h:86-212, the soft-max / soft-inlier derivatives :204-262, 340-352) plus one it evaluates numerically itself
+# (dPNP :140-200, central differences of the minimal solver).  Here the CHAIN is the reference's - same paths, same clamps,
+# same early-outs - but every analytic Jacobian is replaced by central differences of the independent forward pieces above
+# (project / scipy rotations / numpy norms), the pseudo-inverse is numpy's SVD one, the refinement is MINPACK, the minimal
+# solver is p3p_plus_one.  What oracle/dsac_bwd_oracle.c (and the HIP kernels, bit-identical to it) must reproduce.
+
+PROB_THRESH = 0.001                 # dsacstar_derivative.h:36
+MAXLOSS = 10000000.0                # dsacstar_loss.h:35
+EPS_R = 1e-8                        # dsacstar_util.h:45 (EPS of the C++ side)
+
+
+def _cdiff(fn, x, steps):
+    """Central differences of fn: R^n -> R^m; returns [m, n]."""
+    x = np.asarray(x, np.float64)
+    cols = []
+    for i, h in enumerate(steps):
+        e = np.zeros_like(x)
+        e[i] = h
+        cols.append((np.asarray(fn(x + e), np.float64) - np.asarray(fn(x - e), np.float64)) / (2.0 * h))
+    return np.stack(cols, -1)
+
+
+def _project64(rvec, tvec, X, f, cx, cy):
+    """The projection in float64 throughout (project() rounds to float32 like cv::projectPoints' output - not differentiable
+    numerically)."""
+    Xc = X @ Rotation.from_rotvec(rvec).as_matrix().T + tvec
+    return np.stack([Xc[:, 0] / Xc[:, 2] * f + cx, Xc[:, 1] / Xc[:, 2] * f + cy], 1)
+
+
+def _proj_jac(hyp, X, f, cx, cy):
+    """d proj / d (rvec, tvec) for all points, numerically: [N, 2, 6]."""
+    def fn(p):
+        return _project64(p[:3], p[3:], X, f, cx, cy)
+    return _cdiff(fn, np.concatenate(hyp), [1e-6] * 3 + [1e-5 * max(1.0, float(np.abs(hyp[1]).max()))] * 3)
+
+
+def _resid_rows(hyp, X, pix, f, cx, cy, max_reproj):
+    """Rows of `jacobeanR` / `jacobeanHyp` (dsacstar.cpp:389-405, dsacstar_util.h:420-434): d |proj - pix| / d pose with
+    the float32 projections the reference holds (cv::Point2f), zero above max_reproj."""
+    proj32 = project(hyp[0], hyp[1], X, f, cx, cy).astype(np.float32)
+    d = proj32.astype(np.float64) - pix
+    err = np.maximum(np.sqrt((d * d).sum(1)), EPS_R)
+    J = _proj_jac(hyp, X, f, cx, cy)                                     # [N,2,6]
+    rows = (d[:, :, None] * J).sum(1) / err[:, None]
+    rows[err > max_reproj] = 0.0
+    return rows
+
+
+def _dproject_dobj(hyp, X, pix, f, cx, cy, max_reproj):
+    """dProjectdObj for every point: d |proj(X) - pix| / dX by central differences, [N,3]; zero where the point is (nearly)
+    in the camera plane or the error is above max_reproj (dsacstar_derivative.h:69-85)."""
+    R = Rotation.from_rotvec(hyp[0]).as_matrix()
+
+    def err_of(Xp):
+        Xc = Xp @ R.T + hyp[1]
+        px, py = f * Xc[:, 0] / Xc[:, 2] + cx, f * Xc[:, 1] / Xc[:, 2] + cy
+        return np.sqrt((pix[:, 0] - px) ** 2 + (pix[:, 1] - py) ** 2)
+    Xc = X @ R.T + hyp[1]
+    out = np.zeros((X.shape[0], 3))
+    scale = max(1.0, float(np.abs(X).max()))
+    h = 1e-7 * scale
+    for k in range(3):
+        e = np.zeros(3)
+        e[k] = h
+        out[:, k] = (err_of(X + e) - err_of(X - e)) / (2 * h)
+    bad = (np.abs(Xc[:, 2]) < EPS_R) | (err_of(X) > max_reproj)
+    out[bad] = 0.0
+    return out
+
+
+def pose_loss(hyp, gt_pose, w_rot, w_trans, cut):
+    """loss() of dsacstar_loss.h:68-85 on est = pose2trans(hyp) (float64) and the ground-truth cam->world matrix."""
+    T = np.eye(4)
+    T[:3, :3] = Rotation.from_rotvec(hyp[0]).as_matrix()
+    T[:3, 3] = hyp[1]
+    est = np.linalg.inv(T)
+    gt = np.asarray(gt_pose, np.float64)
+    tr = np.trace(gt[:3, :3] @ est[:3, :3].T)
+    rot_err = 180.0 * math.acos((min(3.0, max(-1.0, tr)) - 1.0) / 2.0) / math.pi
+    t_err = float(np.linalg.norm(est[:3, 3] - gt[:3, 3]))
+    loss = w_rot * rot_err + w_trans * t_err
+    if loss > cut:
+        loss = math.sqrt(cut * loss)
+    return min(loss, MAXLOSS)
+
+
+GT_MODE = "reference"               # see _dloss
+
+
+def _dloss(hyp, gt_pose, w_rot, w_trans, cut):
+    """dLoss (dsacstar_loss.h:86-212), numerically: the gradient of w_rot * angle + w_trans * distance of the inverted
+    poses w.r.t. (rvec, tvec); above `cut` the reference scales it by 0.5 / sqrt(raw) (:104-108, 201-202 - NOT the
+    derivative of sqrt(cut * raw): its own definition, reproduced); zero above MAXLOSS, for a perfect estimate, and when
+    not finite."""
+    # hypGT = trans2pose(gtTrans) (dsacstar_util.h:777-790): the inverse of the float ground-truth matrix, its rotation
+    # through cv::Rodrigues to a vector and back - i.e. ORTHONORMALISED (the float matrix is not, at the 1e-7 level, which
+    # matters next to angles of 1e-4 rad); loss() above uses the raw matrix, dLoss the pose: reproduced
+    # GT_MODE "reference": exactly that - t2 from the GENERAL inverse of the float matrix, so invT2 = R2^T t2 is the camera
+    # centre moved by ~|C| * 1e-7 (5e-5 m at 500 m).  GT_MODE "oracle": oracle/dsac_bwd_oracle.c's documented deviation, a
+    # rigid inverse (t2 = -R2 C, invT2 = -C exactly, consistent with loss()).  Next to a translation error of centimetres
+    # the two differ by ~1e-3 in dLoss, ~1e-4 in the final gradient.
+    g64 = np.asarray(gt_pose, np.float64)
+    ginv = np.linalg.inv(g64)
+    Rg = Rotation.from_matrix(ginv[:3, :3]).as_matrix()                # world -> camera rotation of the ground truth
+    Cg = -(Rg.T @ ginv[:3, 3]) if GT_MODE == "reference" else g64[:3, 3].copy()      # invT2 = R2^T t2 = -Cg
+
+    def raw(p):
+        R = Rotation.from_rotvec(p[:3]).as_matrix()
+        tr = np.trace(R @ Rg.T)
+        rot = 180.0 * math.acos((min(3.0, max(-1.0, tr)) - 1.0) / 2.0) / math.pi
+        dist = float(np.linalg.norm(R.T @ p[3:] + Cg))                # |invT1 - invT2|, invT = R^T t = -(camera centre)
+        return np.array([w_rot * rot + w_trans * dist]), rot, dist
+    p0 = np.concatenate(hyp)
+    val, rot_err, t_err = raw(p0)
+    loss = float(val[0])
+    cut_loss = loss > cut
+    if cut_loss:
+        loss = math.sqrt(loss)
+    if loss > MAXLOSS or (t_err + rot_err) < EPS_R:
+        return np.zeros(6)
+    g = _cdiff(lambda p: raw(p)[0], p0, [1e-7] * 3 + [1e-6 * max(1.0, float(np.abs(p0[3:]).max()))] * 3)[0]
+    if cut_loss:
+        g = g * (0.5 / loss)
+    return g if np.all(np.isfinite(g)) else np.zeros(6)
+
+
+def _dpnp(P4, uv4, f, cx, cy):
+    """dPNP (dsacstar_derivative.h:140-200) for a minimal set: central differences of the P3P pose w.r.t. the first three
+    object points with the reference's float32 step sequence (+= eps, -= 2 eps, += eps on cv::Point3f); 6 x 12."""
+    eps = np.float32(0.001)
+    two_eps = float(np.float32(2) * eps)
+    obj = np.asarray(P4, np.float32).copy()
+    J = np.zeros((6, 12))
+    for i in range(3):
+        for j in range(3):
+            obj[i, j] = obj[i, j] + eps
+            fs = p3p_plus_one(obj.astype(np.float64), uv4, f, cx, cy)
+            if fs is None:
+                return np.zeros((6, 12))
+            obj[i, j] = obj[i, j] - np.float32(2) * eps
+            bs = p3p_plus_one(obj.astype(np.float64), uv4, f, cx, cy)
+            if bs is None:
+                return np.zeros((6, 12))
+            obj[i, j] = obj[i, j] + eps
+            col = np.concatenate([(fs[0] - bs[0]) / two_eps, (fs[1] - bs[1]) / two_eps])
+            if not np.all(np.isfinite(col)):
+                return np.zeros((6, 12))
+            J[:, i * 3 + j] = col
+    return J
+
+
+def backward_rgb(coords, gt_pose, n_hyp, thr, focal, ppx, ppy, w_rot, w_trans, soft_clamp, alpha, max_reproj, sub, seed,
+                 image=0, max_tries=MAX_HYPOTHESES_TRIES, refined=None):
+    """dsacstar_rgb_backward (dsacstar.cpp:200-483).  Returns (expected loss, gradient [3,Ho,Wo] float64 - the values the
+    reference ADDS to its float gradient tensor -, info).
+    `refined` {h: (rvec, tvec)}: use these refined poses instead of MINPACK's.  Where an iterative solver stops is not
+    part of the algorithm's definition (cv::solvePnP: 20 iterations or a relative step below FLT_EPSILON; MINPACK: 1e-14):
+    two solvers agree on the optimum to ~0.05 mm at |X| ~ 500 m, which the centimetre-scale pose loss shows as ~1e-3
+    relative - so the chain of Jacobians is compared on the SAME refined poses, and the fully independent run is reported
+    next to it."""
+    gt_pose = np.asarray(gt_pose, np.float32).astype(np.float64)      # the reference receives a float tensor (:244-249)
+    fr = Frame(coords, sub)
+    f, cx, cy = float(np.float32(focal)), float(np.float32(ppx)), float(np.float32(ppy))
+    N = fr.Wo * fr.Ho
+    pix = fr.pix.astype(np.float64)
+    hyps, cells, scores, errs_all = [], [], [], []
+    for h in range(n_hyp):
+        hyp, c4, _ = sample_hypothesis(fr, seed, image, h, thr, f, cx, cy, max_tries)
+        hyps.append(hyp)
+        cells.append(c4)
+        e = fr.errors(hyp, f, cx, cy, max_reproj)
+        errs_all.append(e)
+        scores.append(hyp_score(e, thr, alpha, fr.Wo, fr.Ho))
+    probs = soft_max(scores)
+    ref_hyps, inl_maps = [], []
+    for h in range(n_hyp):
+        if probs[h] < PROB_THRESH:
+            ref_hyps.append(hyps[h]); inl_maps.append(None)
+            continue
+        rh, _, _ = refine(fr, hyps[h], errs_all[h], thr, f, cx, cy, max_reproj)
+        if refined is not None and h in refined and refine.last_inliers is not None:
+            rh = (np.asarray(refined[h][0], np.float64), np.asarray(refined[h][1], np.float64))
+        ref_hyps.append(rh)
+        inl_maps.append(refine.last_inliers)
+    losses = np.array([pose_loss(ref_hyps[h], gt_pose, w_rot, w_trans, soft_clamp) for h in range(n_hyp)])
+    expected = float(np.cumsum(probs * losses)[-1])
+    grad = np.zeros((N, 3))                                              # x-major cell order, like fr.X
+    beta = float(np.float32(5.0) / np.float32(thr))
+    active = [h for h in range(n_hyp) if probs[h] >= PROB_THRESH]
+    for h in active:
+        # ---- path I: through the refined pose (dsacstar.cpp:353-445)
+        g1 = np.zeros((N, 3))
+        inl = inl_maps[h]
+        if inl is not None and int(inl.sum()) >= 4:
+            X, px = fr.X[inl], pix[inl]
+            JR = _resid_rows(ref_hyps[h], X, px, f, cx, cy, max_reproj)             # [n,6]
+            JR = -np.linalg.pinv(JR.T @ JR) @ JR.T                                   # 6 x n
+            if np.abs(JR).max() > 10:
+                JR[:] = 0.0
+            dNdO = _dproject_dobj(ref_hyps[h], X, px, f, cx, cy, max_reproj)        # [n,3]
+            dL = _dloss(ref_hyps[h], gt_pose, w_rot, w_trans, soft_clamp)            # [6]
+            g1[inl] = (dL @ JR)[:, None] * dNdO
+        # ---- path II: through the score (dsacstar_derivative.h:204-352)
+        sog = probs[h] * losses[h] - probs[h] * float(np.cumsum(probs * losses)[-1])
+        st = 1.0 / (1.0 + np.exp(-(np.float32(beta) * (errs_all[h] - np.float32(thr))).astype(np.float64)))
+        dRe = -st * (1.0 - st) * beta * sog * (float(np.float32(alpha)) / fr.Wo / fr.Ho)
+        dPdO = _dproject_dobj(hyps[h], fr.X, pix, f, cx, cy, max_reproj)
+        g2 = dPdO * dRe[:, None]
+        c4 = cells[h]
+        P4 = np.array([[fr.c[0, y, x], fr.c[1, y, x], fr.c[2, y, x]] for x, y in c4], np.float32)
+        uv4 = np.array([[x * sub + sub // 2, y * sub + sub // 2] for x, y in c4], np.float64)
+        dHdO = _dpnp(P4, uv4, f, cx, cy)
+        if np.abs(dHdO).max() > 10:
+            dHdO[:] = 0.0
+        dPdH = _resid_rows(hyps[h], fr.X, pix, f, cx, cy, max_reproj)               # [N,6]
+        support = (dRe[:, None] * dPdH).sum(0) @ dHdO                                # [12]
+        for i, (x, y) in enumerate(c4):
+            g2[x * fr.Ho + y] += support[3 * i:3 * i + 3]
+        grad += probs[h] * g1 + g2
+    out = np.zeros((3, fr.Ho, fr.Wo))
+    out[:, fr.ys, fr.xs] = grad.T
+    return expected, out, dict(probs=probs, losses=losses, active=active, scores=np.array(scores),
+                               inliers=[None if m is None else int(m.sum()) for m in inl_maps])
 
 
 # ------------------------------------------------------------------------------------------ comparison with the oracle

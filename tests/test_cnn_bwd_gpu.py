@@ -351,3 +351,64 @@ def test_mlr_network_backward_with_frozen_encoders(form, monkeypatch):
         _check_direct_form(worst, worst2)
     else:
         assert worst2[-1][0] <= 1e-1 and worst[-1][0] <= 0.5, (worst2[-3:], worst[-3:])
+
+
+@pytest.mark.parametrize("cin,cout,B,H,W", [(512, 512, 2, 20, 31), (256, 512, 3, 16, 16), (512, 1024, 1, 24, 37)])
+def test_conv1x1_data_gradient_on_the_split_pipe_with_accumulate(cin, cout, B, H, W):
+    """Training plans (round 3): dX = dY W of a 1x1 layer as a plain 1x1 convolution of dY with the TRANSPOSED weight matrix
+    on the split-bf16 pipe (weights split by xl_cnn_split_weight with taps = 0), the second producer of a gradient
+    accumulating in the epilogue (XL_CONV_ACCUMULATE) - against autograd, at the fp32 kernels' tolerance."""
+    import torch.nn as nn
+    L = networks._bind()
+    g = torch.Generator().manual_seed(cin + cout + H)
+    x = torch.randn(B, cin, H, W, generator=g, requires_grad=True)
+    conv = nn.Conv2d(cin, cout, 1)
+    y = conv(x)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    ws = conv.weight.detach().cuda().contiguous()
+    planes = torch.zeros(3 * ws.numel(), dtype=torch.int16, device="cuda")
+    networks._check(L.xl_cnn_split_weight(ws.data_ptr(), planes.data_ptr(), cin, cout, 0, None))
+    assert torch.equal(planes, networks._Plan.split_bf16_interleaved(ws.reshape(cout, cin).t().contiguous(), cout).reshape(-1))
+    dyd = _nhwc(dy).cuda()
+    gx = torch.full((B, H, W, cin), float("nan"), device="cuda")
+    op = networks.XlOp()
+    op.type, op.flags = networks.XL_OP_CONV, networks.CONV_SPLIT_BF16 | networks.CONV_SPLIT_IL
+    op.B, op.Hi, op.Wi, op.Cin, op.Ho, op.Wo, op.Cout = B, H, W, cout, H, W, cin
+    op.ksize, op.stride, op.ld_in, op.ld_out, op.reserved_i = 1, 1, cout, cin, 256
+    op.in_, op.w, op.out = dyd.data_ptr(), planes.data_ptr(), gx.data_ptr()
+    _run([op])
+    ref = x.grad
+    assert ((gx.cpu().permute(0, 3, 1, 2) - ref).abs().max() / ref.abs().max()).item() < 2e-5
+    op.flags |= networks.CONV_ACCUMULATE
+    _run([op, op])
+    assert ((gx.cpu().permute(0, 3, 1, 2) - 3 * ref).abs().max() / ref.abs().max()).item() < 6e-5
+
+
+@pytest.mark.parametrize("cin,cout,M,Z,splits", [(512, 512, 2 * 20 * 31, 1, 3), (256, 512, 1500, 1, 1), (512, 256, 777, 4, 2),
+                                                 (512, 512, 2400, 36, 1), (256, 256, 300, 2, 5)])
+def test_weight_gradient_products_on_the_split_pipe(cin, cout, M, Z, splits):
+    """XL_OP_WGRAD with XL_CONV_SPLIT_BF16 (csrc/xl_wgrad_split.hip): P_z = dY_z^T X_z with the pixels / Winograd tiles as the
+    K dimension, both operands fp32 and split inside the kernel, split-K partials reduced in fixed order - against float64,
+    and within a small factor of the fp32-MFMA kernel's own rounding error.  Ragged K (not a multiple of 16) included."""
+    g = torch.Generator().manual_seed(cin + cout + M + Z)
+    x = torch.randn(Z, M, cin, generator=g)
+    dy = torch.randn(Z, M, cout, generator=g)
+    ref = torch.einsum("zto,ztc->zoc", dy.double(), x.double())
+    xd, dyd = x.cuda(), dy.cuda()
+
+    def run(flags, sp):
+        out = torch.full((Z, cout, cin), float("nan"), device="cuda")
+        scratch = torch.full((Z * sp * cout * cin,), float("nan"), device="cuda")
+        op = networks.XlOp()
+        op.type, op.flags = networks.XL_OP_WGRAD, flags
+        op.B, op.Hi, op.Wi, op.Cin, op.Ho, op.Wo, op.Cout = 1, M, 1, cin, M, 1, cout
+        op.ksize, op.stride, op.ld_in, op.ld_aux, op.groups, op.nchunks2 = 1, 1, cin, cout, Z, sp
+        op.in_, op.aux, op.out, op.stats2 = xd.data_ptr(), dyd.data_ptr(), out.data_ptr(), scratch.data_ptr()
+        _run([op])
+        return out.cpu().double()
+    got = run(networks.CONV_SPLIT_BF16, splits)
+    scale = ref.abs().max().item()
+    esp = (got - ref).abs().max().item() / scale
+    e32 = (run(0, splits) - ref).abs().max().item() / scale
+    assert esp < 2e-6 and esp < 4 * e32 + 2e-7, (esp, e32)

@@ -69,3 +69,61 @@ def test_collate_gpu_follows_the_reference_draws(tmp_path):
     assert torch.equal(poses.cpu(), torch.stack([it[1] for it in items]))              # poses untouched in batch mode
     assert focals.dtype == torch.float64 and np.allclose(focals.numpy(), 480.0 * scale)
     assert len(files) == 3
+
+
+@pytest.mark.parametrize("Hs,Ws,Cs", [(480, 720, 3), (600, 800, 4), (300, 451, 3)])
+@pytest.mark.parametrize("mode", ["normalized", "jitter"])
+def test_prepare_images_grayscale_is_bit_exact(Hs, Ws, Cs, mode):
+    """The one-channel pipeline (xl_data_prepare_images_gray): Pillow's 'L' conversion after the resize, jitter on it."""
+    rng = np.random.default_rng(Hs + Ws + Cs + 1)
+    frames = rng.integers(0, 256, (3, Hs, Ws, Cs), dtype=np.uint8)
+    jitter = [(0.93, 1.07, 0.0), (1.08, 0.91, 1.0), (1.02, 0.97, 0.0)] if mode == "jitter" else None
+    got = data.prepare_images(torch.from_numpy(frames).cuda(), 480, jitter=jitter, normalize=True, grayscale=True).cpu().numpy()
+    assert got.shape[1] == 1
+    for b in range(3):
+        ref = do.prepare_image(frames[b], 480, jitter[b] if jitter else None, data.MEAN_GRAY, data.STD_GRAY, grayscale=True)
+        assert np.array_equal(got[b], ref), "frame %d: max diff %g" % (b, np.abs(got[b] - ref).max())
+
+
+def test_prepare_images_more_frames_than_one_argument_pack():
+    """The jitter records ride in the kernel arguments, 64 frames per launch: 70 frames run as two chunks."""
+    rng = np.random.default_rng(3)
+    frames = rng.integers(0, 256, (70, 60, 90, 3), dtype=np.uint8)
+    jitter = [(0.9 + 0.003 * i, 1.1 - 0.002 * i, float(i % 2)) for i in range(70)]
+    got = data.prepare_images(torch.from_numpy(frames).cuda(), 60, jitter=jitter, normalize=True).cpu().numpy()
+    for b in (0, 63, 64, 69):
+        assert np.array_equal(got[b], do.prepare_image(frames[b], 60, jitter[b], data.MEAN, data.STD))
+
+
+def test_collate_gpu_semantics_labels_follow_the_image_size(tmp_path):
+    """semantics=True (dataloader.py:540-543): the label map is resized to the IMAGE size with 'nearest' and rotated with
+    fill 0; the other labels of a multi-label batch keep the 1/8 grid and fill -1."""
+    root = dataset.write_synthetic_scene(str(tmp_path / "scene"), 2, seed=5, semantics=True)
+    ds = dataset.CamLocDataset(root, augment=True, batch=True, coord=True, semantics=True)
+    items = [ds[i] for i in range(2)]
+    assert set(items[0][2]) == {"coord", "semantics"} and items[0][2]["semantics"].shape == (1, 480, 720)
+    assert items[0][2]["semantics"].max() <= 5                                    # trimmed to the 6 training classes
+    random.seed(4)
+    images, poses, labels, focals, files = ds.collate_gpu(items)
+    random.seed(4)
+    for _ in items:
+        data.draw_jitter(0.1, 0.1)
+    scale = random.uniform(2 / 3, 3 / 2)
+    angle = random.uniform(-30, 30)
+    H, W = images.shape[2], images.shape[3]
+    assert (H, W) == (math.ceil(480 * scale), math.ceil(720 * scale))
+    sem = torch.stack([it[2]["semantics"] for it in items])
+    assert torch.equal(labels["semantics"].cpu(), do.batch_resize_labels(sem, H, W, angle, fill=0.0))
+    co = torch.stack([it[2]["coord"] for it in items])
+    assert torch.equal(labels["coord"].cpu(), do.batch_resize_labels(co, math.ceil(H / 8), math.ceil(W / 8), angle))
+
+
+def test_collate_host_plus_to_gpu_equals_collate_gpu(tmp_path):
+    root = dataset.write_synthetic_scene(str(tmp_path / "scene"), 2, seed=9)
+    ds = dataset.CamLocDataset(root, augment=True, batch=True, grayscale=True)
+    items = [ds[i] for i in range(2)]
+    random.seed(2)
+    a = ds.collate_gpu(items)
+    random.seed(2)
+    b = ds.to_gpu(ds.collate_host(items))
+    assert a[0].shape[1] == 1 and torch.equal(a[0], b[0]) and torch.equal(a[2], b[2])

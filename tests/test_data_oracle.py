@@ -71,3 +71,20 @@ def test_batch_resize_shapes_and_fill():
     # every label value inside the frame is one of the source values (nearest twice)
     inside = ol[ol != -1.0]
     assert np.isin(inside.numpy(), lab.numpy()).all()
+
+
+@pytest.mark.parametrize("b,c,contrast_first", [(0.93, 1.07, False), (1.08, 0.91, True), (1.0, 1.0, False)])
+def test_grayscale_pipeline_equals_pillow(b, c, contrast_first):
+    """Resize -> Grayscale -> ColorJitter(brightness, contrast) on the 'L' image (dataloader.py:359-373) against Pillow."""
+    rng = np.random.default_rng(7)
+    img = rng.integers(0, 256, (97, 131, 3), dtype=np.uint8)
+    pil = Image.fromarray(img).convert("L")
+    assert np.array_equal(do.to_gray_u8(img), np.asarray(pil))
+    if contrast_first:
+        want = ImageEnhance.Brightness(ImageEnhance.Contrast(pil).enhance(c)).enhance(b)
+    else:
+        want = ImageEnhance.Contrast(ImageEnhance.Brightness(pil).enhance(b)).enhance(c)
+    assert np.array_equal(do.color_jitter_gray_u8(do.to_gray_u8(img), b, c, contrast_first), np.asarray(want))
+    x = do.prepare_image(img, 97, (b, c, contrast_first), (0.4308,), (0.1724,), grayscale=True)
+    assert x.shape == (1, 97, 131)
+    assert np.allclose(x[0], (np.asarray(want, np.float32) / 255.0 - 0.4308) / 0.1724, atol=1e-6)

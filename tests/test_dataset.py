@@ -53,3 +53,48 @@ def test_training_items_are_decoded_frames_only(tmp_path):
     assert pose.shape == (4, 4) and gt.shape == (3, 60, 90) and focal == pytest.approx(480.0)
     # raw_image supersedes augmentation (dataloader.py:217-219)
     assert dataset.CamLocDataset(root, augment=True, raw_image=True)[0][0].dtype == torch.float32
+
+
+def test_semantics_labels_and_grayscale_evaluation_path(tmp_path):
+    """semantics/*.npy: raw class ids trimmed to the 6 training classes, float [1,H,W] (dataloader.py:337-338,
+    loss/semantics.py:21-41); grayscale: Resize -> Grayscale -> ToTensor -> Normalize(0.4308, 0.1724) (:171-187)."""
+    from PIL import Image
+    from crossloc_amd.loss import trim_semantic_label
+    root = dataset.write_synthetic_scene(str(tmp_path / "scene"), 2, seed=3, semantics=True)
+    raw = np.load(root + "/semantics/frame_00001.npy")
+    assert set(np.unique(raw)) <= {0, 1, 2, 3, 6, 9, 17} and raw.max() > 5
+    assert np.array_equal(trim_semantic_label(np.array([0, 1, 2, 3, 6, 9, 17])), [0, 1, 1, 2, 3, 4, 5])
+    with pytest.raises(AssertionError):
+        trim_semantic_label(np.array([0, 8]))
+    ds = dataset.CamLocDataset(root, coord=False, semantics=True)
+    image, pose, gt, focal, name = ds[1]
+    assert gt.shape == (1, 480, 720) and gt.dtype == torch.float32
+    assert torch.equal(gt[0], torch.from_numpy(trim_semantic_label(raw)).float())
+    both = dataset.CamLocDataset(root, coord=True, semantics=True)[0][2]
+    assert set(both) == {"coord", "semantics"}
+    gray = dataset.CamLocDataset(root, grayscale=True)[1][0]
+    want = np.asarray(Image.open(root + "/rgb/frame_00001.png").convert("L"), np.float32) / 255.0
+    assert gray.shape == (1, 480, 720) and torch.allclose(gray[0], (torch.from_numpy(want) - 0.4308) / 0.1724, atol=1e-6)
+
+
+def test_evaluation_path_resizes_like_torchvision(tmp_path):
+    """Resize(image_height): the SMALLER edge becomes image_height and the other one is truncated - 600 x 801 stored at
+    height 480 gives 640 columns (not round(640.8) = 641), and a portrait frame scales its width."""
+    from PIL import Image
+    root = dataset.write_synthetic_scene(str(tmp_path / "scene"), 1, seed=5)
+    p = root + "/rgb/frame_00000.png"
+    Image.open(p).resize((801, 600)).save(p)
+    assert dataset.CamLocDataset(root, raw_image=True)[0][0].shape == (3, 480, 640)
+    Image.open(p).resize((600, 801)).save(p)
+    assert dataset.CamLocDataset(root, raw_image=True)[0][0].shape == (3, 640, 480)
+    assert dataset._resized_shape(480, 720, 480) == (480, 720)
+
+
+def test_collate_gpu_refuses_to_run_in_a_dataloader_worker(tmp_path, monkeypatch):
+    root = dataset.write_synthetic_scene(str(tmp_path / "scene"), 1)
+    ds = dataset.CamLocDataset(root, augment=True, batch=True)
+    monkeypatch.setattr(torch.utils.data, "get_worker_info", lambda: object())
+    with pytest.raises(RuntimeError, match="collate_host"):
+        ds.collate_gpu([ds[0]])
+    frames, poses, labels, focals, files = dataset.CamLocDataset.collate_host([ds[0], ds[0]])
+    assert frames.shape == (2, 480, 720, 3) and frames.dtype == torch.uint8 and not frames.is_cuda and len(focals) == 2
