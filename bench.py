@@ -674,6 +674,39 @@ def secondary_configs(dev, n_hyp, train_batch=16, mlr_batch=24, steps=5):
     del sd
     torch.cuda.empty_cache()
 
+    # ---- the reference's own API shape: batch 1 (test_single_task.py:347-363), and 8 frames per step.  Plans of <= 8 frames
+    # replay their op list as one HIP graph; launches whose 256 x 256 tiles cannot fill the chip use 128 x 128 tiles.
+    net = networks.TransPoseNet(mean, False, False, 2, 2, 3, 1)
+    net.load_state_dict(seeded_state_dict(net, seed=2021))
+    net = net.to(dev).eval()
+    for nb, key in ((1, "latency_b1_ms"), (8, "b8_images_per_s")):
+        imgs = torch.rand((nb, 3, H, W), generator=torch.Generator().manual_seed(nb)).to(dev)
+        c_np, _, _ = synth.make_batch(7000, nb, noise=0.5, outlier_ratio=0.3)
+        c_t = torch.from_numpy(c_np).to(dev)
+        pipe = evaluation.PipelinedLocalizer(net, n_hyp, synth.FOCAL, H, W)
+
+        def small_step():
+            pipe.submit(imgs, image0=0, plant=c_t)
+        for _ in range(5):
+            small_step()
+        pipe.finish()
+        torch.cuda.synchronize()
+        n_it = 200 if nb == 1 else 60
+        t0 = time.perf_counter()
+        for _ in range(n_it):
+            small_step()
+        pipe.finish()
+        torch.cuda.synchronize()
+        ms_small = (time.perf_counter() - t0) / n_it * 1e3
+        out[key] = round(ms_small, 3) if nb == 1 else round(nb / ms_small * 1e3, 1)
+        if nb == 1:
+            out["latency_b1_images_per_s"] = round(1e3 / ms_small, 1)
+        plan = [p for k, p in net._plans.items() if k[0] == nb][0]
+        out["latency_b%d_hip_graph" % nb] = bool(getattr(plan, "graph", None))
+        del pipe
+    del net
+    torch.cuda.empty_cache()
+
     # ---- configs[4], single-GPU share
     B = mlr_batch
     net = networks.TransPoseNet(mean, False, False, 2, 2, 3, 1, num_mlr=3)

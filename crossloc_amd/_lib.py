@@ -20,9 +20,19 @@ class XlError(RuntimeError):
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise XlError("libcrossloc_hip.so is not built (%s). Run `python -m crossloc_amd.build` "
-                          "(or __graft_entry__.build()); there is no CPU fallback." % LIB_PATH)
+        # a library built from OTHER sources than the ones next to it (a tree copied between an edit and a rebuild) binds
+        # the wrong ABI: rebuild it here when the toolchain is present (one minute, once), otherwise say so loudly
+        from . import build as _build
+        if not os.path.exists(LIB_PATH) or (os.path.exists(_build.STAMP) and _build.needs_build()):
+            try:
+                _build.build()
+            except Exception as e:                                       # no hipcc on this machine
+                if not os.path.exists(LIB_PATH):
+                    raise XlError("libcrossloc_hip.so is not built (%s) and could not be built here (%s). Run "
+                                  "`python -m crossloc_amd.build` (or __graft_entry__.build()); there is no CPU fallback."
+                                  % (LIB_PATH, e))
+                raise XlError("libcrossloc_hip.so is STALE (built from other sources than csrc/ and include/ hold now) and "
+                              "could not be rebuilt here (%s). Run `python -m crossloc_amd.build`." % (e,))
         # torch first (like the reference: README.md:51 "import torch before dsacstar"): its HIP runtime must be the
         # one already mapped when this library resolves libamdhip64, otherwise the process holds two runtimes and
         # the second one sees no device

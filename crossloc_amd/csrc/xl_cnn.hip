@@ -2448,6 +2448,49 @@ int xl_cnn_run(const xl_op *ops, int n_ops, void *stream)
 
 int xl_cnn_op_size(void) { return (int)sizeof(xl_op); }
 
+// ---- the op list of a plan as ONE executable HIP graph (latency path: a single frame is ~95 short launches, and the host
+// side of an eager launch costs about as much as the shortest kernels run)
+int xl_cnn_graph_capture(const xl_op *ops, int n_ops, void *stream, void **graph_out)
+{
+    if (!ops || n_ops < 1 || !stream || !graph_out) return XL_ERR_ARG;     // (the NULL stream cannot be captured)
+    hipStream_t st = (hipStream_t)stream;
+    const bool prof = g_profOn;
+    g_profOn = false;                                                      // event records are not part of a graph
+    if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) { g_profOn = prof; return XL_ERR_HIP; }
+    int rc = XL_OK;
+    for (int i = 0; i < n_ops && rc == XL_OK; ++i) rc = run_op(ops[i], st);
+    hipGraph_t g = nullptr;
+    const hipError_t e = hipStreamEndCapture(st, &g);
+    g_profOn = prof;
+    if (rc != XL_OK || e != hipSuccess || !g) {
+        if (g) (void)hipGraphDestroy(g);
+        (void)hipGetLastError();
+        if (rc == XL_OK) snprintf(g_err, sizeof(g_err), "hipStreamEndCapture: %s", hipGetErrorString(e));
+        return rc != XL_OK ? rc : XL_ERR_HIP;
+    }
+    hipGraphExec_t ex = nullptr;
+    const hipError_t ei = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    if (ei != hipSuccess || !ex) { snprintf(g_err, sizeof(g_err), "hipGraphInstantiate: %s", hipGetErrorString(ei)); return XL_ERR_HIP; }
+    *graph_out = (void *)ex;
+    return XL_OK;
+}
+
+int xl_cnn_graph_launch(void *graph, void *stream)
+{
+    if (!graph) return XL_ERR_ARG;
+    if (g_profOn) return XL_ERR_UNSUPPORTED;                               // per-op timing needs the eager path
+    const hipError_t e = hipGraphLaunch((hipGraphExec_t)graph, (hipStream_t)stream);
+    if (e != hipSuccess) { snprintf(g_err, sizeof(g_err), "hipGraphLaunch: %s", hipGetErrorString(e)); return XL_ERR_HIP; }
+    return XL_OK;
+}
+
+int xl_cnn_graph_destroy(void *graph)
+{
+    if (!graph) return XL_OK;
+    return hipGraphExecDestroy((hipGraphExec_t)graph) == hipSuccess ? XL_OK : XL_ERR_HIP;
+}
+
 int xl_cnn_pack_conv_weight(const float *w_oihw_dev, float *w_ohwi_dev, int Cout, int Cin, int k, void *stream)
 {
     if (!w_oihw_dev || !w_ohwi_dev || Cout <= 0 || Cin <= 0 || k <= 0) return XL_ERR_ARG;

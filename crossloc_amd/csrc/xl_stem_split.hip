@@ -56,6 +56,7 @@ struct StemArgs {
     const float *in; const uint16_t *u; const float *bias; float *out;
     const float *coef; float normLo;                 // NORM: [B][Cin][2] {scale, shift}; lower clamp (0 = ReLU, -inf = none)
     int B, Hi, Wi, Cin, Ho, Wo, ldIn, ldOut, M, nbm;
+    int nbn;                                         // column tiles of NT channels (1, or 2 when Cout = 256 runs on 128-wide tiles)
 };
 
 template <int NT, bool NORM, int NW>                                  // Cout; normalise on load; waves per workgroup
@@ -71,7 +72,7 @@ void split_conv3x3s2_kernel(StemArgs a)
     constexpr int kW = NT * kUnit;                                    // one weight stage
     constexpr int kA = 3 * kW;                                        // activation stages
     constexpr int kCoef = kA + 2 * kAStage;                           // coefficient tables of two tiles, 2 KB each (Cin <= 128)
-    constexpr int kBias = kCoef + 4096;
+    constexpr int kBias = kCoef + 4096;                               // bias[Cout <= 256]
     constexpr int NDMA = NT * kUnit / 1024;                           // DMA instructions per weight stage
     constexpr int NS = 8 * RI;                                        // stores per wave and tile
     const int tid = threadIdx.x, lane = tid & 63;
@@ -79,14 +80,15 @@ void split_conv3x3s2_kernel(StemArgs a)
     const int wm = wave / WN, wn = wave % WN;
     const bool dmaWave = wave * 3 < NDMA;
 
-    const int total = a.nbm;
+    const int total = a.nbm * a.nbn;
     const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3, nloc = gridDim.x >> 3;
     const int q8 = total >> 3, r8 = total & 7;
     const int runStart = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
     const int runLen = q8 + (xcd < r8 ? 1 : 0);
     const int myCount = runLen > local ? (runLen - local + nloc - 1) / nloc : 0;
     if (myCount == 0) return;
-    auto tile_m0 = [&](int i) { return (runStart + local + i * nloc) * BM; };
+    auto tile_m0 = [&](int i) { return ((runStart + local + i * nloc) / a.nbn) * BM; };
+    auto tile_n0 = [&](int i) { return ((runStart + local + i * nloc) % a.nbn) * NT; };
     auto tile_rows = [&](int m0) { const int rows = a.M - m0; return rows < BM ? rows : BM; };
 
     constexpr unsigned OOB = 0x80000000u;
@@ -97,7 +99,7 @@ void split_conv3x3s2_kernel(StemArgs a)
     const long long imgIn = (long long)a.Hi * a.Wi * a.ldIn;          // floats per input image
 
     // ---- stream two K-steps ahead of the multiplies
-    const __amdgpu_buffer_rsrc_t srdU = __builtin_amdgcn_make_buffer_rsrc((void *)a.u, 0, (int)(NT * rowU), 0x00020000);
+    const __amdgpu_buffer_rsrc_t srdU = __builtin_amdgcn_make_buffer_rsrc((void *)a.u, 0, (int)(a.nbn * NT * rowU), 0x00020000);
     __amdgpu_buffer_rsrc_t srdIn = __builtin_amdgcn_make_buffer_rsrc((void *)a.in, 0, 0, 0x00020000);
     const int arow = tid >> 1, ahalf = tid & 1;
     unsigned gB[3];
@@ -132,7 +134,7 @@ void split_conv3x3s2_kernel(StemArgs a)
                 const int row = sl / 6, phys = sl - row * 6;
                 int logical = phys - ((row >> 3) & 1);
                 if (logical < 0) logical += 6;
-                gB[q] = i < myCount ? (unsigned)((long long)row * rowU + logical * 16) : OOB;
+                gB[q] = i < myCount ? (unsigned)((long long)(tile_n0(i) + row) * rowU + logical * 16) : OOB;
             }
         }
         dDy = 0; dDx = 0; dChunk = 0;
@@ -236,12 +238,12 @@ void split_conv3x3s2_kernel(StemArgs a)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[pu][j], fa[pv][i], acc[i][j], 0, 0, 0);
     };
     const int rhalf = kh * 4;
-    auto init_acc = [&]() {                                            // accumulators start at the bias
+    auto init_acc = [&](int n0) {                                      // accumulators start at the bias
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const f32x4 b = *reinterpret_cast<const f32x4 *>(dsm + kBias + (wn * 64 + j * 32 + rhalf + 8 * q) * 4);
+                const f32x4 b = *reinterpret_cast<const f32x4 *>(dsm + kBias + (n0 + wn * 64 + j * 32 + rhalf + 8 * q) * 4);
 #pragma unroll
                 for (int i = 0; i < RI; ++i)
 #pragma unroll
@@ -250,7 +252,7 @@ void split_conv3x3s2_kernel(StemArgs a)
     };
 
     // ---- prologue: bias and the first two coefficient tables into LDS, steps 0 and 1 of the stream, step 0 converted
-    for (int i = tid; i < NT; i += NTH) reinterpret_cast<float *>(dsm + kBias)[i] = a.bias[i];
+    for (int i = tid; i < a.nbn * NT; i += NTH) reinterpret_cast<float *>(dsm + kBias)[i] = a.bias[i];
     if constexpr (NORM) {
         const u32x4 t0 = load_table(0), t1 = load_table(1);
         store_table(0, t0);
@@ -273,7 +275,7 @@ void split_conv3x3s2_kernel(StemArgs a)
     __builtin_amdgcn_s_waitcnt(0x0070 | 5);                           // my writes of step 0; stage 0 of the ring landed before
     __builtin_amdgcn_s_barrier();
     int sc = 0, sd = 2;
-    init_acc();
+    init_acc(tile_n0(0));
     // one K-step; FIRST: the first step of a tile that follows another one (NS stores of its epilogue are in flight)
     auto step = [&](auto firstTag, auto parTag) __attribute__((always_inline)) {
         constexpr int sa = decltype(parTag)::value;                   // parity of the K-step
@@ -339,7 +341,7 @@ void split_conv3x3s2_kernel(StemArgs a)
     auto epilogue = [&](int ti) __attribute__((always_inline)) {
         __builtin_amdgcn_sched_barrier(0);
         // ---- tile ti (swapped operands): row = lane & 31, channels (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
-        const int m0 = tile_m0(ti);
+        const int m0 = tile_m0(ti), n0 = tile_n0(ti);
         if constexpr (NORM) {                                          // (waits for everything older than the table)
             const u32x4 tab = load_table(ti + 2);
             store_table(ti + 2, tab);
@@ -355,13 +357,13 @@ void split_conv3x3s2_kernel(StemArgs a)
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const int n = wn * 64 + j * 32 + rhalf + 8 * q;
+                    const int n = n0 + wn * 64 + j * 32 + rhalf + 8 * q;
                     const unsigned off = rowOff + (unsigned)n * 4u;
                     const f32x4 v = f32x4{ acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3] };
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), srdO, (int)off, 0, 0);
                 }
         }
-        if (ti + 1 < myCount) init_acc();
+        if (ti + 1 < myCount) init_acc(tile_n0(ti + 1));
         __builtin_amdgcn_sched_barrier(0);
     };
     auto tile_steps = [&](auto firstTag) __attribute__((always_inline)) {
@@ -385,7 +387,7 @@ template <int NT, int NW, int PER_CU>
 int launch_stem(StemArgs a, bool norm, hipStream_t st)
 {
     constexpr int BM = 32 * NW;
-    const size_t lds = 3 * NT * kUnit + 2 * BM * kUnit + 4096 + NT * 4;
+    const size_t lds = 3 * NT * kUnit + 2 * BM * kUnit + 4096 + 1024;
     static XlLdsLimit configured[2];
     int cfgDev;
     const void *fn = norm ? reinterpret_cast<const void *>(split_conv3x3s2_kernel<NT, true, NW>)
@@ -396,7 +398,7 @@ int launch_stem(StemArgs a, bool norm, hipStream_t st)
     }
     a.nbm = (a.M + BM - 1) / BM;
     int grid = 256 * PER_CU;                                          // persistent: PER_CU workgroups per CU (LDS- and register-bound)
-    if (grid > ((a.nbm + 7) & ~7)) grid = (a.nbm + 7) & ~7;
+    if (grid > ((a.nbm * a.nbn + 7) & ~7)) grid = (a.nbm * a.nbn + 7) & ~7;
     if (norm) hipLaunchKernelGGL((split_conv3x3s2_kernel<NT, true, NW>), dim3(grid), dim3(64 * NW), lds, st, a);
     else hipLaunchKernelGGL((split_conv3x3s2_kernel<NT, false, NW>), dim3(grid), dim3(64 * NW), lds, st, a);
     return XL_OK;
@@ -424,8 +426,12 @@ int xl_run_split_stem(const xl_op &op, hipStream_t st)
     a.coef = (const float *)op.aux2;
     a.normLo = (op.flags & XL_CONV_NORM_RELU) ? 0.f : -__builtin_inff();
     a.B = op.B; a.Hi = op.Hi; a.Wi = op.Wi; a.Cin = op.Cin; a.Ho = op.Ho; a.Wo = op.Wo;
-    a.ldIn = op.ld_in; a.ldOut = op.ld_out; a.M = (int)M; a.nbm = 0;
+    a.ldIn = op.ld_in; a.ldOut = op.ld_out; a.M = (int)M; a.nbm = 0; a.nbn = 1;
     if (op.Cout == 64) return launch_stem<64, 4, 3>(a, norm, st);
     if (op.Cout == 128) return launch_stem<128, 4, 2>(a, norm, st);
+    if (op.reserved_i == 128) {                                       // latency form (the host asks when 256-row tiles cannot fill
+        a.nbn = 2;                                                    // the chip): 128 x 128 tiles, two column tiles per row tile
+        return launch_stem<128, 4, 2>(a, norm, st);
+    }
     return launch_stem<256, 8, 1>(a, norm, st);
 }

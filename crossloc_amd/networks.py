@@ -33,6 +33,7 @@ CONV_DGRAD, CONV_ACCUMULATE, CONV_SPLIT_BF16 = 1, 2, 64
 CONV_NORM_IN, CONV_NORM_RELU = 128, 256
 CONV_SPLIT_IL = 512
 CONV_SPLIT_ACT = 1024
+XL_ERR_UNSUPPORTED = -4            # include/crossloc_dsac.h
 
 
 class XlOp(ctypes.Structure):
@@ -58,6 +59,12 @@ def _bind():
         L.xl_cnn_pack_wino_weight.argtypes = [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 5 + [ctypes.c_void_p]
         L.xl_cnn_split_weight.restype = ctypes.c_int
         L.xl_cnn_split_weight.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+        L.xl_cnn_graph_capture.restype = ctypes.c_int
+        L.xl_cnn_graph_capture.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]
+        L.xl_cnn_graph_launch.restype = ctypes.c_int
+        L.xl_cnn_graph_launch.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        L.xl_cnn_graph_destroy.restype = ctypes.c_int
+        L.xl_cnn_graph_destroy.argtypes = [ctypes.c_void_p]
         L.xl_cnn_last_error.restype = ctypes.c_char_p
         if L.xl_cnn_op_size() != ctypes.sizeof(XlOp):
             raise _lib.XlError("xl_op layout mismatch: C %d vs ctypes %d" % (L.xl_cnn_op_size(), ctypes.sizeof(XlOp)))
@@ -542,6 +549,8 @@ class _Plan:
             op.flags |= CONV_SPLIT_BF16 | CONV_SPLIT_IL
             op.w = self.pack_conv_stem_split(conv).data_ptr()
             op.reserved_i = 0
+            if (cout == 256 and -(-self.B * Ho * Wo // 256) < 128 and not os.environ.get("XL_NO_SMALL_TILES")):
+                op.reserved_i = 128                  # latency form: 128 x 128 tiles when 256-row tiles leave the chip idle
         elif split:
             op.flags |= CONV_SPLIT_BF16 | CONV_SPLIT_IL
             op.w = self.pack_conv_1x1_split(conv).data_ptr()
@@ -1441,12 +1450,53 @@ class _Plan:
         for i in patch_d:
             self.bwd_array[i].stats2 = self.bwd_scratch_d.data_ptr()
 
+    GRAPH_MAX_BATCH = 8            # plans of at most this many frames replay their op list as one HIP graph (XL_CNN_GRAPH)
+
+    def _graph_wanted(self, stream):
+        env = os.environ.get("XL_CNN_GRAPH")
+        if self.train or stream == 0 or env == "0":
+            return False
+        return env == "1" or self.B <= self.GRAPH_MAX_BATCH
+
+    def _run_graph(self, image, stream):
+        """Latency path: the ~95 launches of a small-batch forward as one executable HIP graph.  The graph holds pointers,
+        so the image is copied into a buffer of the plan (4 MB per frame, one device-to-device copy) and the result is
+        handed out as a copy of the plan's result buffer.  Returns None when the eager path has to run (first call of the
+        plan: every kernel configures itself on its first launch; per-op profiling)."""
+        L = _bind()
+        if not hasattr(self, "graph_in"):
+            self.graph_in = torch.empty_like(image)
+            self.graph_out = torch.empty(self.out_shape, dtype=torch.float32, device=self.device)
+            self.graph, self.graph_runs = None, 0
+        self.graph_runs += 1
+        if self.graph_runs == 1:
+            return None                                     # warm-up: eager
+        for i in self.image_op_indices:
+            self.op_array[i].in_ = self.graph_in.data_ptr()
+        self.op_array[self.out_op_index].out = self.graph_out.data_ptr()
+        if self.graph is None:
+            h = ctypes.c_void_p()
+            _check(L.xl_cnn_graph_capture(self.op_array, len(self.op_array), ctypes.c_void_p(stream), ctypes.byref(h)))
+            self.graph = h
+            weakref.finalize(self, L.xl_cnn_graph_destroy, h)
+        self.graph_in.copy_(image)
+        rc = L.xl_cnn_graph_launch(self.graph, ctypes.c_void_p(stream))
+        if rc == XL_ERR_UNSUPPORTED:                        # per-op profiling is on: this call runs eagerly
+            return None
+        _check(rc)
+        return self.graph_out.clone()
+
     def run(self, image):
+        stream = torch.cuda.current_stream().cuda_stream
+        if self._graph_wanted(stream):
+            out = self._run_graph(image, stream)
+            if out is not None:
+                self.last_image, self.last_out = image, out.detach()
+                return out
         out = torch.empty(self.out_shape, dtype=torch.float32, device=self.device)
         for i in self.image_op_indices:
             self.op_array[i].in_ = image.data_ptr()
         self.op_array[self.out_op_index].out = out.data_ptr()
-        stream = torch.cuda.current_stream().cuda_stream
         _check(_bind().xl_cnn_run(self.op_array, len(self.op_array), ctypes.c_void_p(stream)))
         # (a detached alias: the returned tensor itself becomes the output of the autograd node in training, and a
         # reference to it from here would keep that graph - and the plan's busy token - alive)

@@ -140,6 +140,15 @@ int xl_cnn_run(const xl_op *ops, int n_ops, void *stream);
 /* sizeof(xl_op) as compiled, so a binding can verify its struct layout. */
 int xl_cnn_op_size(void);
 
+/* The same op list as ONE executable HIP graph: xl_cnn_graph_capture records the launches of ops[0..n_ops) on `stream`
+ * (a created stream, not NULL; nothing executes during the capture, and every kernel of the list must have run once
+ * before - the first launch of a kernel configures it) and returns an opaque handle; xl_cnn_graph_launch replays it on a
+ * stream with the pointers the ops held at capture time (bind the image / result to fixed buffers); _destroy frees it.
+ * Returns XL_ERR_UNSUPPORTED from _launch while per-op profiling is on.  For batch-1 test_single_task.py:347-363. */
+int xl_cnn_graph_capture(const xl_op *ops, int n_ops, void *stream, void **graph_out);
+int xl_cnn_graph_launch(void *graph, void *stream);
+int xl_cnn_graph_destroy(void *graph);
+
 /* Weight layout transform used at load time: PyTorch conv weight [Cout][Cin][k][k] (device) ->
  * [Cout][Cin/32][k*k][32] (device): 32-channel chunk major, tap, channel within chunk; Cin % 32 == 0. */
 int xl_cnn_pack_conv_weight(const float *w_oihw_dev, float *w_ohwi_dev, int Cout, int Cin, int k, void *stream);

@@ -898,3 +898,46 @@ def test_split_weight_kernel_is_the_exact_three_term_split():
     networks._check(L.xl_cnn_split_weight(w3.data_ptr(), p.data_ptr(), 64, 288, 9, None))
     assert torch.equal(p, networks._Plan.split_bf16_interleaved(networks._Plan._stem_rows(w3), 288).reshape(-1))
     assert L.xl_cnn_split_weight(w3.data_ptr(), p.data_ptr(), 64, 280, 9, None) != 0      # K % 16
+
+
+def test_small_batch_forward_as_a_hip_graph_and_small_tile_form(monkeypatch):
+    """Latency path: on a created stream a plan of <= 8 frames replays its op list as ONE HIP graph (first call eager, second
+    captures, later ones replay) - bitwise the eager result; new images and new weights are picked up.  1x1 layers whose
+    256 x 256 tiles would leave the chip idle run on 128 x 128 tiles: every convolution output is bitwise the same (same
+    K order per element), but the GroupNorm partial sums are grouped per tile, so the network output agrees with the
+    throughput tiles to the last fp32 bit or two at |X| ~ 500 m, like a frame inside another batch."""
+    net = networks.TransPoseNet(MEAN, False, False, 1, 1, 3, 1)
+    net.load_state_dict(seeded_state_dict(net, seed=19))
+    net = net.cuda().eval()
+    xs = [torch.rand(1, 3, 480, 720, generator=torch.Generator().manual_seed(s)).cuda() for s in (1, 2, 3)]
+    monkeypatch.setenv("XL_CNN_GRAPH", "0")
+    with torch.no_grad():
+        want = [net(x).clone() for x in xs]                          # eager, latency tiles
+    plan = list(net._plans.values())[0]
+    assert any(op.type == networks.XL_OP_CONV and (op.flags & networks.CONV_SPLIT_IL) and op.reserved_i == 128 for op in plan.ops)
+    monkeypatch.setenv("XL_NO_SMALL_TILES", "1")
+    net.invalidate()
+    with torch.no_grad():
+        big = net(xs[0]).clone()                                      # eager, throughput tiles
+    assert torch.allclose(big[:, :3], want[0][:, :3], rtol=0, atol=3e-4) and torch.allclose(big[:, 3], want[0][:, 3], rtol=2e-4)
+    monkeypatch.delenv("XL_NO_SMALL_TILES")
+    monkeypatch.delenv("XL_CNN_GRAPH")
+    net.invalidate()
+    st = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(st), torch.no_grad():
+        got = [net(x) for x in xs] + [net(xs[0])]
+    st.synchronize()
+    plan = list(net._plans.values())[0]
+    assert plan.graph is not None and plan.graph_runs == 4
+    for g, w in zip(got, want + [want[0]]):
+        assert torch.equal(g, w)
+    with torch.no_grad():                                   # an in-place weight update reaches the replayed graph
+        net.decoder.fc2.weight.mul_(1.25)
+    with torch.cuda.stream(st), torch.no_grad():
+        y2 = net(xs[1])
+    st.synchronize()
+    monkeypatch.setenv("XL_CNN_GRAPH", "0")
+    net.invalidate()
+    with torch.no_grad():
+        assert torch.equal(net(xs[1]), y2) and not torch.equal(y2, want[1])
