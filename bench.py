@@ -40,7 +40,7 @@ def kernel_source_hash():
     measured on."""
     import hashlib
     h = hashlib.sha256()
-    for name in ("xl_cnn.hip", "xl_gemm_split.hip", "xl_common.h"):
+    for name in ("xl_cnn.hip", "xl_gemm_split.hip", "xl_stem_split.hip", "xl_common.h"):
         with open(os.path.join(ROOT, "crossloc_amd", "csrc", name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
@@ -331,6 +331,7 @@ def main():
     has_wino = any(op.type == 1 and op.nchunks2 > 1 for op in plan.ops)
     split_gemm = any(op.type == 1 and op.nchunks2 > 1 and (op.flags & networks.CONV_SPLIT_BF16) for op in plan.ops)
     split_il = any(op.type == 1 and op.nchunks2 > 1 and (op.flags & networks.CONV_SPLIT_IL) for op in plan.ops)
+    split_act = any(op.type == 1 and op.nchunks2 > 1 and (op.flags & networks.CONV_SPLIT_ACT) for op in plan.ops)
     if os.environ.get("XL_BENCH_VERBOSE"):
         L.xl_cnn_prof_filter(-1, 0)
     else:
@@ -427,9 +428,13 @@ def main():
 
     if rank == 0:
         value = total_imgs / elapsed
-        traffic, traffic_source = lookup_traffic(("split%d" if mfma_passes == 6 else "wino%d") % wino if wino else "direct", Bl)
+        form = ("splitact%d" if (mfma_passes == 6 and split_act) else
+                "split%d" if mfma_passes == 6 else "wino%d") % wino if wino else "direct"
+        traffic, traffic_source = lookup_traffic(form, Bl)
         if mfma_passes == 6:
-            kernel_name = ("split_gemm_persist_kernel<512> (256x256 tiles, interleaved 3xbf16 operand planes)" if split_il else
+            kernel_name = ("split_conv1x1_kernel<false,false,8,1> (256x256 tiles; V read as fp32 and split into its three bf16 "
+                           "terms inside the kernel, weights as interleaved 3xbf16 planes)" if split_act else
+                           "split_gemm_persist_kernel<512> (256x256 tiles, interleaved 3xbf16 operand planes)" if split_il else
                            "split_gemm_kernel (128x128 tiles, separate bf16 planes)") + \
                           " batched x%d: the Winograd %s GEMMs of a 3x3 512->512 layer @60x90 x%d images per launch, every fp32 " \
                           "operand as an exact sum of three bf16 terms, six v_mfma_f32_32x32x16_bf16 passes, fp32 accumulation" % (
@@ -439,8 +444,9 @@ def main():
                             "512->512 layer @60x90" % (wino, WINO_NAME.get(wino, "?")) if wino else
                             "igemm_conv_kernel<3,1,128,512> (3x3 512->512 @60x90") + " x%d images per launch)" % Bl)
         alg_bytes = (wino * (2 * Bl * wino_tiles * 512 + 512 * 512) * 4 if wino else 2 * Bl * 5400 * 512 * 4 + 512 * 4608 * 4)
-        if mfma_passes == 6:                         # V and U as 6 bytes per element (three bf16), M written as fp32
-            alg_bytes = wino * ((Bl * wino_tiles * 512 + 512 * 512) * 6 + Bl * wino_tiles * 512 * 4)
+        if mfma_passes == 6:                         # U as 6 bytes per element (three bf16), M written as fp32, V read as
+            v_bytes = 4 if split_act else 6          # fp32 (split inside the kernel) or as three bf16 planes
+            alg_bytes = wino * (Bl * wino_tiles * 512 * v_bytes + 512 * 512 * 6 + Bl * wino_tiles * 512 * 4)
         out = {
             "metric": "images/sec localized (480x720, 256 hyps)", "value": round(value, 2), "unit": "images/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(elapsed / K * 1e3, 3),

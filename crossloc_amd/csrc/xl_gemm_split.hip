@@ -465,7 +465,9 @@ __device__ __forceinline__ void split_pair(float x, float y, unsigned &w1, unsig
 // NW = waves per workgroup: 8 -> tiles of 256 x 256 (2 x 4 waves of 128 x 64), the throughput form; 4 -> tiles of 128 x 128
 // (2 x 2 waves of 64 x 64) for launches whose 256 x 256 tiles would leave most of the 256 CUs idle (a single frame: 44 tiles).
 // Every output element accumulates its K-steps and term pairs in the same order in both forms: bitwise the same result.
-template <bool NORM, bool ACC = false, int NW = 8>  // ACC: out += result (a data gradient with a second producer, training plans)
+// ZB = 1: the instantiation of the batched launches (Z > 1, the GEMMs of a Winograd layer): the same code under a name of its
+// own, so that a profiler's dispatch table tells the dominant kernel of the forward pass from the 1x1 layers.
+template <bool NORM, bool ACC = false, int NW = 8, int ZB = 0>  // ACC: out += result (a data gradient with a second producer)
 __global__ __launch_bounds__(64 * NW)
 void split_conv1x1_kernel(SplitConvArgs a)
 {
@@ -892,10 +894,11 @@ static int launch_split_conv1x1(const xl_op &op, SplitConvArgs a, bool norm, int
     const bool accumulate = (op.flags & XL_CONV_ACCUMULATE) != 0;
     const void *fn = accumulate ? reinterpret_cast<const void *>(split_conv1x1_kernel<false, true, NW>)
                    : norm ? reinterpret_cast<const void *>(split_conv1x1_kernel<true, false, NW>)
-                          : reinterpret_cast<const void *>(split_conv1x1_kernel<false, false, NW>);
-    static XlLdsLimit configured[3];
+                   : Z > 1 ? reinterpret_cast<const void *>(split_conv1x1_kernel<false, false, NW, 1>)
+                           : reinterpret_cast<const void *>(split_conv1x1_kernel<false, false, NW>);
+    static XlLdsLimit configured[4];
     int cfgDev;
-    const int slot = accumulate ? 2 : (norm ? 1 : 0);
+    const int slot = accumulate ? 2 : (norm ? 1 : (Z > 1 ? 3 : 0));
     if (configured[slot].needs(lds, &cfgDev)) {
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return XL_ERR_HIP;
         configured[slot].done(lds, cfgDev);
@@ -905,6 +908,7 @@ static int launch_split_conv1x1(const xl_op &op, SplitConvArgs a, bool norm, int
     if (grid > ((nwg + 7) & ~7)) grid = (nwg + 7) & ~7;
     if (accumulate) hipLaunchKernelGGL((split_conv1x1_kernel<false, true, NW>), dim3(grid), dim3(64 * NW), lds, st, a);
     else if (norm) hipLaunchKernelGGL((split_conv1x1_kernel<true, false, NW>), dim3(grid), dim3(64 * NW), lds, st, a);
+    else if (Z > 1) hipLaunchKernelGGL((split_conv1x1_kernel<false, false, NW, 1>), dim3(grid), dim3(64 * NW), lds, st, a);
     else hipLaunchKernelGGL((split_conv1x1_kernel<false, false, NW>), dim3(grid), dim3(64 * NW), lds, st, a);
     return XL_OK;
 }

@@ -1151,9 +1151,19 @@ class _Plan:
         self.conv1_wgrad_indices = []
         producers = {self._key(e["raw"]): e for e in self.tape if e["kind"] in ("conv", "conv1")}
 
+        # every parameter gradient is a slice of ONE flat buffer (16-byte aligned slices): a backward pass hands its result
+        # out with one device-to-device copy of that buffer instead of one clone per parameter (run_backward)
+        total = sum((p.numel() + 3) // 4 * 4 for p in self.net.parameters() if p.requires_grad)
+        self.grad_flat = torch.zeros(max(total, 4), dtype=torch.float32, device=dev)
+        self.grad_slices, cursor = [], [0]
+
         def pgrad(param):
-            t = torch.zeros(param.numel(), dtype=torch.float32, device=dev)
+            n = param.numel()
+            t = self.grad_flat[cursor[0]:cursor[0] + n]
             self.param_grads.append((param, t))
+            self.grad_slices.append((param, cursor[0], n))
+            cursor[0] += (n + 3) // 4 * 4
+            assert cursor[0] <= self.grad_flat.numel()
             return t
 
         def find_grad(act):
@@ -1512,7 +1522,22 @@ class _Plan:
             self.bwd_array[i].in_ = self.last_image.data_ptr()
         stream = torch.cuda.current_stream().cuda_stream
         _check(_bind().xl_cnn_run(self.bwd_array, len(self.bwd_array), ctypes.c_void_p(stream)))
-        return self.param_grads
+        # hand the gradients out as slices of a copy of the flat buffer (ONE device-to-device copy; the plan's own buffer
+        # is overwritten by the next backward pass).  Two result buffers alternate - their addresses repeat, which keeps
+        # the fused optimizer's pointer table valid - unless a parameter's .grad still lives in the one whose turn it is
+        # (gradient accumulation without zero_grad): then a fresh buffer is used.
+        if not hasattr(self, "grad_results"):
+            self.grad_results, self.grad_turn = [None, None], 0
+        self.grad_turn ^= 1
+        buf = self.grad_results[self.grad_turn]
+        if buf is not None:
+            lo, hi = buf.data_ptr(), buf.data_ptr() + 4 * buf.numel()
+            if any(p.grad is not None and lo <= p.grad.data_ptr() < hi for p, _, _ in self.grad_slices):
+                buf = None
+        if buf is None:
+            buf = self.grad_results[self.grad_turn] = torch.empty_like(self.grad_flat)
+        buf.copy_(self.grad_flat)
+        return [(p, buf[o:o + n]) for p, o, n in self.grad_slices]
 
 
 class _NetFunction(torch.autograd.Function):
@@ -1539,7 +1564,7 @@ class _NetFunction(torch.autograd.Function):
                                "(backward twice through one graph after another forward?)")
         produced = {id(p): g for p, g in ctx.plan.run_backward(gout)}
         ctx.plan.busy = False
-        grads = tuple(produced[id(p)].view_as(p).clone() if (p.requires_grad and id(p) in produced) else None
+        grads = tuple(produced[id(p)].view_as(p) if (p.requires_grad and id(p) in produced) else None
                       for p in ctx.params)
         return (None, None) + grads
 

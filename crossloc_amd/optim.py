@@ -47,9 +47,11 @@ class Adam(torch.optim.Optimizer):
                 return (0, 0)
             return (st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr())
         sig = tuple((p.data_ptr(), p.grad.data_ptr()) + moments(p) for p in ps)
-        cached = self._tables.get(gi)
-        if cached is not None and cached[0] == sig:
-            return cached[1], cached[2]
+        cached = self._tables.setdefault(gi, {})      # a few tables per group: the network hands its gradients out in
+        if sig in cached:                              # alternating buffers (networks._Plan.run_backward)
+            return cached[sig]
+        if len(cached) >= 4:
+            cached.clear()
         rows = []
         for p in ps:
             if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous() or not p.grad.is_contiguous():
@@ -71,7 +73,7 @@ class Adam(torch.optim.Optimizer):
         dev = torch.empty(ctypes.sizeof(host), dtype=torch.uint8, device=ps[0].device)
         dev.copy_(torch.frombuffer(bytearray(bytes(host)), dtype=torch.uint8))
         sig = tuple((p.data_ptr(), p.grad.data_ptr()) + moments(p) for p in ps)      # the state may just have been made
-        self._tables[gi] = (sig, dev, len(rows))
+        cached[sig] = (dev, len(rows))
         return dev, len(rows)
 
     def load_state_dict(self, state_dict):
@@ -132,7 +134,7 @@ def train_step(network, optimizer, images, gt_poses, gt_coords, pixel_grid, cam_
     """One iteration of train_single_task.py:245-301 for the coord task on the HIP path: forward, split of the
     uncertainty channel (:269), fused coordinate loss, backward, (gradient all-reduce), fused Adam."""
     from . import loss as xl_loss
-    optimizer.zero_grad(set_to_none=False)
+    optimizer.zero_grad(set_to_none=True)             # (no fill kernels; backward hands fresh gradient tensors out)
     pred = network(images)
     nt = network.num_task_channel
     sc, unc = torch.split(pred, [nt, network.num_pos_channel], dim=1)

@@ -20,6 +20,8 @@ def main():
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--eager", action="store_true", help="also time PyTorch-ROCm eager")
+    ap.add_argument("--full", action="store_true", help="the step as the reference runs it: + fused Adam + weight re-pack "
+                                                        "(optim.train_step)")
     a = ap.parse_args()
     B = a.batch
     dev = torch.device("cuda")
@@ -41,6 +43,13 @@ def main():
         loss.backward()
         return loss
 
+    if a.full:
+        from crossloc_amd import optim as xl_optim
+        opt = xl_optim.Adam(net.parameters(), lr=1e-4)
+        fwd_bwd = step
+
+        def step():                                                       # noqa: F811
+            return xl_optim.train_step(net, opt, images, poses_t, gt_t, grid, cam)[0]
     for _ in range(2):
         step()
     torch.cuda.synchronize()
