@@ -1354,7 +1354,7 @@ template <int VW>
 __global__ __launch_bounds__(256)
 void wino6_out_kernel(const float *__restrict__ M, const float *__restrict__ bias, float *__restrict__ out,
                       double *__restrict__ stats, int B, int H, int W, int C, int ldOut, int Th, int Tw, int tpb,
-                      int G, int nchunks, int accumulate)
+                      int G, int nchunks, int accumulate, int tileMajor)
 {
     typedef typename WinoVec<VW>::type V;
     __shared__ double sS[256 * 2 * VW];
@@ -1367,15 +1367,18 @@ void wino6_out_kernel(const float *__restrict__ M, const float *__restrict__ bia
     const int n = blockIdx.y, k = blockIdx.x;
     const int Timg = Th * Tw;
     const long long T = (long long)B * Timg;
-    const long long zs = T * C;
+    // M is [64][tiles][C] (plane-major: what the fp32 GEMMs write) or - tileMajor, XL_CONV_M_TILE_MAJOR - [tiles][64][C]: the
+    // 64 x C block of a tile is then ONE contiguous piece (128 KB at 512 channels) instead of 64 rows 14 MB apart
+    const long long zs = tileMajor ? (long long)C : T * C;            // elements between frequency planes
+    const long long ts = tileMajor ? 64LL * C : (long long)C;         // ... between tiles
     int t1 = (k + 1) * tpb; if (t1 > Timg) t1 = Timg;
     V bv = V(0.f);
     if (bias) bv = *reinterpret_cast<const V *>(bias + cch);
     V s1 = V(0.f), s2 = V(0.f);
-    const __amdgpu_buffer_rsrc_t srdM = __builtin_amdgcn_make_buffer_rsrc((void *)M, 0, (int)(unsigned)(64 * zs * 4 > 0xffffffffLL ? 0xffffffffLL : 64 * zs * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t srdM = __builtin_amdgcn_make_buffer_rsrc((void *)M, 0, (int)(unsigned)(64 * T * C * 4 > 0xffffffffLL ? 0xffffffffLL : 64 * T * C * 4), 0x00020000);
     for (int tl = k * tpb + sub; tl < t1; tl += S) {
         const int ty = tl / Tw, tx = tl - ty * Tw;
-        const float *m = M + ((long long)n * Timg + tl) * C + cch;
+        const float *m = M + ((long long)n * Timg + tl) * ts + cch;
         if constexpr (VW == 1) {
             V q[6][8];                               // q[p][j] = (A^T r)[p][j]
 #pragma unroll
@@ -1420,7 +1423,7 @@ void wino6_out_kernel(const float *__restrict__ M, const float *__restrict__ bia
                 for (int qI = 0; qI < 6; ++qI) y[pI][qI] = bv;
             // frequency planes through one buffer descriptor: the lane part of the address is ONE VGPR and the plane
             // offset a scalar (with flat pointers the compiler keeps 64 loop-invariant 64-bit addresses in registers)
-            const unsigned vo = (unsigned)(((long long)n * Timg + tl) * C + cch) * 4u;
+            const unsigned vo = (unsigned)(((long long)n * Timg + tl) * ts + cch) * 4u;
             const unsigned zsB = (unsigned)(zs * 4);
             auto ldp = [&](int plane) {
                 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
@@ -1515,7 +1518,7 @@ void wino6_out_kernel(const float *__restrict__ M, const float *__restrict__ bia
 __global__ __launch_bounds__(256, 1)
 void wino6_out_dma_kernel(const float *__restrict__ M, const float *__restrict__ bias, float *__restrict__ out,
                           double *__restrict__ stats, int B, int H, int W, int C, int ldOut, int Th, int Tw, int tpb,
-                          int G, int nchunks, long long units)
+                          int G, int nchunks, long long units, int tileMajor)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char dsmW[];
     typedef __attribute__((address_space(3))) void lds_void;
@@ -1531,15 +1534,16 @@ void wino6_out_dma_kernel(const float *__restrict__ M, const float *__restrict__
     unsigned char *ring = dsmW + wave * 32768;
     const int Timg = Th * Tw;
     const long long T = (long long)B * Timg;
-    const unsigned zsB = (unsigned)(T * C * 4);                          // bytes per frequency plane (host: 64 planes < 4 GiB)
+    const unsigned zsB = (unsigned)((tileMajor ? (long long)C : T * C) * 4);   // bytes between frequency planes (host: M < 2 GiB)
+    const long long tsB = (tileMajor ? 64LL * C : (long long)C) * 4;     // ... between tiles
     const int t0 = k * tpb;
     int t1 = t0 + tpb; if (t1 > Timg) t1 = Timg;
     const int cch = slice * 128 + 2 * lane;                              // first of this lane's two channels
-    const __amdgpu_buffer_rsrc_t srdM = __builtin_amdgcn_make_buffer_rsrc((void *)M, 0, (int)(unsigned)(64ull * zsB), 0x00020000);
+    const __amdgpu_buffer_rsrc_t srdM = __builtin_amdgcn_make_buffer_rsrc((void *)M, 0, (int)(unsigned)(64ull * T * C * 4), 0x00020000);
     // lane part of a DMA address: plane parity (lane >> 5) -> +8 planes... see dma_col: planes 8 (2h + (lane >> 5)) + j
     const unsigned laneOff = (unsigned)(lane >> 5) * 8u * zsB + (unsigned)(lane & 31) * 16u + (unsigned)slice * 512u;
     auto dma_col = [&](int tl, int j) {                                  // column j of tile tl (of this image) -> ring slot j
-        const unsigned vo = tl < t1 ? (unsigned)(((long long)n * Timg + tl) * C * 4) + laneOff : OOB;
+        const unsigned vo = tl < t1 ? (unsigned)(((long long)n * Timg + tl) * tsB) + laneOff : OOB;
 #pragma unroll
         for (int h = 0; h < 4; ++h)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(srdM, (lds_void *)(ring + j * 4096 + h * 1024), 16, (int)vo,
@@ -2339,16 +2343,18 @@ int run_op(const xl_op &op, hipStream_t st)
                     const long long units = (long long)op.B * op.nchunks * (op.Cin / 128);
                     hipLaunchKernelGGL(wino6_out_dma_kernel, dim3((unsigned)((units + 3) / 4)), dim3(256), 131072, st, (const float *)op.in,
                                        (const float *)op.bias, (float *)op.out, (double *)op.stats, op.B, op.Hi, op.Wi, op.Cin,
-                                       op.ld_out, Th6, Tw6, op.reserved_i, op.groups, op.nchunks, units);
+                                       op.ld_out, Th6, Tw6, op.reserved_i, op.groups, op.nchunks, units,
+                                       (op.flags & XL_CONV_M_TILE_MAJOR) ? 1 : 0);
                     return XL_OK;
                 }
                 hipLaunchKernelGGL(two ? wino6_out_kernel<2> : wino6_out_kernel<1>, dim3(op.nchunks, op.B, op.Cin / CB), dim3(256), 0, st, (const float *)op.in,
                                    (const float *)op.bias, (float *)op.out, (double *)op.stats, op.B, op.Hi, op.Wi, op.Cin,
                                    op.ld_out, Th6, Tw6, op.reserved_i, op.groups, op.nchunks,
-                                   (op.flags & XL_CONV_ACCUMULATE) ? 1 : 0);
+                                   (op.flags & XL_CONV_ACCUMULATE) ? 1 : 0, (op.flags & XL_CONV_M_TILE_MAJOR) ? 1 : 0);
                 return XL_OK;
             }
             if (op.ksize == 4) {
+                if (op.flags & XL_CONV_M_TILE_MAJOR) return XL_ERR_UNSUPPORTED;
                 const int Th4 = (op.Hi + 3) / 4, Tw4 = (op.Wi + 3) / 4;
                 const int CB = op.Cin < 512 ? op.Cin : 512;
                 if (op.Cin % 2 != 0 || op.Cin % CB != 0 || 256 % (CB / 2) != 0 || op.ld_out % 2 != 0 || op.reserved_i < 1 ||

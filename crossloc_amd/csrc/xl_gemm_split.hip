@@ -940,6 +940,10 @@ static int xl_run_split_conv1x1(const xl_op &op, hipStream_t st)
     a.stats = (double *)op.stats; a.HW = HW; a.G = op.groups; a.nchunks = op.nchunks; a.B = op.B;
     a.M = (int)M; a.C = op.Cin; a.N = op.Cout; a.ldIn = op.ld_in; a.ldOut = op.ld_out;
     a.Z = Z; a.zIn = M * op.ld_in; a.zOut = M * op.ld_out;
+    if (op.flags & XL_CONV_M_TILE_MAJOR) {            // result [row][Z][Cout]: a row of product z starts Z*Cout floats after the one before
+        if (Z < 2 || op.ld_out != op.Cout || 256LL * Z * op.Cout * 4 >= 0x7fffffffLL) return XL_ERR_ARG;
+        a.zOut = op.Cout; a.ldOut = Z * op.Cout;
+    }
     a.tpi = 0; a.nbm = 0; a.nbn = 0;
     return small ? launch_split_conv1x1<4>(op, a, norm, Z, st) : launch_split_conv1x1<8>(op, a, norm, Z, st);
 }

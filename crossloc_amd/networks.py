@@ -33,6 +33,7 @@ CONV_DGRAD, CONV_ACCUMULATE, CONV_SPLIT_BF16 = 1, 2, 64
 CONV_NORM_IN, CONV_NORM_RELU = 128, 256
 CONV_SPLIT_IL = 512
 CONV_SPLIT_ACT = 1024
+CONV_M_TILE_MAJOR = 2048
 XL_ERR_UNSUPPORTED = -4            # include/crossloc_dsac.h
 
 
@@ -718,8 +719,13 @@ class _Plan:
         op.B, op.Hi, op.Wi, op.Cin, op.Ho, op.Wo, op.Cout = B, Th, Tw, C, Th, Tw, cout
         op.ksize, op.stride, op.ld_in, op.ld_out, op.nchunks2 = 1, 1, C, cout, nf
         op.in_, op.out = V.data_ptr(), Mb.data_ptr()
+        # XL_WINO_M_TILE_MAJOR=1: the product M as [tiles][64][C], so that the block the output transform reads per tile is one
+        # contiguous piece.  Measured at 47 frames: output transforms 3.21 -> 3.05 ms per step, GEMM epilogues +0.17 ms: no net
+        # gain, so [64][tiles][C] (what every other form reads and writes) stays the default
+        m_tile_major = CONV_M_TILE_MAJOR if (split_act and m == 6 and os.environ.get("XL_WINO_M_TILE_MAJOR")) else 0
         if split:
-            op.flags = CONV_SPLIT_BF16 | (CONV_SPLIT_IL if split_il else 0) | (CONV_SPLIT_ACT if split_act else 0)
+            op.flags = (CONV_SPLIT_BF16 | (CONV_SPLIT_IL if split_il else 0) | (CONV_SPLIT_ACT if split_act else 0)
+                        | m_tile_major)
             op.w = self.pack_conv_wino_split(conv, m, split_il).data_ptr()
         else:
             op.w = self.pack_conv_wino(conv, m).data_ptr()
@@ -744,6 +750,7 @@ class _Plan:
         op.ksize = m
         op.B, op.Hi, op.Wi, op.Cin, op.ld_out, op.groups, op.nchunks, op.reserved_i = B, H, W, cout, cout, G, nchunks, tpb
         op.in_, op.out = Mb.data_ptr(), out.data_ptr()
+        op.flags = m_tile_major
         op.bias = self.dev(conv.bias).data_ptr()
         y = (out, H, W, cout, cout, 0)
         if self.train:
@@ -1394,8 +1401,10 @@ class _Plan:
                     gm.B, gm.Hi, gm.Wi, gm.Cin, gm.Ho, gm.Wo, gm.Cout = B, Th, Tw, Cout, Th, Tw, C
                     gm.ksize, gm.stride, gm.ld_in, gm.ld_out, gm.nchunks2 = 1, 1, Cout, C, nf
                     gm.in_, gm.out = Vb.data_ptr(), Mb.data_ptr()
+                    tile_major = 0
                     if self.wino_gemm_form(Cout, C, m, T)[2]:       # on the split pipe, V(dY) split inside the GEMM kernel
-                        gm.flags = CONV_SPLIT_BF16 | CONV_SPLIT_IL | CONV_SPLIT_ACT
+                        tile_major = CONV_M_TILE_MAJOR if (m == 6 and os.environ.get("XL_WINO_M_TILE_MAJOR")) else 0
+                        gm.flags = CONV_SPLIT_BF16 | CONV_SPLIT_IL | CONV_SPLIT_ACT | tile_major
                         gm.w = self.pack_conv_wino_split(conv, m, True, dgrad=True).data_ptr()
                     else:
                         gm.w = self.pack_conv_wino(conv, m, dgrad=True).data_ptr()
@@ -1409,7 +1418,7 @@ class _Plan:
                         tpb //= 2
                     wo.B, wo.Hi, wo.Wi, wo.Cin, wo.ld_out, wo.groups = B, H, W, C, gx[1], 1
                     wo.nchunks, wo.reserved_i = -(-(Th * Tw) // tpb), tpb
-                    wo.flags = op.flags & CONV_ACCUMULATE
+                    wo.flags = (op.flags & CONV_ACCUMULATE) | tile_major
                     wo.in_, wo.out = Mb.data_ptr(), gx[0].data_ptr() + 4 * gx[2]
                     bops.append(wo)
                     self.release_grad(Vb); self.release_grad(Mb)

@@ -85,6 +85,9 @@ enum {
                                   flags) and is split into its three bf16 terms inside the GEMM kernel on its way into LDS, like
                                   the activations of a 1x1 layer: V costs 4 bytes per element in HBM (written once, read
                                   once) instead of 6; only `w` is pre-split ([Z][Cout][Cin/16][3][16] bf16) */
+#define XL_CONV_M_TILE_MAJOR 2048 /* on the batched GEMM op (with XL_CONV_SPLIT_ACT) and on the XL_OP_WINO_OUT (ksize 6) that
+                                  consumes its result: the product M is laid out [tiles][Z][Cout] instead of [Z][tiles][Cout], so
+                                  the Z x Cout block the output transform reads per tile is one contiguous piece */
 /* xl_op.flags for XL_OP_CONV */
 #define XL_CONV_DGRAD 1        /* data gradient: `in` is dY (Hi x Wi x Cin = forward output), result is dX; weights
                                   packed with xl_cnn_pack_conv_weight_dgrad; `stride` is the forward stride */

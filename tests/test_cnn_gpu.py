@@ -941,3 +941,21 @@ def test_small_batch_forward_as_a_hip_graph_and_small_tile_form(monkeypatch):
     net.invalidate()
     with torch.no_grad():
         assert torch.equal(net(xs[1]), y2) and not torch.equal(y2, want[1])
+
+
+def test_tile_major_winograd_product_is_bitwise_the_plane_major_form(monkeypatch):
+    """XL_WINO_M_TILE_MAJOR=1 (XL_CONV_M_TILE_MAJOR on the batched GEMM and on the output transform): M as [tiles][64][C]
+    instead of [64][tiles][C] - a layout choice only."""
+    net = networks.TransPoseNet(MEAN, False, False, 1, 1, 3, 1)
+    net.load_state_dict(seeded_state_dict(net, seed=23))
+    net = net.cuda().eval()
+    x = torch.rand(3, 3, 192, 288, generator=torch.Generator().manual_seed(4)).cuda()
+    with torch.no_grad():
+        y0 = net(x).clone()
+    monkeypatch.setenv("XL_WINO_M_TILE_MAJOR", "1")
+    net.invalidate()
+    with torch.no_grad():
+        y1 = net(x)
+    plan = list(net._plans.values())[0]
+    assert any(op.flags & networks.CONV_M_TILE_MAJOR for op in plan.ops if op.type == networks.XL_OP_WINO_OUT)
+    assert torch.equal(y0, y1)

@@ -25,7 +25,8 @@ def main():
                 continue
             d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
             name = m.group(1).replace(" ", "")
-            if "persist" in name:      # persistent kernels: the grid is the CU count whatever the problem, so the layers
+            if "persist" in name or name.startswith(("split_conv1x1_kernel", "split_conv3x3s2_kernel")):
+                # persistent kernels: the grid is the CU count whatever the problem, so the layers
                 name += "@%dus" % (4 ** round(math.log(max(d, 1.0), 4)))  # are told apart by their duration class (power of 4)
             key = (name, int(r["Grid_Size"]), int(r["VGPR_Count"]) + int(r["Accum_VGPR_Count"]),
                    int(r["LDS_Block_Size"]), r["Counter_Name"])
