@@ -1671,13 +1671,17 @@ void gn_final_kernel(const double *__restrict__ stats, const float *__restrict__
         valid = (int)((((long long)(n + 1) * HW - 1) / statTile) - (((long long)n * HW) / statTile)) + 1;
     else if (statTile < 0)     // ... from a conv whose tiles start at image boundaries (batch-invariant plans)
         valid = (HW - statTile - 1) / -statTile;
-    // 8 threads per group each sum a contiguous slice of the chunks, then the 8 slices are added in order
+    // P = 256 / (G rounded up to a power of two) threads per group (8 for 32 groups, 128 for the 2 groups of conv1) each sum
+    // a contiguous slice of the chunks, then the P slices are added as a fixed binary tree.  P depends on the layer only.
     __shared__ double sP[256 * 2];
+    int gp = 1;
+    while (gp < G) gp <<= 1;
+    const int P = 256 / gp;
     {
-        const int g = tid >> 3, part = tid & 7;
+        const int g = tid / P, part = tid - g * P;
         double a = 0.0, b = 0.0;
         if (g < G) {
-            const int per = (valid + 7) / 8;
+            const int per = (valid + P - 1) / P;
             int k0 = part * per, k1 = k0 + per;
             if (k1 > valid) k1 = valid;
             // four interleaved partial sums (k % 4), added in order: the loads of four entries are in flight together - as
@@ -1698,11 +1702,17 @@ void gn_final_kernel(const double *__restrict__ stats, const float *__restrict__
             b = (pb[0] + pb[1]) + (pb[2] + pb[3]);
         }
         sP[2 * tid] = a; sP[2 * tid + 1] = b;
+        for (int s = P >> 1; s >= 1; s >>= 1) {
+            __syncthreads();
+            if (part < s) {
+                a += sP[2 * (tid + s)]; b += sP[2 * (tid + s) + 1];
+                sP[2 * tid] = a; sP[2 * tid + 1] = b;
+            }
+        }
     }
     __syncthreads();
     for (int g = tid; g < G; g += 256) {
-        double a = 0.0, b = 0.0;
-        for (int part = 0; part < 8; ++part) { a += sP[2 * (g * 8 + part)]; b += sP[2 * (g * 8 + part) + 1]; }
+        const double a = sP[2 * (g * P)], b = sP[2 * (g * P) + 1];
         const double cnt = (double)HW * (double)cpg;
         const double mean = a / cnt;
         double var = b / cnt - mean * mean;

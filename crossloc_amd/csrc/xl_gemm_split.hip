@@ -411,6 +411,200 @@ void split_gemm_persist_kernel(SplitArgs2 a)
 }
 
 
+// ---- the same loop with FOUR waves of 128 x 128 (one per SIMD, 256 accumulator registers each) instead of eight of 128 x 64:
+// 24 fragment reads per 96 MFMAs instead of 18 per 48 - a third fewer LDS reads per MFMA, the "energy per FLOP" lever the
+// round-2 review asked to try (XL_GEMM_PERSIST_WAVES=4 with XL_WINO_V_SPLIT=1; measured A/B in profiles/r3_gemm_ab.*).
+// vmcnt bookkeeping: younger than the operands of step s+1 are the 11 DMAs of step s+2 issued so far and, in the first step
+// of a tile, the 64 stores of the tile before - 75 > the 63 the counter can express: vmcnt(63) then also waits for the
+// oldest 12 of those stores (stricter than needed, correct).
+template <int CT>
+__global__ __launch_bounds__(256)
+void split_gemm_persist4_kernel(SplitArgs2 a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+    typedef __attribute__((address_space(3))) void lds_void;
+    constexpr int kStage = 2 * kIOperand;                             // activations then weights: 48 KB
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;                          // 2 x 2 waves of 128 x 128
+
+    // tiles of this workgroup: XCD x (= block % 8) owns a contiguous run of the (z, m-tile, n-tile) order, its
+    // workgroups take every nloc-th tile of the run, so the workgroups of an XCD work on neighbouring tiles at any time
+    const int total = a.nbm * a.nbn * a.Z;
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3, nloc = gridDim.x >> 3;
+    const int q8 = total >> 3, r8 = total & 7;
+    const int runStart = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+    const int runLen = q8 + (xcd < r8 ? 1 : 0);
+    const int myCount = runLen > local ? (runLen - local + nloc - 1) / nloc : 0;
+    if (myCount == 0) return;
+
+    constexpr unsigned OOB = 0x80000000u;
+    const long long rowB = (long long)a.C * 6;                        // bytes per operand row
+    const int nk = CT ? CT / 16 : a.C / 16;
+
+    // ---- operand stream
+    // every wave issues 6 of the 48 DMA instructions of a step (3 of each operand), one after each term group.  (Letting
+    // waves 0-3 - the older ones on their SIMDs, which win the MFMA arbitration and then sit at the barrier - issue all
+    // of them was measured slower: 1.09 vs 1.05 ms.)
+    __amdgpu_buffer_rsrc_t srdV, srdU;
+    unsigned gA[6], gB[6];
+    int dTile = 0, dK = 0;                                            // position of the stream: tile of my list, K-step
+    auto set_dma_tile = [&](int i) {
+        if (i < myCount) {
+            int t = runStart + local + i * nloc;
+            const int z = t / (a.nbm * a.nbn);
+            t -= z * (a.nbm * a.nbn);
+            const int mt = t / a.nbn, nt = t - mt * a.nbn;
+            const int m0 = mt * 256, n0 = nt * 256;
+            srdV = __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)a.v + (long long)z * a.T * rowB), 0, (int)(a.T * rowB), 0x00020000);
+            srdU = __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)a.u + (long long)z * a.N * rowB), 0, (int)(a.N * rowB), 0x00020000);
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+                const int sl = (wave * 6 + q) * 64 + lane;
+                const int row = sl / 6, phys = sl - row * 6;
+                int logical = phys - ((row >> 3) & 1);
+                if (logical < 0) logical += 6;
+                gA[q] = (m0 + row < a.T) ? (unsigned)((long long)(m0 + row) * rowB + logical * 16) : OOB;
+                gB[q] = (n0 + row < a.N) ? (unsigned)((long long)(n0 + row) * rowB + logical * 16) : OOB;
+            }
+        } else {                                                      // past my last tile: zero-fill, same instruction count
+#pragma unroll
+            for (int q = 0; q < 6; ++q) { gA[q] = OOB; gB[q] = OOB; }
+        }
+    };
+    auto dma_instr = [&](int q, int stage) {                          // instruction q of 12 of the stream's current step
+        unsigned char *base = dsm + stage * kStage + wave * 6 * 1024;
+        const int kb = dK * kIUnit;
+        if (q < 6) __builtin_amdgcn_raw_ptr_buffer_load_lds(srdV, (lds_void *)(base + q * 1024), 16, (int)gA[q], kb, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(srdU, (lds_void *)(base + kIOperand + (q - 6) * 1024), 16, (int)gB[q - 6], kb, 0, 0);
+    };
+    auto advance_dma = [&]() {
+        if (++dK == nk) { dK = 0; ++dTile; set_dma_tile(dTile); }
+    };
+
+    // ---- fragments (as in the kernel above)
+    const int fr = lane & 31, kh = lane >> 5;
+    unsigned slotOff[3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        int ph = 2 * p + kh + ((fr >> 3) & 1);
+        if (ph >= 6) ph -= 6;
+        slotOff[p] = (unsigned)(ph * 16);
+    }
+    const unsigned frA = (unsigned)((wm * 128 + fr) * kIUnit), frB = (unsigned)(kIOperand + (wn * 128 + fr) * kIUnit);
+    bf16x8 fa[3][4], fb[3][4];
+    bf16x8 faN[4], fbN[4];
+    f32x16 acc[4][4];
+    auto ldA = [&](const unsigned char *sb, int p, int i) { return *reinterpret_cast<const bf16x8 *>(sb + frA + i * 32 * kIUnit + slotOff[p]); };
+    auto ldB = [&](const unsigned char *sb, int p, int j) { return *reinterpret_cast<const bf16x8 *>(sb + frB + j * 32 * kIUnit + slotOff[p]); };
+    auto mma_term = [&](int pu, int pv) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[pu][j], fa[pv][i], acc[i][j], 0, 0, 0);
+    };
+
+    // ---- prologue: steps 0 and 1 of the stream
+    set_dma_tile(0);
+#pragma unroll
+    for (int q = 0; q < 12; ++q) dma_instr(q, 0);
+    advance_dma();
+#pragma unroll
+    for (int q = 0; q < 12; ++q) dma_instr(q, 1);
+    advance_dma();
+    __builtin_amdgcn_s_waitcnt(0x0F70 | 12);
+    // (a bare s_barrier: the workgroup fence of __syncthreads() makes the compiler wait for EVERY outstanding LDS-DMA,
+    //  vmcnt(0), which puts the memory latency of the stream back on the critical path; what has to be ordered is
+    //  covered by the counted vmcnt wait above and by program order)
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) fbN[j] = ldB(dsm, 2, j);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) faN[i] = ldA(dsm, 0, i);
+    int sc = 0, sd = 2;                                               // stage being multiplied / being filled
+    const int rhalf = (lane >> 5) * 4;
+    long long cPre = 0, cVm = 0, cBar = 0, cTail = 0, cEpi = 0, cT = 0;
+    if (a.clk) cT = clock64();
+    for (int ti = 0; ti < myCount; ++ti) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int kk = 0; kk < nk; ++kk) {
+            const unsigned char *sb = dsm + sc * kStage;
+            const int next = sc == 2 ? 0 : sc + 1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fb[2][j] = fbN[j];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[0][i] = faN[i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fb[1][j] = ldB(sb, 1, j);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[1][i] = ldA(sb, 1, i);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fb[0][j] = ldB(sb, 0, j);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[2][i] = ldA(sb, 2, i);
+            mma_term(2, 0); dma_instr(0, sd); dma_instr(1, sd);
+            mma_term(1, 1); dma_instr(2, sd); dma_instr(3, sd);
+            mma_term(0, 2); dma_instr(4, sd); dma_instr(5, sd);
+            mma_term(1, 0); dma_instr(6, sd); dma_instr(7, sd);
+            mma_term(0, 1); dma_instr(8, sd); dma_instr(9, sd); dma_instr(10, sd);
+            __builtin_amdgcn_sched_barrier(0);
+            if (a.clk) { const long long t = clock64(); cPre += t - cT; cT = t; }
+            // younger than the operands of step s+1: the 5 DMAs of step s+2 issued so far (and, in the first step of a
+            // tile, the 32 stores of the tile before: vmcnt(37) = 0b100101, high bits in [15:14])
+            if (kk == 0 && ti > 0) __builtin_amdgcn_s_waitcnt(0xCF7F);         // vmcnt(63), see the header
+            else __builtin_amdgcn_s_waitcnt(0x0F70 | 11);
+            if (a.clk) { const long long t = clock64(); cVm += t - cT; cT = t; }
+            __builtin_amdgcn_s_barrier();
+            if (a.clk) { const long long t = clock64(); cBar += t - cT; cT = t; }
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned char *sn = dsm + next * kStage;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fbN[j] = ldB(sn, 2, j);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) faN[i] = ldA(sn, 0, i);
+            mma_term(0, 0); dma_instr(11, sd);
+            advance_dma();
+            sc = next;
+            sd = sd == 2 ? 0 : sd + 1;
+            if (a.clk) { const long long t = clock64(); cTail += t - cT; cT = t; }
+        }
+        // ---- epilogue of tile ti (swapped operands): row = lane & 31, channels (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+        int t = runStart + local + ti * nloc;
+        const int z = t / (a.nbm * a.nbn);
+        t -= z * (a.nbm * a.nbn);
+        const int mt = t / a.nbn, nt = t - mt * a.nbn;
+        const int m0 = mt * 256, n0 = nt * 256;
+        const __amdgpu_buffer_rsrc_t srdO = __builtin_amdgcn_make_buffer_rsrc((void *)(a.out + (long long)z * a.T * a.N), 0, (int)((long long)a.T * a.N * 4), 0x00020000);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            // (exactly 64 stores per wave and tile: rows past T fall outside the descriptor, N is a multiple of 256)
+            const int m = m0 + wm * 128 + i * 32 + (lane & 31);
+            const unsigned rowOff = (unsigned)((long long)m * a.N * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int n = n0 + wn * 128 + j * 32 + rhalf + 8 * q;
+                    const unsigned off = rowOff + (unsigned)n * 4u;
+                    const f32x4 v = f32x4{ acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3] };
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), srdO, (int)off, 0, 0);
+                }
+        }
+    }
+    if (a.clk && lane == 0) {
+        long long *c = a.clk + ((long long)blockIdx.x * 8 + wave) * 8;     // (4 of the 8 slots)
+        c[0] = cPre; c[1] = cVm; c[2] = cBar; c[3] = cTail; c[4] = (long long)myCount * nk;
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);                             // vmcnt(0)
+}
+
+
 // ---------------------------------------------------------------------------------------------- 1x1 convolution on the split pipe
 //
 // out[m][n] = bias[n] + sum_c f(in[m][c]) * W[n][c],   m = pixel (B*H*W of them, NHWC), f = identity or the producer's
@@ -430,11 +624,6 @@ void split_gemm_persist_kernel(SplitArgs2 a)
 // LDS (157 KB): weights 3 x 24 KB | activations 2 x 24 KB | 8 KB | fp64 partials 8 KB | coefficient tables 2 x 8 KB |
 // bias 4 KB.  The statistics epilogue stages its per-lane sums in activation stage 1 + the 8 KB behind it: C / 16 is even,
 // so when a tile ends stage 1 has just been multiplied and stage 0 holds the first step of the next tile.
-constexpr int split_conv_lds(int NW)                  // bytes of LDS of split_conv1x1_kernel<., ., NW>
-{
-    return 3 * (NW == 8 ? 256 : 128) * kIUnit + 2 * (32 * NW) * kIUnit + 2 * 16 * (64 * NW) + 16384 + 4096;
-}
-
 struct SplitConvArgs {
     const float *in; const uint16_t *u; const float *bias; float *out;
     const float *coef; float normLo;                 // NORM: [B][C][2] {scale, shift}; lower clamp (0 = ReLU, -inf = none)
@@ -443,7 +632,9 @@ struct SplitConvArgs {
     int tpi;                                         // > 0: tiles start at image boundaries, tpi = ceil(HW / 256) per image (the
                                                      // grouping of the statistics is then independent of the batch); 0: dense
     int Z; long long zIn, zOut;                      // Z > 1: Z independent products in one launch (the frequencies of a Winograd
-};                                                   // layer: in / out advance by zIn / zOut floats, the weights by N rows; no bias)
+                                                     // layer: in / out advance by zIn / zOut floats, the weights by N rows; no bias)
+    int tile0, ntiles;                               // the launch's range of the (z, m-tile, n-tile) order
+};
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -467,15 +658,19 @@ __device__ __forceinline__ void split_pair(float x, float y, unsigned &w1, unsig
 // Every output element accumulates its K-steps and term pairs in the same order in both forms: bitwise the same result.
 // ZB = 1: the instantiation of the batched launches (Z > 1, the GEMMs of a Winograd layer): the same code under a name of its
 // own, so that a profiler's dispatch table tells the dominant kernel of the forward pass from the 1x1 layers.
-template <bool NORM, bool ACC = false, int NW = 8, int ZB = 0>  // ACC: out += result (a data gradient with a second producer)
+// BN = tile columns: 256 x 256 (NW 8, BN 256), 256 x 128 (NW 8, BN 128: 4 x 2 waves of 64 x 64 - launches that would run a
+// last round of 256 x 256 tiles mostly empty) or 128 x 128 (NW 4, BN 128).
+template <bool NORM, bool ACC = false, int NW = 8, int ZB = 0, int BN = (NW == 8 ? 256 : 128)>  // ACC: out += result
 __global__ __launch_bounds__(64 * NW)
 void split_conv1x1_kernel(SplitConvArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
     typedef __attribute__((address_space(3))) void lds_void;
-    constexpr int NTH = 64 * NW, BM = NTH / 2, BN = NW == 8 ? 256 : 128;      // threads; tile rows (a thread = 8 channels of a row); columns
+    constexpr int NTH = 64 * NW, BM = NTH / 2;                                // threads; tile rows (a thread = 8 channels of a row)
     constexpr int WN = BN / 64, WM = NW / WN, RI = BM / WM / 32;              // waves across columns / rows; 32-row blocks per wave
-    static_assert(WM == 2 && RI * WM * 32 == BM, "tile shape");
+    static_assert(RI >= 1 && RI * WM * 32 == BM && WN * WM == NW, "tile shape");
+    constexpr int NDMA = BN * kIUnit / 1024;                                  // DMA instructions per weight stage: waves 0 .. NDMA/3 - 1
+    constexpr int PARTS = NTH * 8 / BN;                                       // statistics: threads per (group, slot) = 8 lane blocks x WM
     constexpr int kW = BN * kIUnit, kAS = BM * kIUnit;                         // one weight stage / one activation stage
     constexpr int kCvA = 3 * kW, kCvStage1 = kCvA + kAS;                       // activation stages; statistics staging: 64 NTH bytes
     constexpr int kCvPart = kCvA + 2 * kAS + 16 * NTH;                         // fp64 partials [NTH / 16][16][2]
@@ -485,11 +680,19 @@ void split_conv1x1_kernel(SplitConvArgs a)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
+    // every wave issues three DMA instructions per K-step: the K-step is straight-line code for the scheduler and the counted
+    // vmcnt waits are the same in all waves.  With 8 waves on 128 columns (12 instructions per stage) those of waves 4 .. 7 read
+    // out of range and write their zeros into a scratch KB of LDS.
+    constexpr bool ALLDMA = NDMA >= 3 * NW;
+    constexpr int kCvScratch = kCvBias + 4096;
+    const bool dmaWave = ALLDMA || wave * 3 < NDMA;
+    const int dmaBase = __builtin_amdgcn_readfirstlane(dmaWave ? wave * 3 * 1024 : kCvScratch);
+    const int dmaStage = __builtin_amdgcn_readfirstlane(dmaWave ? kW : 0), dmaQ = __builtin_amdgcn_readfirstlane(dmaWave ? 1024 : 0);
 
-    const int total = a.nbm * a.nbn * a.Z;
+    const int total = a.ntiles;                                               // tiles tile0 .. tile0 + ntiles - 1 of the (z, m, n) order
     const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3, nloc = gridDim.x >> 3;
     const int q8 = total >> 3, r8 = total & 7;
-    const int runStart = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+    const int runStart = a.tile0 + (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8);
     const int runLen = q8 + (xcd < r8 ? 1 : 0);
     const int myCount = runLen > local ? (runLen - local + nloc - 1) / nloc : 0;
     if (myCount == 0) return;
@@ -538,7 +741,7 @@ void split_conv1x1_kernel(SplitConvArgs a)
                 const int row = sl / 6, phys = sl - row * 6;
                 int logical = phys - ((row >> 3) & 1);
                 if (logical < 0) logical += 6;
-                gB[q] = (unsigned)((long long)(n0 + row) * rowU + logical * 16);
+                gB[q] = dmaWave ? (unsigned)((long long)(n0 + row) * rowU + logical * 16) : OOB;
             }
         } else {
             gA = OOB;
@@ -547,8 +750,8 @@ void split_conv1x1_kernel(SplitConvArgs a)
         }
     };
     auto dma_instr = [&](int q, int stage) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(srdU, (lds_void *)(dsm + stage * kW + (wave * 3 + q) * 1024), 16,
-                                                 (int)gB[q], dK * kIUnit, 0, 0);
+        const int dst = ALLDMA ? stage * kW + (wave * 3 + q) * 1024 : dmaBase + stage * dmaStage + q * dmaQ;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(srdU, (lds_void *)(dsm + dst), 16, (int)gB[q], dK * kIUnit, 0, 0);
     };
     u32x4 rA[2][2];                                                    // [K-step parity][half of my 8 channels]
     auto load_a = [&](auto parTag) {
@@ -677,13 +880,15 @@ void split_conv1x1_kernel(SplitConvArgs a)
     set_conv_tile(0);
     using P0 = std::integral_constant<int, 0>;
     using P1 = std::integral_constant<int, 1>;
-    load_a(P0{}); dma_instr(0, 0); dma_instr(1, 0); dma_instr(2, 0);
+    load_a(P0{});
+    dma_instr(0, 0); dma_instr(1, 0); dma_instr(2, 0);
     advance_dma();
     __builtin_amdgcn_s_waitcnt(0x0070);                               // everything landed
     __syncthreads();                                                  // tables and bias visible
     convert(P0{});
     advance_conv();
-    load_a(P1{}); dma_instr(0, 1); dma_instr(1, 1); dma_instr(2, 1);  // (the order of a steady-state step)
+    load_a(P1{});                                                     // (the order of a steady-state step)
+    dma_instr(0, 1); dma_instr(1, 1); dma_instr(2, 1);
     advance_dma();
     __builtin_amdgcn_s_waitcnt(0x0070 | 5);                           // my writes of step 0; stage 0 of the ring landed before
     __builtin_amdgcn_s_barrier();
@@ -790,7 +995,7 @@ void split_conv1x1_kernel(SplitConvArgs a)
             __builtin_amdgcn_s_waitcnt(0x0070 | 0xC00F);               // lgkmcnt(0)
             __builtin_amdgcn_s_barrier();
             {
-                const int gs = tid >> 4, part = tid & 15;              // (group of the tile, slot) x 16 parts
+                const int gs = tid / PARTS, part = tid % PARTS;        // (group of the tile, slot) x PARTS parts (8 lane blocks x WM)
                 const int gt = gs >> 1, sl = gs & 1;
                 const int src = ((part >> 3) * WN + (gt >> 2)) * 64 + (part & 7) * 8;
                 const f32x2 *o = sS + ((gt & 3) * 2 + sl) * NTH + src;
@@ -802,15 +1007,15 @@ void split_conv1x1_kernel(SplitConvArgs a)
             }
             __builtin_amdgcn_s_waitcnt(0x0070 | 0xC00F);
             __builtin_amdgcn_s_barrier();
-            if (tid < NTH / 16) {
+            if (tid < 2 * (BN / 16)) {
                 const int gt = tid >> 1, sl = tid & 1;
                 const int n = nLo + sl;
                 const int firstRow = sl ? split : 0;
                 const int g = (n0 >> 4) + gt;
                 if (n < a.B && m0 + firstRow < a.M && (sl == 0 || (split < BM && !a.tpi)) && g < a.G) {
-                    const double *sC = reinterpret_cast<const double *>(dsm + kCvPart) + tid * 32;
+                    const double *sC = reinterpret_cast<const double *>(dsm + kCvPart) + tid * (2 * PARTS);
                     double s1 = 0.0, s2 = 0.0;
-                    for (int e = 0; e < 16; ++e) { s1 += sC[2 * e]; s2 += sC[2 * e + 1]; }
+                    for (int e = 0; e < PARTS; ++e) { s1 += sC[2 * e]; s2 += sC[2 * e + 1]; }
                     const int k = a.tpi ? (m0 - n * a.HW) / BM                            // tile index within the image
                                         : m0 / BM - (int)(((long long)n * a.HW) / BM);
                     double *o = a.stats + (((long long)n * a.nchunks + k) * a.G + g) * 2;
@@ -881,21 +1086,23 @@ void split_conv1x1_kernel(SplitConvArgs a)
 // XL_OP_CONV with XL_CONV_SPLIT_BF16 | XL_CONV_SPLIT_IL and nchunks2 <= 1: a 1x1 stride-1 convolution, fp32 NHWC in / out
 // (ld_in / ld_out), w = [Cout][Cin/16][3][16] bf16, bias, optionally XL_CONV_NORM_IN (aux2 = [B][Cin][2] coefficients) and the
 // statistics epilogue (stats / groups / nchunks with 256-row tiles: nchunks >= ceil(HW / 256) + 1, 16 channels per group).
-template <int NW>
-static int launch_split_conv1x1(const xl_op &op, SplitConvArgs a, bool norm, int Z, hipStream_t st)
+// tileFrom / tileCount: this launch covers the tiles [tileFrom, tileFrom + tileCount) of the form's own (z, m-tile, n-tile)
+// numbering (tileCount < 0: all of them).  A 256 x 256 tile t is the 256 x 128 tiles 2t and 2t + 1.
+template <int NW, int BN>
+static int launch_split_conv1x1(const xl_op &op, SplitConvArgs a, bool norm, int Z, hipStream_t st, int tileFrom = 0, int tileCount = -1)
 {
-    constexpr int BM = 32 * NW, BN = NW == 8 ? 256 : 128;
+    constexpr int BM = 32 * NW;
     const long long M = a.M;
     const bool perImage = op.reserved_i < 0;         // tiles start at image boundaries (reserved_i = -256 / -128)
     a.tpi = perImage ? (a.HW + BM - 1) / BM : 0;
     a.nbm = perImage ? op.B * a.tpi : (int)((M + BM - 1) / BM);
     a.nbn = (op.Cout + BN - 1) / BN;
-    const size_t lds = split_conv_lds(NW);
+    const size_t lds = 3 * BN * kIUnit + 2 * BM * kIUnit + 2 * 16 * (64 * NW) + 16384 + 4096 + 1024;
     const bool accumulate = (op.flags & XL_CONV_ACCUMULATE) != 0;
-    const void *fn = accumulate ? reinterpret_cast<const void *>(split_conv1x1_kernel<false, true, NW>)
-                   : norm ? reinterpret_cast<const void *>(split_conv1x1_kernel<true, false, NW>)
-                   : Z > 1 ? reinterpret_cast<const void *>(split_conv1x1_kernel<false, false, NW, 1>)
-                           : reinterpret_cast<const void *>(split_conv1x1_kernel<false, false, NW>);
+    const void *fn = accumulate ? reinterpret_cast<const void *>(split_conv1x1_kernel<false, true, NW, 0, BN>)
+                   : norm ? reinterpret_cast<const void *>(split_conv1x1_kernel<true, false, NW, 0, BN>)
+                   : Z > 1 ? reinterpret_cast<const void *>(split_conv1x1_kernel<false, false, NW, 1, BN>)
+                           : reinterpret_cast<const void *>(split_conv1x1_kernel<false, false, NW, 0, BN>);
     static XlLdsLimit configured[4];
     int cfgDev;
     const int slot = accumulate ? 2 : (norm ? 1 : (Z > 1 ? 3 : 0));
@@ -903,19 +1110,21 @@ static int launch_split_conv1x1(const xl_op &op, SplitConvArgs a, bool norm, int
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return XL_ERR_HIP;
         configured[slot].done(lds, cfgDev);
     }
-    const int nwg = a.nbm * a.nbn * Z;
+    const int nwg = tileCount < 0 ? a.nbm * a.nbn * Z : tileCount;
+    a.tile0 = tileFrom; a.ntiles = nwg;
     int grid = 256;                                   // persistent: one workgroup per CU
     if (grid > ((nwg + 7) & ~7)) grid = (nwg + 7) & ~7;
-    if (accumulate) hipLaunchKernelGGL((split_conv1x1_kernel<false, true, NW>), dim3(grid), dim3(64 * NW), lds, st, a);
-    else if (norm) hipLaunchKernelGGL((split_conv1x1_kernel<true, false, NW>), dim3(grid), dim3(64 * NW), lds, st, a);
-    else if (Z > 1) hipLaunchKernelGGL((split_conv1x1_kernel<false, false, NW, 1>), dim3(grid), dim3(64 * NW), lds, st, a);
-    else hipLaunchKernelGGL((split_conv1x1_kernel<false, false, NW>), dim3(grid), dim3(64 * NW), lds, st, a);
+    if (accumulate) hipLaunchKernelGGL((split_conv1x1_kernel<false, true, NW, 0, BN>), dim3(grid), dim3(64 * NW), lds, st, a);
+    else if (norm) hipLaunchKernelGGL((split_conv1x1_kernel<true, false, NW, 0, BN>), dim3(grid), dim3(64 * NW), lds, st, a);
+    else if (Z > 1) hipLaunchKernelGGL((split_conv1x1_kernel<false, false, NW, 1, BN>), dim3(grid), dim3(64 * NW), lds, st, a);
+    else hipLaunchKernelGGL((split_conv1x1_kernel<false, false, NW, 0, BN>), dim3(grid), dim3(64 * NW), lds, st, a);
     return XL_OK;
 }
 
-// reserved_i selects the tile form: +-256 (or 0 / 64, what the fp32 path passes): 256 x 256 tiles; +-128: 128 x 128 tiles (the
-// statistics epilogue then writes one entry per 128-row tile: nchunks >= ceil(HW / 128) + 1, GN_FINAL / GN_APPLY take 128);
-// negative: tiles start at image boundaries.
+// reserved_i selects the tile form: +-256 (or 0 / 64, what the fp32 path passes): 256 x 256 tiles; 192: 256 rows x 128 columns;
+// 384: 256 x 256 tiles for the full rounds of the 256 CUs and 256 x 128 tiles for a last partial round (same statistics rows);
+// +-128: 128 x 128 tiles (the statistics epilogue then writes one entry per 128-row tile: nchunks >= ceil(HW / 128) + 1,
+// GN_FINAL / GN_APPLY take 128); negative: tiles start at image boundaries.
 static int xl_run_split_conv1x1(const xl_op &op, hipStream_t st)
 {
     const long long M = (long long)op.B * op.Ho * op.Wo;
@@ -945,7 +1154,19 @@ static int xl_run_split_conv1x1(const xl_op &op, hipStream_t st)
         a.zOut = op.Cout; a.ldOut = Z * op.Cout;
     }
     a.tpi = 0; a.nbm = 0; a.nbn = 0;
-    return small ? launch_split_conv1x1<4>(op, a, norm, Z, st) : launch_split_conv1x1<8>(op, a, norm, Z, st);
+    if (small) return launch_split_conv1x1<4, 128>(op, a, norm, Z, st);
+    if (op.reserved_i == 192) return launch_split_conv1x1<8, 128>(op, a, norm, Z, st);
+    if (op.reserved_i == 384) {
+        // full rounds of 256 x 256 tiles on the 256 CUs, then the rest as 256 x 128 tiles when those fit in ONE round (0.65 of
+        // the time of a round of large tiles): two launches over disjoint tile ranges of the same output
+        const int nbig = (int)((M + 255) / 256) * (op.Cout / 256) * Z, full = nbig / 256 * 256, rem = nbig - full;
+        if (full > 0 && rem > 0 && 2 * rem <= 256) {
+            const int rc = launch_split_conv1x1<8, 256>(op, a, norm, Z, st, 0, full);
+            return rc != XL_OK ? rc : launch_split_conv1x1<8, 128>(op, a, norm, Z, st, 2 * full, 2 * rem);
+        }
+        if (full == 0 && 2 * rem <= 256) return launch_split_conv1x1<8, 128>(op, a, norm, Z, st);
+    }
+    return launch_split_conv1x1<8, 256>(op, a, norm, Z, st);
 }
 
 int xl_run_split_gemm(const xl_op &op, hipStream_t st)
@@ -967,20 +1188,23 @@ int xl_run_split_gemm(const xl_op &op, hipStream_t st)
         const size_t lds = 3 * 2 * (size_t)kIOperand;                 // 144 KB: one workgroup per CU
         // (the 512-channel layers have an instantiation of their own: a compile-time K-step count, and a kernel name that
         //  tells them apart in a profiler's dispatch table - the grid of a persistent kernel is the CU count for any problem)
-        auto kernel = op.Cin == 512 ? split_gemm_persist_kernel<512> : split_gemm_persist_kernel<0>;
-        static XlLdsLimit configured[2];
+        static const bool fourWaves = getenv("XL_GEMM_PERSIST_WAVES") && atoi(getenv("XL_GEMM_PERSIST_WAVES")) == 4;
+        auto kernel = fourWaves ? (op.Cin == 512 ? split_gemm_persist4_kernel<512> : split_gemm_persist4_kernel<0>)
+                                : (op.Cin == 512 ? split_gemm_persist_kernel<512> : split_gemm_persist_kernel<0>);
+        static XlLdsLimit configured[4];
         int cfgDev;
-        if (configured[op.Cin == 512].needs(lds, &cfgDev)) {
+        const int slot = (op.Cin == 512 ? 1 : 0) + (fourWaves ? 2 : 0);
+        if (configured[slot].needs(lds, &cfgDev)) {
             if (hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)lds) != hipSuccess) return XL_ERR_HIP;
-            configured[op.Cin == 512].done(lds, cfgDev);
+            configured[slot].done(lds, cfgDev);
         }
         static const bool clkDbg = getenv("XL_SPLIT_CLK") != nullptr;
         const int nwg = a.nbm * a.nbn * Z;
         int grid = 256;
         if (grid > ((nwg + 7) & ~7)) grid = (nwg + 7) & ~7;
         if (clkDbg && hipMalloc(&a.clk, sizeof(long long) * 64 * grid) != hipSuccess) return XL_ERR_HIP;
-        hipLaunchKernelGGL(kernel, dim3(grid), dim3(512), lds, st, a);
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(fourWaves ? 256 : 512), lds, st, a);
         if (clkDbg) {
             std::vector<long long> h((size_t)64 * grid);
             if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(h.data(), a.clk, sizeof(long long) * 64 * grid, hipMemcpyDeviceToHost) == hipSuccess) {

@@ -16,11 +16,16 @@
 // Cout 128: 4 waves (2 x 2 of 64 x 64) on tiles of 128 pixels, two per CU; Cout 64: 4 waves (4 x 1 of 32 x 64) on tiles of 128
 // pixels, three per CU - a K-step of the narrow layers has few MFMAs per wave (24 / 12) under the same fixed costs
 // (conversion, LDS traffic, the barrier), so several independent workgroups per CU fill each other's gaps.
-// The weight stage of a K-step is Cout x 96 bytes = 24 / 12 / 6 DMA instructions: waves 0 .. Cout/32 - 1 issue three each,
-// and the counted vmcnt waits differ between the waves that stream weights and those that do not (a wave-uniform branch).
+// The weight stage of a K-step is Cout x 96 bytes = 24 / 12 / 6 DMA instructions: every wave issues three per K-step (so that
+// the K-step is straight-line code and the counted vmcnt waits are the same in all waves); with Cout 64 the instructions of
+// waves 2 and 3 read out of range and write their zeros into a scratch KB of LDS.  Everything the buffer instructions take as
+// scalars (descriptor, scalar offsets, the LDS base in M0) is passed through readfirstlane where the compiler would otherwise
+// carry it in vector registers across the loop and wrap each load in a readfirstlane loop.
 // The GroupNorm statistics of the output are NOT produced here (XL_OP_GN_STATS follows: one read of the output tensor).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
 #include <type_traits>
 
 #include "../../include/crossloc_cnn.h"
@@ -59,13 +64,16 @@ struct StemArgs {
     int nbn;                                         // column tiles of NT channels (1, or 2 when Cout = 256 runs on 128-wide tiles)
 };
 
-template <int NT, bool NORM, int NW>                                  // Cout; normalise on load; waves per workgroup
-__global__ __launch_bounds__(64 * NW, (NT == 64 ? 3 : 2))           // waves per SIMD: 3 workgroups of 4 waves per CU / 2 of 4 / 1 of 8
+// CPT = channels of a K-step a thread converts: 8 (two threads per row, tiles of 32 NW rows) or 16 (one thread per row, tiles of
+// 64 NW rows: a wave then owns 64 rows - twice the MFMAs per byte of LDS traffic, what the 64-column layer is bound by)
+template <int NT, bool NORM, int NW, int WPS = (NT == 64 ? 3 : 2), int CPT = 8>    // Cout; normalise on load; waves per workgroup; per SIMD
+__global__ __launch_bounds__(64 * NW, WPS)                          // waves per SIMD: 3 workgroups of 4 waves per CU / 2 of 4 / 1 of 8
 void split_conv3x3s2_kernel(StemArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
     typedef __attribute__((address_space(3))) void lds_void;
-    constexpr int NTH = 64 * NW, BM = NTH / 2;                        // threads; rows per tile (a thread = 8 channels of one row)
+    constexpr int NTH = 64 * NW, BM = NTH * CPT / 16;                 // threads; rows per tile (a thread = CPT channels of one row)
+    constexpr int NH = CPT / 8, NL = CPT / 4;                         // 8-channel halves / 16-byte loads per thread and K-step
     constexpr int kAStage = BM * kUnit;                               // one activation stage
     constexpr int WN = NT / 64, WM = NW / WN, RI = BM / WM / 32;      // waves across columns / rows; 32-row blocks per wave
     static_assert(WN * WM == NW && RI >= 1 && RI * WM * 32 == BM, "tile shape");
@@ -73,12 +81,17 @@ void split_conv3x3s2_kernel(StemArgs a)
     constexpr int kA = 3 * kW;                                        // activation stages
     constexpr int kCoef = kA + 2 * kAStage;                           // coefficient tables of two tiles, 2 KB each (Cin <= 128)
     constexpr int kBias = kCoef + 4096;                               // bias[Cout <= 256]
+    constexpr int kScratch = kBias + 1024;                            // 1 KB the DMA instructions of idle waves write zeros into
     constexpr int NDMA = NT * kUnit / 1024;                           // DMA instructions per weight stage
     constexpr int NS = 8 * RI;                                        // stores per wave and tile
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
-    const bool dmaWave = wave * 3 < NDMA;
+    // every wave issues three DMA instructions per K-step - the K-step is straight-line code with the same vmcnt arithmetic
+    // in all waves; those of the waves beyond the stage (Cout 64: waves 2, 3) read out of range and land in a scratch KB
+    const bool dmaWave = NDMA >= 3 * NW || wave * 3 < NDMA;
+    const int dmaBase = __builtin_amdgcn_readfirstlane(dmaWave ? wave * 3 * 1024 : kScratch);
+    const int dmaStage = __builtin_amdgcn_readfirstlane(dmaWave ? kW : 0), dmaQ = __builtin_amdgcn_readfirstlane(dmaWave ? 1024 : 0);
 
     const int total = a.nbm * a.nbn;
     const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3, nloc = gridDim.x >> 3;
@@ -100,8 +113,15 @@ void split_conv3x3s2_kernel(StemArgs a)
 
     // ---- stream two K-steps ahead of the multiplies
     const __amdgpu_buffer_rsrc_t srdU = __builtin_amdgcn_make_buffer_rsrc((void *)a.u, 0, (int)(a.nbn * NT * rowU), 0x00020000);
-    __amdgpu_buffer_rsrc_t srdIn = __builtin_amdgcn_make_buffer_rsrc((void *)a.in, 0, 0, 0x00020000);
-    const int arow = tid >> 1, ahalf = tid & 1;
+    // the descriptor of the stream's input window, as scalars (the descriptor is rebuilt from them at each load: values that
+    // live in SGPRs - a descriptor carried across the loop in vector registers costs a readfirstlane loop per load)
+    int inLo = 0, inHi = 0, inBytes = 0;
+    auto srd_in = [&]() {
+        const unsigned long long p = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(inHi) << 32) |
+                                     (unsigned)__builtin_amdgcn_readfirstlane(inLo);
+        return __builtin_amdgcn_make_buffer_rsrc((void *)p, 0, __builtin_amdgcn_readfirstlane(inBytes), 0x00020000);
+    };
+    const int arow = CPT == 8 ? tid >> 1 : tid, ahalf = CPT == 8 ? tid & 1 : 0;
     unsigned gB[3];
     int dTile = 0, dK = 0, dChunk = 0, dDy = 0, dDx = 0;
     int pY = 0, pX = 0;                                               // 2 oy - 1, 2 ox - 1 of my row in the stream's tile
@@ -115,10 +135,13 @@ void split_conv3x3s2_kernel(StemArgs a)
     auto set_dma_tile = [&](int i) {
         pBase = OOB;
         if (i < myCount) {
-            const int m0 = tile_m0(i);
-            const int nLo = m0 / HWo;
+            const int m0 = __builtin_amdgcn_readfirstlane(tile_m0(i));
+            const int nLo = __builtin_amdgcn_readfirstlane(m0 / HWo);
             const int left = a.B - nLo < 2 ? a.B - nLo : 2;           // a tile touches at most two images (Ho*Wo >= 256)
-            srdIn = __builtin_amdgcn_make_buffer_rsrc((void *)(a.in + nLo * imgIn), 0, (int)(left * imgIn * 4), 0x00020000);
+            const unsigned long long p = (unsigned long long)(a.in + nLo * imgIn);
+            inLo = __builtin_amdgcn_readfirstlane((int)(unsigned)p);
+            inHi = __builtin_amdgcn_readfirstlane((int)(unsigned)(p >> 32));
+            inBytes = __builtin_amdgcn_readfirstlane((int)(left * imgIn * 4));
             const int m = m0 + arow;
             if (m < a.M) {
                 const int n = m / HWo, p = m - n * HWo;
@@ -127,48 +150,54 @@ void split_conv3x3s2_kernel(StemArgs a)
                 pBase = (unsigned)((n - nLo) * imgIn * 4);
             }
         }
-        if (dmaWave) {
 #pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                const int sl = (wave * 3 + q) * 64 + lane;
-                const int row = sl / 6, phys = sl - row * 6;
-                int logical = phys - ((row >> 3) & 1);
-                if (logical < 0) logical += 6;
-                gB[q] = i < myCount ? (unsigned)((long long)(tile_n0(i) + row) * rowU + logical * 16) : OOB;
-            }
+        for (int q = 0; q < 3; ++q) {
+            const int sl = (wave * 3 + q) * 64 + lane;
+            const int row = sl / 6, phys = sl - row * 6;
+            int logical = phys - ((row >> 3) & 1);
+            if (logical < 0) logical += 6;
+            gB[q] = (i < myCount && dmaWave) ? (unsigned)((long long)(tile_n0(i) + row) * rowU + logical * 16) : OOB;
         }
         dDy = 0; dDx = 0; dChunk = 0;
         set_tap();
     };
     auto dma_instr = [&](int q, int stage) {                           // (waves that stream weights only)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(srdU, (lds_void *)(dsm + stage * kW + (wave * 3 + q) * 1024), 16,
-                                                 (int)gB[q], dK * kUnit, 0, 0);
+        const int dst = dmaBase + __builtin_amdgcn_readfirstlane(stage) * dmaStage + q * dmaQ;     // (scalar arithmetic, no branch)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(srdU, (lds_void *)(dsm + dst), 16,
+                                                 (int)gB[q], __builtin_amdgcn_readfirstlane(dK) * kUnit, 0, 0);
     };
-    u32x4 rA[2][2];                                                    // [K-step parity][half of my 8 channels]
+    u32x4 rA[2][NL];                                                   // [K-step parity][four channels of mine]
     unsigned mOK[2] = { 0u, 0u };                                      // [K-step parity] my source pixel is inside the image
     auto load_a = [&](auto parTag) {
         constexpr int P = decltype(parTag)::value;
-        rA[P][0] = __builtin_amdgcn_raw_buffer_load_b128(srdIn, (int)gTap, dChunk * 64, 0);
-        rA[P][1] = __builtin_amdgcn_raw_buffer_load_b128(srdIn, (int)(gTap + 16u), dChunk * 64, 0);
+        const __amdgpu_buffer_rsrc_t srdIn = srd_in();
+#pragma unroll
+        for (int l = 0; l < NL; ++l)
+            rA[P][l] = __builtin_amdgcn_raw_buffer_load_b128(srdIn, (int)(gTap + 16u * l), __builtin_amdgcn_readfirstlane(dChunk) * 64, 0);
         mOK[P] = gTap != OOB ? 0xffffffffu : 0u;
     };
     auto advance_dma = [&]() {
-        if (++dK == nk) { dK = 0; ++dTile; set_dma_tile(dTile); return; }
-        if (++dChunk == nch) {
+        dK = __builtin_amdgcn_readfirstlane(dK + 1);
+        if (dK == nk) { dK = 0; dTile = __builtin_amdgcn_readfirstlane(dTile + 1); set_dma_tile(dTile); return; }
+        dChunk = __builtin_amdgcn_readfirstlane(dChunk + 1);
+        if (dChunk == nch) {
             dChunk = 0;
-            if (++dDx == 3) { dDx = 0; ++dDy; }
+            dDx = __builtin_amdgcn_readfirstlane(dDx + 1);
+            if (dDx == 3) { dDx = 0; dDy = __builtin_amdgcn_readfirstlane(dDy + 1); }
             set_tap();
         }
     };
 
     // ---- conversion, one K-step ahead of the multiplies
-    unsigned wOff[3];
+    unsigned wOff[NH][3];
 #pragma unroll
-    for (int p = 0; p < 3; ++p) {
-        int ph = 2 * p + ahalf + ((arow >> 3) & 1);
-        if (ph >= 6) ph -= 6;
-        wOff[p] = (unsigned)(kA + arow * kUnit + ph * 16);
-    }
+    for (int hh = 0; hh < NH; ++hh)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            int ph = 2 * p + ahalf + hh + ((arow >> 3) & 1);
+            if (ph >= 6) ph -= 6;
+            wOff[hh][p] = (unsigned)(kA + arow * kUnit + ph * 16);
+        }
     int cTile = 0, cK = 0, cChunk = 0;
     unsigned cCoef = 0;                                              // LDS offset of my row's {scale, shift} run
     auto set_conv_tile = [&](int i) {
@@ -181,13 +210,15 @@ void split_conv3x3s2_kernel(StemArgs a)
     };
     auto convert = [&](auto parTag) {                                  // registers of parity P -> activation stage P
         constexpr int P = decltype(parTag)::value;
+#pragma unroll
+        for (int hh = 0; hh < NH; ++hh) {
         unsigned w[3][4];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            f32x4 x = __builtin_bit_cast(f32x4, rA[P][h]);
+            f32x4 x = __builtin_bit_cast(f32x4, rA[P][2 * hh + h]);
             if constexpr (NORM) {
-                const f32x4 c0 = *reinterpret_cast<const f32x4 *>(dsm + cCoef + cChunk * 128 + h * 32);
-                const f32x4 c1 = *reinterpret_cast<const f32x4 *>(dsm + cCoef + cChunk * 128 + h * 32 + 16);
+                const f32x4 c0 = *reinterpret_cast<const f32x4 *>(dsm + cCoef + cChunk * 128 + hh * 64 + h * 32);
+                const f32x4 c1 = *reinterpret_cast<const f32x4 *>(dsm + cCoef + cChunk * 128 + hh * 64 + h * 32 + 16);
                 const bool ok = mOK[P] != 0u;                        // the zero padding stays zero
                 x[0] = ok ? fmaxf(fmaf(x[0], c0[0], c0[1]), a.normLo) : 0.f;
                 x[1] = ok ? fmaxf(fmaf(x[1], c0[2], c0[3]), a.normLo) : 0.f;
@@ -199,7 +230,8 @@ void split_conv3x3s2_kernel(StemArgs a)
         }
 #pragma unroll
         for (int p = 0; p < 3; ++p)
-            *reinterpret_cast<u32x4 *>(dsm + P * kAStage + wOff[p]) = u32x4{ w[p][0], w[p][1], w[p][2], w[p][3] };
+            *reinterpret_cast<u32x4 *>(dsm + P * kAStage + wOff[hh][p]) = u32x4{ w[p][0], w[p][1], w[p][2], w[p][3] };
+        }
     };
     auto advance_conv = [&]() {
         if (++cK == nk) { cK = 0; cChunk = 0; ++cTile; set_conv_tile(cTile); return; }
@@ -263,16 +295,16 @@ void split_conv3x3s2_kernel(StemArgs a)
     using P0 = std::integral_constant<int, 0>;
     using P1 = std::integral_constant<int, 1>;
     load_a(P0{});
-    if (dmaWave) { dma_instr(0, 0); dma_instr(1, 0); dma_instr(2, 0); }
+    dma_instr(0, 0); dma_instr(1, 0); dma_instr(2, 0);
     advance_dma();
     __builtin_amdgcn_s_waitcnt(0x0070);                               // everything landed
     __syncthreads();                                                  // tables and bias visible
     convert(P0{});
     advance_conv();
     load_a(P1{});
-    if (dmaWave) { dma_instr(0, 1); dma_instr(1, 1); dma_instr(2, 1); }
+    dma_instr(0, 1); dma_instr(1, 1); dma_instr(2, 1);
     advance_dma();
-    __builtin_amdgcn_s_waitcnt(0x0070 | 5);                           // my writes of step 0; stage 0 of the ring landed before
+    __builtin_amdgcn_s_waitcnt(0x0070 | (3 + NL));                    // my writes of step 0; stage 0 of the ring landed before
     __builtin_amdgcn_s_barrier();
     int sc = 0, sd = 2;
     init_acc(tile_n0(0));
@@ -291,13 +323,13 @@ void split_conv3x3s2_kernel(StemArgs a)
         for (int i = 0; i < RI; ++i) fa[1][i] = ldA(sa, 1, i);
 #pragma unroll
         for (int j = 0; j < 2; ++j) fb[0][j] = ldB(sc, 0, j);
-        mma_term(2, 0); if (dmaWave) dma_instr(0, sd);
+        mma_term(2, 0); dma_instr(0, sd);
         // (the third plane of the activations is first used by term 3: read it here, into the registers the first term's
         //  weight fragments have just left - all 18 fragment reads up front cost 16 more live registers and spilled)
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < RI; ++i) fa[2][i] = ldA(sa, 2, i);
-        mma_term(1, 1); if (dmaWave) dma_instr(1, sd);
+        mma_term(1, 1); dma_instr(1, sd);
         __builtin_amdgcn_sched_barrier(0);
         mma_term(0, 2);
         __builtin_amdgcn_sched_barrier(0);
@@ -308,31 +340,25 @@ void split_conv3x3s2_kernel(StemArgs a)
         {
             constexpr int nM = 4 * RI;                                // MFMAs of the two terms
             constexpr int groups = nM < 12 ? nM : 12;
-            constexpr int valu = (NORM ? 84 : 60) / groups;
+            constexpr int valu = (NORM ? 84 : 60) * NH / groups;
 #pragma unroll
             for (int g = 0; g < groups; ++g) {
-                if constexpr (NORM) { if (g == 0 || g == groups / 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); }
+                if constexpr (NORM) { if (g == 0 || g == groups / 2) __builtin_amdgcn_sched_group_barrier(0x100, 2 * NH, 0); }
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x002, valu, 0);
             }
-            __builtin_amdgcn_sched_group_barrier(0x200, 3, 0);                      // the three LDS writes
+            __builtin_amdgcn_sched_group_barrier(0x200, 3 * NH, 0);                 // the LDS writes
             if constexpr (nM > groups) __builtin_amdgcn_sched_group_barrier(0x008, nM - groups, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
         advance_conv();
-        // the weights of step kk + 1 have landed: younger are 2 DMAs and 2 loads of step kk + 2 (2 loads in the waves that do
-        // not stream weights) - and, in the first step of a tile, the NS stores of the tile before; lgkmcnt(0): my
-        // activation writes are done
-        if (dmaWave) {
-            if constexpr (decltype(firstTag)::value) __builtin_amdgcn_s_waitcnt(0x0070 | ((4 + NS) & 15) | (((4 + NS) >> 4) << 14));
-            else __builtin_amdgcn_s_waitcnt(0x0070 | 4);
-        } else {
-            if constexpr (decltype(firstTag)::value) __builtin_amdgcn_s_waitcnt(0x0070 | ((2 + NS) & 15) | (((2 + NS) >> 4) << 14));
-            else __builtin_amdgcn_s_waitcnt(0x0070 | 2);
-        }
+        // the weights of step kk + 1 have landed: younger are 2 DMAs and the NL loads of step kk + 2 - and, in the first step
+        // of a tile, the NS stores of the tile before; lgkmcnt(0): my activation writes are done
+        if constexpr (decltype(firstTag)::value) __builtin_amdgcn_s_waitcnt(0x0070 | ((2 + NL + NS) & 15) | (((2 + NL + NS) >> 4) << 14));
+        else __builtin_amdgcn_s_waitcnt(0x0070 | (2 + NL));
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        mma_term(0, 0); if (dmaWave) dma_instr(2, sd);
+        mma_term(0, 0); dma_instr(2, sd);
         advance_dma();
         sc = next;
         sd = sd == 2 ? 0 : sd + 1;
@@ -383,15 +409,16 @@ void split_conv3x3s2_kernel(StemArgs a)
     __builtin_amdgcn_s_waitcnt(0x0F70);                             // vmcnt(0)
 }
 
-template <int NT, int NW, int PER_CU>
+template <int NT, int NW, int PER_CU, int CPT = 8>
 int launch_stem(StemArgs a, bool norm, hipStream_t st)
 {
-    constexpr int BM = 32 * NW;
-    const size_t lds = 3 * NT * kUnit + 2 * BM * kUnit + 4096 + 1024;
+    constexpr int BM = 4 * NW * CPT;
+    const size_t lds = 3 * NT * kUnit + 2 * BM * kUnit + 4096 + 1024 + 1024;
     static XlLdsLimit configured[2];
     int cfgDev;
-    const void *fn = norm ? reinterpret_cast<const void *>(split_conv3x3s2_kernel<NT, true, NW>)
-                          : reinterpret_cast<const void *>(split_conv3x3s2_kernel<NT, false, NW>);
+    constexpr int WPS = NW * PER_CU / 4 < 2 ? 2 : NW * PER_CU / 4;
+    const void *fn = norm ? reinterpret_cast<const void *>(split_conv3x3s2_kernel<NT, true, NW, WPS, CPT>)
+                          : reinterpret_cast<const void *>(split_conv3x3s2_kernel<NT, false, NW, WPS, CPT>);
     if (configured[norm].needs(lds, &cfgDev)) {
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return XL_ERR_HIP;
         configured[norm].done(lds, cfgDev);
@@ -399,8 +426,8 @@ int launch_stem(StemArgs a, bool norm, hipStream_t st)
     a.nbm = (a.M + BM - 1) / BM;
     int grid = 256 * PER_CU;                                          // persistent: PER_CU workgroups per CU (LDS- and register-bound)
     if (grid > ((a.nbm * a.nbn + 7) & ~7)) grid = (a.nbm * a.nbn + 7) & ~7;
-    if (norm) hipLaunchKernelGGL((split_conv3x3s2_kernel<NT, true, NW>), dim3(grid), dim3(64 * NW), lds, st, a);
-    else hipLaunchKernelGGL((split_conv3x3s2_kernel<NT, false, NW>), dim3(grid), dim3(64 * NW), lds, st, a);
+    if (norm) hipLaunchKernelGGL((split_conv3x3s2_kernel<NT, true, NW, WPS, CPT>), dim3(grid), dim3(64 * NW), lds, st, a);
+    else hipLaunchKernelGGL((split_conv3x3s2_kernel<NT, false, NW, WPS, CPT>), dim3(grid), dim3(64 * NW), lds, st, a);
     return XL_OK;
 }
 
@@ -427,8 +454,10 @@ int xl_run_split_stem(const xl_op &op, hipStream_t st)
     a.normLo = (op.flags & XL_CONV_NORM_RELU) ? 0.f : -__builtin_inff();
     a.B = op.B; a.Hi = op.Hi; a.Wi = op.Wi; a.Cin = op.Cin; a.Ho = op.Ho; a.Wo = op.Wo;
     a.ldIn = op.ld_in; a.ldOut = op.ld_out; a.M = (int)M; a.nbm = 0; a.nbn = 1;
-    if (op.Cout == 64) return launch_stem<64, 4, 3>(a, norm, st);
-    if (op.Cout == 128) return launch_stem<128, 4, 2>(a, norm, st);
+    static const char *form = getenv("XL_STEM_FORM");                // measurement switch: "8x2" = 8-wave workgroups, two per CU
+    if (op.Cout == 64) return form && !strcmp(form, "8x2") ? launch_stem<64, 8, 2>(a, norm, st)
+                            : form && !strcmp(form, "c16") ? launch_stem<64, 4, 2, 16>(a, norm, st) : launch_stem<64, 4, 3>(a, norm, st);
+    if (op.Cout == 128) return form && !strcmp(form, "8x2") ? launch_stem<128, 8, 1>(a, norm, st) : launch_stem<128, 4, 2>(a, norm, st);
     if (op.reserved_i == 128) {                                       // latency form (the host asks when 256-row tiles cannot fill
         a.nbn = 2;                                                    // the chip): 128 x 128 tiles, two column tiles per row tile
         return launch_stem<128, 4, 2>(a, norm, st);

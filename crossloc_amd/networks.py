@@ -459,6 +459,28 @@ class _Plan:
         """Split-K factor of the split-pipe weight gradient: fill the 256 CUs once, at least 256 rows of K per split."""
         return max(1, min(256 // max(tiles, 1), K // 256))
 
+    def split_tile_form(self, M, N, Z=1, HW=1 << 30):
+        """Tile form of a 1x1 layer / of the Z batched GEMMs of a Winograd layer on the split pipe, as the op's reserved_i:
+        256 = 256 x 256 tiles (8 waves), 192 = 256 rows x 128 columns (8 waves), 128 = 128 x 128 (4 waves), 384 = 256 x 256
+        for the full rounds + 256 x 128 for the last partial round (two launches over disjoint tile ranges).  The persistent
+        kernels run one workgroup per CU, so a launch costs (rounds of 256 tiles) x (time of a tile); the tile times per
+        K-step were measured at 60 x 90 (2.05 / 1.30 / 1.10 us).  At 47 frames the large tiles win everywhere; a single frame
+        has 44 large tiles for a 1x1 layer (172 small ones: one round at half the tile time) and 128 for a Winograd layer
+        (256 of the 256 x 128 form).  Every output element accumulates in the same order in all forms - the convolution
+        results are bitwise the same - but the GroupNorm partial sums are per tile: batch-invariant plans keep 256."""
+        if self.separate_stats or self.train or os.environ.get("XL_NO_SMALL_TILES"):
+            return 256
+        forced = os.environ.get("XL_TILE_FORM_WINO" if Z > 1 else "XL_TILE_FORM_1X1")      # measurement switch
+        if forced:
+            return int(forced) if (HW >= 128 or forced != "128") else 256
+        big = -(-M // 256) * (N // 256) * Z
+        cands = [(256, -(-big // 256) * 2.05), (192, -(-2 * big // 256) * 1.30)]
+        if big > 256 and 0 < 2 * (big % 256) <= 256:     # 384: full rounds of large tiles, the rest as ONE round of 256 x 128
+            cands.append((384, big // 256 * 2.05 + 1.30 + 0.15))          # (+ the second launch's pipeline fill)
+        if HW >= 128:
+            cands.append((128, -(-(-(-M // 128) * (N // 128) * Z) // 256) * 1.10))
+        return min(cands, key=lambda c: (c[1], -c[0]))[0]
+
     def split_train_ok(self):
         """Training plans run their forward GEMMs (and the Winograd data gradients) on the split pipe too (round 3);
         XL_NO_SPLIT_TRAIN=1: fp32 MFMA throughout, the round-2 training plans."""
@@ -557,14 +579,7 @@ class _Plan:
             op.w = self.pack_conv_1x1_split(conv).data_ptr()
             # rows per tile (the statistics epilogue writes one entry per tile); negative: tiles start at image boundaries,
             # so the grouping of the partial sums does not depend on where a frame sits in the batch (batch-invariant plans)
-            op.reserved_i = -256 if self.separate_stats else 256
-            # latency form: when the 256 x 256 tiles would leave most of the chip idle and 128 x 128 tiles fit in ONE round
-            # of the 256 CUs (a single 60 x 90 frame: 44 tiles vs 172), the 4-wave kernel - same bits, a tile has a quarter
-            # of the MFMAs behind the same number of K-steps.  A choice by the layer's M = B*H*W; batch-invariant plans keep
-            # the 256-row tiles (their statistics entries are per tile).
-            if (not self.separate_stats and not self.train and not os.environ.get("XL_NO_SMALL_TILES")
-                    and -(-self.B * Ho * Wo // 128) * (cout // 128) <= 256 and Ho * Wo >= 128):
-                op.reserved_i = 128
+            op.reserved_i = -256 if self.separate_stats else self.split_tile_form(self.B * Ho * Wo, cout, 1, Ho * Wo)
         if norm_in is not None:                       # the producer's deferred GroupNorm apply, folded into the operand load
             op.flags |= CONV_NORM_IN | (CONV_NORM_RELU if norm_in.flags & GN_RELU_IN else 0)
             self.deferred_gn_consumers = getattr(self, "deferred_gn_consumers", []) + [len(self.ops)]
@@ -731,6 +746,8 @@ class _Plan:
             op.w = self.pack_conv_wino(conv, m).data_ptr()
         if -(-T // 128) * (cout // 128) * nf <= 256:
             op.reserved_i = 64
+        if split_act:
+            op.reserved_i = self.split_tile_form(T, cout, nf)
         self.ops.append(op)
         self.wino_gemm_indices = getattr(self, "wino_gemm_indices", []) + [len(self.ops) - 1]
         self.release(V)
@@ -870,7 +887,7 @@ class _Plan:
         t, H, W, C, ld, off = act
         G, HW = norm.num_groups, H * W
         cop = self.ops[conv_index]
-        tile = cop.reserved_i if cop.reserved_i in (64, 256, -256) else 128
+        tile = cop.reserved_i if cop.reserved_i in (64, 256, -256) else (256 if cop.reserved_i in (192, 384) else 128)
         nchunks = (HW + abs(tile) - 1) // abs(tile) + 1
         self.max_stats = max(self.max_stats, self.B * nchunks * G * 2)
         cop.groups, cop.nchunks = G, nchunks

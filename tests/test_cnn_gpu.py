@@ -199,6 +199,41 @@ def test_conv1x1_on_the_split_bf16_pipe(cin, cout, B, H, W, norm, relu, stats, p
         assert torch.allclose(sums[:, :, 1], (grp * grp).sum(2), rtol=1e-5)
 
 
+@pytest.mark.parametrize("cin,cout,B,H,W,norm", [(512, 512, 8, 60, 90, True), (96, 256, 1, 60, 90, False), (64, 1024, 3, 17, 23, True)])
+def test_conv1x1_split_tile_forms_give_the_same_bits(cin, cout, B, H, W, norm):
+    """reserved_i = 256 / 192 / 128: 256 x 256, 256 x 128 and 128 x 128 tiles of the same kernel.  Every output element
+    accumulates its K-steps in the same order in all three, so the convolution output is BITWISE the same; the GroupNorm
+    partial sums are one entry per row tile (256 rows for the first two forms, 128 for the third) of the same elements."""
+    g = torch.Generator().manual_seed(cin + cout + B)
+    xd = (torch.randn(B, H, W, cin, generator=g) * 2.0 + 0.5).cuda()
+    cd = torch.stack([torch.rand(B, cin, generator=g) + 0.5, torch.randn(B, cin, generator=g)], 2).contiguous().cuda()
+    wd = networks._Plan.split_bf16_interleaved((torch.randn(cout, cin, generator=g) * (2.0 / cin) ** 0.5).cuda(), cin)
+    bd = torch.randn(cout, generator=g).cuda()
+    G = cout // 16
+    outs, sums = [], []
+    for form in (256, 192, 384, 128):
+        rows = 128 if form == 128 else 256
+        nchunks = (H * W + rows - 1) // rows + 1
+        st = torch.zeros(B * nchunks * G * 2, dtype=torch.float64, device="cuda")
+        out = torch.full((B, H, W, cout), float("nan"), device="cuda")
+        op = networks.XlOp()
+        op.type = networks.XL_OP_CONV
+        op.B, op.Hi, op.Wi, op.Cin, op.Ho, op.Wo, op.Cout = B, H, W, cin, H, W, cout
+        op.ksize, op.stride, op.ld_in, op.ld_out, op.reserved_i = 1, 1, cin, cout, form
+        op.flags = networks.CONV_SPLIT_BF16 | networks.CONV_SPLIT_IL | ((networks.CONV_NORM_IN | networks.CONV_NORM_RELU) if norm else 0)
+        op.aux2 = cd.data_ptr() if norm else None
+        op.in_, op.w, op.bias, op.out = xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), out.data_ptr()
+        op.stats, op.groups, op.nchunks = st.data_ptr(), G, nchunks
+        _run([op, op])
+        outs.append(out.cpu())
+        sums.append(st.cpu().view(B, nchunks, G, 2).sum(1))
+    assert all(torch.equal(outs[0], o) for o in outs[1:])
+    grp = outs[0].double().reshape(B, H * W, G, 16).permute(0, 2, 1, 3).reshape(B, G, -1)
+    for s in sums:
+        assert torch.allclose(s[:, :, 0], grp.sum(2), rtol=1e-6, atol=1e-3)      # (lane partials are fp32, then fp64)
+        assert torch.allclose(s[:, :, 1], (grp * grp).sum(2), rtol=1e-6)
+
+
 def test_conv_reads_and_writes_channel_slices():
     """ld/offset addressing used by the concat-free MLR fusion."""
     g = torch.Generator().manual_seed(3)

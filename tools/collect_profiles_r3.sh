@@ -35,7 +35,7 @@ cd $GRAFT_REPO_ROOT
 python - <<PY
 import csv, glob, json
 f = glob.glob("$OUT/kt/*/*kernel_trace.csv")[0]
-name = "split_conv1x1_kernel<false,false,8,1>"
+name = "split_conv1x1_kernel<false,false,8,1,256>"
 d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in csv.DictReader(open(f)) if name in r["Kernel_Name"].replace(" ", "")]
 big = [x for x in d if x > 0.6 * max(d)]                             # the 512-channel layers (the 256-channel ones share the name)
 json.dump({"kernel": name, "launches": len(big), "avg_ms": sum(big) / max(len(big), 1), "all_launches_of_that_name": len(d),

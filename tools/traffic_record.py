@@ -37,7 +37,7 @@ def main():
         r = max(cand, key=lambda r: float(r["profiled_us"]))
         recs.append(record("split64", r["kernel"], r))
     # round 3: the batched GEMMs read V as fp32 and split it inside the kernel (their own instantiation, ZB = 1)
-    cand = [r for r in rows if r["kernel"].replace(" ", "").startswith("split_conv1x1_kernel<false,false,8,1>")]   # (+ "@<us class>")
+    cand = [r for r in rows if r["kernel"].replace(" ", "").startswith("split_conv1x1_kernel<false,false,8,1,256>")]   # (+ "@<us class>")
     if cand:
         r = max(cand, key=lambda r: float(r["profiled_us"]))
         recs.append(record("splitact64", r["kernel"], r))
