@@ -645,12 +645,14 @@ __device__ __forceinline__ unsigned pk_bf16(float x, float y)        // {bf16(x)
 __device__ __forceinline__ float hi_f(unsigned w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
 __device__ __forceinline__ float lo_f(unsigned w) { return __builtin_bit_cast(float, w << 16); }
 // x = t1 + t2 + t3 exactly, for two values at a time (one 32-bit word per term)
-__device__ __forceinline__ void split_pair(float x, float y, unsigned &w1, unsigned &w2, unsigned &w3)
+// (two values at a time as a float pair: v_pk_add_f32 for the residuals)
+__device__ __forceinline__ void split_pair(f32x2 v, unsigned &w1, unsigned &w2, unsigned &w3)
 {
-    w1 = pk_bf16(x, y);
-    const float rx = x - lo_f(w1), ry = y - hi_f(w1);
-    w2 = pk_bf16(rx, ry);
-    w3 = pk_bf16(rx - lo_f(w2), ry - hi_f(w2));
+    w1 = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+    const f32x2 r = v - f32x2{ lo_f(w1), hi_f(w1) };
+    w2 = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
+    const f32x2 r2 = r - f32x2{ lo_f(w2), hi_f(w2) };
+    w3 = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2));
 }
 
 // NW = waves per workgroup: 8 -> tiles of 256 x 256 (2 x 4 waves of 128 x 64), the throughput form; 4 -> tiles of 128 x 128
@@ -792,13 +794,13 @@ void split_conv1x1_kernel(SplitConvArgs a)
             if constexpr (NORM) {
                 const f32x4 c0 = *reinterpret_cast<const f32x4 *>(dsm + cCoef + cK * 128 + h * 32);
                 const f32x4 c1 = *reinterpret_cast<const f32x4 *>(dsm + cCoef + cK * 128 + h * 32 + 16);
-                x[0] = fmaxf(fmaf(x[0], c0[0], c0[1]), a.normLo);
-                x[1] = fmaxf(fmaf(x[1], c0[2], c0[3]), a.normLo);
-                x[2] = fmaxf(fmaf(x[2], c1[0], c1[1]), a.normLo);
-                x[3] = fmaxf(fmaf(x[3], c1[2], c1[3]), a.normLo);
+                // (one rounding per element, as everywhere a GroupNorm is applied; two elements per v_pk_fma_f32)
+                const f32x2 lo = __builtin_elementwise_fma(f32x2{ x[0], x[1] }, f32x2{ c0[0], c0[2] }, f32x2{ c0[1], c0[3] });
+                const f32x2 hi = __builtin_elementwise_fma(f32x2{ x[2], x[3] }, f32x2{ c1[0], c1[2] }, f32x2{ c1[1], c1[3] });
+                x = f32x4{ fmaxf(lo[0], a.normLo), fmaxf(lo[1], a.normLo), fmaxf(hi[0], a.normLo), fmaxf(hi[1], a.normLo) };
             }
-            split_pair(x[0], x[1], w[0][2 * h], w[1][2 * h], w[2][2 * h]);
-            split_pair(x[2], x[3], w[0][2 * h + 1], w[1][2 * h + 1], w[2][2 * h + 1]);
+            split_pair(f32x2{ x[0], x[1] }, w[0][2 * h], w[1][2 * h], w[2][2 * h]);
+            split_pair(f32x2{ x[2], x[3] }, w[0][2 * h + 1], w[1][2 * h + 1], w[2][2 * h + 1]);
         }
 #pragma unroll
         for (int p = 0; p < 3; ++p)

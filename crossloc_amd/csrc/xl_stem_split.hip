@@ -49,12 +49,14 @@ __device__ __forceinline__ unsigned pk_bf16(float x, float y)        // {bf16(x)
 }
 __device__ __forceinline__ float hi_f(unsigned w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
 __device__ __forceinline__ float lo_f(unsigned w) { return __builtin_bit_cast(float, w << 16); }
-__device__ __forceinline__ void split_pair(float x, float y, unsigned &w1, unsigned &w2, unsigned &w3)
+// (two values at a time as a float pair: v_pk_add_f32 for the residuals)
+__device__ __forceinline__ void split_pair(f32x2 v, unsigned &w1, unsigned &w2, unsigned &w3)
 {
-    w1 = pk_bf16(x, y);
-    const float rx = x - lo_f(w1), ry = y - hi_f(w1);
-    w2 = pk_bf16(rx, ry);
-    w3 = pk_bf16(rx - lo_f(w2), ry - hi_f(w2));
+    w1 = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+    const f32x2 r = v - f32x2{ lo_f(w1), hi_f(w1) };
+    w2 = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
+    const f32x2 r2 = r - f32x2{ lo_f(w2), hi_f(w2) };
+    w3 = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2));
 }
 
 struct StemArgs {
@@ -210,6 +212,7 @@ void split_conv3x3s2_kernel(StemArgs a)
     };
     auto convert = [&](auto parTag) {                                  // registers of parity P -> activation stage P
         constexpr int P = decltype(parTag)::value;
+        const float clampLo = mOK[P] != 0u ? a.normLo : 0.f, clampHi = mOK[P] != 0u ? __builtin_inff() : 0.f;
 #pragma unroll
         for (int hh = 0; hh < NH; ++hh) {
         unsigned w[3][4];
@@ -219,14 +222,15 @@ void split_conv3x3s2_kernel(StemArgs a)
             if constexpr (NORM) {
                 const f32x4 c0 = *reinterpret_cast<const f32x4 *>(dsm + cCoef + cChunk * 128 + hh * 64 + h * 32);
                 const f32x4 c1 = *reinterpret_cast<const f32x4 *>(dsm + cCoef + cChunk * 128 + hh * 64 + h * 32 + 16);
-                const bool ok = mOK[P] != 0u;                        // the zero padding stays zero
-                x[0] = ok ? fmaxf(fmaf(x[0], c0[0], c0[1]), a.normLo) : 0.f;
-                x[1] = ok ? fmaxf(fmaf(x[1], c0[2], c0[3]), a.normLo) : 0.f;
-                x[2] = ok ? fmaxf(fmaf(x[2], c1[0], c1[1]), a.normLo) : 0.f;
-                x[3] = ok ? fmaxf(fmaf(x[3], c1[2], c1[3]), a.normLo) : 0.f;
+                // one rounding per element (two elements per v_pk_fma_f32), then ONE v_med3_f32 that is both the lower clamp and
+                // the padding mask: in-image pixels clamp to [normLo, +inf), the zero padding of the convolution to [0, 0]
+                const f32x2 lo = __builtin_elementwise_fma(f32x2{ x[0], x[1] }, f32x2{ c0[0], c0[2] }, f32x2{ c0[1], c0[3] });
+                const f32x2 hi = __builtin_elementwise_fma(f32x2{ x[2], x[3] }, f32x2{ c1[0], c1[2] }, f32x2{ c1[1], c1[3] });
+                x = f32x4{ __builtin_amdgcn_fmed3f(lo[0], clampLo, clampHi), __builtin_amdgcn_fmed3f(lo[1], clampLo, clampHi),
+                           __builtin_amdgcn_fmed3f(hi[0], clampLo, clampHi), __builtin_amdgcn_fmed3f(hi[1], clampLo, clampHi) };
             }
-            split_pair(x[0], x[1], w[0][2 * h], w[1][2 * h], w[2][2 * h]);
-            split_pair(x[2], x[3], w[0][2 * h + 1], w[1][2 * h + 1], w[2][2 * h + 1]);
+            split_pair(f32x2{ x[0], x[1] }, w[0][2 * h], w[1][2 * h], w[2][2 * h]);
+            split_pair(f32x2{ x[2], x[3] }, w[0][2 * h + 1], w[1][2 * h + 1], w[2][2 * h + 1]);
         }
 #pragma unroll
         for (int p = 0; p < 3; ++p)
@@ -234,8 +238,10 @@ void split_conv3x3s2_kernel(StemArgs a)
         }
     };
     auto advance_conv = [&]() {
-        if (++cK == nk) { cK = 0; cChunk = 0; ++cTile; set_conv_tile(cTile); return; }
-        if (++cChunk == nch) cChunk = 0;
+        cK = __builtin_amdgcn_readfirstlane(cK + 1);
+        if (cK == nk) { cK = 0; cChunk = 0; cTile = __builtin_amdgcn_readfirstlane(cTile + 1); set_conv_tile(cTile); return; }
+        cChunk = __builtin_amdgcn_readfirstlane(cChunk + 1);
+        if (cChunk == nch) cChunk = 0;
     };
     // coefficient table of tile i: the {scale, shift} pairs of its (at most two) images, 4 Cin floats, into table i & 1
     const __amdgpu_buffer_rsrc_t srdCoef = __builtin_amdgcn_make_buffer_rsrc((void *)a.coef, 0, NORM ? a.B * a.Cin * 8 : 0, 0x00020000);
@@ -351,7 +357,6 @@ void split_conv3x3s2_kernel(StemArgs a)
             if constexpr (nM > groups) __builtin_amdgcn_sched_group_barrier(0x008, nM - groups, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
-        advance_conv();
         // the weights of step kk + 1 have landed: younger are 2 DMAs and the NL loads of step kk + 2 - and, in the first step
         // of a tile, the NS stores of the tile before; lgkmcnt(0): my activation writes are done
         if constexpr (decltype(firstTag)::value) __builtin_amdgcn_s_waitcnt(0x0070 | ((2 + NL + NS) & 15) | (((2 + NL + NS) >> 4) << 14));
@@ -359,6 +364,7 @@ void split_conv3x3s2_kernel(StemArgs a)
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         mma_term(0, 0); dma_instr(2, sd);
+        advance_conv();                                               // (the branches of the two streams' bookkeeping end the step)
         advance_dma();
         sc = next;
         sd = sd == 2 ? 0 : sd + 1;
