@@ -259,7 +259,8 @@ def main():
                     help="images per step per GPU.  The two persistent GEMM kernels walk 256 x 256 tiles with one workgroup "
                          "per CU, so what matters is how evenly the tiles divide over 256 CUs: 47 frames = 3584 tiles (14.0 "
                          "rounds) for the 64 batched Winograd GEMMs of a 512-channel layer and 1984 tiles (7.75 rounds) for a "
-                         "1x1 layer (44: 13.0 / 7.26 rounds, 1333 vs 1359 images/s measured).  Default 47; 24 with --mlr 3")
+                         "1x1 layer (44 frames: 13.0 / 7.26 rounds - profiles/r3_bench_b44.json beside profiles/r3_bench.json).  "
+                         "Default 47; 24 with --mlr 3")
     ap.add_argument("--hyps", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cnn-streams", type=int, default=1,
@@ -681,7 +682,8 @@ def secondary_configs(dev, n_hyp, train_batch=16, mlr_batch=24, steps=5):
     torch.cuda.empty_cache()
 
     # ---- the reference's own API shape: batch 1 (test_single_task.py:347-363), and 8 frames per step.  Plans of <= 8 frames
-    # replay their op list as one HIP graph; launches whose 256 x 256 tiles cannot fill the chip use 128 x 128 tiles.
+    # replay their op list as one HIP graph; launches whose 256 x 256 tiles cannot fill the chip use 256 x 128 or 128 x 128
+    # tiles, or 256 x 128 tiles for the last partial round of the 256 CUs (networks._Plan.split_tile_form).
     net = networks.TransPoseNet(mean, False, False, 2, 2, 3, 1)
     net.load_state_dict(seeded_state_dict(net, seed=2021))
     net = net.to(dev).eval()
@@ -698,12 +700,15 @@ def secondary_configs(dev, n_hyp, train_batch=16, mlr_batch=24, steps=5):
         pipe.finish()
         torch.cuda.synchronize()
         n_it = 200 if nb == 1 else 60
-        t0 = time.perf_counter()
-        for _ in range(n_it):
-            small_step()
-        pipe.finish()
-        torch.cuda.synchronize()
-        ms_small = (time.perf_counter() - t0) / n_it * 1e3
+        reps = []
+        for _ in range(3):                                                    # median of three timed runs of n_it steps
+            t0 = time.perf_counter()
+            for _ in range(n_it):
+                small_step()
+            pipe.finish()
+            torch.cuda.synchronize()
+            reps.append((time.perf_counter() - t0) / n_it * 1e3)
+        ms_small = sorted(reps)[1]
         out[key] = round(ms_small, 3) if nb == 1 else round(nb / ms_small * 1e3, 1)
         if nb == 1:
             out["latency_b1_images_per_s"] = round(1e3 / ms_small, 1)

@@ -831,7 +831,9 @@ class _Plan:
         cpg = conv.out_channels // norm.num_groups
         # a 1x1 layer on the split pipe applies a pending GroupNorm on load at ANY batch size (the tile-count condition of
         # norm_on_load_ok belongs to the fp32 kernel's 64-row form)
-        split_1x1 = self.split_1x1_ok(act, conv) and (cpg == 16 or self.separate_stats)
+        # (the statistics epilogue of the split kernel sums 16-channel groups; a layer with other groups - res1_conv2: 8 per
+        #  group - still runs on the split pipe in inference plans, followed by a statistics pass over its output)
+        split_1x1 = self.split_1x1_ok(act, conv) and (cpg == 16 or self.separate_stats or not self.train)
         absorbs = (split_1x1 and act[3] <= 512 and act[1] * act[2] >= 256 and not os.environ.get("XL_NO_NORM_ON_LOAD"))
         if pend is not None and m not in (4, 6) and not self.norm_on_load_ok(act, conv) and not stem and not absorbs:
             self.stats_ops.append(len(self.ops))       # consumer cannot absorb it: materialise now
@@ -856,7 +858,8 @@ class _Plan:
         bn = 128 if conv.out_channels % 128 == 0 else 64
         # a conv tile's columns cover whole groups, and the statistics epilogue sums 2- or 4-channel pieces
         whole_groups = bn % cpg == 0 and (cpg == 2 or cpg % 4 == 0)
-        if not self.train and y[1] * y[2] >= 128 and whole_groups and (not self.separate_stats or (split and cpg == 16)):
+        if (not self.train and y[1] * y[2] >= 128 and whole_groups and (not split or cpg == 16)
+                and (not self.separate_stats or (split and cpg == 16))):
             # inference: the conv epilogue produces the GroupNorm statistics, the separate stats pass is dropped
             return self.gn_fused(y, norm, flags, aux, len(self.ops) - 1,
                                  defer=defer and flags == GN_RELU_IN and aux is None
@@ -873,6 +876,9 @@ class _Plan:
             self.keep.append(stats_t)
             cop.stats, cop.groups, cop.nchunks = stats_t.data_ptr(), G, nchunks
             return self.gn(y, norm, flags, aux, pre_stats=(stats_t, nchunks), stat_tile=tile)
+        if not self.train:
+            return self.gn(y, norm, flags, aux, defer=defer and flags == GN_RELU_IN and aux is None
+                           and not os.environ.get("XL_NO_DEFERRED_GN"), share=share)
         r = self.gn(y, norm, flags, aux)
         if r[0] is not y[0]:
             self.release(y[0])
