@@ -1215,7 +1215,9 @@ __device__ __forceinline__ void bf16_split3(float a, unsigned &h1, unsigned &h2,
 // gn_apply_kernel, flags as XL_GN_*), and the thread that owns a pixel - the tile whose 6 x 6 output footprint contains it -
 // also writes v to `side`: the activation is materialised for its other consumers (the residual branch) by the pass that had
 // to read it anyway.  `side` must not alias `in` or `res` (other tiles read their halo pixels from those).
-struct WinoFold { const float *res; float *side; int ldRes, ldSide, flags; };
+// resCoef: the residual is itself the RAW output of a convolution whose GroupNorm + ReLU apply was deferred (its only consumer is
+// this addition): {scale, shift} pairs like `coeff`, applied with ReLU while the residual is read.
+struct WinoFold { const float *res; float *side; int ldRes, ldSide, flags; const float *resCoef; };
 
 template <int DEFER, int SPLIT = 0, int FOLD = 0>
 __global__ __launch_bounds__(256, (SPLIT == 2 ? 3 : 1))
@@ -1235,6 +1237,10 @@ void wino6_in_kernel(const float *__restrict__ in, float *__restrict__ V, int B,
         const int n = (int)(t / ((long long)Tw * Th));
         f32x4 ss = f32x4{ 1.f, 0.f, 1.f, 0.f };
         if (DEFER) ss = *reinterpret_cast<const f32x4 *>(coeff + ((long long)n * C + 2 * c2) * 2);
+        f32x4 rs = f32x4{ 1.f, 0.f, 1.f, 0.f };
+        if constexpr (FOLD != 0) {
+            if (fold.resCoef) rs = *reinterpret_cast<const f32x4 *>(fold.resCoef + ((long long)n * C + 2 * c2) * 2);
+        }
         f32x2 w[8][8];                               // w[i][b] = (B^T d)[i][b]
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
@@ -1259,6 +1265,11 @@ void wino6_in_kernel(const float *__restrict__ in, float *__restrict__ V, int B,
                         for (int a = 0; a < 8; ++a) {
                             const int yc = min(max(6 * ty - 1 + a, 0), H - 1), xc = min(max(x, 0), W - 1);
                             rcol[a] = *reinterpret_cast<const f32x2 *>(fold.res + (((long long)n * H + yc) * W + xc) * fold.ldRes + 2 * c2);
+                        }
+                        if (fold.resCoef) {                  // the residual's own deferred GroupNorm + ReLU (gn_apply's arithmetic)
+#pragma unroll
+                            for (int a = 0; a < 8; ++a)
+                                rcol[a] = f32x2{ fmaxf(fmaf(rcol[a][0], rs[0], rs[1]), 0.f), fmaxf(fmaf(rcol[a][1], rs[2], rs[3]), 0.f) };
                         }
                     }
                 }
@@ -2282,15 +2293,17 @@ int run_op(const xl_op &op, hipStream_t st)
                     if (op.Cin % 128 != 0) return XL_ERR_ARG;          // a wave = 128 consecutive channels of one tile
                     kin = !op.aux2 ? wino6_in_kernel<0, 2> : (op.flags & XL_GN_RELU_IN) ? wino6_in_kernel<2, 2> : wino6_in_kernel<1, 2>;
                 }
-                WinoFold fold = { nullptr, nullptr, 0, 0, 0 };
+                WinoFold fold = { nullptr, nullptr, 0, 0, 0, nullptr };
                 if (op.out2) {
                     // fold form: aux2 = coefficients, out2 = the materialised activation (pixel stride ld_out), aux = residual
-                    // (pixel stride ld_aux) when XL_GN_ADD is set; flags & (XL_GN_RELU_IN | XL_GN_ADD | XL_GN_RELU_OUT)
+                    // (pixel stride ld_aux) when XL_GN_ADD is set; flags & (XL_GN_RELU_IN | XL_GN_ADD | XL_GN_RELU_OUT);
+                    // w (optional) = {scale, shift} pairs of the residual's own deferred GroupNorm + ReLU
                     if (!op.aux2 || op.ld_out % 2 != 0 || ((op.flags & XL_GN_ADD) && (!op.aux || op.ld_aux % 2 != 0)) ||
                         op.out2 == op.in || op.out2 == op.aux) return XL_ERR_ARG;
                     fold.res = (op.flags & XL_GN_ADD) ? (const float *)op.aux : nullptr;
                     fold.side = (float *)op.out2; fold.ldRes = op.ld_aux; fold.ldSide = op.ld_out;
                     fold.flags = op.flags & (XL_GN_RELU_IN | XL_GN_RELU_OUT);
+                    fold.resCoef = (op.flags & XL_GN_ADD) ? (const float *)op.w : nullptr;
                     if (op.flags & XL_CONV_SPLIT_BF16) return XL_ERR_UNSUPPORTED;     // the fold form writes V as fp32
                     kin = wino6_in_kernel<1, 0, 1>;
                 }

@@ -261,7 +261,7 @@ class PipelinedLocalizer:
         import dsacstar
         pred, events = self.forward_cnn(images, plant)
         coords = pred[:, :self.net.num_task_channel] if scene_coords is None else scene_coords
-        poses = torch.zeros((coords.shape[0], 4, 4), dtype=torch.float32, device=coords.device)
+        poses = torch.empty((coords.shape[0], 4, 4), dtype=torch.float32, device=coords.device)   # (the solver writes all 16)
         for ev in events:
             self.side.wait_event(ev)
         self.side.wait_stream(torch.cuda.current_stream())      # `poses` / `scene_coords` come from the caller's stream

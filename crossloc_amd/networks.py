@@ -231,7 +231,16 @@ class _Plan:
                 self.op_array[i].aux2 = self.coeff.data_ptr()
         for i in getattr(self, "deferred_gn_consumers", []):
             self.op_array[i].aux2 = self.coeff.data_ptr()
+        if getattr(self, "aux_final_ops", None):      # the second table: residuals normalised by the pass that adds them
+            self.coeff_aux = torch.zeros_like(self.coeff)
+            for i in self.aux_final_ops:
+                self.op_array[i].out = self.coeff_aux.data_ptr()
+            for i in getattr(self, "aux_apply_ops", []):
+                self.op_array[i].aux2 = self.coeff_aux.data_ptr()
+            for i in getattr(self, "aux_coef_consumers", []):
+                self.op_array[i].w = self.coeff_aux.data_ptr()
         assert not getattr(self, "pending_gn", None), "a deferred GroupNorm was never consumed"
+        assert not getattr(self, "pending_aux", None), "a deferred residual GroupNorm was never consumed"
         assert not getattr(self, "pending_fold", None), "a folded GroupNorm apply was never consumed"
         if train:
             self._lower_backward()
@@ -268,7 +277,7 @@ class _Plan:
         tensors = [raw[0]] + ([aux[0]] if aux is not None else [])
         for x in tensors:
             self.held[id(x)] = [x, x is raw[0]]           # the raw conv output has no other owner: released with the fold
-        self.pending_fold[self._act_key(res)] = dict(ap=ap, raw=raw, tensors=tensors)
+        self.pending_fold[self._act_key(res)] = dict(ap=ap, raw=raw, tensors=tensors, aux_ap=self._aux_take(aux))
         return res
 
     def _fold_end(self, fold):
@@ -281,9 +290,34 @@ class _Plan:
         """The first consumer cannot apply it on load: run the GroupNorm apply as a pass (raw -> the activation's buffer)."""
         ap = fold["ap"]
         ap.out, ap.ld_out = act[0].data_ptr() + 4 * act[5], act[4]
+        if fold.get("aux_ap") is not None:
+            self._aux_apply(fold["aux_ap"])
         self.stats_ops.append(len(self.ops))
         self.ops.append(ap)
         self._fold_end(fold)
+
+    # -- a residual whose own GroupNorm + ReLU has no other consumer than the addition (res2_conv3 -> res2_norm3 -> ReLU, added to
+    # the normalised skip branch, networks.py:247-250 of the reference): its apply pass is left to the pass that performs the
+    # addition - the fold form of the next block's input transform reads the RAW residual and normalises it while loading.  Its
+    # {scale, shift} pairs must outlive the GN_FINAL of the skip branch: they go to a second coefficient table.
+    def _aux_defer(self, act):
+        """`act` was produced by cgr(..., defer=True): move its pending GroupNorm apply to the residual slot."""
+        ap = getattr(self, "pending_gn", {}).pop(self._act_key(act), None)
+        if ap is None:
+            return                                    # (the layer's form could not defer it: it ran as a pass)
+        assert not getattr(self, "pending_aux", None)
+        fin = max(i for i, op in enumerate(self.ops) if op.type == XL_OP_GN_FINAL)
+        self.aux_final_ops = getattr(self, "aux_final_ops", []) + [fin]
+        self.pending_aux = {self._act_key(act): ap}
+
+    def _aux_take(self, aux):
+        return getattr(self, "pending_aux", {}).pop(self._act_key(aux), None) if aux is not None else None
+
+    def _aux_apply(self, ap):
+        """The addition is not performed by a fold: apply the residual's GroupNorm as a pass after all (in place)."""
+        self.aux_apply_ops = getattr(self, "aux_apply_ops", []) + [len(self.ops)]
+        self.stats_ops.append(len(self.ops))
+        self.ops.append(ap)
 
     def release_grad(self, t):
         self.free.setdefault(t.numel(), []).append(t)
@@ -649,6 +683,9 @@ class _Plan:
                 return res
             if share and self.fold_ok():              # ... or the first of several consumers does, and materialises it
                 return self._fold_begin(ap, act, aux)
+        aux_ap = self._aux_take(aux)
+        if aux_ap is not None:
+            self._aux_apply(aux_ap)
         self.ops.append(ap)
         self.tape.append(dict(kind="gn", norm=norm, raw=act, out=res, aux=aux, flags=flags, table=table,
                               gamma=gamma, beta=beta))
@@ -724,6 +761,8 @@ class _Plan:
             op.out2, op.ld_out = t.data_ptr() + 4 * off, ld
             if fap.flags & GN_ADD:
                 op.aux, op.ld_aux = fap.aux, fap.ld_aux
+                if fold.get("aux_ap") is not None:    # the residual is a raw conv output: its {scale, shift} pairs in `w`
+                    self.aux_coef_consumers = getattr(self, "aux_coef_consumers", []) + [len(self.ops)]
             self.deferred_gn_consumers = getattr(self, "deferred_gn_consumers", []) + [len(self.ops)]
         self.ops.append(op)
         if fold is not None:
@@ -813,6 +852,9 @@ class _Plan:
             return y
         if share and self.fold_ok():
             return self._fold_begin(ap, y, aux)
+        aux_ap = self._aux_take(aux)
+        if aux_ap is not None:
+            self._aux_apply(aux_ap)
         self.stats_ops.append(len(self.ops))
         self.ops.append(ap)
         return y
@@ -923,6 +965,9 @@ class _Plan:
             return res
         if share and out is None and self.fold_ok():
             return self._fold_begin(ap, act, aux)
+        aux_ap = self._aux_take(aux)
+        if aux_ap is not None:
+            self._aux_apply(aux_ap)
         self.stats_ops.append(len(self.ops))
         self.ops.append(ap)
         return res
@@ -1058,9 +1103,14 @@ class _Plan:
         res = c
         a = self.cgr(res, enc.res2_conv1, enc.res2_norm1, defer=True)
         b = self.cgr(a, enc.res2_conv2, enc.res2_norm2, defer=True); self.release(a[0])
-        c = self.cgr(b, enc.res2_conv3, enc.res2_norm3); self.release(b[0])
         n_add = len(enc.enc_add_res_block_ls)
         last_out = out if n_add == 0 else None
+        # (c is consumed by the addition below only: when that addition is folded into the next block's input transform, so is
+        #  c's own GroupNorm + ReLU)
+        aux_fold = last_out is None and self.fold_ok() and not os.environ.get("XL_NO_AUX_FOLD")
+        c = self.cgr(b, enc.res2_conv3, enc.res2_norm3, defer=aux_fold); self.release(b[0])
+        if aux_fold:
+            self._aux_defer(c)
         if last_out is None:                        # conv -> GroupNorm with the statistics out of the conv epilogue
             skip_in = res
             res = self.cgr(skip_in, enc.res2_skip, enc.res2_skip_norm, GN_ADD | GN_RELU_OUT, aux=c, share=True)

@@ -52,7 +52,11 @@ enum {
                                of m x m outputs; ksize = m: 2 = F(2x2,3x3) (Hi, Wi even), 4 = F(4x4,3x3) (Ho = ceil(Hi/4)), 6 = F(6x6,3x3)
                                (Ho = ceil(Hi/6)).
                                m = 4 and 6: aux2 = per-(image, channel) {scale, shift} pairs of a deferred GroupNorm, applied
-                               (with ReLU when flags has XL_GN_RELU_IN) to every in-image pixel before the transform */
+                               (with ReLU when flags has XL_GN_RELU_IN) to every in-image pixel before the transform.
+                               m = 6 with out2 (the fold form): `in` is the raw output of a convolution whose GroupNorm(+ReLU,
+                               +residual aux, +ReLU: flags XL_GN_*) apply pass is performed here, and the activation is also
+                               written to out2 (pixel stride ld_out); w, optional: {scale, shift} pairs of the RESIDUAL's own
+                               deferred GroupNorm + ReLU (aux is then a raw convolution output too) */
     XL_OP_WINO_OUT = 13,    /* Winograd output transform + bias (+ GroupNorm partial sums): in M [(m+2)^2][tiles][Cin] ->
                                out [B,Hi,Wi,Cin]; ksize = m; reserved_i = tiles per workgroup, nchunks = workgroups per image */
     XL_OP_DUC_HEAD = 14,    /* full-size (semantics) head: x8 pixel shuffle of in [B,Hi,Wi,Cout*64] + bilinear resize to

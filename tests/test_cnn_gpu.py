@@ -799,13 +799,26 @@ def test_folded_groupnorm_apply_is_bitwise_the_separate_pass(monkeypatch):
     assert len(folds) >= 5, len(folds)                 # conv4, res1, res2 skip, and the blocks that feed another block
     assert any(op.flags & networks.GN_ADD for op in folds) and any(not (op.flags & networks.GN_ADD) for op in folds)
     n_apply = sum(op.type == networks.XL_OP_GN_APPLY for op in plan.ops)
+    # one of the folds also normalises its residual while reading it (res2_conv3's GroupNorm + ReLU, whose only consumer is the
+    # addition to the skip branch): `w` = the residual's own coefficient table
+    n_aux = sum(1 for op in plan.op_array if op.type == networks.XL_OP_WINO_IN and op.out2 and op.w)
+    assert n_aux == 1
+    monkeypatch.setenv("XL_NO_AUX_FOLD", "1")
+    net.invalidate()
+    with torch.no_grad():
+        y1 = net(x)
+    plan1 = list(net._plans.values())[0]
+    assert sum(op.type == networks.XL_OP_GN_APPLY for op in plan1.ops) == n_apply + 1
+    assert not any(op.type == networks.XL_OP_WINO_IN and op.out2 and op.w for op in plan1.op_array)
+    assert torch.equal(y, y1)
+    monkeypatch.delenv("XL_NO_AUX_FOLD")
     monkeypatch.setenv("XL_NO_FOLD_GN", "1")
     net.invalidate()
     with torch.no_grad():
         y0 = net(x)
     plan0 = list(net._plans.values())[0]
     assert not any(op.type == networks.XL_OP_WINO_IN and op.out2 for op in plan0.ops)
-    assert sum(op.type == networks.XL_OP_GN_APPLY for op in plan0.ops) == n_apply + len(folds)
+    assert sum(op.type == networks.XL_OP_GN_APPLY for op in plan0.ops) == n_apply + len(folds) + n_aux
     assert torch.equal(y, y0)
     # ragged 6x6 tiles (a 16 x 24 grid): the owner of a pixel is the tile whose footprint holds it, also at the edges
     monkeypatch.delenv("XL_NO_FOLD_GN")
