@@ -794,9 +794,10 @@ void split_conv1x1_kernel(SplitConvArgs a)
             if constexpr (NORM) {
                 const f32x4 c0 = *reinterpret_cast<const f32x4 *>(dsm + cCoef + cK * 128 + h * 32);
                 const f32x4 c1 = *reinterpret_cast<const f32x4 *>(dsm + cCoef + cK * 128 + h * 32 + 16);
-                // (one rounding per element, as everywhere a GroupNorm is applied; two elements per v_pk_fma_f32)
-                const f32x2 lo = __builtin_elementwise_fma(f32x2{ x[0], x[1] }, f32x2{ c0[0], c0[2] }, f32x2{ c0[1], c0[3] });
-                const f32x2 hi = __builtin_elementwise_fma(f32x2{ x[2], x[3] }, f32x2{ c1[0], c1[2] }, f32x2{ c1[1], c1[3] });
+                // (one rounding per element, as everywhere a GroupNorm is applied.  Scalar fmaf: v_pk_fma_f32 would halve the
+                //  fma count but hipcc adds three register-pair moves per packed instruction - 64 VALU per K-step against 56)
+                const f32x2 lo = f32x2{ fmaf(x[0], c0[0], c0[1]), fmaf(x[1], c0[2], c0[3]) };
+                const f32x2 hi = f32x2{ fmaf(x[2], c1[0], c1[1]), fmaf(x[3], c1[2], c1[3]) };
                 x = f32x4{ fmaxf(lo[0], a.normLo), fmaxf(lo[1], a.normLo), fmaxf(hi[0], a.normLo), fmaxf(hi[1], a.normLo) };
             }
             split_pair(f32x2{ x[0], x[1] }, w[0][2 * h], w[1][2 * h], w[2][2 * h]);

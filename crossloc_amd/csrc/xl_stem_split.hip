@@ -222,10 +222,10 @@ void split_conv3x3s2_kernel(StemArgs a)
             if constexpr (NORM) {
                 const f32x4 c0 = *reinterpret_cast<const f32x4 *>(dsm + cCoef + cChunk * 128 + hh * 64 + h * 32);
                 const f32x4 c1 = *reinterpret_cast<const f32x4 *>(dsm + cCoef + cChunk * 128 + hh * 64 + h * 32 + 16);
-                // one rounding per element (two elements per v_pk_fma_f32), then ONE v_med3_f32 that is both the lower clamp and
+                // one rounding per element (scalar fmaf: the packed form costs more moves than it saves), then ONE v_med3_f32 that is both the lower clamp and
                 // the padding mask: in-image pixels clamp to [normLo, +inf), the zero padding of the convolution to [0, 0]
-                const f32x2 lo = __builtin_elementwise_fma(f32x2{ x[0], x[1] }, f32x2{ c0[0], c0[2] }, f32x2{ c0[1], c0[3] });
-                const f32x2 hi = __builtin_elementwise_fma(f32x2{ x[2], x[3] }, f32x2{ c1[0], c1[2] }, f32x2{ c1[1], c1[3] });
+                const f32x2 lo = f32x2{ fmaf(x[0], c0[0], c0[1]), fmaf(x[1], c0[2], c0[3]) };
+                const f32x2 hi = f32x2{ fmaf(x[2], c1[0], c1[1]), fmaf(x[3], c1[2], c1[3]) };
                 x = f32x4{ __builtin_amdgcn_fmed3f(lo[0], clampLo, clampHi), __builtin_amdgcn_fmed3f(lo[1], clampLo, clampHi),
                            __builtin_amdgcn_fmed3f(hi[0], clampLo, clampHi), __builtin_amdgcn_fmed3f(hi[1], clampLo, clampHi) };
             }
