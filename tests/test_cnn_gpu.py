@@ -321,8 +321,12 @@ def test_conv1_inference_form_vs_torch(B, H, W, ppt):
     b.aux2, b.out, b.flags = coeff.data_ptr(), out.data_ptr(), networks.GN_RELU_IN
     _run([a, f, b])
     st = stats.sum(1).cpu()                                              # [B, 32, 2]: per-channel sums
-    assert torch.allclose(st[..., 0], raw.sum((2, 3)), rtol=1e-6, atol=1e-4)
-    assert torch.allclose(st[..., 1], (raw * raw).sum((2, 3)), rtol=1e-6, atol=1e-4)
+    # (against a float64 convolution: the fp32 CPU convolution above carries its own rounding, whose sum over 345600 pixels
+    #  depends on the host's blocking - one box in twenty missed 1e-4 on a channel whose sum is near zero)
+    with torch.no_grad():
+        raw64 = F.conv2d(x.double(), conv.weight.double(), conv.bias.double(), padding=1)
+    assert torch.allclose(st[..., 0], raw64.sum((2, 3)), rtol=1e-6, atol=2e-4)
+    assert torch.allclose(st[..., 1], (raw64 * raw64).sum((2, 3)), rtol=1e-6, atol=2e-4)
     got = out.cpu().permute(0, 3, 1, 2).double()
     assert torch.isfinite(got).all()
     _close(got, ref, 2e-5)
@@ -784,6 +788,8 @@ def test_winograd_weight_gradient_vs_autograd(m, cin, cout, B, H, W):
     _close(dw.cpu().double(), ref, 1e-4)
 
 
+@pytest.mark.skipif(any(os.environ.get(k) for k in ("XL_NO_FOLD_GN", "XL_NO_DEFERRED_GN", "XL_WINO_V_SPLIT", "XL_NO_AUX_FOLD"))
+                    or os.environ.get("XL_GEMM_SPLIT_BF16") in ("0", "1"), reason="a switch that disables the fold form is set")
 def test_folded_groupnorm_apply_is_bitwise_the_separate_pass(monkeypatch):
     """Inference plans leave the GroupNorm(+ReLU, +residual, +ReLU) apply of a block's last layer to the F(6x6,3x3) input
     transform of the next block, which also writes the activation for the residual branch (XL_OP_WINO_IN with out2).  Same
@@ -948,6 +954,7 @@ def test_split_weight_kernel_is_the_exact_three_term_split():
     assert L.xl_cnn_split_weight(w3.data_ptr(), p.data_ptr(), 64, 280, 9, None) != 0      # K % 16
 
 
+@pytest.mark.skipif(os.environ.get("XL_GEMM_SPLIT_BF16") in ("0", "1"), reason="the tile forms belong to the split-pipe kernels")
 def test_small_batch_forward_as_a_hip_graph_and_small_tile_form(monkeypatch):
     """Latency path: on a created stream a plan of <= 8 frames replays its op list as ONE HIP graph (first call eager, second
     captures, later ones replay) - bitwise the eager result; new images and new weights are picked up.  1x1 layers whose
@@ -991,6 +998,8 @@ def test_small_batch_forward_as_a_hip_graph_and_small_tile_form(monkeypatch):
         assert torch.equal(net(xs[1]), y2) and not torch.equal(y2, want[1])
 
 
+@pytest.mark.skipif(bool(os.environ.get("XL_WINO_V_SPLIT")) or os.environ.get("XL_GEMM_SPLIT_BF16") in ("0", "1"),
+                    reason="the tile-major product belongs to the GEMM form that reads an fp32 V")
 def test_tile_major_winograd_product_is_bitwise_the_plane_major_form(monkeypatch):
     """XL_WINO_M_TILE_MAJOR=1 (XL_CONV_M_TILE_MAJOR on the batched GEMM and on the output transform): M as [tiles][64][C]
     instead of [64][tiles][C] - a layout choice only."""
