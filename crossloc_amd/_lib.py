@@ -23,9 +23,19 @@ def lib():
         # a library built from OTHER sources than the ones next to it (a tree copied between an edit and a rebuild) binds
         # the wrong ABI: rebuild it here when the toolchain is present (one minute, once), otherwise say so loudly
         from . import build as _build
-        if not os.path.exists(LIB_PATH) or (os.path.exists(_build.STAMP) and _build.needs_build()):
+        try:
+            stale = not os.path.exists(LIB_PATH) or (os.path.exists(_build.STAMP) and _build.needs_build())
+        except OSError as e:
+            # a deployed tree that ships the library without csrc/ or include/: nothing to compare against, load what is there
+            if not os.path.exists(LIB_PATH):
+                raise XlError("libcrossloc_hip.so is not built (%s) and its sources are not readable (%s); there is no CPU "
+                              "fallback." % (LIB_PATH, e))
+            import warnings
+            warnings.warn("crossloc_amd: cannot check libcrossloc_hip.so against its sources (%s); loading it as is" % (e,))
+            stale = False
+        if stale:
             try:
-                _build.build()
+                _build.build()                                           # serialised across processes by a file lock
             except Exception as e:                                       # no hipcc on this machine
                 if not os.path.exists(LIB_PATH):
                     raise XlError("libcrossloc_hip.so is not built (%s) and could not be built here (%s). Run "

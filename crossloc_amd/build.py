@@ -43,26 +43,61 @@ def needs_build():
         return f.read().strip() != source_hash()
 
 
+class _BuildLock:
+    """Exclusive advisory lock (flock on libcrossloc_hip.so.lock) around the rebuild decision and the build: under
+    torch.distributed.run every rank imports the package at the same moment, and only one of them may compile."""
+
+    def __enter__(self):
+        import fcntl
+        self.f = open(LIB + ".lock", "w")
+        fcntl.flock(self.f, fcntl.LOCK_EX)
+        return self
+
+    def __exit__(self, *exc):
+        import fcntl
+        fcntl.flock(self.f, fcntl.LOCK_UN)
+        self.f.close()
+
+
 def build(force=False, verbose=False):
+    """Compile and link the library if the sources changed.  Safe to call from several processes at once: the ranks
+    serialise on a file lock, the one that gets it first builds, the others find the stamp up to date when their turn
+    comes.  Objects go to a directory private to the building process and the library and its stamp are moved into place
+    with os.replace(), so a process that loads the library without the lock never maps a half-written file."""
     if not force and not needs_build():
         return LIB
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    if not os.path.exists(hipcc):
-        hipcc = "hipcc"
-    objs, procs = [], []
-    for src in sources():
-        obj = src[:-4] + ".o"
-        cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
-        if verbose:
-            print(" ".join(cmd), file=sys.stderr)
-        procs.append((subprocess.Popen(cmd), cmd))
-        objs.append(obj)
-    for p, cmd in procs:
-        if p.wait() != 0:
-            raise RuntimeError("hipcc failed: " + " ".join(cmd))
-    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
-    with open(STAMP, "w") as f:
-        f.write(source_hash() + "\n")
+    import shutil
+    import tempfile
+    with _BuildLock():
+        if not force and not needs_build():                      # another process built it while this one waited
+            return LIB
+        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+        if not os.path.exists(hipcc):
+            hipcc = "hipcc"
+        want = source_hash()
+        tmp = tempfile.mkdtemp(prefix=".build.", dir=HERE)
+        try:
+            objs, procs = [], []
+            for src in sources():
+                obj = os.path.join(tmp, os.path.basename(src)[:-4] + ".o")
+                cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+                if verbose:
+                    print(" ".join(cmd), file=sys.stderr)
+                procs.append((subprocess.Popen(cmd), cmd))
+                objs.append(obj)
+            failed = [cmd for p, cmd in procs if p.wait() != 0]
+            if failed:
+                raise RuntimeError("hipcc failed: " + " ".join(failed[0]))
+            out = os.path.join(tmp, "libcrossloc_hip.so")
+            subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
+            with open(os.path.join(tmp, "srchash"), "w") as f:
+                f.write(want + "\n")
+            if os.path.exists(STAMP):
+                os.remove(STAMP)                                 # never an old library beside a new stamp, or vice versa
+            os.replace(out, LIB)
+            os.replace(os.path.join(tmp, "srchash"), STAMP)
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
     return LIB
 
 

@@ -1606,20 +1606,28 @@ class _Plan:
         _check(_bind().xl_cnn_run(self.bwd_array, len(self.bwd_array), ctypes.c_void_p(stream)))
         # hand the gradients out as slices of a copy of the flat buffer (ONE device-to-device copy; the plan's own buffer
         # is overwritten by the next backward pass).  Two result buffers alternate - their addresses repeat, which keeps
-        # the fused optimizer's pointer table valid - unless a parameter's .grad still lives in the one whose turn it is
-        # (gradient accumulation without zero_grad): then a fresh buffer is used.
+        # the fused optimizer's pointer table valid - but a buffer is reused only when NOTHING else references its
+        # storage any more: a .grad that is still alive (accumulation without zero_grad), a result of torch.autograd.grad,
+        # a tensor kept by a hook or for logging all hold a view, and then a fresh buffer is handed out instead.
         if not hasattr(self, "grad_results"):
             self.grad_results, self.grad_turn = [None, None], 0
         self.grad_turn ^= 1
         buf = self.grad_results[self.grad_turn]
-        if buf is not None:
-            lo, hi = buf.data_ptr(), buf.data_ptr() + 4 * buf.numel()
-            if any(p.grad is not None and lo <= p.grad.data_ptr() < hi for p, _, _ in self.grad_slices):
-                buf = None
+        if buf is not None and not _sole_owner(buf):
+            buf = None
         if buf is None:
             buf = self.grad_results[self.grad_turn] = torch.empty_like(self.grad_flat)
         buf.copy_(self.grad_flat)
         return [(p, buf[o:o + n]) for p, o, n in self.grad_slices]
+
+
+def _sole_owner(buf):
+    """True when `buf` is the only tensor left on its storage (no view of it is alive anywhere): 2 = this tensor + the
+    Python storage object the query itself creates.  Unknown (private API missing) counts as shared."""
+    try:
+        return torch._C._storage_Use_Count(buf.untyped_storage()._cdata) <= 2
+    except (AttributeError, RuntimeError, TypeError):
+        return False
 
 
 class _NetFunction(torch.autograd.Function):

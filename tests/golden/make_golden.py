@@ -12,6 +12,14 @@ Reference entry points exercised:
   utils/learning.py:20-35       get_pixel_grid;  loss/coord.py:7-17 get_cam_mat
   networks/networks.py:259-273, 311-349  DenseUpsamplingConvolution / full_size_output decoder (semantics.npz)
   loss/semantics.py:10-18, 44-91         CrossEntropyLoss2d, semantics_classification_loss (semantics.npz)
+Round 4 - the BASELINE sizes and the backward pass (inputs regenerated from seeds by golden_inputs.py on both sides):
+  full_size.npz   networks/networks.py:466-502 at 480x720, batch 1: single-task and 3-encoder output [1,4,60,90]
+  grads.npz       train_single_task.py:262-298: forward, torch.split, scene_coords_regression_loss (MLE), loss.backward()
+                  on the reference module, 64x96 batch 2 - loss, rate, dL/dprediction, and for each of the 114 parameters
+                  the L2 norm, the sum and a strided sample of .grad (network evaluated in float64: the fixture holds
+                  no ReLU-mask flips of its own; the fp32 run's loss is stored beside it)
+  losses_b16.npz  loss/coord.py:87-188, loss/depth.py:7-76, loss/normal.py:8-127 at [16,*,60,90]: value, rate, gradient
+                  moments and strided samples
 """
 import builtins
 import os
@@ -42,6 +50,8 @@ from loss.normal import normal_regression_loss                  # noqa: E402
 from utils.learning import get_pixel_grid                       # noqa: E402
 
 from crossloc_amd.weights import seeded_state_dict              # noqa: E402
+sys.path.insert(0, HERE)
+import golden_inputs                                            # noqa: E402
 
 _print = builtins.print
 
@@ -210,8 +220,106 @@ def semantics_goldens():
     _print("semantics.npz", {k: v.shape for k, v in out.items()})
 
 
+def full_size_goldens():
+    """BASELINE configs[2] / [4] frame size: the reference forward at 480x720, batch 1 (networks/networks.py:466-502)."""
+    mean = torch.tensor([-455.934, 417.50, 520.31])
+    out = {}
+    for tag, num_mlr in (("single", 0), ("mlr3", 3)):
+        net = quiet(TransPoseNet, mean, False, False, 2, 2, 3, 1, 32, num_mlr, 0, False)
+        net.load_state_dict(seeded_state_dict(net, seed=2021), strict=True)
+        net.eval()
+        x = golden_inputs.full_size_image(tag)
+        with torch.no_grad():
+            y = net(torch.from_numpy(x))
+        out[tag + "_y"] = y.numpy()
+        out[tag + "_x_checksum"] = np.array(golden_inputs.checksum(x))
+    np.savez_compressed(os.path.join(HERE, "full_size.npz"), **out)
+    _print("full_size.npz", {k: v.shape for k, v in out.items()})
+
+
+def grad_goldens():
+    """One training step's forward + loss + backward on the reference module (train_single_task.py:262-298), 64x96, batch 2."""
+    mean = torch.tensor([-455.934, 417.50, 520.31])
+    x, poses, delta = golden_inputs.grad_inputs()
+    H, W = golden_inputs.GRAD_H, golden_inputs.GRAD_W
+    pixel_grid = get_pixel_grid(8)
+    cam_mat = get_cam_mat(W, H, golden_inputs.GRAD_FOCAL)
+    out = {}
+    gt = None
+    for dtype, tag in ((torch.float64, "f64"), (torch.float32, "f32")):
+        net = quiet(TransPoseNet, mean, False, False, 2, 2, 3, 1, 32, 0, 0, False)
+        net.load_state_dict(seeded_state_dict(net, seed=2021), strict=True)
+        net = net.to(dtype).train()
+        pred = net(torch.from_numpy(x).to(dtype))
+        if gt is None:
+            # labels = the reference's own (float64) prediction + the seeded offset field, two cells without data
+            gt = (pred.detach()[:, :3].float() + torch.from_numpy(delta)).numpy()
+            gt[0, :, 0, 0] = -1.0
+            gt[1, :, 5, 7] = -1.0
+        pred32 = pred.float()                       # the loss runs in fp32 like train_single_task.py; autograd carries the
+        pred32.retain_grad()                        # gradient back through the cast into the float64 network
+        sc, unc = torch.split(pred32, [3, 1], dim=1)                                       # train_single_task.py:269
+        loss, rate = quiet(scene_coords_regression_loss, 0.1, 100.0, 1000.0, 50.0, "MLE", pixel_grid, -1, cam_mat,
+                           sc, unc, torch.from_numpy(poses), torch.from_numpy(gt), 'mean')
+        loss.backward()
+        out["loss_" + tag] = np.array(loss.item(), np.float64)
+        out["rate_" + tag] = np.array(float(rate))
+        if tag == "f32":
+            continue
+        out["y"] = pred.detach().float().numpy()
+        out["dpred"] = pred32.grad.numpy().copy()
+        names, norms, sums, samples = [], [], [], []
+        for name, p in net.named_parameters():
+            g = p.grad.double().numpy()
+            names.append("%s:%s" % (name, "x".join(map(str, p.shape))))
+            norms.append(np.sqrt((g * g).sum()))
+            sums.append(g.sum())
+            s = golden_inputs.strided(g)
+            samples.append(np.pad(s, (0, 256 - s.size)))
+        out["param_names"] = np.array(names)
+        out["param_grad_l2"] = np.array(norms)
+        out["param_grad_sum"] = np.array(sums)
+        out["param_grad_sample"] = np.stack(samples).astype(np.float32)
+    out.update(gt=gt, x_checksum=np.array(golden_inputs.checksum(x)), poses_checksum=np.array(golden_inputs.checksum(poses)))
+    np.savez_compressed(os.path.join(HERE, "grads.npz"), **out)
+    _print("grads.npz", {k: v.shape for k, v in out.items()}, "loss f64-net %.6f fp32 %.6f rate %.4f" % (
+        out["loss_f64"], out["loss_f32"], out["rate_f64"]))
+
+
+def loss_b16_goldens():
+    """The three per-pixel losses at the BASELINE configs[1] batch, [16,*,60,90] (MLE and plain)."""
+    I = golden_inputs.loss_b16_inputs()
+    pixel_grid = get_pixel_grid(8)
+    cam_mat = get_cam_mat(720, 480, 480.0)
+    out = {}
+
+    def record(tag, loss, rate, p, u):
+        loss.backward()
+        out[tag + "_loss"] = np.array(loss.item(), np.float64)
+        out[tag + "_rate"] = np.array(float(rate))
+        for nm, t in (("dpred", p), ("dunc", u)):
+            g = t.grad.double().numpy() if t.grad is not None else np.zeros(tuple(t.shape))
+            out["%s_%s_moments" % (tag, nm)] = np.array([g.sum(), np.abs(g).sum(), np.sqrt((g * g).sum())])
+            out["%s_%s_sample" % (tag, nm)] = g[:, :, ::4, ::5].astype(np.float32)
+
+    for mode in ("MLE", None):
+        p = torch.tensor(I["pred"], requires_grad=True); u = torch.tensor(I["unc"], requires_grad=True)
+        loss, rate = quiet(scene_coords_regression_loss, 0.1, 100.0, 1000.0, 50.0, mode, pixel_grid, -1, cam_mat,
+                           p, u, torch.tensor(I["poses"]), torch.tensor(I["gt"]), 'mean')
+        record("coord_%s" % (mode or "plain"), loss, rate, p, u)
+        p = torch.tensor(I["depth_pred"], requires_grad=True); u = torch.tensor(I["unc"], requires_grad=True)
+        loss, rate = quiet(depth_regression_loss, 0.1, 10.0, mode, -1, p, u, torch.tensor(I["depth_gt"]), 'mean')
+        record("depth_%s" % (mode or "plain"), loss, rate, p, u)
+        p = torch.tensor(I["normal_logits"], requires_grad=True); u = torch.tensor(I["unc"], requires_grad=True)
+        loss, rate = quiet(normal_regression_loss, 10.0, mode, -1, p, u, torch.tensor(I["normal_gt"]), 'mean')
+        record("normal_%s" % (mode or "plain"), loss, rate, p, u)
+    out["input_checksums"] = np.array([golden_inputs.checksum(I[k]) for k in sorted(I)])
+    np.savez_compressed(os.path.join(HERE, "losses_b16.npz"), **out)
+    _print("losses_b16.npz", {k: (v.shape if v.ndim else float(v)) for k, v in out.items()})
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["net", "net4", "loss", "semantics"]
+    which = sys.argv[1:] or ["net", "net4", "loss", "semantics", "full", "grads", "loss16"]
     if "net" in which:
         net_goldens()
     if "net4" in which:
@@ -220,3 +328,9 @@ if __name__ == "__main__":
         loss_goldens()
     if "semantics" in which:
         semantics_goldens()
+    if "full" in which:
+        full_size_goldens()
+    if "grads" in which:
+        grad_goldens()
+    if "loss16" in which:
+        loss_b16_goldens()

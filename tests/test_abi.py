@@ -62,3 +62,31 @@ def test_dsacstar_module_surface(hiplib):
     with pytest.raises(RuntimeError):
         dsacstar.forward_rgb(torch.zeros(1, 3, 60, 90, dtype=torch.float64), torch.zeros(4, 4), 64, 10.0, 480.0,
                              360.0, 240.0, 100.0, 100.0, 8)
+
+
+def test_concurrent_imports_with_a_stale_stamp_leave_one_loadable_library():
+    """bench.py --gpus N / torchrun: every rank runs _lib.lib() at the same moment.  With a stale stamp exactly one of them
+    may compile (file lock in crossloc_amd/build.py), the library is moved into place atomically, and all of them load it."""
+    import shutil
+    import subprocess
+    import sys
+    from crossloc_amd import build
+    if not (os.path.exists("/opt/rocm/bin/hipcc") or shutil.which("hipcc")):
+        pytest.skip("no hipcc here: a stale library cannot be rebuilt")
+    build.build()
+    with open(build.STAMP, "w") as f:
+        f.write("stale\n")
+    assert build.needs_build()
+    code = ("import ctypes, os, sys, time; sys.path.insert(0, %r); t0 = time.time();"
+            "from crossloc_amd import _lib; L = _lib.lib();"
+            "L.xl_status_string.restype = ctypes.c_char_p; assert L.xl_status_string(0) == b'ok';"
+            "print('built' if time.time() - t0 > 8 else 'waited-or-found')" % ROOT)
+    procs = [subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for _ in range(3)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-400:] for o in outs]
+    assert not build.needs_build()
+    with open(build.STAMP) as f:
+        assert f.read().strip() == build.source_hash()
+    assert not [d for d in os.listdir(os.path.dirname(build.LIB)) if d.startswith(".build.")]     # no leftovers
+    ctypes.CDLL(build.LIB)

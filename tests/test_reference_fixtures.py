@@ -1,0 +1,197 @@
+"""The BASELINE sizes and the backward pass pinned to the REFERENCE ITSELF (round 4).
+
+tests/golden/full_size.npz, grads.npz and losses_b16.npz hold what the imported reference modules computed
+(tests/golden/make_golden.py: networks/networks.py:466-502 at 480x720; train_single_task.py:262-298 forward + MLE
+coordinate loss + loss.backward() on the reference TransPoseNet; loss/coord.py, depth.py, normal.py at [16,*,60,90]); the
+inputs are regenerated from seeds on both sides (tests/golden/golden_inputs.py, checksums in the fixtures).
+
+CPU tests (not gpu): the oracle restatements against the fixtures - they pin the checker at these sizes too.
+GPU tests: the HIP path through crossloc_amd against the fixtures; cnn_oracle / loss_oracle are not in that loop.
+
+Tolerances.  Forward at 480x720: <= 2e-4 of the coordinate range (SURVEY 8(d) asks 1e-4 relative of the output for the fp32
+path; measured 6e-5 m = one fp32 ulp at |X| ~ 500 m), sigma 2e-3 relative.  Parameter gradients: the fixture comes from a
+float64 evaluation of the reference module (no ReLU-mask flips of its own); the fp32 forward on the GPU may put a
+pre-activation that is within an ulp of 0 on the other side, which moves single elements - so every tensor is held to a
+relative L2 error (<= 5e-2; typical 1e-5) on its strided sample, and its L2 norm to 2e-2.  Losses: 1e-4 on the value,
+gradient moments 1e-3, samples 2e-3 relative + 1e-4 of the largest element (fp32 cancellation in |PX - PX_gt| at 500 m).
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+import golden_inputs                                            # noqa: E402
+
+from crossloc_amd import networks                               # noqa: E402
+from crossloc_amd.weights import seeded_state_dict              # noqa: E402
+
+MEAN = torch.tensor([-455.934, 417.50, 520.31])
+FULL = np.load(os.path.join(HERE, "golden", "full_size.npz"))
+GRADS = np.load(os.path.join(HERE, "golden", "grads.npz"))
+L16 = np.load(os.path.join(HERE, "golden", "losses_b16.npz"))
+
+
+def _net(num_mlr=0):
+    net = networks.TransPoseNet(MEAN, False, False, 2, 2, 3, 1, 32, num_mlr, 0, False)
+    net.load_state_dict(seeded_state_dict(net, seed=2021))
+    return net
+
+
+def _check_forward(y, ref, tol_range=2e-4):
+    y, ref = y.double(), torch.from_numpy(np.asarray(ref)).double()
+    rng = (ref[:, :3] - MEAN[None, :, None, None].double()).abs().max().item()
+    err = (y[:, :3] - ref[:, :3]).abs().max().item()
+    assert err <= tol_range * max(1.0, rng), (err, rng)
+    assert torch.allclose(y[:, 3], ref[:, 3], rtol=2e-3), ((y[:, 3] - ref[:, 3]).abs() / ref[:, 3]).max()
+    return err
+
+
+# ------------------------------------------------------------------------------------------ CPU: the oracle at these sizes
+
+def test_inputs_regenerate():
+    for tag in ("single", "mlr3"):
+        assert golden_inputs.checksum(golden_inputs.full_size_image(tag)) == float(FULL[tag + "_x_checksum"])
+    x, poses, _ = golden_inputs.grad_inputs()
+    assert golden_inputs.checksum(x) == float(GRADS["x_checksum"])
+    assert golden_inputs.checksum(poses) == float(GRADS["poses_checksum"])
+    I = golden_inputs.loss_b16_inputs()
+    assert [golden_inputs.checksum(I[k]) for k in sorted(I)] == list(L16["input_checksums"])
+
+
+def test_cnn_oracle_at_480x720_vs_reference_fixture():
+    from oracle import cnn_oracle
+    y = cnn_oracle.transposenet_forward(seeded_state_dict(_net(), seed=2021),
+                                        torch.from_numpy(golden_inputs.full_size_image("single")), 0, 2, 2)
+    assert y.shape == (1, 4, 60, 90)
+    _check_forward(y, FULL["single_y"])
+
+
+def _loss16(mod, on_gpu):
+    """The three losses x {MLE, plain} at [16,*,60,90] through `mod` (loss_oracle on CPU / crossloc_amd.loss on the GPU):
+    yields (tag, loss, rate, dpred, dunc)."""
+    I = golden_inputs.loss_b16_inputs()
+    dev = "cuda" if on_gpu else "cpu"
+
+    def t(name, grad=False):
+        return torch.tensor(I[name], device=dev, requires_grad=grad)
+    for mode in ("MLE", None):
+        for task in ("coord", "depth", "normal"):
+            pname = {"coord": "pred", "depth": "depth_pred", "normal": "normal_logits"}[task]
+            p, u = t(pname, True), t("unc", True)
+            if on_gpu:
+                if task == "coord":
+                    loss, rate = mod.scene_coords_regression_loss(0.1, 100.0, 1000.0, 50.0, mode, mod.get_pixel_grid(8), -1,
+                                                                  mod.get_cam_mat(720, 480, 480.0), p, u, t("poses"), t("gt"))
+                elif task == "depth":
+                    loss, rate = mod.depth_regression_loss(0.1, 10.0, mode, -1, p, u, t("depth_gt"))
+                else:
+                    loss, rate = mod.normal_regression_loss(10.0, mode, -1, p, u, t("normal_gt"))
+            else:
+                if task == "coord":
+                    loss, rate = mod.coord_loss(p, u, t("poses"), t("gt"), 480.0, 360.0, 240.0, 8.0, mle=mode == "MLE")
+                elif task == "depth":
+                    loss, rate = mod.depth_loss(p, u, t("depth_gt"), mle=mode == "MLE")
+                else:
+                    loss, rate = mod.normal_loss(p, u, t("normal_gt"), mle=mode == "MLE")
+            loss.backward()
+            dp = p.grad.detach().double().cpu().numpy()
+            du = u.grad.detach().double().cpu().numpy() if u.grad is not None else np.zeros(tuple(u.shape))
+            yield "%s_%s" % (task, mode or "plain"), float(loss.item()), float(rate), dp, du
+
+
+def _check_loss16(mod, on_gpu, rel_loss, rel_mom, rel_s):
+    for tag, loss, rate, dp, du in _loss16(mod, on_gpu):
+        assert loss == pytest.approx(float(L16[tag + "_loss"]), rel=rel_loss), tag
+        assert rate == pytest.approx(float(L16[tag + "_rate"]), abs=2e-5), tag
+        for nm, g in (("dpred", dp), ("dunc", du)):
+            ref_m, ref_s = L16["%s_%s_moments" % (tag, nm)], L16["%s_%s_sample" % (tag, nm)].astype(np.float64)
+            got_m = np.array([g.sum(), np.abs(g).sum(), np.sqrt((g * g).sum())])
+            # (the signed sum cancels: it is held to the absolute sum's scale)
+            assert abs(got_m[0] - ref_m[0]) <= rel_mom * max(ref_m[1], 1e-30), (tag, nm, got_m, ref_m)
+            assert np.allclose(got_m[1:], ref_m[1:], rtol=rel_mom, atol=1e-30), (tag, nm, got_m, ref_m)
+            s = g[:, :, ::4, ::5]
+            assert np.allclose(s, ref_s, rtol=rel_s, atol=1e-4 * max(np.abs(ref_s).max(), 1e-30)), (tag, nm)
+
+
+def test_loss_oracle_at_batch16_vs_reference_fixture():
+    from oracle import loss_oracle
+    _check_loss16(loss_oracle, False, 2e-6, 1e-5, 1e-4)
+
+
+# ------------------------------------------------------------------------------------------ GPU: the HIP path
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,num_mlr", [("single", 0), ("mlr3", 3)])
+def test_hip_forward_at_480x720_vs_reference_fixture(tag, num_mlr):
+    """BASELINE configs[2] / configs[4] frame size against the reference module's own output."""
+    net = _net(num_mlr).cuda().eval()
+    x = torch.from_numpy(golden_inputs.full_size_image(tag)).cuda()
+    with torch.no_grad():
+        y = net(x).cpu()
+    assert y.shape == (1, 4, 60, 90)
+    err = _check_forward(y, FULL[tag + "_y"])
+    print("%s 480x720: max coordinate error vs the reference %.2e m" % (tag, err))
+    # the plan under test is the benchmarked one: GEMMs on the split-bf16 pipe (unless the fp32-MFMA switch is set)
+    plan = list(net._plans.values())[0]
+    if os.environ.get("XL_GEMM_SPLIT_BF16", "il") not in ("", "0"):
+        assert any(op.flags & networks.CONV_SPLIT_BF16 for op in plan.ops if op.type == networks.XL_OP_CONV)
+
+
+@pytest.mark.gpu
+def test_hip_training_step_gradients_vs_reference_fixture():
+    """a14: forward + MLE coordinate loss + backward through crossloc_amd (HIP kernels) against the gradients autograd
+    produced on the reference module (train_single_task.py:262-298)."""
+    from crossloc_amd import loss as xl_loss
+    x, poses, _ = golden_inputs.grad_inputs()
+    H, W = golden_inputs.GRAD_H, golden_inputs.GRAD_W
+    net = _net().cuda().train()
+    pred = net(torch.from_numpy(x).cuda())
+    _check_forward(pred.detach().cpu(), GRADS["y"], tol_range=1e-3)
+    pred.retain_grad()
+    sc, unc = torch.split(pred, [3, 1], dim=1)
+    loss, rate = xl_loss.scene_coords_regression_loss(0.1, 100.0, 1000.0, 50.0, "MLE", xl_loss.get_pixel_grid(8), -1,
+                                                      xl_loss.get_cam_mat(W, H, golden_inputs.GRAD_FOCAL), sc, unc,
+                                                      torch.from_numpy(poses).cuda(), torch.from_numpy(GRADS["gt"]).cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    assert loss.item() == pytest.approx(float(GRADS["loss_f64"]), rel=2e-4)
+    assert loss.item() == pytest.approx(float(GRADS["loss_f32"]), rel=2e-4)
+    assert float(rate) == pytest.approx(float(GRADS["rate_f64"]), abs=1e-6)
+    dref = GRADS["dpred"].astype(np.float64)
+    dgot = pred.grad.double().cpu().numpy()
+    assert np.linalg.norm(dgot - dref) <= 2e-3 * np.linalg.norm(dref)
+    names = [n.split(":")[0] for n in GRADS["param_names"]]
+    params = dict(net.named_parameters())
+    assert names == list(params.keys()) and len(names) == 114
+    gmax = float(np.abs(GRADS["param_grad_sample"]).max())
+    worst = []
+    for i, name in enumerate(names):
+        g = params[name].grad
+        assert g is not None, name
+        g = g.double().cpu().numpy()
+        s = golden_inputs.strided(g)
+        ref = GRADS["param_grad_sample"][i, :s.size].astype(np.float64)
+        if name == "encoder.conv1.bias":
+            # GroupNorm(32, 32) is an instance norm: d/d(conv1.bias) is exactly 0; the reference holds rounding noise
+            assert np.abs(g).max() <= 1e-4 * gmax and float(GRADS["param_grad_l2"][i]) <= 1e-4 * gmax
+            continue
+        floor = 1e-4 * gmax * np.sqrt(s.size)
+        e2 = np.linalg.norm(s - ref) / max(np.linalg.norm(ref), floor)
+        l2 = np.sqrt((g * g).sum())
+        en = abs(l2 - float(GRADS["param_grad_l2"][i])) / max(float(GRADS["param_grad_l2"][i]), 1e-4 * gmax * np.sqrt(g.size))
+        worst.append((max(e2, en), e2, en, name))
+    worst.sort(reverse=True)
+    print("parameter gradients vs the reference module: worst sample L2 %.2e / norm %.2e (%s), median %.2e" % (
+        worst[0][1], worst[0][2], worst[0][3], worst[len(worst) // 2][0]))
+    assert worst[0][1] <= 5e-2 and worst[0][2] <= 2e-2, worst[:5]
+
+
+@pytest.mark.gpu
+def test_hip_losses_at_batch16_vs_reference_fixture():
+    from crossloc_amd import loss as xl_loss
+    _check_loss16(xl_loss, True, 1e-4, 1e-3, 2e-3)

@@ -135,6 +135,35 @@ def test_second_training_forward_before_backward_keeps_the_first_graph_intact():
         net(xa)
 
 
+def test_gradient_tensors_held_by_the_caller_are_never_overwritten():
+    """The backward pass hands its gradients out as views of alternating result buffers.  A view that is still alive
+    anywhere - kept across zero_grad(set_to_none=True) for logging or gradient surgery, or returned by torch.autograd.grad -
+    pins its buffer: later backward passes take another one."""
+    net = networks.TransPoseNet(MEAN, False, False, 0, 0, 3, 1)
+    net.load_state_dict(seeded_state_dict(net, seed=8))
+    net = net.cuda().train()
+    xs = [torch.rand(1, 3, 64, 96, generator=torch.Generator().manual_seed(i)).cuda() for i in range(5)]
+    net(xs[0]).sum().backward()
+    held = [p.grad for p in net.parameters()]                     # references only, no clone
+    snap = [g.clone() for g in held]
+    ag = torch.autograd.grad(net(xs[1]).sum(), [net.decoder.fc3.weight, net.encoder.conv2.weight])
+    ag_snap = [g.clone() for g in ag]
+    for x in xs[2:]:                                              # three more backward passes: both buffers had their turn
+        net.zero_grad(set_to_none=True)
+        net(x).sum().backward()
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(held, snap))
+    assert all(torch.equal(a, b) for a, b in zip(ag, ag_snap))
+    # ... and with nothing held, the two buffers alternate (stable addresses for the fused optimizer's pointer table)
+    del held, ag
+    ptrs = []
+    for x in xs + xs[:3]:
+        net.zero_grad(set_to_none=True)
+        net(x).sum().backward()
+        ptrs.append(net.decoder.fc3.weight.grad.data_ptr())
+    assert len(set(ptrs[-4:])) == 2 and ptrs[-1] == ptrs[-3] and ptrs[-2] == ptrs[-4]
+
+
 def test_rccl_collectives_on_a_one_rank_group():
     """The two data-path collectives of the N > 1 runs - the flat gradient all-reduce (optim.allreduce_gradients) and the
     NaN-padded all-gather of per-image errors (evaluation.gather_errors) - through the `nccl` backend, which is RCCL on
