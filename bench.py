@@ -76,6 +76,19 @@ def lookup_solver_counters():
             "select_and_refine_valu_busy": k2["valu_busy"] if k2 else None, "source": sv["source"]}
 
 
+def strict(obj):
+    """The bench line must parse with a strict (RFC 8259) parser: non-finite floats become null."""
+    if isinstance(obj, float):
+        return obj if np.isfinite(obj) else None
+    if isinstance(obj, dict):
+        return {k: strict(v) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return [strict(v) for v in obj]
+    if isinstance(obj, np.generic):
+        return strict(obj.item())
+    return obj
+
+
 def gather_and_median(local_err, world, dist=None, group=None):
     """Per-image (t_err [m], r_err [deg]) rows of every rank -> (median cm, median deg, rows gathered).  Equal shards
     (each rank localises batch x steps images), ONE all-gather (RCCL on GPU tensors, gloo on CPU tensors in the test);
@@ -278,14 +291,20 @@ def main():
         args.batch = 24 if args.mlr else 47
 
     stub = bool(os.environ.get("XL_BENCH_STUB"))       # tests only: the rank / collective / timing plumbing on CPU (gloo)
+    # XL_BENCH_SHARED_GPU=1 (tests/test_multiprocess_gpu.py): the multi-process preflight on a ONE-GPU box.  Every rank runs the
+    # real kernels on cuda:0; RCCL refuses two ranks on one device, so the gather and the max-over-ranks go through gloo on CPU
+    # tensors and the line says rccl_ranks = 0.  Not a scaling measurement: the ranks share one chip.
+    shared = bool(os.environ.get("XL_BENCH_SHARED_GPU"))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` without a launcher: become the launcher (one rank per GPU, rendezvous on 127.0.0.1)
         raise SystemExit(respawn_under_torchrun(args.gpus, sys.argv[1:]))
 
     import torch
-    rank, local_rank, world, dist, rccl_ranks = init_ranks(args.gpus, "gloo" if stub else "nccl")
+    rank, local_rank, world, dist, rccl_ranks = init_ranks(args.gpus, "gloo" if (stub or shared) else "nccl")
     if stub:
         return run_stub(args, rank, world, dist)
+    if shared:
+        local_rank, rccl_ranks = 0, 0
     from crossloc_amd import networks, synth, evaluation
     from crossloc_amd.weights import seeded_state_dict
     import dsacstar
@@ -414,8 +433,10 @@ def main():
     t_err, r_err = evaluation.pose_errors(gt_poses.repeat(K, 1, 1), est)
     local = torch.stack([t_err, r_err], 1)
     total_imgs = world * B * K
-    med_t_cm, med_r_deg, n_rows = gather_and_median(local, world, dist)
+    med_t_cm, med_r_deg, n_rows = gather_and_median(local.cpu() if shared else local, world, dist)
     assert n_rows == total_imgs
+    if os.environ.get("XL_BENCH_DUMP_POSES"):          # per-rank poses of every image of every step, in step order (tests)
+        np.save("%s.rank%d.npy" % (os.environ["XL_BENCH_DUMP_POSES"], rank), est.cpu().numpy())
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -463,7 +484,10 @@ def main():
                                    + " + HIP dsacstar.forward_rgb, 480x720 frames, 60x90 coordinate grid",
                        "hypotheses": NH, "batch_per_gpu": B, "global_batch": B * world,
                        "parallelism": "images sharded over %d GPU(s), no data-path collective" % world,
-                       "rccl_ranks": rccl_ranks,
+                       "rccl_ranks": rccl_ranks, "rows_gathered": n_rows,
+                       **({"preflight": "XL_BENCH_SHARED_GPU=1: %d ranks share cuda:0 (RCCL refuses two ranks on one device): gloo "
+                                        "all-gather / max-over-ranks on CPU tensors, real kernels; not a scaling measurement" % world}
+                          if shared else {}),
                        "solver_input": "the network's own output tensor pred[:, :3] (strided NCHW view, CNN stream -> solver "
                                        "stream); untrained seeded weights do not predict a scene, so synthetic scene "
                                        "coordinates (0.5 m noise, 30% outliers) are written into its coordinate channels "
@@ -523,7 +547,7 @@ def main():
             "cpu_baseline": cpu,
         }
         out["config"].update(secondary)
-        print(json.dumps(out))
+        print(json.dumps(strict(out), allow_nan=False))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -598,6 +622,97 @@ def _eager_coord_loss(sc, unc, poses, gt, focal=480.0, W=720, H=480):
     s = unc.reshape(B, -1).clamp(min=1e-7)
     lu = 3.0 * torch.log(s) + d.square().clamp(min=1e-7) / (2.0 * s.square().clamp(min=1e-7))
     return (lu * g + lr).sum() / g.numel()
+
+
+def inference_leg(dev, env, n_hyp, batch=47, steps=5, warmup=2):
+    """The headline step (CNN forward + solver through PipelinedLocalizer, 480x720, `batch` frames) under the environment
+    switches `env` (read when a plan is lowered), outside the headline's timed region: wall clock over `steps` steps between
+    synchronisations, and the launches of the 3x3 512 -> 512 layers timed by HIP events on their own stream like the headline.
+    Returns (images/s, average launch ms of the dominant kernel, launches timed, Z of that launch)."""
+    import torch
+    from crossloc_amd import evaluation, networks, synth
+    from crossloc_amd.weights import seeded_state_dict
+    H, W = 480, 720
+    saved = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        net = networks.TransPoseNet(torch.tensor(synth.SCENE_MEAN, dtype=torch.float32), False, False, 2, 2, 3, 1)
+        net.load_state_dict(seeded_state_dict(net, seed=2021))
+        net = net.to(dev).eval()
+        images = torch.rand((batch, 3, H, W), generator=torch.Generator().manual_seed(2021)).to(dev)
+        coords = torch.from_numpy(synth.make_batch(2021, batch, noise=0.5, outlier_ratio=0.3)[0]).to(dev)
+        pipe = evaluation.PipelinedLocalizer(net, n_hyp, synth.FOCAL, H, W)
+        for s_ in range(warmup):
+            pipe.submit(images, image0=s_ * batch, plant=coords)
+        pipe.finish()
+        torch.cuda.synchronize()
+        plan = [p for k, p in net._plans.items() if k[0] == batch][0]
+        L = networks._bind()
+        L.xl_cnn_prof_begin.argtypes = [ctypes.c_int]
+        L.xl_cnn_prof_end.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+        L.xl_cnn_prof_filter(1, 0)
+        cap = len(plan.op_array) * steps
+        L.xl_cnn_prof_begin(cap)
+        t0 = time.perf_counter()
+        for s_ in range(steps):
+            pipe.submit(images, image0=s_ * batch, plant=coords)
+        pipe.finish()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        idx, typ, ms = (ctypes.c_int32 * cap)(), (ctypes.c_int32 * cap)(), (ctypes.c_float * cap)()
+        n = L.xl_cnn_prof_end(idx, typ, ms, cap)
+        dom, z = [], 0
+        for i in range(max(n, 0)):
+            op = plan.op_array[idx[i]]
+            if typ[i] == networks.XL_OP_CONV and op.Cin == 512 and op.Cout == 512 and op.stride == 1 and (
+                    (op.ksize == 3 and op.nchunks2 <= 1) or (op.ksize == 1 and op.nchunks2 > 1)):
+                dom.append(ms[i])
+                z = int(op.nchunks2) if op.nchunks2 > 1 else 0
+        del pipe, plan, net
+        torch.cuda.empty_cache()
+        return batch * steps / dt, (float(np.mean(dom)) if dom else None), len(dom), z
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def gemm_error_leg(dev, frames=47):
+    """What justifies `dtype: f32` for the split-bf16 GEMMs, measured on the bench box: the 64 batched [7050 x 512] x [512 x 512]
+    products of a Winograd layer at `frames` frames on random fp32 operands, through the split kernel (six bf16-MFMA passes) and
+    through the fp32-MFMA kernel, both against a float64 product of the SAME fp32 operands (torch.matmul in float64 on the GPU - a
+    checker, not part of the product path).  Returns max |M - M64| / max |M64| for both."""
+    import torch
+    from crossloc_amd import networks
+    Z, T, C, N = 64, frames * 150, 512, 512
+    g = torch.Generator(device="cpu").manual_seed(99)
+    V = torch.randn((Z, T, C), generator=g).to(dev)
+    U = (torch.randn((Z, N, C), generator=g) * (1.0 / C) ** 0.5).to(dev)
+    planes = networks._Plan.split_bf16_interleaved(U, C)
+    out = {}
+    for name, flags, w in (("split", networks.CONV_SPLIT_BF16 | networks.CONV_SPLIT_IL | networks.CONV_SPLIT_ACT, planes), ("f32", 0, U)):
+        Mb = torch.empty((Z, T, N), dtype=torch.float32, device=dev)
+        op = networks.XlOp()
+        op.type = networks.XL_OP_CONV
+        op.B, op.Hi, op.Wi, op.Cin, op.Ho, op.Wo, op.Cout = frames, 10, 15, C, 10, 15, N
+        op.ksize, op.stride, op.ld_in, op.ld_out, op.nchunks2, op.flags = 1, 1, C, N, Z, flags
+        op.reserved_i = 256 if flags else 0
+        op.in_, op.w, op.out = V.data_ptr(), w.data_ptr(), Mb.data_ptr()
+        arr = (networks.XlOp * 1)(op)
+        networks._check(networks._bind().xl_cnn_run(arr, 1, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        torch.cuda.synchronize()
+        err = scale = 0.0
+        for z0 in range(0, Z, 8):                                            # float64 reference, 8 products at a time
+            ref = torch.matmul(V[z0:z0 + 8].double(), U[z0:z0 + 8].double().transpose(1, 2))
+            err = max(err, (Mb[z0:z0 + 8].double() - ref).abs().max().item())
+            scale = max(scale, ref.abs().max().item())
+        out[name] = err / scale
+        del Mb
+    del V, U, planes
+    torch.cuda.empty_cache()
+    return out["split"], out["f32"]
 
 
 def secondary_configs(dev, n_hyp, train_batch=16, mlr_batch=24, steps=5):
@@ -740,6 +855,22 @@ def secondary_configs(dev, n_hyp, train_batch=16, mlr_batch=24, steps=5):
     out["mlr3_ms_per_step"] = round(ms, 2)
     out["mlr3_fwd_algorithmic_tflops"] = round(FWD_GFLOP_PER_IMAGE_3ENC * B / ms, 1)
     out["mlr3_median_err_cm"] = round(float(torch.median(t_err).item()) * 100.0, 3)
+    del pipe, net
+    torch.cuda.empty_cache()
+
+    # ---- the strict fp32-MFMA form of the headline (every GEMM on v_mfma_f32_32x32x2_f32, XL_GEMM_SPLIT_BF16=0) and the GEMM
+    # error figures that justify calling the split-bf16 form f32: driver-visible, not builder-run files
+    ips, dom_ms, n_dom, z = inference_leg(dev, {"XL_GEMM_SPLIT_BF16": "0"}, n_hyp)
+    out["f32_mfma_images_per_s"] = round(ips, 1)
+    if dom_ms:
+        flop = (z * 2.0 * (47 * 150) * 512 * 512) if z else 2.0 * (47 * 5400) * 512 * 4608
+        out["f32_mfma_dominant_kernel"] = {"avg_launch_ms": round(dom_ms, 4), "launches_timed": n_dom,
+                                           "tflops": round(flop / (dom_ms * 1e-3) / 1e12, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                                           "frac": round(flop / (dom_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)}
+    esp, e32 = gemm_error_leg(dev)
+    out["split_gemm_err_vs_f64"] = float("%.3e" % esp)
+    out["f32_mfma_err_vs_f64"] = float("%.3e" % e32)
+    out["split_gemm_err_over_f32_mfma_err"] = round(esp / max(e32, 1e-30), 2)
     return out
 
 
@@ -798,6 +929,18 @@ def cpu_baseline(net, images, coords_np, n_hyp, num_mlr=0, frames=5):
     t_dsac_1 = solver(1)
     t_dsac_n = solver(cores)
     t_cnn = float(np.median(t_cnn))
+
+    # BASELINE configs[0]: ONE 480x720 frame, coord regression forward + forward_rgb with 64 hypotheses on the CPU path
+    def solver64(nthreads):
+        dsac_oracle.set_num_threads(nthreads)
+        dsac_oracle.forward_rgb(coords_np[0], 64, 10.0, 480.0, 360.0, 240.0, 100.0, 100.0, 8)
+        ts = []
+        for b in range(frames):
+            t0 = time.perf_counter()
+            dsac_oracle.forward_rgb(coords_np[b], 64, 10.0, 480.0, 360.0, 240.0, 100.0, 100.0, 8, image=b)
+            ts.append(time.perf_counter() - t0)
+        return float(np.median(ts))
+    t64_1, t64_n = solver64(1), solver64(cores)
     return {"value": round(1.0 / (t_cnn + t_dsac_n), 3), "unit": "images/s", "cores": cores, "kind": "port",
             "sample": "median of %d frames each, after one warm-up frame: CNN forward (PyTorch CPU fp32, batch 1, %d threads) + "
                       "oracle dsacstar %d hyps (C/OpenMP, %d threads); reference binary unbuildable (needs OpenCV)" % (
@@ -805,7 +948,13 @@ def cpu_baseline(net, images, coords_np, n_hyp, num_mlr=0, frames=5):
             "cpu_model": model, "hardware_threads": threads, "physical_cores": phys,
             "cnn_s_per_image": round(t_cnn, 4), "dsac_s_per_image": round(t_dsac_n, 5),
             "dsac_s_per_image_omp1": round(t_dsac_1, 5),
-            "value_omp1_solver": round(1.0 / (t_cnn + t_dsac_1), 3)}
+            "value_omp1_solver": round(1.0 / (t_cnn + t_dsac_1), 3),
+            "configs0_single_image_64hyps": {
+                "workload": "BASELINE configs[0]: one 480x720 frame, CNN forward (PyTorch CPU fp32) + forward_rgb with 64 "
+                            "hypotheses (C/OpenMP restatement), no GPU",
+                "latency_s": round(t_cnn + t64_n, 4), "images_per_s": round(1.0 / (t_cnn + t64_n), 3),
+                "cnn_s": round(t_cnn, 4), "dsac_s": round(t64_n, 5), "dsac_s_omp1": round(t64_1, 5),
+                "latency_s_omp1_solver": round(t_cnn + t64_1, 4)}}
 
 
 if __name__ == "__main__":

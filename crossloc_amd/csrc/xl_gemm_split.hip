@@ -658,8 +658,10 @@ __device__ __forceinline__ void split_pair(f32x2 v, unsigned &w1, unsigned &w2, 
 // NW = waves per workgroup: 8 -> tiles of 256 x 256 (2 x 4 waves of 128 x 64), the throughput form; 4 -> tiles of 128 x 128
 // (2 x 2 waves of 64 x 64) for launches whose 256 x 256 tiles would leave most of the 256 CUs idle (a single frame: 44 tiles).
 // Every output element accumulates its K-steps and term pairs in the same order in both forms: bitwise the same result.
-// ZB = 1: the instantiation of the batched launches (Z > 1, the GEMMs of a Winograd layer): the same code under a name of its
-// own, so that a profiler's dispatch table tells the dominant kernel of the forward pass from the 1x1 layers.
+// ZB = 1 / 2: the instantiations of the batched launches (Z > 1, the GEMMs of a Winograd layer): the same code under names of
+// their own, so that a profiler's dispatch table tells them from the 1x1 layers - and, ZB = 2, the 512 -> 512 layers (the
+// dominant kernel of the forward pass: compile-time K-step count) from the batched launches of every other shape.  The grid
+// of a persistent kernel is the CU count whatever the problem, so the NAME is the only key a dispatch table has.
 // BN = tile columns: 256 x 256 (NW 8, BN 256), 256 x 128 (NW 8, BN 128: 4 x 2 waves of 64 x 64 - launches that would run a
 // last round of 256 x 256 tiles mostly empty) or 128 x 128 (NW 4, BN 128).
 template <bool NORM, bool ACC = false, int NW = 8, int ZB = 0, int BN = (NW == 8 ? 256 : 128)>  // ACC: out += result
@@ -719,7 +721,7 @@ void split_conv1x1_kernel(SplitConvArgs a)
 
     constexpr unsigned OOB = 0x80000000u;
     const long long rowU = (long long)a.C * 6;
-    const int nk = a.C / 16;
+    const int nk = ZB == 2 ? 32 : a.C / 16;
 
     // ---- stream two K-steps ahead of the multiplies: weights by LDS-DMA (3 instructions per wave and step), activations
     // into registers (row tid >> 1, channels 8 (tid & 1) .. + 7 of the step; two register sets, by the parity of the step)
@@ -1102,13 +1104,15 @@ static int launch_split_conv1x1(const xl_op &op, SplitConvArgs a, bool norm, int
     a.nbn = (op.Cout + BN - 1) / BN;
     const size_t lds = 3 * BN * kIUnit + 2 * BM * kIUnit + 2 * 16 * (64 * NW) + 16384 + 4096 + 1024;
     const bool accumulate = (op.flags & XL_CONV_ACCUMULATE) != 0;
+    const bool dominant = Z > 1 && op.Cin == 512 && op.Cout == 512 && !accumulate && !norm;     // the 512 -> 512 Winograd layers
     const void *fn = accumulate ? reinterpret_cast<const void *>(split_conv1x1_kernel<false, true, NW, 0, BN>)
                    : norm ? reinterpret_cast<const void *>(split_conv1x1_kernel<true, false, NW, 0, BN>)
+                   : dominant ? reinterpret_cast<const void *>(split_conv1x1_kernel<false, false, NW, 2, BN>)
                    : Z > 1 ? reinterpret_cast<const void *>(split_conv1x1_kernel<false, false, NW, 1, BN>)
                            : reinterpret_cast<const void *>(split_conv1x1_kernel<false, false, NW, 0, BN>);
-    static XlLdsLimit configured[4];
+    static XlLdsLimit configured[5];
     int cfgDev;
-    const int slot = accumulate ? 2 : (norm ? 1 : (Z > 1 ? 3 : 0));
+    const int slot = accumulate ? 2 : (norm ? 1 : (dominant ? 4 : (Z > 1 ? 3 : 0)));
     if (configured[slot].needs(lds, &cfgDev)) {
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return XL_ERR_HIP;
         configured[slot].done(lds, cfgDev);
@@ -1119,6 +1123,7 @@ static int launch_split_conv1x1(const xl_op &op, SplitConvArgs a, bool norm, int
     if (grid > ((nwg + 7) & ~7)) grid = (nwg + 7) & ~7;
     if (accumulate) hipLaunchKernelGGL((split_conv1x1_kernel<false, true, NW, 0, BN>), dim3(grid), dim3(64 * NW), lds, st, a);
     else if (norm) hipLaunchKernelGGL((split_conv1x1_kernel<true, false, NW, 0, BN>), dim3(grid), dim3(64 * NW), lds, st, a);
+    else if (dominant) hipLaunchKernelGGL((split_conv1x1_kernel<false, false, NW, 2, BN>), dim3(grid), dim3(64 * NW), lds, st, a);
     else if (Z > 1) hipLaunchKernelGGL((split_conv1x1_kernel<false, false, NW, 1, BN>), dim3(grid), dim3(64 * NW), lds, st, a);
     else hipLaunchKernelGGL((split_conv1x1_kernel<false, false, NW, 0, BN>), dim3(grid), dim3(64 * NW), lds, st, a);
     return XL_OK;

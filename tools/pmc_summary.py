@@ -1,7 +1,10 @@
 """Summarise the per-pass rocprofv3 counter_collection.csv files of one `-i <pmc file>` run over bench.py into a compact
 table: one row per (kernel of this library, grid size, counter) with the number of dispatches, the mean / min / max
-counter value and the mean duration of those dispatches in the profiled pass (persistent kernels: also per duration
-class, appended to the kernel name).
+counter value and the mean duration of those dispatches in the profiled pass.  Persistent kernels launch one workgroup per CU
+whatever the problem, so a dispatch table can tell their launch shapes apart by NAME only: the dominant kernel (the 64 batched
+GEMMs of a 512 -> 512 Winograd layer) has an instantiation of its own, split_conv1x1_kernel<false,false,8,2,256>, and its row
+holds launches of exactly that shape.  The other persistent kernels serve several layers; their rows are additionally keyed by
+a duration class ("@<us>", powers of 4) - a convenience for reading the table, NOT a shape key: such a row may mix layers.
     python tools/pmc_summary.py <rocprof output dir> <out.csv>
 Derived figures (GB/s, VALU busy, ...) are computed by tools/pmc_derive.py from the table."""
 import csv
@@ -25,9 +28,10 @@ def main():
                 continue
             d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
             name = m.group(1).replace(" ", "")
-            if "persist" in name or name.startswith(("split_conv1x1_kernel", "split_conv3x3s2_kernel")):
-                # persistent kernels: the grid is the CU count whatever the problem, so the layers
-                name += "@%dus" % (4 ** round(math.log(max(d, 1.0), 4)))  # are told apart by their duration class (power of 4)
+            if name.startswith("split_conv1x1_kernel<false,false,") and name.split(",")[3] == "2":
+                pass                                  # ZB = 2: one launch shape by construction (Cin = Cout = 512, Z = 64)
+            elif "persist" in name or name.startswith(("split_conv1x1_kernel", "split_conv3x3s2_kernel")):
+                name += "@%dus" % (4 ** round(math.log(max(d, 1.0), 4)))  # (reading aid only, see the header)
             key = (name, int(r["Grid_Size"]), int(r["VGPR_Count"]) + int(r["Accum_VGPR_Count"]),
                    int(r["LDS_Block_Size"]), r["Counter_Name"])
             v = float(r["Counter_Value"])
