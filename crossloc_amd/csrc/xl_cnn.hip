@@ -1387,6 +1387,25 @@ void wino6_out_kernel(const float *__restrict__ M, const float *__restrict__ bia
     if (bias) bv = *reinterpret_cast<const V *>(bias + cch);
     V s1 = V(0.f), s2 = V(0.f);
     const __amdgpu_buffer_rsrc_t srdM = __builtin_amdgcn_make_buffer_rsrc((void *)M, 0, (int)(unsigned)(64 * T * C * 4 > 0xffffffffLL ? 0xffffffffLL : 64 * T * C * 4), 0x00020000);
+    // VW = 2: the first frequency column of a tile is fetched while the tile BEFORE it is still being reduced and stored (round
+    // 4): without that every tile started with an empty memory pipeline - 8 loads issued, one full HBM latency waited - and the
+    // 36 stores of a tile went out with no read in flight behind them.
+    typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+    const unsigned zsB = (unsigned)(zs * 4);
+    auto tile_off = [&](int tl) { return (unsigned)(((long long)n * Timg + tl) * ts + cch) * 4u; };
+    auto ldp = [&](unsigned vo, int plane) {
+        // frequency planes through one buffer descriptor: the lane part of the address is ONE VGPR and the plane offset a
+        // scalar (with flat pointers the compiler keeps 64 loop-invariant 64-bit addresses in registers)
+        return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(srdM, (int)vo, (int)(plane * zsB), 0));
+    };
+    f32x2 colN[8];
+    if constexpr (VW == 2) {
+        if (k * tpb + sub < t1) {
+            const unsigned vo0 = tile_off(k * tpb + sub);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) colN[i] = ldp(vo0, 8 * i);
+        }
+    }
     for (int tl = k * tpb + sub; tl < t1; tl += S) {
         const int ty = tl / Tw, tx = tl - ty * Tw;
         const float *m = M + ((long long)n * Timg + tl) * ts + cch;
@@ -1432,26 +1451,16 @@ void wino6_out_kernel(const float *__restrict__ M, const float *__restrict__ bia
             for (int pI = 0; pI < 6; ++pI)
 #pragma unroll
                 for (int qI = 0; qI < 6; ++qI) y[pI][qI] = bv;
-            // frequency planes through one buffer descriptor: the lane part of the address is ONE VGPR and the plane
-            // offset a scalar (with flat pointers the compiler keeps 64 loop-invariant 64-bit addresses in registers)
-            const unsigned vo = (unsigned)(((long long)n * Timg + tl) * ts + cch) * 4u;
-            const unsigned zsB = (unsigned)(zs * 4);
-            auto ldp = [&](int plane) {
-                typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-                return __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b64(srdM, (int)vo, (int)(plane * zsB), 0));
-            };
-            V colN[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) colN[i] = ldp(8 * i);
+            const unsigned vo = tile_off(tl);
+            // the tile after this one (behind the last tile: this tile's own first column again - a valid address, L2 hits)
+            const unsigned voNext = tile_off(tl + S < t1 ? tl + S : tl);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 V col[8], o[6];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) col[i] = colN[i];
-                if (j + 1 < 8) {
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) colN[i] = ldp(8 * i + j + 1);
-                }
+                for (int i = 0; i < 8; ++i) colN[i] = j + 1 < 8 ? ldp(vo, 8 * i + j + 1) : ldp(voNext, 8 * i);
                 __builtin_amdgcn_sched_barrier(0);
                 wino6_at(col, o);
 #pragma unroll

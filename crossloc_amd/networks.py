@@ -729,9 +729,10 @@ class _Plan:
             split = nf * T * max(C, cout) * 6 < 2 ** 31 - 1             # (the first form addresses a plane as a whole)
         return split, split_il, split_act
 
-    def conv_wino(self, act, conv, norm, flags, aux, m, deferred=None, defer=False, fold=None, share=False):
+    def conv_wino(self, act, conv, norm, flags, aux, m, deferred=None, defer=False, fold=None, share=False, dst=None):
         """conv3x3 + GroupNorm(+epilogue) as F(m x m, 3x3): input transform, (m+2)^2 GEMMs in one batched launch, output
-        transform that also emits the GroupNorm partial sums, GN_FINAL, GN_APPLY (in place)."""
+        transform that also emits the GroupNorm partial sums, GN_FINAL, GN_APPLY (in place; `dst` = (tensor, ld, channel
+        offset): the apply writes the activation there instead - an encoder's last layer into its slice of the concat buffer)."""
         t, H, W, C, ld, off = act
         B, cout = self.B, conv.out_channels
         Th, Tw = -(-H // m), -(-W // m)
@@ -796,6 +797,13 @@ class _Plan:
         zblocks = max(1, cout // (256 if m == 6 else 512))          # channel blocks of the output-transform grid
         while tpb > 1 and B * -(-(Th * Tw) // tpb) * zblocks < 1024:
             tpb //= 2                                # small batches: more, shorter workgroups (latency-bound otherwise)
+        if m == 6 and cout % 512 == 0 and not os.environ.get("XL_WINO_OUT_TPB16"):
+            # the two-channels-per-lane form: 2 workgroups of 4 waves are resident per CU (230 VGPRs), so a launch costs
+            # (rounds of 512 workgroups) x (tiles per workgroup + a workgroup's start-up, ~half a tile).  47 frames of 150
+            # tiles: 15 tiles per workgroup = 470 workgroups of equal length in ONE round (16: nine chunks of 16 and one of 6
+            # per image - the round takes 16 tile-times for 13.8 tiles of work per slot)
+            zb = cout // 512
+            tpb = min(range(1, 17), key=lambda t: (-(-(B * -(-(Th * Tw) // t) * zb) // 512) * (t + 0.5), -t))
         if os.environ.get("XL_WINO_OUT_TPB"):
             tpb = int(os.environ["XL_WINO_OUT_TPB"])
         if self.separate_stats:
@@ -827,7 +835,7 @@ class _Plan:
             else:
                 self.free.setdefault(V.numel(), []).append(V)
             self.tape.append(dict(kind="conv", conv=conv, x=act, raw=y, v=kept_v, wm=m))
-            return self.gn(y, norm, flags, aux, pre_stats=(stats_t, nchunks))
+            return self.gn(y, norm, flags, aux, pre_stats=(stats_t, nchunks), out=dst)
         self.max_stats = max(self.max_stats, B * nchunks * G * 2)
         self.stats_ops.append(len(self.ops))
         self.ops.append(op)
@@ -844,6 +852,16 @@ class _Plan:
             ap.aux = aux[0].data_ptr() + 4 * aux[5]
             ap.ld_aux = aux[4]
         ap.out, ap.ld_out = ap.in_, cout
+        if dst is not None:                            # the apply is a pass of its own: raw conv output -> the destination slice
+            ot, old, ooff = dst
+            ap.out, ap.ld_out = ot.data_ptr() + 4 * ooff, old
+            aux_ap = self._aux_take(aux)
+            if aux_ap is not None:
+                self._aux_apply(aux_ap)
+            self.stats_ops.append(len(self.ops))
+            self.ops.append(ap)
+            self.release(out)
+            return (ot, H, W, cout, old, ooff)
         if defer and flags == GN_RELU_IN and aux is None and not os.environ.get("XL_NO_DEFERRED_GN"):
             # the only consumer applies it while loading its operand (a 1x1 conv: norm_on_load_ok; or a Winograd transform)
             if not hasattr(self, "pending_gn"):
@@ -862,13 +880,25 @@ class _Plan:
     def fold_ok(self):
         return not self.train and not os.environ.get("XL_NO_DEFERRED_GN") and not os.environ.get("XL_NO_FOLD_GN")
 
-    def cgr(self, act, conv, norm, flags=GN_RELU_IN, aux=None, defer=False, share=False):
+    def cgr(self, act, conv, norm, flags=GN_RELU_IN, aux=None, defer=False, share=False, out=None):
         """conv -> GroupNorm -> epilogue.  `defer`: the caller promises that the next cgr() is the only consumer of the
         result; when that consumer is an F(4x4,3x3) layer its input transform applies the normalisation and the separate
-        GN_APPLY pass (one read + one write of the activation) disappears."""
+        GN_APPLY pass (one read + one write of the activation) disappears.  `out` = (tensor, ld, channel offset): the
+        activation is written there (an encoder's last layer into its slice of the MLR concat buffer)."""
         pend = getattr(self, "pending_gn", {}).pop(self._act_key(act), None)
         fold = getattr(self, "pending_fold", {}).pop(self._act_key(act), None)
         m = self.wino_tile(act, conv)
+        if out is not None and not m:                  # no Winograd form for this layer: direct conv, then the apply into `out`
+            if pend is not None:
+                self.stats_ops.append(len(self.ops))
+                self.ops.append(pend)
+            if fold is not None:
+                self._fold_materialise(fold, act)
+            y = self.conv(act, conv)
+            r = self.gn(y, norm, flags, aux, out=out)
+            if r[0] is not y[0]:
+                self.release(y[0])
+            return r
         stem = self.stem_split_ok(act, conv)
         cpg = conv.out_channels // norm.num_groups
         # a 1x1 layer on the split pipe applies a pending GroupNorm on load at ANY batch size (the tile-count condition of
@@ -888,7 +918,7 @@ class _Plan:
                 self._fold_materialise(fold, act)
                 fold = None
         if m:
-            return self.conv_wino(act, conv, norm, flags, aux, m, pend, defer=defer, fold=fold, share=share)
+            return self.conv_wino(act, conv, norm, flags, aux, m, pend, defer=defer, fold=fold, share=share, dst=out)
         if stem:
             # conv on the split pipe with the producer's GroupNorm applied on load; statistics pass; the apply is left to the
             # consumer (the next stem layer, or - conv4 - the input transform of res1_conv1)
@@ -1124,11 +1154,22 @@ class _Plan:
                 self.release(sk[0])
         for i, block in enumerate(enc.enc_add_res_block_ls):
             if i == n_add - 1 and out is not None:
-                x = self.cgr(res, block[0], block[1])
-                x2 = self.cgr(x, block[3], block[4]); self.release(x[0])
-                y = self.conv(x2, block[6]); self.release(x2[0])
-                r = self.gn(y, block[7], GN_RELU_IN | GN_ADD | GN_RELU_OUT, aux=res, out=out)
-                self.release(y[0]); self.release(res[0])
+                # (round 4: like every other block - GroupNorm applies deferred to the consumer, the last 3x3 layer as
+                #  Winograd - except that the block's final apply writes into the encoder's slice of the concat buffer.
+                #  Until round 3 this block ran undeferred and its last layer as the DIRECT fp32-MFMA convolution: 4.3 ms
+                #  instead of 0.9 per encoder at 24 frames)
+                if os.environ.get("XL_MLR_LAST_DIRECT"):          # the round-3 lowering, kept for the A/B
+                    x = self.cgr(res, block[0], block[1])
+                    x2 = self.cgr(x, block[3], block[4]); self.release(x[0])
+                    y = self.conv(x2, block[6]); self.release(x2[0])
+                    r = self.gn(y, block[7], GN_RELU_IN | GN_ADD | GN_RELU_OUT, aux=res, out=out)
+                    self.release(y[0]); self.release(res[0])
+                    res = r
+                    continue
+                x = self.cgr(res, block[0], block[1], defer=True)
+                x2 = self.cgr(x, block[3], block[4], defer=True); self.release(x[0])
+                r = self.cgr(x2, block[6], block[7], GN_RELU_IN | GN_ADD | GN_RELU_OUT, aux=res, out=out)
+                self.release(x2[0]); self.release(res[0])
                 res = r
             else:
                 res = self.res_block(res, block)

@@ -293,26 +293,41 @@ def loss_b16_goldens():
     cam_mat = get_cam_mat(720, 480, 480.0)
     out = {}
 
-    def record(tag, loss, rate, p, u):
+    def record(tag, loss, rate, p, u, f64=False):
         loss.backward()
-        out[tag + "_loss"] = np.array(loss.item(), np.float64)
-        out[tag + "_rate"] = np.array(float(rate))
+        if not f64:
+            out[tag + "_loss"] = np.array(loss.item(), np.float64)
+            out[tag + "_rate"] = np.array(float(rate))
         for nm, t in (("dpred", p), ("dunc", u)):
             g = t.grad.double().numpy() if t.grad is not None else np.zeros(tuple(t.shape))
+            if f64:
+                # the same reference functions evaluated in float64: how far the reference's OWN fp32 result is from the
+                # exact gradient, element by element (fp32 cancellation in |PX - PX_gt| at |X| ~ 500 m) - the tests allow
+                # the HIP path that band on top of their tolerance
+                out["%s_%s_sample64" % (tag, nm)] = g[:, :, ::4, ::5].astype(np.float32)
+                continue
             out["%s_%s_moments" % (tag, nm)] = np.array([g.sum(), np.abs(g).sum(), np.sqrt((g * g).sum())])
             out["%s_%s_sample" % (tag, nm)] = g[:, :, ::4, ::5].astype(np.float32)
 
-    for mode in ("MLE", None):
-        p = torch.tensor(I["pred"], requires_grad=True); u = torch.tensor(I["unc"], requires_grad=True)
-        loss, rate = quiet(scene_coords_regression_loss, 0.1, 100.0, 1000.0, 50.0, mode, pixel_grid, -1, cam_mat,
-                           p, u, torch.tensor(I["poses"]), torch.tensor(I["gt"]), 'mean')
-        record("coord_%s" % (mode or "plain"), loss, rate, p, u)
-        p = torch.tensor(I["depth_pred"], requires_grad=True); u = torch.tensor(I["unc"], requires_grad=True)
-        loss, rate = quiet(depth_regression_loss, 0.1, 10.0, mode, -1, p, u, torch.tensor(I["depth_gt"]), 'mean')
-        record("depth_%s" % (mode or "plain"), loss, rate, p, u)
-        p = torch.tensor(I["normal_logits"], requires_grad=True); u = torch.tensor(I["unc"], requires_grad=True)
-        loss, rate = quiet(normal_regression_loss, 10.0, mode, -1, p, u, torch.tensor(I["normal_gt"]), 'mean')
-        record("normal_%s" % (mode or "plain"), loss, rate, p, u)
+    for dt in (torch.float32, torch.float64):
+        f64 = dt == torch.float64
+        torch.set_default_dtype(dt)
+        pg, cm = pixel_grid.to(dt), cam_mat.to(dt)
+
+        def T(name, grad=False):
+            return torch.tensor(I[name], dtype=dt, requires_grad=grad)
+        for mode in ("MLE", None):
+            p, u = T("pred", True), T("unc", True)
+            loss, rate = quiet(scene_coords_regression_loss, 0.1, 100.0, 1000.0, 50.0, mode, pg, -1, cm,
+                               p, u, T("poses"), T("gt"), 'mean')
+            record("coord_%s" % (mode or "plain"), loss, rate, p, u, f64)
+            p, u = T("depth_pred", True), T("unc", True)
+            loss, rate = quiet(depth_regression_loss, 0.1, 10.0, mode, -1, p, u, T("depth_gt"), 'mean')
+            record("depth_%s" % (mode or "plain"), loss, rate, p, u, f64)
+            p, u = T("normal_logits", True), T("unc", True)
+            loss, rate = quiet(normal_regression_loss, 10.0, mode, -1, p, u, T("normal_gt"), 'mean')
+            record("normal_%s" % (mode or "plain"), loss, rate, p, u, f64)
+    torch.set_default_dtype(torch.float32)
     out["input_checksums"] = np.array([golden_inputs.checksum(I[k]) for k in sorted(I)])
     np.savez_compressed(os.path.join(HERE, "losses_b16.npz"), **out)
     _print("losses_b16.npz", {k: (v.shape if v.ndim else float(v)) for k, v in out.items()})

@@ -13,7 +13,8 @@ path; measured 6e-5 m = one fp32 ulp at |X| ~ 500 m), sigma 2e-3 relative.  Para
 float64 evaluation of the reference module (no ReLU-mask flips of its own); the fp32 forward on the GPU may put a
 pre-activation that is within an ulp of 0 on the other side, which moves single elements - so every tensor is held to a
 relative L2 error (<= 5e-2; typical 1e-5) on its strided sample, and its L2 norm to 2e-2.  Losses: 1e-4 on the value,
-gradient moments 1e-3, samples 2e-3 relative + 1e-4 of the largest element (fp32 cancellation in |PX - PX_gt| at 500 m).
+gradient moments 1e-3, samples 2e-3 relative + 1e-4 of the largest element against the float64 evaluation of the reference
+functions, plus twice the reference's own fp32-to-float64 distance at that element (fp32 cancellation in |PX - PX_gt| at 500 m).
 """
 import os
 import sys
@@ -115,7 +116,16 @@ def _check_loss16(mod, on_gpu, rel_loss, rel_mom, rel_s):
             assert abs(got_m[0] - ref_m[0]) <= rel_mom * max(ref_m[1], 1e-30), (tag, nm, got_m, ref_m)
             assert np.allclose(got_m[1:], ref_m[1:], rtol=rel_mom, atol=1e-30), (tag, nm, got_m, ref_m)
             s = g[:, :, ::4, ::5]
-            assert np.allclose(s, ref_s, rtol=rel_s, atol=1e-4 * max(np.abs(ref_s).max(), 1e-30)), (tag, nm)
+            # element-wise against the float64 evaluation of the reference functions, allowing - on top of the tolerance - twice
+            # the distance the reference's OWN fp32 result keeps from it at that element (a near-cancelling sum of the distance
+            # and reprojection terms leaves single elements of the fp32 reference 2e-2 off; measured on the MI355X: the kernel
+            # lands closer to the float64 value than the fp32 reference does)
+            ref64 = L16["%s_%s_sample64" % (tag, nm)].astype(np.float64)
+            atol = 1e-4 * max(np.abs(ref_s).max(), 1e-30)
+            excess = np.abs(s - ref64) - rel_s * np.abs(ref64) - 2.0 * np.abs(ref_s - ref64)
+            i = np.unravel_index(np.argmax(excess), excess.shape)
+            assert excess[i] <= atol, (tag, nm, "worst element", i, float(s[i]), float(ref_s[i]), float(ref64[i]), "excess / atol",
+                                       float(excess[i] / atol), "elements over", int((excess > atol).sum()))
 
 
 def test_loss_oracle_at_batch16_vs_reference_fixture():
