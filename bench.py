@@ -454,7 +454,7 @@ def main():
                 "split%d" if mfma_passes == 6 else "wino%d") % wino if wino else "direct"
         traffic, traffic_source = lookup_traffic(form, Bl)
         if mfma_passes == 6:
-            kernel_name = ("split_conv1x1_kernel<false,false,8,1,256> (256x256 tiles; V read as fp32 and split into its three bf16 "
+            kernel_name = ("split_conv1x1_kernel<false,false,8,2,256> (256x256 tiles; V read as fp32 and split into its three bf16 "
                            "terms inside the kernel, weights as interleaved 3xbf16 planes)" if split_act else
                            "split_gemm_persist_kernel<512> (256x256 tiles, interleaved 3xbf16 operand planes)" if split_il else
                            "split_gemm_kernel (128x128 tiles, separate bf16 planes)") + \
