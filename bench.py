@@ -141,6 +141,11 @@ def plan_work(plan, networks):
             else:
                 byts += act_in * 4
             byts += Z * M * op.Cout * 4 + Z * op.Cout * K * (6 if split else 4)
+        elif t == getattr(networks, "XL_OP_STEM12", -1):
+            # conv1 evaluated on the 17 x 33 patch of every 8 x 16 tile of conv2 outputs (1.096x its output pixels), then conv2
+            px1 = op.B * (-(-op.Ho // 8)) * (-(-op.Wo // 16)) * 17 * 33
+            bf16 += 6 * 2.0 * px1 * 32 * 27 + 6 * 2.0 * op.B * op.Ho * op.Wo * op.Cout * 288
+            byts += op.B * op.Hi * op.Wi * 3 * 4 + op.B * op.Ho * op.Wo * op.Cout * 4
         elif t == networks.XL_OP_CONV1:
             px = op.B * op.Hi * op.Wi
             if op.reserved_i == 0 and (op.stats or op.aux2):     # matrix-pipe form, one evaluation per launch
@@ -406,7 +411,7 @@ def main():
         for i in range(max(nrec, 0)):
             per_op.setdefault(idx[i], []).append(ms[i])
         names = {0: "conv1", 1: "conv", 2: "gn_stats", 3: "gn_apply", 4: "head", 11: "gn_final", 12: "wino_in",
-                 13: "wino_out"}
+                 13: "wino_out", 19: "stem12"}
         for i in sorted(per_op):
             op = plan.op_array[i]
             sys.stderr.write("op %3d %-8s k%d s%d %4d->%4d %3dx%3d  %.4f ms\n" % (

@@ -1,0 +1,364 @@
+// crossloc_hip: conv1 evaluated INSIDE conv2's operand stage (round 4; inference plans).
+//
+//   conv2( relu( groupnorm( conv1(image) ) ) )      networks.py:186-193 of the reference: 3 -> 32 (3x3 s1) -> 32 -> 64 (3x3 s2)
+//
+// Until round 3 conv1 wrote its raw 32-channel full-resolution output (2.08 GB at 47 frames of 480 x 720) and conv2 read it
+// back, applying GroupNorm + ReLU and splitting every value into its three bf16 terms once per (output pixel, tap) that uses
+// it - 2.25 times per value - inside its K-loop: 7 VALU instructions per MFMA, the layer ran at a third of the matrix pipe.
+// Here the full-resolution tensor never exists.  The GroupNorm statistics of conv1 come from a statistics-only evaluation
+// (conv1_mfma_kernel<0>, csrc/xl_cnn.hip, then XL_OP_GN_FINAL); this kernel then walks tiles of 8 x 16 conv2 outputs:
+//   1. the 19 x 36 image halo of the tile is split into bf16 planes in LDS ({R, G, B, 0} words, as conv1_mfma_kernel);
+//   2. conv1 is evaluated on the 17 x 33 patch of its outputs the tile needs - 18 blocks of 32 pixels, 18 MFMAs each, the
+//      arithmetic of conv1_mfma_kernel term for term -, normalised with the {scale, shift} pairs (one fmaf, one v_med3_f32 that
+//      is both the ReLU and the zero padding of conv2), split ONCE per value and written to the patch in LDS:
+//      [pixel][plane][32 channels] bf16, 208 bytes per pixel (13 x 16: consecutive pixels fall on distinct 16-byte slots of the
+//      256-byte bank window), the columns of a patch row de-interleaved (even columns first) so that the stride-2 gather of
+//      conv2 reads CONSECUTIVE pixel records;
+//   3. conv2: every wave owns 32 output pixels (two tile rows) x all 64 channels; a K-step = 16 channels of one tap; the
+//      activation fragments are plain ds_read_b128 from the patch at compile-time offsets, the weight fragments come from
+//      global memory in fragment order (1 KB contiguous per load instruction, L2-resident: 110 KB for the layer), three
+//      K-steps ahead in registers.  No barrier, no conversion, no staging in the K-loop: 12 MFMAs per 9 fragment reads.
+// Term pairs and K order are those of split_conv3x3s2_kernel<64,...> (csrc/xl_stem_split.hip): the raw conv2 output is
+// bitwise what the two-kernel path produces (tests/test_cnn_gpu.py::test_fused_stem_is_bitwise_the_two_kernel_path).
+// One workgroup of 4 waves per CU (133 KB of LDS), persistent over tiles; two barriers per tile.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+
+#include "../../include/crossloc_cnn.h"
+#include "../../include/crossloc_dsac.h"   // status codes
+#include "xl_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kTW = 16;                                // conv2 output columns per tile (rows: the template parameter TH)
+constexpr int kPW = 2 * kTW + 1;                       // conv1 output columns the tile needs: 33
+constexpr int kEven = kTW + 1;                         // even patch columns come first in a patch row (17 of them)
+constexpr int kHW = kPW + 3;                           // image halo columns: 36 (35 + the dx = 3 slot of the last pixel)
+constexpr int kPix = 208;                              // bytes per patch pixel: 3 planes x 64 B + 16
+// TH = 8: 17 x 33 patch (116 688 B) + 19 x 36 halo (16 416 B): one workgroup per CU.  TH = 4: 9 x 33 patch (61 776 B) + 11 x 36
+// halo (9 504 B) = 71 KB: TWO workgroups per CU (8 waves: the conversion-heavy conv1 phase of one overlaps the MFMA-only conv2
+// phase of the other), or one beside a workgroup of the solver (64.8 KB), which runs on a side stream under the stem.
+template <int TH> struct S12 {
+    static constexpr int kPH = 2 * TH + 1, kHH = kPH + 2;
+    static constexpr int kNPix = kPH * kPW, kBlocks = (kNPix + 31) / 32;
+    static constexpr int kPatchBytes = kNPix * kPix, kHaloPix = kHH * kHW, kHaloBytes = 3 * kHaloPix * 8;
+    static constexpr int kE = (kHaloPix + 255) / 256;                // halo pixels per thread
+    static constexpr int kPB = TH / 2;                               // 32-pixel blocks per tile (4 waves: kPB x 4 / kPB column blocks)
+};
+
+// the split of conv1_mfma_kernel (integer round-to-nearest-even) - the image halo must be split exactly as there
+__device__ __forceinline__ unsigned s12_bf16_rn(float x)
+{
+    unsigned u = __builtin_bit_cast(unsigned, x);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+__device__ __forceinline__ void s12_split3(float a, unsigned &h1, unsigned &h2, unsigned &h3)
+{
+    h1 = s12_bf16_rn(a);
+    const float r1 = a - __builtin_bit_cast(float, h1 << 16);
+    h2 = s12_bf16_rn(r1);
+    h3 = s12_bf16_rn(r1 - __builtin_bit_cast(float, h2 << 16));
+}
+// the split of split_conv3x3s2_kernel (v_cvt_pk_bf16_f32, exact residuals): the normalised activations, two at a time
+__device__ __forceinline__ float s12_hi(unsigned w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
+__device__ __forceinline__ float s12_lo(unsigned w) { return __builtin_bit_cast(float, w << 16); }
+__device__ __forceinline__ void s12_split_pair(f32x2 v, unsigned &w1, unsigned &w2, unsigned &w3)
+{
+    w1 = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+    const f32x2 r = v - f32x2{ s12_lo(w1), s12_hi(w1) };
+    w2 = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
+    const f32x2 r2 = r - f32x2{ s12_lo(w2), s12_hi(w2) };
+    w3 = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2));
+}
+
+struct Stem12Args {
+    const float *img;            // [B][3][H][W]
+    const u32x4 *w1;             // conv1 weight fragments [3 planes][3 window rows][64 lanes] x 16 B (networks._Plan.conv1_fragments)
+    const float *b1;             // [32]
+    const float *coef;           // [B][32][2] {scale, shift} of conv1's GroupNorm (XL_OP_GN_FINAL)
+    const u32x4 *w2;             // conv2 weight fragments [18 K-steps][3 planes][2 column blocks][64 lanes] x 16 B
+    const float *b2;             // [64]
+    float *out;                  // [B][Ho][Wo][64], pixel stride ldOut
+    int B, H, W, Ho, Wo, ldOut, tilesX, tilesY;
+    float normLo;                // 0 (ReLU) or -inf
+    int *queue;                  // [2] = {next tile, workgroups done}: tiles are handed out dynamically (both zero before and after a launch)
+    long long *clk;              // diagnostics (XL_STEM12_CLK=1): per-wave shader-clock sums of the phases of a tile, else NULL
+};
+
+template <int TH>
+__global__ __launch_bounds__(256, TH == 8 ? 1 : 2)
+void stem12_kernel(Stem12Args a)
+{
+    typedef S12<TH> K;
+    constexpr int kTH = TH, kHH = K::kHH, kNPix = K::kNPix, kBlocks = K::kBlocks, kPatchBytes = K::kPatchBytes;
+    constexpr int kHaloPix = K::kHaloPix, kE = K::kE, kPB = K::kPB, kNJ = kPB == 4 ? 2 : 1;
+    extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+    unsigned char *sPatch = dsm;
+    u32x2 *sH = reinterpret_cast<u32x2 *>(dsm + kPatchBytes);
+    float *sTab = reinterpret_cast<float *>(dsm + kPatchBytes + K::kHaloBytes);   // scale[32], shift[32] of the tile's image; conv2 bias[64]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 31, kh = lane >> 5;
+    const long long HW = (long long)a.H * a.W;
+    const int tilesPerImage = a.tilesX * a.tilesY;
+    const int total = a.B * tilesPerImage;
+
+    // conv1 weight fragments and biases (registers for the whole kernel)
+    bf16x8 wf[3][3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) wf[p][dy] = __builtin_bit_cast(bf16x8, a.w1[(p * 3 + dy) * 64 + lane]);
+    // accumulator element r of a lane: pixel lane & 31, channel 8 (r >> 2) + 4 kh + (r & 3) (+ 32 j for conv2's column block j)
+    // conv2: wave -> (32-pixel block pxb: tile rows 2 pxb, 2 pxb + 1; first column block jb; kNJ column blocks of 32 channels)
+    const int pxb = wave % kPB, jb = (wave / kPB) * kNJ;
+    if (tid < 64) sTab[64 + tid] = a.b2[tid];                         // (visible after the first barrier)
+    else if (tid < 96) sTab[64 + tid] = a.b1[tid - 64];               // conv1 bias[32] at sTab[128]
+
+    // image halo of a tile: pixel i = tid + 256 e of the 19 x 36 window, three channels each, fetched one tile ahead
+    float pre[kE][3];
+    auto prefetch = [&](int t) {
+        const int n = t / tilesPerImage, tt = t - n * tilesPerImage;
+        const int ty = tt / a.tilesX, tx = tt - ty * a.tilesX;
+        const float *img = a.img + (long long)n * 3 * HW;
+#pragma unroll
+        for (int e = 0; e < kE; ++e) {
+            const int i = tid + 256 * e;
+            const int r = i / kHW, c = i - r * kHW;
+            const int y = 2 * kTH * ty - 2 + r, x = 2 * kTW * tx - 2 + c;
+            const bool inb = (t < total) & (i < kHaloPix) & ((unsigned)y < (unsigned)a.H) & ((unsigned)x < (unsigned)a.W);
+            const long long off = inb ? (long long)y * a.W + x : 0;
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) pre[e][ch] = inb ? img[ch * HW + off] : 0.f;
+        }
+    };
+
+    // conv2: my output pixel inside the tile and the byte offset of its patch record (tap (0, 0), plane 0)
+    const int oyl = 2 * pxb + (fr >> 4), oxl = fr & 15;
+    const unsigned aBase = (unsigned)(((2 * oyl) * kPW + oxl) * kPix + kh * 16);
+
+    long long cPh[6] = { 0, 0, 0, 0, 0, 0 }, cT = 0, nTiles = 0;
+    auto stamp = [&](int ph) { if (a.clk) { const long long now = clock64(); cPh[ph] += now - cT; cT = now; } };
+    // Tiles come from a queue (one atomic per tile, fetched two tiles ahead), not from a static stride: the solver of the batch
+    // before runs on a side stream under the stem and holds CUs (LDS, registers) for a millisecond - with a static partition the
+    // workgroups that do not fit beside it start when others END, and the launch takes twice as long (measured: 2.2 vs 1.26 ms).
+    int *sQ = reinterpret_cast<int *>(sTab + 192);
+    if (tid == 0) { sQ[0] = atomicAdd(a.queue, 1); sQ[1] = atomicAdd(a.queue, 1); }
+    __syncthreads();
+    int t = sQ[0], tNext = sQ[1];
+    __syncthreads();                                                  // (sQ[0] is rewritten in the first tile)
+    prefetch(t);
+    if (a.clk) cT = clock64();
+    while (t < total) {
+        ++nTiles;
+        if (tid == 0) sQ[0] = atomicAdd(a.queue, 1);                  // the tile after the next one (read behind barrier 1)
+        const int n = t / tilesPerImage, tt = t - n * tilesPerImage;
+        const int ty = tt / a.tilesX, tx = tt - ty * a.tilesX;
+        const int oy0 = kTH * ty, ox0 = kTW * tx;
+
+        // ---- 1. halo -> LDS, split ({R | G << 16, B} per pixel and plane)
+#pragma unroll
+        for (int e = 0; e < kE; ++e) {
+            const int i = tid + 256 * e;
+            if (i < kHaloPix) {
+                unsigned h[3][3];
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) s12_split3(pre[e][ch], h[0][ch], h[1][ch], h[2][ch]);
+#pragma unroll
+                for (int p = 0; p < 3; ++p) sH[p * kHaloPix + i] = u32x2{ h[p][0] | (h[p][1] << 16), h[p][2] };
+            }
+        }
+        // {scale, shift} of the 32 conv1 channels for this image (a table in LDS: 32 registers fewer than per-lane copies)
+        if (tid < 32) {
+            const f32x2 c2 = *reinterpret_cast<const f32x2 *>(a.coef + ((long long)n * 32 + tid) * 2);
+            sTab[tid] = c2[0]; sTab[32 + tid] = c2[1];
+        }
+        stamp(0);                                                      // halo split + coefficient loads
+        __syncthreads();
+        stamp(1);                                                      // barrier 1
+        const int tAfter = sQ[0];
+        // conv2's weight fragments of the first three K-steps: in flight under conv1
+        u32x4 fbr[3][3][kNJ];
+        auto load_b = [&](int kk, int slot) {
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int j = 0; j < kNJ; ++j) fbr[slot][p][j] = a.w2[((kk * 3 + p) * 2 + jb + j) * 64 + lane];
+        };
+        load_b(0, 0); load_b(1, 1); load_b(2, 2);
+
+        // ---- 2. conv1 on the patch: blocks of 32 patch pixels (linear index L = row * 33 + de-interleaved column)
+#pragma unroll 1
+        for (int blk = wave; blk < kBlocks; blk += 4) {
+            const int L = blk * 32 + fr;
+            const bool valid = L < kNPix;
+            const int Lc = valid ? L : kNPix - 1;
+            const int pr = Lc / kPW, idx = Lc - pr * kPW;
+            const int x = idx < kEven ? 2 * idx : 2 * (idx - kEven) + 1;          // patch column
+            f32x16 acc;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 b4 = *reinterpret_cast<const f32x4 *>(sTab + 128 + 8 * q + 4 * kh);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[4 * q + e] = b4[e];
+            }
+            bf16x8 pf[3][3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) {
+                    const u32x2 *src = sH + p * kHaloPix + (pr + dy) * kHW + x + 2 * kh;
+                    const u32x2 v0 = src[0], v1 = src[1];
+                    pf[p][dy] = __builtin_bit_cast(bf16x8, u32x4{ v0[0], v0[1], v1[0], v1[1] });
+                }
+            constexpr int PW_[6] = { 2, 1, 0, 1, 0, 0 }, PP_[6] = { 0, 1, 2, 0, 1, 0 };   // smallest terms first (conv1_mfma_kernel)
+#pragma unroll
+            for (int tm = 0; tm < 6; ++tm)
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[PW_[tm]][dy], pf[PP_[tm]][dy], acc, 0, 0, 0);
+            // GroupNorm + ReLU; a conv1 pixel outside the image is conv2's zero padding
+            const int iy = 2 * oy0 - 1 + pr, ix = 2 * ox0 - 1 + x;
+            const bool inimg = ((unsigned)iy < (unsigned)a.H) & ((unsigned)ix < (unsigned)a.W);
+            const float lo = inimg ? a.normLo : 0.f, hi = inimg ? __builtin_inff() : 0.f;
+            unsigned char *dst = sPatch + Lc * kPix + kh * 8;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 sc4 = *reinterpret_cast<const f32x4 *>(sTab + 8 * q + 4 * kh), sh4 = *reinterpret_cast<const f32x4 *>(sTab + 32 + 8 * q + 4 * kh);
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(fmaf(acc[4 * q + e], sc4[e], sh4[e]), lo, hi);
+                unsigned wa[3], wb[3];
+                s12_split_pair(f32x2{ v[0], v[1] }, wa[0], wa[1], wa[2]);
+                s12_split_pair(f32x2{ v[2], v[3] }, wb[0], wb[1], wb[2]);
+                if (valid) {
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x2 *>(dst + p * 64 + q * 16) = u32x2{ wa[p], wb[p] };
+                }
+            }
+        }
+        stamp(2);                                                      // conv1 on my blocks of the patch
+        __syncthreads();
+        stamp(3);                                                      // barrier 2
+
+        // ---- 3. conv2 on the patch; the image halo of my next tile is fetched meanwhile
+        prefetch(tNext);
+        f32x16 acc2[kNJ];
+#pragma unroll
+        for (int j = 0; j < kNJ; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 b4 = *reinterpret_cast<const f32x4 *>(sTab + 64 + 32 * (jb + j) + 8 * q + 4 * kh);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc2[j][4 * q + e] = b4[e];
+            }
+#pragma unroll
+        for (int kk = 0; kk < 18; ++kk) {
+            const int tap = kk >> 1, c = kk & 1, ky = tap / 3, kx = tap - 3 * ky;
+            const unsigned off = (unsigned)((ky * kPW + (kx & 1) * kEven + (kx >> 1)) * kPix + c * 32);
+            bf16x8 fa[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) fa[p] = *reinterpret_cast<const bf16x8 *>(sPatch + aBase + off + p * 64);
+            const int slot = kk % 3;
+            constexpr int PU[6] = { 2, 1, 0, 1, 0, 0 }, PV[6] = { 0, 1, 2, 0, 1, 0 };   // (weights, activations): split_conv3x3s2's order
+#pragma unroll
+            for (int tm = 0; tm < 6; ++tm)
+#pragma unroll
+                for (int j = 0; j < kNJ; ++j)
+                    acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fbr[slot][PU[tm]][j]), fa[PV[tm]], acc2[j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kk + 3 < 18) load_b(kk + 3, slot);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+
+        stamp(4);                                                      // conv2
+        // ---- 4. store: pixel (oy0 + oyl, ox0 + oxl), channels 32 j + 8 q + 4 kh + {0..3}
+        const int oy = oy0 + oyl, ox = ox0 + oxl;
+        if (oy < a.Ho && ox < a.Wo) {
+            float *o = a.out + (((long long)n * a.Ho + oy) * a.Wo + ox) * a.ldOut + 4 * kh;
+#pragma unroll
+            for (int j = 0; j < kNJ; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<f32x4 *>(o + 32 * (jb + j) + 8 * q) = f32x4{ acc2[j][4 * q], acc2[j][4 * q + 1], acc2[j][4 * q + 2], acc2[j][4 * q + 3] };
+        }
+        stamp(5);                                                      // stores issued
+        t = tNext; tNext = tAfter;
+    }
+    // the last workgroup to finish leaves the queue as it found it (every workgroup made its last fetch before it counts itself done)
+    if (tid == 0) {
+        __threadfence();
+        if (atomicAdd(a.queue + 1, 1) == (int)gridDim.x - 1) { a.queue[0] = 0; a.queue[1] = 0; __threadfence(); }
+    }
+    if (a.clk && lane == 0) {
+        long long *c = a.clk + ((long long)blockIdx.x * 4 + wave) * 8;
+        for (int i = 0; i < 6; ++i) c[i] = cPh[i];
+        c[6] = nTiles;
+    }
+}
+
+}  // namespace
+
+// XL_OP_STEM12: in = image [B,3,Hi,Wi] NCHW; w = conv1 weight fragments; bias = conv1 bias[32]; aux2 = {scale, shift} pairs
+// [B][32][2] of conv1's GroupNorm; aux = conv2 weight fragments [18][3][2][64][8] bf16; stats2 = conv2 bias[64] (read only);
+// out = raw conv2 output [B,Ho,Wo,64] NHWC (ld_out); flags & XL_GN_RELU_IN: ReLU after the GroupNorm; stats = two ints, zero (the
+// tile queue of the launch; left zero again - one buffer per op and stream).
+int xl_run_stem12(const xl_op &op, hipStream_t st)
+{
+    if (op.Cin != 3 || op.Cout != 64 || op.Ho != (op.Hi - 1) / 2 + 1 || op.Wo != (op.Wi - 1) / 2 + 1 || op.ld_out < 64 || (op.ld_out & 3) ||
+        !op.in || !op.w || !op.bias || !op.aux || !op.aux2 || !op.stats2 || !op.stats || !op.out || op.B < 1 ||
+        (((uintptr_t)op.out | (uintptr_t)op.w | (uintptr_t)op.aux | (uintptr_t)op.aux2) & 15))
+        return XL_ERR_ARG;
+    Stem12Args a;
+    a.img = (const float *)op.in; a.w1 = (const u32x4 *)op.w; a.b1 = (const float *)op.bias; a.coef = (const float *)op.aux2;
+    a.w2 = (const u32x4 *)op.aux; a.b2 = (const float *)op.stats2; a.out = (float *)op.out; a.queue = (int *)op.stats;
+    a.B = op.B; a.H = op.Hi; a.W = op.Wi; a.Ho = op.Ho; a.Wo = op.Wo; a.ldOut = op.ld_out;
+    // tile rows: 4 (two workgroups per CU, 71 KB each - default) or 8 (one of 133 KB; XL_STEM12_TILE=8)
+    static const int tileRows = getenv("XL_STEM12_TILE") && atoi(getenv("XL_STEM12_TILE")) == 8 ? 8 : 4;
+    a.tilesX = (op.Wo + kTW - 1) / kTW; a.tilesY = (op.Ho + tileRows - 1) / tileRows;
+    a.normLo = (op.flags & XL_GN_RELU_IN) ? 0.f : -__builtin_inff();
+    const long long total = (long long)op.B * a.tilesX * a.tilesY;
+    if (total >= 0x7fffffffLL) return XL_ERR_ARG;
+    const size_t lds = (tileRows == 8 ? S12<8>::kPatchBytes + S12<8>::kHaloBytes : S12<4>::kPatchBytes + S12<4>::kHaloBytes) + 1024;
+    const void *fn = tileRows == 8 ? reinterpret_cast<const void *>(stem12_kernel<8>) : reinterpret_cast<const void *>(stem12_kernel<4>);
+    static XlLdsLimit configured[2];
+    int cfgDev;
+    if (configured[tileRows == 8].needs(lds, &cfgDev)) {
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return XL_ERR_HIP;
+        configured[tileRows == 8].done(lds, cfgDev);
+    }
+    int grid = tileRows == 8 ? 256 : 512;                             // persistent: one / two workgroups per CU
+    if (grid > total) grid = (int)total;
+    static const bool clkDbg = getenv("XL_STEM12_CLK") != nullptr;
+    a.clk = nullptr;
+    if (clkDbg && hipMalloc(&a.clk, sizeof(long long) * 32 * grid) != hipSuccess) return XL_ERR_HIP;
+    if (tileRows == 8) hipLaunchKernelGGL(stem12_kernel<8>, dim3(grid), dim3(256), lds, st, a);
+    else hipLaunchKernelGGL(stem12_kernel<4>, dim3(grid), dim3(256), lds, st, a);
+    if (clkDbg) {
+        std::vector<long long> h((size_t)32 * grid);
+        if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(h.data(), a.clk, sizeof(long long) * 32 * grid, hipMemcpyDeviceToHost) == hipSuccess) {
+            static const char *names[6] = { "halo split", "barrier 1", "conv1", "barrier 2", "conv2", "stores" };
+            for (int w = 0; w < 4; ++w) {
+                double v[6] = { 0 }, tiles = 0;
+                for (int b = 0; b < grid; ++b) { for (int i = 0; i < 6; ++i) v[i] += (double)h[((size_t)b * 4 + w) * 8 + i]; tiles += (double)h[((size_t)b * 4 + w) * 8 + 6]; }
+                fprintf(stderr, "[stem12 clk] wave %d, ticks per tile:", w);
+                for (int i = 0; i < 6; ++i) fprintf(stderr, " %s %.0f", names[i], v[i] / tiles);
+                fprintf(stderr, "\n");
+            }
+        }
+        (void)hipFree(a.clk);
+    }
+    return XL_OK;
+}

@@ -29,6 +29,7 @@ XL_OP_WINO_IN, XL_OP_WINO_OUT = 12, 13
 XL_OP_DUC_HEAD = 14
 XL_OP_DUC_HEAD_BWD = 15
 XL_OP_WINO_DY, XL_OP_WINO_WFINAL, XL_OP_GNB_FINAL = 16, 17, 18
+XL_OP_STEM12 = 19
 CONV_DGRAD, CONV_ACCUMULATE, CONV_SPLIT_BF16 = 1, 2, 64
 CONV_NORM_IN, CONV_NORM_RELU = 128, 256
 CONV_SPLIT_IL = 512
@@ -448,8 +449,8 @@ class _Plan:
             self._pack_wino_split(*entry)
         for entry in self.packed_1x1.values():
             self._split_weight(*entry)
-        for planes, src in self.packed_c1.values():
-            planes.copy_(self.conv1_fragments(src))
+        for key, (planes, src) in self.packed_c1.items():
+            planes.copy_(self.conv2_fragments(src) if isinstance(key, tuple) else self.conv1_fragments(src))
 
     def dev(self, p):
         t = p.detach().to(device=self.device, dtype=torch.float32).contiguous()
@@ -572,6 +573,23 @@ class _Plan:
                     f[:, kh, :, i] = w[:, c, :, dx].t()
         planes = _Plan.split_bf16(f.reshape(3, 64, 8))                           # [3 planes][3 dy][64][8]
         return planes.contiguous()
+
+    @staticmethod
+    def conv2_fragments(weight):
+        """[18 K-steps][3 planes][2 column blocks][64 lanes][8] bf16 (int16 storage): the MFMA weight fragments of stem12_kernel
+        (csrc/xl_stem_fused.hip) for the 32 -> 64 3x3 stride-2 layer.  K = tap * 32 + channel (tap = 3 ky + kx), a K-step = 16
+        channels of one tap; lane = 32 * K-half + output channel within the 32-channel block; a lane's 8 values are consecutive K."""
+        w = weight.detach().to(torch.float32)                                    # [64][32][ky][kx]
+        rows = w.permute(0, 2, 3, 1).reshape(64, 288)
+        planes = _Plan.split_bf16(rows).view(3, 2, 32, 18, 2, 8)                 # [plane][j][fr][kk][kh][8]
+        return planes.permute(3, 0, 1, 4, 2, 5).contiguous()                     # [kk][plane][j][kh][fr][8]
+
+    def pack_conv2_fragments(self, conv):
+        key = (id(conv.weight), "c2frag")
+        if key not in self.packed_c1:
+            src = conv.weight.detach().to(device=self.device, dtype=torch.float32).contiguous()   # aliases the live parameter
+            self.packed_c1[key] = (self.conv2_fragments(src), src)
+        return self.packed_c1[key][0]
 
     def pack_conv1_split(self, conv):
         key = id(conv.weight)
@@ -1047,11 +1065,13 @@ class _Plan:
         B, H, W = self.B, self.H, self.W
         cin = enc.conv1.in_channels
         c1 = enc.conv1.out_channels
-        t1 = self.alloc(B * H * W * c1)
         if (not self.train and cin == 3 and c1 == 32 and enc.norm1.num_groups == 32
                 and not os.environ.get("XL_NO_CONV1_FUSED")):
-            x = self._conv1_fused(enc, image, t1)
+            if self.stem12_ok(enc):
+                return self._encoder_tail(enc, None, out, x2=self._stem12(enc, image))
+            x = self._conv1_fused(enc, image, self.alloc(B * H * W * c1))
             return self._encoder_tail(enc, x, out)
+        t1 = self.alloc(B * H * W * c1)
         op = XlOp()
         op.type = XL_OP_CONV1
         op.B, op.Hi, op.Wi, op.Cin, op.Ho, op.Wo, op.Cout, op.ld_out = B, H, W, cin, H, W, c1, c1
@@ -1065,6 +1085,57 @@ class _Plan:
         self.tape.append(dict(kind="conv1", conv=enc.conv1, raw=raw1))
         x = self.gn(raw1, enc.norm1, GN_RELU_IN)
         return self._encoder_tail(enc, x, out)
+
+    def stem12_ok(self, enc):
+        """conv1 evaluated inside conv2's operand stage (csrc/xl_stem_fused.hip, round 4): inference plans whose stem runs on
+        the split pipe.  A choice by layer, never by batch.  XL_NO_STEM12=1: the two-kernel path (conv1 writes its raw output,
+        conv2 normalises and splits it on load)."""
+        c2 = enc.conv2
+        return (c2.in_channels == 32 and c2.out_channels == 64 and c2.kernel_size[0] == 3 and c2.stride[0] == 2
+                and self.split_train_ok() and os.environ.get("XL_GEMM_SPLIT_BF16", self.SPLIT_DEFAULT) not in ("", "0", "1")
+                and not os.environ.get("XL_NO_SPLIT_STEM") and not os.environ.get("XL_NO_STEM12")
+                and not os.environ.get("XL_CONV1_VALU") and not os.environ.get("XL_NO_DEFERRED_GN"))
+
+    def _stem12(self, enc, image):
+        """conv1 statistics (one evaluation of conv1, nothing written), GN_FINAL, then the fused kernel: raw conv2 output.  The
+        32-channel full-resolution activation (2 GB at 47 frames) is never allocated.  Returns conv2's GroupNorm'ed activation
+        with its apply left to the consumer (conv3 on the split pipe)."""
+        B, H, W = self.B, self.H, self.W
+        c1, G = enc.conv1.out_channels, enc.norm1.num_groups
+        nchunks = -(-H // 16) * -(-W // 64)
+        w1, b1 = self.pack_conv1_split(enc.conv1), self.dev(enc.conv1.bias)
+        gamma, beta = self.dev(enc.norm1.weight), self.dev(enc.norm1.bias)
+        st = XlOp()
+        st.type = XL_OP_CONV1
+        st.B, st.Hi, st.Wi, st.Cin, st.Ho, st.Wo, st.Cout, st.ld_out = B, H, W, 3, H, W, c1, c1
+        st.groups, st.nchunks, st.reserved_i, st.eps = G, nchunks, 0, enc.norm1.eps
+        st.in_, st.w, st.bias = image.data_ptr(), w1.data_ptr(), b1.data_ptr()
+        self.max_stats = max(self.max_stats, B * nchunks * G * 2)
+        self.stats_ops.append(len(self.ops))
+        self.image_op_indices.append(len(self.ops))
+        self.ops.append(st)
+        shape = XlOp()                                 # GN_FINAL sees the normalised tensor: c1 channels, G groups
+        shape.B, shape.Hi, shape.Wi, shape.Cin, shape.groups, shape.nchunks, shape.eps = B, H, W, c1, G, nchunks, enc.norm1.eps
+        self._emit_final(shape, gamma, beta, 0)
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        c2 = enc.conv2.out_channels
+        y = self.alloc(B * Ho * Wo * c2)
+        op = XlOp()
+        op.type = XL_OP_STEM12
+        op.B, op.Hi, op.Wi, op.Cin, op.Ho, op.Wo, op.Cout, op.ld_out = B, H, W, 3, Ho, Wo, c2, c2
+        op.ksize, op.stride, op.flags = 3, 2, GN_RELU_IN
+        op.in_, op.w, op.bias = image.data_ptr(), w1.data_ptr(), b1.data_ptr()
+        op.aux = self.pack_conv2_fragments(enc.conv2).data_ptr()
+        op.stats2 = self.dev(enc.conv2.bias).data_ptr()
+        queue = torch.zeros(4, dtype=torch.int32, device=self.device)      # the launch's tile queue (zero before and after)
+        self.keep.append(queue)
+        op.stats = queue.data_ptr()
+        op.out = y.data_ptr()
+        self.deferred_gn_consumers = getattr(self, "deferred_gn_consumers", []) + [len(self.ops)]
+        self.image_op_indices.append(len(self.ops))
+        self.ops.append(op)
+        raw2 = (y, Ho, Wo, c2, c2, 0)
+        return self.gn(raw2, enc.norm2, GN_RELU_IN, None, defer=not os.environ.get("XL_NO_DEFERRED_GN"))
 
     def _conv1_fused(self, enc, image, t1):
         """Inference form of conv1 + GroupNorm + ReLU: a statistics-only evaluation of the convolution, GN_FINAL, then
@@ -1122,8 +1193,9 @@ class _Plan:
         self.ops.append(ap)
         return (t1, H, W, c1, c1, 0)
 
-    def _encoder_tail(self, enc, x, out=None):
-        x2 = self.cgr(x, enc.conv2, enc.norm2, defer=True); self.release(x[0])
+    def _encoder_tail(self, enc, x, out=None, x2=None):
+        if x2 is None:
+            x2 = self.cgr(x, enc.conv2, enc.norm2, defer=True); self.release(x[0])
         x3 = self.cgr(x2, enc.conv3, enc.norm3, defer=True); self.release(x2[0])
         res = self.cgr(x3, enc.conv4, enc.norm4, share=True); self.release(x3[0])
         a = self.cgr(res, enc.res1_conv1, enc.res1_norm1, defer=True)

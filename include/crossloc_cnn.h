@@ -67,6 +67,15 @@ enum {
     XL_OP_GNB_FINAL = 18,   /* GroupNorm backward, pass 2 (between STATS and APPLY): totals of the chunk sums, per-(image,
                                channel) apply coefficients and the sums XL_OP_GNB_PARAMS turns into d gamma / d beta / d bias */
     XL_OP_WINO_WFINAL = 17, /* in dU [(m+2)^2][Cout][Cin] -> out dg = G^T dU G, OIHW [Cout][Cin][3][3]; ksize = m as above */
+    XL_OP_STEM12 = 19,      /* conv1 (3 -> 32, 3x3 s1) + GroupNorm + ReLU evaluated inside the operand stage of conv2 (32 -> 64, 3x3 s2),
+                               csrc/xl_stem_fused.hip (networks.py:186-193 of the reference): the 32-channel full-resolution tensor
+                               never exists.  in = image [B,3,Hi,Wi] NCHW; w = conv1 weight fragments (as XL_OP_CONV1, reserved_i = 0);
+                               bias = conv1 bias[32]; aux2 = {scale, shift} pairs [B][32][2] of conv1's GroupNorm (XL_OP_GN_FINAL on
+                               the statistics of a statistics-only XL_OP_CONV1); aux = conv2 weight fragments
+                               [18 K-steps][3 planes][2 column blocks][64 lanes][8] bf16 (networks._Plan.conv2_fragments);
+                               stats2 = conv2 bias[64] (read only); stats = two int32, zero (tile queue, zero
+                               again after the launch); out = RAW conv2 output [B,Ho,Wo,64] NHWC (ld_out),
+                               Ho = (Hi-1)/2+1; flags & XL_GN_RELU_IN: ReLU behind the GroupNorm */
     XL_OP_GN_FINAL = 11  /* per-(image, channel) GroupNorm scale/shift [B][C][2] from the partial sums (out);
                             GN_APPLY with aux2 = that buffer skips its own finalisation.  out2 (training plans):
                             [B][C][2] {mean, rstd} for the GroupNorm backward ops */

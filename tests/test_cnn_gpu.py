@@ -1016,3 +1016,27 @@ def test_tile_major_winograd_product_is_bitwise_the_plane_major_form(monkeypatch
     plan = list(net._plans.values())[0]
     assert any(op.flags & networks.CONV_M_TILE_MAJOR for op in plan.ops if op.type == networks.XL_OP_WINO_OUT)
     assert torch.equal(y0, y1)
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 64, 96), (1, 70, 100), (3, 41, 57), (2, 480, 720)])
+def test_fused_stem_is_bitwise_the_two_kernel_path(B, H, W, monkeypatch):
+    """Round 4: conv1 + GroupNorm + ReLU evaluated inside conv2's operand stage (XL_OP_STEM12, csrc/xl_stem_fused.hip) against the
+    two-kernel path (conv1 writes its raw output, conv2 normalises and splits it on load; XL_NO_STEM12=1).  Same term pairs, same
+    K order, same conversion instructions: the network outputs are equal to the bit.  70 x 100 / 41 x 57: ragged tiles of 8 x 16
+    conv2 outputs, odd image sizes (the last conv1 row / column is conv2's zero padding, not a convolution over padding)."""
+    x = torch.rand(B, 3, H, W, generator=torch.Generator().manual_seed(H + W)).cuda()
+
+    def run():
+        net = networks.TransPoseNet(MEAN, False, False, 1, 1, 3, 1)
+        net.load_state_dict(seeded_state_dict(net, seed=5))
+        net = net.cuda().eval()
+        with torch.no_grad():
+            y = net(x)
+        plan = list(net._plans.values())[0]
+        return y.cpu(), [op.type for op in plan.ops]
+    y_new, ops_new = run()
+    monkeypatch.setenv("XL_NO_STEM12", "1")
+    y_old, ops_old = run()
+    assert networks.XL_OP_STEM12 in ops_new and networks.XL_OP_STEM12 not in ops_old
+    assert torch.isfinite(y_new).all()
+    assert torch.equal(y_new, y_old), (y_new - y_old).abs().max()
