@@ -1672,24 +1672,44 @@ class _Plan:
         if not hasattr(self, "graph_in"):
             self.graph_in = torch.empty_like(image)
             self.graph_out = torch.empty(self.out_shape, dtype=torch.float32, device=self.device)
-            self.graph, self.graph_runs = None, 0
+            self.graph, self.graph_runs, self.graph_stream, self.graph_off = None, 0, None, False
+        if self.graph_off:
+            return None
         self.graph_runs += 1
         if self.graph_runs == 1:
             return None                                     # warm-up: eager
+        # one stream per plan: the graph's input / result buffers belong to the plan, and a launch on another stream could
+        # overlap the copy-in of the next call or the copy-out of this one (callers that drive one network from several
+        # streams pass distinct plan_slots).  A call from any other stream than the capturing one runs eagerly.
+        if self.graph_stream is not None and stream != self.graph_stream:
+            return None
         for i in self.image_op_indices:
             self.op_array[i].in_ = self.graph_in.data_ptr()
         self.op_array[self.out_op_index].out = self.graph_out.data_ptr()
         if self.graph is None:
             h = ctypes.c_void_p()
-            _check(L.xl_cnn_graph_capture(self.op_array, len(self.op_array), ctypes.c_void_p(stream), ctypes.byref(h)))
-            self.graph = h
+            rc = L.xl_cnn_graph_capture(self.op_array, len(self.op_array), ctypes.c_void_p(stream), ctypes.byref(h))
+            if rc != 0:
+                return self._graph_give_up("capture", rc)
+            self.graph, self.graph_stream = h, stream
             weakref.finalize(self, L.xl_cnn_graph_destroy, h)
         self.graph_in.copy_(image)
         rc = L.xl_cnn_graph_launch(self.graph, ctypes.c_void_p(stream))
         if rc == XL_ERR_UNSUPPORTED:                        # per-op profiling is on: this call runs eagerly
             return None
-        _check(rc)
+        if rc != 0:
+            return self._graph_give_up("launch", rc)
         return self.graph_out.clone()
+
+    def _graph_give_up(self, what, rc):
+        """A capture / launch failure must not make small-batch inference unusable where the eager path works (a call inside the
+        op list that cannot be captured, e.g. a first-use hipFuncSetAttribute on another device): say so once, stop trying."""
+        import warnings
+        L = _lib.lib()
+        warnings.warn("crossloc_amd: HIP-graph %s of a %d-frame plan failed (%s %s); this plan runs its op list eagerly from now on"
+                      % (what, self.B, L.xl_status_string(rc).decode(), L.xl_cnn_last_error().decode()))
+        self.graph_off = True
+        return None
 
     def run(self, image):
         stream = torch.cuda.current_stream().cuda_stream

@@ -50,8 +50,8 @@ class Adam(torch.optim.Optimizer):
         cached = self._tables.setdefault(gi, {})      # a few tables per group: the network hands its gradients out in
         if sig in cached:                              # alternating buffers (networks._Plan.run_backward)
             return cached[sig]
-        if len(cached) >= 4:
-            cached.clear()
+        while len(cached) >= 4:                         # evict the oldest table (dicts keep insertion order)
+            cached.pop(next(iter(cached)))
         rows = []
         for p in ps:
             if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous() or not p.grad.is_contiguous():
@@ -72,8 +72,8 @@ class Adam(torch.optim.Optimizer):
         host = (_Chunk * len(rows))(*rows)
         dev = torch.empty(ctypes.sizeof(host), dtype=torch.uint8, device=ps[0].device)
         dev.copy_(torch.frombuffer(bytearray(bytes(host)), dtype=torch.uint8))
-        sig = tuple((p.data_ptr(), p.grad.data_ptr()) + moments(p) for p in ps)      # the state may just have been made
-        cached[sig] = (dev, len(rows))
+        sig = tuple((p.data_ptr(), p.grad.data_ptr()) + moments(p) for p in ps)      # (the state may just have been made: the
+        cached[sig] = (dev, len(rows))                                               #  pre-state signature is never a key)
         return dev, len(rows)
 
     def load_state_dict(self, state_dict):
