@@ -1264,7 +1264,9 @@ class _Plan:
                 self.encoder(enc, _DUMMY, out=(cat, ctot, i * c))
             mlr = (cat, Ho, Wo, ctot, ctot, 0)
             sk = self.cgr(mlr, net.mlr_skip[0], net.mlr_skip[1], 0)
-            mlr = self.gn(mlr, net.mlr_norm, 0)
+            # (mlr_norm's only consumer is the fusion layer: its input transform applies the normalisation - no apply pass over
+            #  the 1536-channel buffer)
+            mlr = self.gn(mlr, net.mlr_norm, 0, defer=not os.environ.get("XL_NO_DEFERRED_GN"))
             f = net.mlr_forward
             a = self.cgr(mlr, f[0], f[1], defer=True); self.release(cat)
             b = self.cgr(a, f[3], f[4], defer=True); self.release(a[0])
