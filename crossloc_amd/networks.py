@@ -1072,6 +1072,28 @@ class _Plan:
             x = self._conv1_fused(enc, image, self.alloc(B * H * W * c1))
             return self._encoder_tail(enc, x, out)
         t1 = self.alloc(B * H * W * c1)
+        if (self.train and cin == 3 and c1 == 32 and enc.norm1.num_groups == 32 and self.split_train_ok()
+                and os.environ.get("XL_GEMM_SPLIT_BF16", self.SPLIT_DEFAULT) not in ("", "0", "1")
+                and not os.environ.get("XL_CONV1_VALU")):
+            # round 4, training plans: the matrix-pipe form of the inference plans, ONE evaluation that writes the raw output
+            # (kept for the backward pass) together with its GroupNorm partial sums - no separate statistics pass over the
+            # largest tensor of the network (conv1_direct_kernel + gn_stats: 0.52 + 0.13 ms at batch 16; this: 0.25)
+            G = enc.norm1.num_groups
+            nchunks = -(-H // 16) * -(-W // 64)
+            stats_t = torch.zeros(B * nchunks * G * 2, dtype=torch.float64, device=self.device)
+            self.keep.append(stats_t)
+            op = XlOp()
+            op.type = XL_OP_CONV1
+            op.B, op.Hi, op.Wi, op.Cin, op.Ho, op.Wo, op.Cout, op.ld_out = B, H, W, 3, H, W, c1, c1
+            op.groups, op.nchunks, op.reserved_i, op.eps = G, nchunks, 0, enc.norm1.eps
+            op.in_, op.w, op.bias = image.data_ptr(), self.pack_conv1_split(enc.conv1).data_ptr(), self.dev(enc.conv1.bias).data_ptr()
+            op.out, op.stats = t1.data_ptr(), stats_t.data_ptr()
+            self.ops.append(op)
+            self.image_op_indices.append(len(self.ops) - 1)
+            raw1 = (t1, H, W, c1, c1, 0)
+            self.tape.append(dict(kind="conv1", conv=enc.conv1, raw=raw1))
+            x = self.gn(raw1, enc.norm1, GN_RELU_IN, pre_stats=(stats_t, nchunks))
+            return self._encoder_tail(enc, x, out)
         op = XlOp()
         op.type = XL_OP_CONV1
         op.B, op.Hi, op.Wi, op.Cin, op.Ho, op.Wo, op.Cout, op.ld_out = B, H, W, cin, H, W, c1, c1
@@ -1604,6 +1626,8 @@ class _Plan:
                     tpb = 16
                     while tpb > 1 and B * -(-(Th * Tw) // tpb) * max(1, C // (256 if m == 6 else 512)) < 1024:
                         tpb //= 2
+                    if m == 6 and C % 512 == 0 and not os.environ.get("XL_WINO_OUT_TPB16"):      # (as conv_wino: equal workgroups)
+                        tpb = min(range(1, 17), key=lambda t: (-(-(B * -(-(Th * Tw) // t) * (C // 512)) // 512) * (t + 0.5), -t))
                     wo.B, wo.Hi, wo.Wi, wo.Cin, wo.ld_out, wo.groups = B, H, W, C, gx[1], 1
                     wo.nchunks, wo.reserved_i = -(-(Th * Tw) // tpb), tpb
                     wo.flags = (op.flags & CONV_ACCUMULATE) | tile_major
