@@ -36,6 +36,7 @@ int xl_run_bwd_op(const xl_op &op, hipStream_t st);   // xl_cnn_bwd.hip
 int xl_run_split_gemm(const xl_op &op, hipStream_t st);   // xl_gemm_split.hip
 int xl_run_split_stem(const xl_op &op, hipStream_t st);   // xl_stem_split.hip
 int xl_run_stem12(const xl_op &op, hipStream_t st);       // xl_stem_fused.hip
+int xl_run_s2_dgrad(const xl_op &op, hipStream_t st);     // xl_stem_dgrad.hip
 
 namespace {
 
@@ -2292,6 +2293,8 @@ int run_op(const xl_op &op, hipStream_t st)
             return run_conv(op, st);
         case XL_OP_STEM12:
             return xl_run_stem12(op, st);
+        case XL_OP_S2_DGRAD:
+            return xl_run_s2_dgrad(op, st);
         case XL_OP_WINO_IN: {
             if (op.ksize == 6) {                    // F(6x6,3x3): Ho x Wo tiles of 6x6 outputs, partial tiles allowed
                 if (op.Cin % 4 != 0 || op.ld_in % 2 != 0 || op.Ho != (op.Hi + 5) / 6 || op.Wo != (op.Wi + 5) / 6) return XL_ERR_ARG;

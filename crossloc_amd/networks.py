@@ -30,6 +30,7 @@ XL_OP_DUC_HEAD = 14
 XL_OP_DUC_HEAD_BWD = 15
 XL_OP_WINO_DY, XL_OP_WINO_WFINAL, XL_OP_GNB_FINAL = 16, 17, 18
 XL_OP_STEM12 = 19
+XL_OP_S2_DGRAD = 20
 CONV_DGRAD, CONV_ACCUMULATE, CONV_SPLIT_BF16 = 1, 2, 64
 CONV_NORM_IN, CONV_NORM_RELU = 128, 256
 CONV_SPLIT_IL = 512
@@ -450,7 +451,9 @@ class _Plan:
         for entry in self.packed_1x1.values():
             self._split_weight(*entry)
         for key, (planes, src) in self.packed_c1.items():
-            planes.copy_(self.conv2_fragments(src) if isinstance(key, tuple) else self.conv1_fragments(src))
+            kind = key[1] if isinstance(key, tuple) else "c1"
+            planes.copy_(self.s2_dgrad_fragments(src) if kind == "s2dgrad" else self.conv2_fragments(src) if kind == "c2frag"
+                         else self.conv1_fragments(src))
 
     def dev(self, p):
         t = p.detach().to(device=self.device, dtype=torch.float32).contiguous()
@@ -583,6 +586,24 @@ class _Plan:
         rows = w.permute(0, 2, 3, 1).reshape(64, 288)
         planes = _Plan.split_bf16(rows).view(3, 2, 32, 18, 2, 8)                 # [plane][j][fr][kk][kh][8]
         return planes.permute(3, 0, 1, 4, 2, 5).contiguous()                     # [kk][plane][j][kh][fr][8]
+
+    @staticmethod
+    def s2_dgrad_fragments(weight):
+        """[9 taps][CO/16][3 planes][CI/32][64 lanes][8] bf16 (int16 storage): the MFMA weight fragments of s2_dgrad_kernel
+        (csrc/xl_stem_dgrad.hip) for a stride-2 3x3 layer with weight [CO][CI][3][3]: rows = the layer's INPUT channels (the
+        gradient's channels), K = its output channels; lane = 32 * K-half + row within the 32-row block."""
+        w = weight.detach().to(torch.float32)
+        CO, CI = w.shape[0], w.shape[1]
+        wt = w.permute(2, 3, 1, 0).reshape(9, CI, CO)                            # [tap][ci][co]
+        planes = _Plan.split_bf16(wt).view(3, 9, CI // 32, 32, CO // 16, 2, 8)   # [plane][tap][j][fr][c][kh][8]
+        return planes.permute(1, 4, 0, 2, 5, 3, 6).contiguous()                  # [tap][c][plane][j][kh][fr][8]
+
+    def pack_s2_dgrad_fragments(self, conv):
+        key = (id(conv.weight), "s2dgrad")
+        if key not in self.packed_c1:
+            src = conv.weight.detach().to(device=self.device, dtype=torch.float32).contiguous()   # aliases the live parameter
+            self.packed_c1[key] = (self.s2_dgrad_fragments(src), src)
+        return self.packed_c1[key][0]
 
     def pack_conv2_fragments(self, conv):
         key = (id(conv.weight), "c2frag")
@@ -1639,6 +1660,21 @@ class _Plan:
                 op.B, op.Hi, op.Wi, op.Cin, op.Ho, op.Wo, op.Cout = B, Ho, Wo, Cout, H, W, C
                 op.ksize, op.stride, op.ld_in, op.ld_out = k, s, Cout, gx[1]
                 op.in_, op.out = dy.data_ptr(), gx[0].data_ptr() + 4 * gx[2]
+                if (k == 3 and s == 2 and (Cout, C) in ((64, 32), (128, 64)) and not (op.flags & CONV_ACCUMULATE)
+                        and gx[1] % 4 == 0 and gx[2] % 4 == 0 and self.split_train_ok()
+                        and os.environ.get("XL_GEMM_SPLIT_BF16", self.SPLIT_DEFAULT) not in ("", "0", "1")
+                        and not os.environ.get("XL_NO_S2_DGRAD")):
+                    # round 4: the stem's data gradients on the split pipe, one launch over tiles of the result instead of four
+                    # parity-class launches of the fp32 implicit GEMM (csrc/xl_stem_dgrad.hip)
+                    op.type = XL_OP_S2_DGRAD
+                    op.flags = 0
+                    op.w = self.pack_s2_dgrad_fragments(conv).data_ptr()
+                    queue = torch.zeros(4, dtype=torch.int32, device=dev)
+                    self.keep.append(queue)
+                    op.stats = queue.data_ptr()
+                    bops.append(op)
+                    self.release_grad(dy)
+                    continue
                 if (k == 1 and s == 1 and Cout % 32 == 0 and C % 256 == 0 and C <= 1024 and H * W >= 256
                         and gx[1] % 4 == 0 and gx[2] % 4 == 0 and self.split_train_ok()
                         and os.environ.get("XL_GEMM_SPLIT_BF16", self.SPLIT_DEFAULT) not in ("", "0", "1")

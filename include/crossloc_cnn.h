@@ -76,6 +76,10 @@ enum {
                                stats2 = conv2 bias[64] (read only); stats = two int32, zero (tile queue, zero
                                again after the launch); out = RAW conv2 output [B,Ho,Wo,64] NHWC (ld_out),
                                Ho = (Hi-1)/2+1; flags & XL_GN_RELU_IN: ReLU behind the GroupNorm */
+    XL_OP_S2_DGRAD = 20,    /* data gradient of a 3x3 stride-2 stem convolution (conv2 / conv3 of training plans) on the bf16 matrix pipe,
+                               csrc/xl_stem_dgrad.hip: in = dY [B,Hi,Wi,Cin] (Cin = the layer's output channels, 64 or 128), w = weight
+                               fragments [9 taps][Cin/16][3 planes][Cout/32][64 lanes][8] bf16 (networks._Plan.s2_dgrad_fragments),
+                               out = dX [B,Ho,Wo,Cout] (Cout = 32 or 64, overwritten), stats = two int32, zero (tile queue) */
     XL_OP_GN_FINAL = 11  /* per-(image, channel) GroupNorm scale/shift [B][C][2] from the partial sums (out);
                             GN_APPLY with aux2 = that buffer skips its own finalisation.  out2 (training plans):
                             [B][C][2] {mean, rstd} for the GroupNorm backward ops */
