@@ -54,7 +54,7 @@ struct S2DgradArgs {
 };
 
 template <int CO, int CI>
-__global__ __launch_bounds__(256, 2)
+__global__ __launch_bounds__(256, CO == 64 ? 2 : 1)        // (CO = 128: a 120 KB patch, one workgroup per CU)
 void s2_dgrad_kernel(S2DgradArgs a)
 {
     constexpr int kPix = CO * 6 + 16;                  // bytes per patch pixel: 3 planes of CO bf16 + 16 (an odd multiple of 16)
@@ -70,6 +70,7 @@ void s2_dgrad_kernel(S2DgradArgs a)
     const int tilesPerImage = a.tilesX * a.tilesY;
     const int total = a.B * tilesPerImage;
 
+    const __amdgpu_buffer_rsrc_t srdW = __builtin_amdgcn_make_buffer_rsrc((void *)a.wf, 0, 9 * NC * 3 * NJ * 1024, 0x00020000);
     if (tid == 0) { sQ[0] = atomicAdd(a.queue, 1); sQ[1] = atomicAdd(a.queue, 1); }
     __syncthreads();
     int t = sQ[0], tNext = sQ[1];
@@ -79,65 +80,98 @@ void s2_dgrad_kernel(S2DgradArgs a)
     const int pa = 2 * wave + (fr >> 4), pb = fr & 15;
     const unsigned aBase = (unsigned)((pa * kPC + pb) * kPix + kh * 16);
 
+    // the dY patch of a tile: 16-byte pieces (4 channels) of the 9 x 17 x CO block, NP per thread, fetched ONE TILE AHEAD into
+    // registers (all loads of a tile in flight together; as a load - split - store loop the ten dependent round trips to HBM
+    // took longer than the tile's MFMAs)
+    constexpr int PIECES = kPR * kPC * (CO / 4), NP = (PIECES + 255) / 256;
+    f32x4 pre[NP];
+    auto prefetch = [&](int tq) {
+        const int n = tq / tilesPerImage, tt = tq - n * tilesPerImage;
+        const int ty = tt / a.tilesX, tx = tt - ty * a.tilesX;
+        const int oy0 = (kTY * ty) >> 1, ox0 = (kTX * tx) >> 1;
+#pragma unroll
+        for (int e = 0; e < NP; ++e) {
+            const int i = tid + 256 * e;
+            const int pix = i / (CO / 4), c4 = i - pix * (CO / 4);
+            const int r = pix / kPC, c = pix - r * kPC;
+            const int oy = oy0 + r, ox = ox0 + c;
+            const bool inb = (tq < total) & (i < PIECES) & (oy < a.Ho) & (ox < a.Wo);
+            pre[e] = f32x4{ 0.f, 0.f, 0.f, 0.f };
+            if (inb) pre[e] = *reinterpret_cast<const f32x4 *>(a.dy + (((long long)n * a.Ho + oy) * a.Wo + ox) * a.ldDy + 4 * c4);
+        }
+    };
+    prefetch(t);
     while (t < total) {
         if (tid == 0) sQ[0] = atomicAdd(a.queue, 1);
         const int n = t / tilesPerImage, tt = t - n * tilesPerImage;
         const int ty = tt / a.tilesX, tx = tt - ty * a.tilesX;
-        const int iy0 = kTY * ty, ix0 = kTX * tx, oy0 = iy0 >> 1, ox0 = ix0 >> 1;
+        const int iy0 = kTY * ty, ix0 = kTX * tx;
 
-        // ---- 1. the dY patch -> LDS, split once: 16-byte pieces (4 channels) of the 9 x 17 x CO block
-        constexpr int PIECES = kPR * kPC * (CO / 4);
-        for (int i = tid; i < PIECES; i += 256) {
-            const int pix = i / (CO / 4), c4 = i - pix * (CO / 4);
-            const int r = pix / kPC, c = pix - r * kPC;
-            const int oy = oy0 + r, ox = ox0 + c;
-            f32x4 v = f32x4{ 0.f, 0.f, 0.f, 0.f };
-            if (oy < a.Ho && ox < a.Wo) v = *reinterpret_cast<const f32x4 *>(a.dy + (((long long)n * a.Ho + oy) * a.Wo + ox) * a.ldDy + 4 * c4);
-            unsigned wa[3], wb[3];
-            sd_split_pair(f32x2{ v[0], v[1] }, wa[0], wa[1], wa[2]);
-            sd_split_pair(f32x2{ v[2], v[3] }, wb[0], wb[1], wb[2]);
+        // ---- 1. the dY patch -> LDS, split once
 #pragma unroll
-            for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x2 *>(sP + pix * kPix + p * (CO * 2) + c4 * 8) = u32x2{ wa[p], wb[p] };
+        for (int e = 0; e < NP; ++e) {
+            const int i = tid + 256 * e;
+            if (i < PIECES) {
+                const int pix = i / (CO / 4), c4 = i - pix * (CO / 4);
+                unsigned wa[3], wb[3];
+                sd_split_pair(f32x2{ pre[e][0], pre[e][1] }, wa[0], wa[1], wa[2]);
+                sd_split_pair(f32x2{ pre[e][2], pre[e][3] }, wb[0], wb[1], wb[2]);
+#pragma unroll
+                for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x2 *>(sP + pix * kPix + p * (CO * 2) + c4 * 8) = u32x2{ wa[p], wb[p] };
+            }
         }
         __syncthreads();
         const int tAfter = sQ[0];
+        prefetch(tNext);                                               // (in flight under this tile's MFMAs)
 
-        // ---- 2. one 32-pixel block of each parity class per wave
+        // ---- 2. one 32-pixel block of each parity class per wave.  The K-steps of a class - (valid tap, 16-channel chunk) pairs -
+        // form a compile-time list; the weight fragments of step s + D are fetched behind the MFMAs of step s (a ring of D
+        // register sets: with everything unrolled the compiler would otherwise hoist every load of the tile and spill)
 #pragma unroll
         for (int cls = 0; cls < 4; ++cls) {
             const int py = cls >> 1, px = cls & 1;
+            const int nky = py ? 2 : 1, nkx = px ? 2 : 1;
+            const int nsteps = nky * nkx * NC;
             f32x16 acc[NJ];
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+            constexpr int D = NJ == 1 ? 4 : 3;             // K-steps of weight fragments in flight (a step is 6 NJ MFMAs = 192 NJ cycles; an L2 hit ~800)
+            u32x4 fbr[D][3][NJ];
+            auto tap_ky = [&](int s) { const int ti = s / NC / nkx; return py ? 2 * ti : 1; };     // valid ky of a class: py 0 -> {1}; 1 -> {0, 2}
+            auto tap_kx = [&](int s) { const int ti = (s / NC) % nkx; return px ? 2 * ti : 1; };
+            auto load_b = [&](int s, int slot) {
+                const int tap = 3 * tap_ky(s) + tap_kx(s), c = s % NC;
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
-                if (((py + 1 - ky) & 1) != 0) continue;                  // (iy + 1 - ky) must be even
+                for (int p = 0; p < 3; ++p)
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    if (((px + 1 - kx) & 1) != 0) continue;
-                    // source pixel of result (2 a + py, 2 b + px): patch (a + dr, b + dc)
-                    const int dr = (py + 1 - ky) >> 1, dc = (px + 1 - kx) >> 1;
-                    const int tap = 3 * ky + kx;
+                    for (int j = 0; j < NJ; ++j)       // (a buffer load: ONE lane-offset register + a scalar offset per fragment - with
+                                                       //  flat pointers the compiler keeps a 64-bit address per fragment alive and spills)
+                        fbr[slot][p][j] = __builtin_amdgcn_raw_buffer_load_b128(srdW, (int)(lane * 16), (int)((((tap * NC + c) * 3 + p) * NJ + j) * 1024), 0);
+            };
 #pragma unroll
-                    for (int c = 0; c < NC; ++c) {
-                        bf16x8 fa[3];
-                        u32x4 fb[3][NJ];
+            for (int s = 0; s < D; ++s)
+                if (s < nsteps) load_b(s, s);
 #pragma unroll
-                        for (int p = 0; p < 3; ++p) {
-                            fa[p] = *reinterpret_cast<const bf16x8 *>(sP + aBase + (dr * kPC + dc) * kPix + p * (CO * 2) + c * 32);
+            for (int s = 0; s < 4 * NC; ++s) {
+                if (s >= nsteps) break;
+                const int ky = tap_ky(s), kx = tap_kx(s), c = s % NC;
+                // source pixel of result (2 a + py, 2 b + px): patch (a + dr, b + dc)
+                const int dr = (py + 1 - ky) >> 1, dc = (px + 1 - kx) >> 1;
+                bf16x8 fa[3];
 #pragma unroll
-                            for (int j = 0; j < NJ; ++j) fb[p][j] = a.wf[(((tap * NC + c) * 3 + p) * NJ + j) * 64 + lane];
-                        }
-                        constexpr int PU[6] = { 2, 1, 0, 1, 0, 0 }, PV[6] = { 0, 1, 2, 0, 1, 0 };   // (weights, activations), smallest first
+                for (int p = 0; p < 3; ++p)
+                    fa[p] = *reinterpret_cast<const bf16x8 *>(sP + aBase + (dr * kPC + dc) * kPix + p * (CO * 2) + c * 32);
+                constexpr int PU[6] = { 2, 1, 0, 1, 0, 0 }, PV[6] = { 0, 1, 2, 0, 1, 0 };   // (weights, activations), smallest first
 #pragma unroll
-                        for (int tm = 0; tm < 6; ++tm)
+                for (int tm = 0; tm < 6; ++tm)
 #pragma unroll
-                            for (int j = 0; j < NJ; ++j)
-                                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fb[PU[tm]][j]), fa[PV[tm]], acc[j], 0, 0, 0);
-                    }
-                }
+                    for (int j = 0; j < NJ; ++j)
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fbr[s % D][PU[tm]][j]), fa[PV[tm]], acc[j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (s + D < nsteps) load_b(s + D, s % D);
+                __builtin_amdgcn_sched_barrier(0);
             }
             // store: result pixel (iy0 + 2 pa + py, ix0 + 2 pb + px), channels 32 j + 8 q + 4 kh + {0..3}
             const int iy = iy0 + 2 * pa + py, ix = ix0 + 2 * pb + px;

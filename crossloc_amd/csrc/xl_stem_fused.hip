@@ -149,6 +149,7 @@ void stem12_kernel(Stem12Args a)
     const int oyl = 2 * pxb + (fr >> 4), oxl = fr & 15;
     const unsigned aBase = (unsigned)(((2 * oyl) * kPW + oxl) * kPix + kh * 16);
 
+    const __amdgpu_buffer_rsrc_t srdW2 = __builtin_amdgcn_make_buffer_rsrc((void *)a.w2, 0, 18 * 3 * 2 * 1024, 0x00020000);
     long long cPh[6] = { 0, 0, 0, 0, 0, 0 }, cT = 0, nTiles = 0;
     auto stamp = [&](int ph) { if (a.clk) { const long long now = clock64(); cPh[ph] += now - cT; cT = now; } };
     // Tiles come from a queue (one atomic per tile, fetched two tiles ahead), not from a static stride: the solver of the batch
@@ -190,14 +191,17 @@ void stem12_kernel(Stem12Args a)
         stamp(1);                                                      // barrier 1
         const int tAfter = sQ[0];
         // conv2's weight fragments of the first three K-steps: in flight under conv1
-        u32x4 fbr[3][3][kNJ];
+        constexpr int D = kNJ == 1 ? 6 : 3;                 // K-steps of weight fragments in flight (6 kNJ MFMAs = 192 kNJ cycles each)
+        u32x4 fbr[D][3][kNJ];
         auto load_b = [&](int kk, int slot) {
 #pragma unroll
             for (int p = 0; p < 3; ++p)
 #pragma unroll
-                for (int j = 0; j < kNJ; ++j) fbr[slot][p][j] = a.w2[((kk * 3 + p) * 2 + jb + j) * 64 + lane];
+                for (int j = 0; j < kNJ; ++j)          // (buffer load: one lane-offset register + a scalar offset per fragment)
+                    fbr[slot][p][j] = __builtin_amdgcn_raw_buffer_load_b128(srdW2, (int)(lane * 16), (int)(((kk * 3 + p) * 2 + jb + j) * 1024), 0);
         };
-        load_b(0, 0); load_b(1, 1); load_b(2, 2);
+#pragma unroll
+        for (int kk = 0; kk < D; ++kk) load_b(kk, kk);
 
         // ---- 2. conv1 on the patch: blocks of 32 patch pixels (linear index L = row * 33 + de-interleaved column)
 #pragma unroll 1
@@ -271,7 +275,7 @@ void stem12_kernel(Stem12Args a)
             bf16x8 fa[3];
 #pragma unroll
             for (int p = 0; p < 3; ++p) fa[p] = *reinterpret_cast<const bf16x8 *>(sPatch + aBase + off + p * 64);
-            const int slot = kk % 3;
+            const int slot = kk % D;
             constexpr int PU[6] = { 2, 1, 0, 1, 0, 0 }, PV[6] = { 0, 1, 2, 0, 1, 0 };   // (weights, activations): split_conv3x3s2's order
 #pragma unroll
             for (int tm = 0; tm < 6; ++tm)
@@ -279,7 +283,7 @@ void stem12_kernel(Stem12Args a)
                 for (int j = 0; j < kNJ; ++j)
                     acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fbr[slot][PU[tm]][j]), fa[PV[tm]], acc2[j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if (kk + 3 < 18) load_b(kk + 3, slot);
+            if (kk + D < 18) load_b(kk + D, slot);
             __builtin_amdgcn_sched_barrier(0);
         }
 
