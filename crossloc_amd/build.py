@@ -101,5 +101,68 @@ def build(force=False, verbose=False):
     return LIB
 
 
+EXT_SRC = os.path.join(CSRC, "dsacstar_ext.cpp")
+EXT_NAME = "_dsacstar_native"
+
+
+def ext_path():
+    import sysconfig
+    return os.path.join(HERE, EXT_NAME + sysconfig.get_config_var("EXT_SUFFIX"))
+
+
+def _ext_hash():
+    import hashlib
+    import torch
+    h = hashlib.sha256(torch.__version__.encode())
+    for d in (EXT_SRC, os.path.join(INC, "crossloc_dsac.h")):
+        with open(d, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def build_ext(force=False, verbose=False):
+    """The compiled `dsacstar` binding (csrc/dsacstar_ext.cpp: pybind11 + ATen, host-only C++, links libcrossloc_hip.so): built
+    in-tree with g++ against the torch headers of this interpreter, under the same file lock as the library.  Optional: the
+    ctypes shim is the fallback (dsacstar.py), so a missing compiler or torch header is reported, not fatal."""
+    out, stamp = ext_path(), ext_path() + ".srchash"
+    want = _ext_hash()
+    if not force and os.path.exists(out) and os.path.exists(stamp) and open(stamp).read().strip() == want:
+        return out
+    import shutil
+    import sysconfig
+    import tempfile
+    import torch
+    from torch.utils import cpp_extension as ce
+    build()                                                             # the library it links against
+    with _BuildLock():
+        if not force and os.path.exists(out) and os.path.exists(stamp) and open(stamp).read().strip() == want:
+            return out
+        tmp = tempfile.mkdtemp(prefix=".build.", dir=HERE)
+        try:
+            so = os.path.join(tmp, os.path.basename(out))
+            cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-attributes", EXT_SRC, "-o", so,
+                   "-DTORCH_EXTENSION_NAME=" + EXT_NAME, "-DTORCH_API_INCLUDE_EXTENSION_H",
+                   "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch.compiled_with_cxx11_abi()),
+                   "-I" + sysconfig.get_paths()["include"]]
+            cmd += ["-I" + p for p in ce.include_paths()]
+            libdirs = ce.library_paths()
+            cmd += ["-L" + p for p in libdirs] + ["-L" + HERE]
+            cmd += ["-lc10", "-ltorch_cpu", "-ltorch", "-ltorch_python", "-l:libcrossloc_hip.so",
+                    "-Wl,-rpath,$ORIGIN"] + ["-Wl,-rpath," + p for p in libdirs]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            subprocess.check_call(cmd)
+            with open(os.path.join(tmp, "srchash"), "w") as f:
+                f.write(want + "\n")
+            if os.path.exists(stamp):
+                os.remove(stamp)
+            os.replace(so, out)
+            os.replace(os.path.join(tmp, "srchash"), stamp)
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+    return out
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_ext(force="--force" in sys.argv, verbose=True))

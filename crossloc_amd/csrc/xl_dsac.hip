@@ -607,6 +607,7 @@ struct Params {
     double *part;                 // split launch: [B][S*4][16] per-wave bests + [B][12] pose of hypothesis 0
     int S;                        // sub-blocks per image in the split launch
     float thr, focal, ppx, ppy, alpha, maxReproj;
+    int pairCells;                // scoring loop: two cells per lane and trip (same bits, more instruction-level parallelism)
 };
 
 // LDS carve (all dynamic, 16-byte aligned pieces)
@@ -708,7 +709,7 @@ __device__ __forceinline__ void refine_pose(const Coords &co, const Cam &cam, Sm
 // The split (1 then 2) exists for small batches: with B < ~100 images the fused kernel leaves most CUs idle and
 // its latency is the 64 hypotheses each wavefront walks through.  Results are identical in both forms.
 template <int PHASE>
-__global__ __launch_bounds__(kThreads)
+__global__ __launch_bounds__(kThreads, PHASE == 1 ? 2 : 1)     // (sample + score: LDS allows two workgroups per CU, 256 registers per wave)
 void xl_dsac_forward_kernel(Params P)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -775,8 +776,21 @@ void xl_dsac_forward_kernel(Params P)
             break;
         }
 
+        // two cells per lane and trip: two independent chains of ~200 dependent fp64 instructions each (projection, divide, sqrt,
+        // exp, divide) in flight - the kernel runs at 1-2 waves per SIMD and was bound by that latency.  Same operations per
+        // cell, same order of the additions into `acc`: the bits do not change (XL_DSAC_PAIR_CELLS=0: one cell per trip)
         double acc = 0.0;
-        for (int i = lane; i < N; i += 64) {
+        int i = lane;
+        if (P.pairCells)
+        for (; i + 64 < N; i += 128) {
+            const float e0 = cell_err(pose, co, i, cam), e1 = cell_err(pose, co, i + 64, cam);
+            double st0 = (double)(beta * (e0 - cam.thr)), st1 = (double)(beta * (e1 - cam.thr));
+            st0 = 1.0 / (1.0 + det_exp(-st0));
+            st1 = 1.0 / (1.0 + det_exp(-st1));
+            acc += 1.0 - st0;
+            acc += 1.0 - st1;
+        }
+        for (; i < N; i += 64) {
             float e = cell_err(pose, co, i, cam);
             float stf = beta * (e - cam.thr);
             double st = (double)stf;
@@ -1593,6 +1607,8 @@ int xl_dsac_forward_rgb_batch(const float *coords_dev, int64_t sb, int64_t sc, i
     static const char *noSplit = getenv("XL_DSAC_NO_SPLIT");
     if (noSplit) S = 1;
     P.part = nullptr; P.S = S;
+    static const int pairCells = getenv("XL_DSAC_PAIR_CELLS") ? atoi(getenv("XL_DSAC_PAIR_CELLS")) : 1;
+    P.pairCells = pairCells;
     if (S == 1) {
         hipLaunchKernelGGL(xl_dsac_forward_kernel<0>, dim3(B), dim3(kThreads), lds, st, P);
     } else {
@@ -1698,6 +1714,7 @@ int xl_dsac_backward_rgb_batch(const float *coords_dev, int64_t sb, int64_t sc, 
     P.nHyp = n_hyp; P.Ho = Ho; P.Wo = Wo; P.sub = sub; P.Npad = (N + 3) & ~3;
     P.thr = thr; P.focal = focal; P.ppx = ppx; P.ppy = ppy; P.alpha = alpha; P.maxReproj = max_reproj;
     P.part = part; P.S = S;
+    P.pairCells = 1;
     BwdParams Q;
     Q.coords = coords_dev; Q.sb = sb; Q.sc = sc; Q.sy = sy; Q.sx = sx;
     Q.grad = grad_dev; Q.gsb = gsb; Q.gsc = gsc; Q.gsy = gsy; Q.gsx = gsx;

@@ -35,6 +35,14 @@ def set_image_index(index):
     _image_index = int(index)
 
 
+def _take_image_index():
+    """The image index of the next single-image call, consumed (shared by the ctypes shim and the compiled binding)."""
+    global _image_index
+    image = _image_index
+    _image_index += 1
+    return image
+
+
 def _check_coords(t, batched):
     if not isinstance(t, torch.Tensor):
         raise RuntimeError("sceneCoordinates must be a torch.Tensor")
@@ -96,13 +104,11 @@ def forward_rgb(sceneCoordinates, outPose, ransacHypotheses, inlierThreshold, fo
                 inlierAlpha, maxReproj, subSampling):
     """dsacstar_rgb_forward (dsacstar.cpp:63-73): estimate the camera pose of ONE image from its scene
     coordinate prediction [1,3,H,W]; writes the 4x4 cam->world matrix into outPose in place."""
-    global _image_index
     _check_coords(sceneCoordinates, False)
     if not isinstance(outPose, torch.Tensor) or outPose.dim() != 2 or outPose.dtype != torch.float32 \
             or tuple(outPose.shape) != (4, 4):
         raise RuntimeError("outPose must be a float32 [4,4] tensor")
-    image = _image_index
-    _image_index += 1
+    image = _take_image_index()
     _, _, Ho, Wo = sceneCoordinates.shape
     if sceneCoordinates.is_cuda:
         dst = outPose if (outPose.is_cuda and outPose.is_contiguous()) else \

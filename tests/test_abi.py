@@ -44,6 +44,21 @@ def test_status_strings_and_stub_entry_points(hiplib):
     assert hiplib.xl_dsac_forward_rgb_batch(None, 0, 0, 0, 0, 1, 60, 90, None, 64) == -1
 
 
+def test_dsacstar_resolves_to_the_compiled_binding(hiplib):
+    """`import dsacstar` serves forward_rgb / backward_rgb / forward_rgbd / backward_rgbd (dsacstar.cpp:887-892) from the compiled
+    pybind11 / ATen module, like the reference's own extension; the ctypes shim stays importable as the fallback."""
+    import shutil
+    if not shutil.which("g++"):
+        pytest.skip("no g++ here: the binding cannot be built")
+    import dsacstar
+    import crossloc_amd.dsacstar as shim
+    assert dsacstar.NATIVE is not None, getattr(dsacstar, "NATIVE_ERROR", None)
+    assert dsacstar.NATIVE.__file__.endswith(".so")
+    for n in ("forward_rgb", "backward_rgb", "forward_rgbd", "backward_rgbd"):
+        assert getattr(dsacstar, n) is getattr(dsacstar.NATIVE, n) and getattr(dsacstar, n) is not getattr(shim, n)
+    assert dsacstar.forward_rgb_batch is shim.forward_rgb_batch          # the batched entry points live in the shim
+
+
 def test_dsacstar_module_surface(hiplib):
     import dsacstar
     for n in ("forward_rgb", "backward_rgb", "forward_rgbd", "backward_rgbd"):   # dsacstar.cpp:887-892

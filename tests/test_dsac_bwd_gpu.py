@@ -76,8 +76,13 @@ def test_weights_and_soft_clamp(oracle):
         _assert_same(oracle, coords[b], poses[b], 32, 11, b, loss_g[b], rec_g[b], grad_g[b], **over)
 
 
-def test_reference_shaped_call_cpu_and_gpu_tensors(oracle):
+@pytest.mark.parametrize("binding", ["compiled", "ctypes"])
+def test_reference_shaped_call_cpu_and_gpu_tensors(oracle, binding):
     import dsacstar
+    if binding == "compiled":
+        assert dsacstar.NATIVE is not None and dsacstar.backward_rgb is dsacstar.NATIVE.backward_rgb, getattr(dsacstar, "NATIVE_ERROR", "")
+    else:
+        import crossloc_amd.dsacstar as dsacstar
     sc = synth.make_scene(80, noise=0.5, outlier_ratio=0.3)
     coords, pose = np.ascontiguousarray(sc["coords"]), sc["pose"]
     g_o = np.zeros_like(coords)

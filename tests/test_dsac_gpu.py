@@ -101,9 +101,15 @@ def test_strided_device_input(oracle):
     _assert_same(oracle, sc["coords"], out.cpu().numpy(), {k: v.cpu().numpy() for k, v in d.items()}, 0, 32, image=0)
 
 
-def test_reference_shaped_call_cpu_and_gpu_tensors(oracle):
-    """The exact call of utils/evaluation.py:160-172: CPU tensors, in-place 4x4 output."""
+@pytest.mark.parametrize("binding", ["compiled", "ctypes"])
+def test_reference_shaped_call_cpu_and_gpu_tensors(oracle, binding):
+    """The exact call of utils/evaluation.py:160-172: CPU tensors, in-place 4x4 output - through the compiled pybind11 / ATen
+    binding (what `import dsacstar` resolves to) and through the ctypes shim (its fallback)."""
     import dsacstar
+    if binding == "compiled":
+        assert dsacstar.NATIVE is not None and dsacstar.forward_rgb is dsacstar.NATIVE.forward_rgb, getattr(dsacstar, "NATIVE_ERROR", "")
+    else:
+        import crossloc_amd.dsacstar as dsacstar
     sc = synth.make_scene(21, noise=0.5, outlier_ratio=0.3)
     scene_coords = torch.from_numpy(sc["coords"])[None]
     dsacstar.set_image_index(7)
