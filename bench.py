@@ -142,8 +142,8 @@ def plan_work(plan, networks):
                 byts += act_in * 4
             byts += Z * M * op.Cout * 4 + Z * op.Cout * K * (6 if split else 4)
         elif t == getattr(networks, "XL_OP_STEM12", -1):
-            # conv1 evaluated on the 17 x 33 patch of every 8 x 16 tile of conv2 outputs (1.096x its output pixels), then conv2
-            px1 = op.B * (-(-op.Ho // 8)) * (-(-op.Wo // 16)) * 17 * 33
+            # conv1 evaluated on the 9 x 33 patch of every 4 x 16 tile of conv2 outputs (1.16x its output pixels), then conv2
+            px1 = op.B * (-(-op.Ho // 4)) * (-(-op.Wo // 16)) * 9 * 33
             bf16 += 6 * 2.0 * px1 * 32 * 27 + 6 * 2.0 * op.B * op.Ho * op.Wo * op.Cout * 288
             byts += op.B * op.Hi * op.Wi * 3 * 4 + op.B * op.Ho * op.Wo * op.Cout * 4
         elif t == networks.XL_OP_CONV1:

@@ -412,3 +412,34 @@ def test_weight_gradient_products_on_the_split_pipe(cin, cout, M, Z, splits):
     esp = (got - ref).abs().max().item() / scale
     e32 = (run(0, splits) - ref).abs().max().item() / scale
     assert esp < 2e-6 and esp < 4 * e32 + 2e-7, (esp, e32)
+
+
+@pytest.mark.parametrize("CO,CI,B,H,W", [(64, 32, 2, 64, 96), (64, 32, 1, 41, 57), (128, 64, 2, 32, 48), (128, 64, 1, 35, 50)])
+def test_stride2_data_gradient_on_the_split_pipe_vs_float64(CO, CI, B, H, W):
+    """XL_OP_S2_DGRAD (csrc/xl_stem_dgrad.hip, round 4): dX of a 3x3 stride-2 pad-1 convolution from dY, one launch over 16 x 32
+    tiles of the result, against torch.nn.grad.conv2d_input in float64.  41 x 57 / 35 x 50: odd sizes and ragged tiles (the last
+    input row / column is reached by fewer taps).  fp32-class: three-term bf16 splits, six MFMA passes, fp32 accumulation."""
+    import ctypes
+    g = torch.Generator().manual_seed(CO + H)
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    w = torch.randn(CO, CI, 3, 3, generator=g) * (2.0 / (9 * CI)) ** 0.5
+    dy = torch.randn(B, CO, Ho, Wo, generator=g)
+    ref = torch.nn.grad.conv2d_input((B, CI, H, W), w.double(), dy.double(), stride=2, padding=1)
+    frag = networks._Plan.s2_dgrad_fragments(w.cuda())
+    dy_d = dy.permute(0, 2, 3, 1).contiguous().cuda()
+    dx = torch.full((B, H, W, CI), float("nan"), device="cuda")
+    queue = torch.zeros(4, dtype=torch.int32, device="cuda")
+    op = networks.XlOp()
+    op.type = networks.XL_OP_S2_DGRAD
+    op.B, op.Hi, op.Wi, op.Cin, op.Ho, op.Wo, op.Cout = B, Ho, Wo, CO, H, W, CI
+    op.ksize, op.stride, op.ld_in, op.ld_out = 3, 2, CO, CI
+    op.in_, op.w, op.out, op.stats = dy_d.data_ptr(), frag.data_ptr(), dx.data_ptr(), queue.data_ptr()
+    arr = (networks.XlOp * 1)(op)
+    for _ in range(2):                                   # twice: the tile queue must be left as it was found
+        networks._check(networks._bind().xl_cnn_run(arr, 1, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    assert int(queue.abs().sum()) == 0
+    got = dx.permute(0, 3, 1, 2).cpu().double()
+    assert torch.isfinite(got).all()
+    err = (got - ref).abs().max().item() / ref.abs().max().item()
+    assert err <= 2e-6, err

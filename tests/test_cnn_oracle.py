@@ -72,3 +72,20 @@ def test_semantics_head_keys_and_oracle_match_reference_golden():
         y = cnn_oracle.transposenet_forward(sd, torch.from_numpy(SEM[tag + "_x"]), 0, 2, 2, 6, 0)
         ref = torch.from_numpy(SEM[tag + "_y"])
         assert y.shape == ref.shape and torch.allclose(y, ref, atol=2e-5)
+
+
+def test_stem_fragment_packings_hold_the_exact_weights():
+    """The MFMA weight-fragment layouts of the fused stem (conv2) and of the stride-2 data gradient: every fragment is the
+    three-term bf16 split of the fp32 weights it stands for, terms summing back exactly (CPU: pure tensor code)."""
+    g = torch.Generator().manual_seed(3)
+    w = torch.randn(64, 32, 3, 3, generator=g)
+    f = networks._Plan.conv2_fragments(w).view(torch.bfloat16).float()        # [kk][plane][j][kh][fr][8]
+    rows = w.permute(0, 2, 3, 1).reshape(64, 288)
+    back = f.sum(1).permute(1, 3, 0, 2, 4).reshape(64, 288)                  # [j][fr][kk][kh][8] -> [row][K]
+    assert torch.equal(back, rows)
+    for CO, CI in ((64, 32), (128, 64)):
+        w = torch.randn(CO, CI, 3, 3, generator=g)
+        f = networks._Plan.s2_dgrad_fragments(w).view(torch.bfloat16).float()   # [tap][c][plane][j][kh][fr][8]
+        wt = w.permute(2, 3, 1, 0).reshape(9, CI, CO)
+        back = f.sum(2).permute(0, 2, 4, 1, 3, 5).reshape(9, CI, CO)          # [tap][j][fr][c][kh][8]
+        assert torch.equal(back, wt)
