@@ -51,8 +51,13 @@ struct WgSplitArgs {
     int M, Cin, Cout, ldX, ldY, splits, mPerSplit, zCount, nbo, nbc;
     long long zX, zY;
     unsigned xBytes, dyBytes;
+    // NORM: `x` is the RAW output of the producing convolution; its GroupNorm (+ReLU) is applied while the operand is loaded
+    // (round 4, training plans whose GroupNorm applies are left to the consumers): coef = [B][Cin][2] {scale, shift}, HW pixels
+    // per image (a multiple of 8: the 8 consecutive t of a thread belong to one image), normLo = 0 (ReLU) or -inf
+    const float *coef; int HW; float normLo;
 };
 
+template <bool NORM>
 __global__ __launch_bounds__(512)
 void wgrad_split_kernel(WgSplitArgs a)
 {
@@ -79,8 +84,19 @@ void wgrad_split_kernel(WgSplitArgs a)
     const int row = tid & 255, th = tid >> 8;                         // my channel of both tiles; my half of the 16 t of a step
     const bool okO = o0 + row < a.Cout, okC = c0 + row < a.Cin;
     float ra[8], rb[8];
+    float nSc = 1.f, nSh = 0.f;                                        // NORM: {scale, shift} of (image of the loaded step, my channel)
+    int nImg = -1, nLive = 0;                                          // ... that image; how many of my 8 t are inside the split
     auto load_regs = [&](int kk) {                                    // K-step kk -> registers
         const int t0 = mBeg + 16 * kk + 8 * th;
+        if constexpr (NORM) {
+            nLive = mEnd - t0; nLive = nLive < 0 ? 0 : (nLive > 8 ? 8 : nLive);
+            const int n = t0 / a.HW;
+            if (okC && nLive > 0 && n != nImg) {
+                nImg = n;
+                const f32x2 c2 = *reinterpret_cast<const f32x2 *>(a.coef + ((long long)n * a.Cin + c0 + row) * 2);
+                nSc = c2[0]; nSh = c2[1];
+            }
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int t = t0 + e;
@@ -105,6 +121,10 @@ void wgrad_split_kernel(WgSplitArgs a)
         for (int h = 0; h < 4; ++h) split_pair(ra[2 * h], ra[2 * h + 1], w[0][h], w[1][h], w[2][h]);
 #pragma unroll
         for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4 *>(sb + wOff[p]) = u32x4{ w[p][0], w[p][1], w[p][2], w[p][3] };
+        if constexpr (NORM) {                                          // one fmaf, one max: the arithmetic of every apply site
+#pragma unroll
+            for (int e = 0; e < 8; ++e) rb[e] = (okC && e < nLive) ? fmaxf(fmaf(rb[e], nSc, nSh), a.normLo) : 0.f;
+        }
 #pragma unroll
         for (int h = 0; h < 4; ++h) split_pair(rb[2 * h], rb[2 * h + 1], w[0][h], w[1][h], w[2][h]);
 #pragma unroll
@@ -206,11 +226,14 @@ void wgrad_split_kernel(WgSplitArgs a)
 
 // XL_OP_WGRAD with ksize 1 and XL_CONV_SPLIT_BF16: the same operands and scratch layout as the fp32 kernel - in = x [M][Cin]
 // (ld_in), aux = dY [M][Cout] (ld_aux), stats2 = partial [z][splits][Cout][Cin], groups = Z batched GEMMs (dense operands),
-// nchunks2 = splits.  Cin % 4 == 0.  The caller runs wgrad_reduce_kernel afterwards.
+// nchunks2 = splits.  Cin % 4 == 0.  The caller runs wgrad_reduce_kernel afterwards.  XL_CONV_NORM_IN (1x1 layers, Z = 1): `in` is
+// the raw output of the producing convolution, aux2 = its {scale, shift} pairs [B][Cin][2], XL_CONV_NORM_RELU; Ho*Wo % 8 == 0.
 int xl_run_wgrad_split(const xl_op &op, hipStream_t st)
 {
     if (op.ksize != 1 || op.stride != 1 || op.nchunks2 < 1 || op.ld_in % 4 != 0 || op.ld_aux % 4 != 0 || op.Cin % 4 != 0 ||
         !op.in || !op.aux || !op.stats2) return XL_ERR_ARG;
+    const bool norm = (op.flags & XL_CONV_NORM_IN) != 0;
+    if (norm && (!op.aux2 || op.groups > 1 || (op.Ho * op.Wo) % 8 != 0)) return XL_ERR_ARG;
     WgSplitArgs a;
     a.x = (const float *)op.in; a.dy = (const float *)op.aux; a.partial = (float *)op.stats2;
     a.M = op.B * op.Ho * op.Wo; a.Cin = op.Cin; a.Cout = op.Cout; a.ldX = op.ld_in; a.ldY = op.ld_aux;
@@ -223,14 +246,17 @@ int xl_run_wgrad_split(const xl_op &op, hipStream_t st)
     const long long xb = (((long long)a.M - 1) * op.ld_in + op.Cin) * 4, yb = (((long long)a.M - 1) * op.ld_aux + op.Cout) * 4;
     if (xb >= 0x7fffffffLL || yb >= 0x7fffffffLL) return XL_ERR_ARG;
     a.xBytes = (unsigned)xb; a.dyBytes = (unsigned)yb;
+    a.coef = (const float *)op.aux2; a.HW = op.Ho * op.Wo;
+    a.normLo = (op.flags & XL_CONV_NORM_RELU) ? 0.f : -__builtin_inff();
     const size_t lds = 4 * (size_t)kOperand;                          // two stages of two operands: 96 KB
-    static XlLdsLimit configured;
+    static XlLdsLimit configured[2];
     int cfgDev;
-    if (configured.needs(lds, &cfgDev)) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(wgrad_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds) != hipSuccess) return XL_ERR_HIP;
-        configured.done(lds, cfgDev);
+    if (configured[norm].needs(lds, &cfgDev)) {
+        const void *fn = norm ? reinterpret_cast<const void *>(wgrad_split_kernel<true>) : reinterpret_cast<const void *>(wgrad_split_kernel<false>);
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return XL_ERR_HIP;
+        configured[norm].done(lds, cfgDev);
     }
-    hipLaunchKernelGGL(wgrad_split_kernel, dim3(a.zCount * a.nbo * a.nbc * a.splits), dim3(512), lds, st, a);
+    if (norm) hipLaunchKernelGGL(wgrad_split_kernel<true>, dim3(a.zCount * a.nbo * a.nbc * a.splits), dim3(512), lds, st, a);
+    else hipLaunchKernelGGL(wgrad_split_kernel<false>, dim3(a.zCount * a.nbo * a.nbc * a.splits), dim3(512), lds, st, a);
     return XL_OK;
 }

@@ -406,6 +406,15 @@ class _Plan:
                 return m
         return 0
 
+    def wino_wgrad_ok(self, conv, H, W, C, m):
+        """The weight gradient of this F(m x m,3x3) layer will be a Winograd one (the conditions of _lower_backward): it then
+        reads the normalised V and never the layer's input tensor."""
+        Cout = conv.out_channels
+        return (not conv.weight.requires_grad) or (
+            m in (4, 6) and C % 64 == 0 and Cout % 128 == 0 and self.B * -(-H // m) * -(-W // m) >= 64
+            and not os.environ.get("XL_NO_WINOGRAD") and not os.environ.get("XL_NO_WINOGRAD_TRAIN")
+            and not os.environ.get("XL_NO_WINOGRAD_WGRAD"))
+
     def wino_dgrad_m(self, conv, H, W, C):
         """Data gradient of a stride-1 3x3 layer as F(m x m, 3x3) (C = the layer's input channels = gradient channels):
         the tile size, or 0 for the direct MODE 1 kernel."""
@@ -655,10 +664,13 @@ class _Plan:
             op.reserved_i = -256 if self.separate_stats else self.split_tile_form(self.B * Ho * Wo, cout, 1, Ho * Wo)
         if norm_in is not None:                       # the producer's deferred GroupNorm apply, folded into the operand load
             op.flags |= CONV_NORM_IN | (CONV_NORM_RELU if norm_in.flags & GN_RELU_IN else 0)
-            self.deferred_gn_consumers = getattr(self, "deferred_gn_consumers", []) + [len(self.ops)]
+            if self.train:
+                op.aux2 = norm_in.aux2                # (training plans: the producer's own coefficient table)
+            else:
+                self.deferred_gn_consumers = getattr(self, "deferred_gn_consumers", []) + [len(self.ops)]
         self.ops.append(op)
         res = (out, Ho, Wo, cout, out_ld, out_off)
-        self.tape.append(dict(kind="conv", conv=conv, x=act, raw=res))
+        self.tape.append(dict(kind="conv", conv=conv, x=act, raw=res, xnorm=norm_in if self.train else None))
         return res
 
     def gn(self, act, norm, flags, aux=None, out=None, pre_stats=None, stat_tile=0, defer=False, share=False):
@@ -705,7 +717,14 @@ class _Plan:
         if aux is not None:
             ap.aux = aux[0].data_ptr() + 4 * aux[5]
             ap.ld_aux = aux[4]
-        if out is None and self.train:
+        # round 4, training plans: a GroupNorm + ReLU whose only consumer is a convolution that can apply it while loading its
+        # operand (an F(m x m,3x3) layer: input transform, the normalised V is kept for the weight gradient; a 1x1 layer on the
+        # split pipe: forward and weight-gradient kernels normalise on load) is NOT materialised: no apply pass, no activation
+        # tensor.  Its backward pass needs the raw conv output and the coefficient table only.  cgr() materialises it after all
+        # when the consumer turns out not to be able to (XL_NO_TRAIN_DEFER=1: never deferred).
+        train_defer = (self.train and defer and out is None and flags == GN_RELU_IN and aux is None and not self.separate_stats
+                       and HW % 8 == 0 and not os.environ.get("XL_NO_TRAIN_DEFER"))
+        if out is None and self.train and not train_defer:
             out = (self.alloc(self.B * HW * C), C, 0)
         if out is None:
             ap.out, ap.ld_out = ap.in_, ld
@@ -722,12 +741,34 @@ class _Plan:
                 return res
             if share and self.fold_ok():              # ... or the first of several consumers does, and materialises it
                 return self._fold_begin(ap, act, aux)
+        if train_defer:
+            entry = dict(kind="gn", norm=norm, raw=act, out=res, aux=None, flags=flags, table=table, gamma=gamma, beta=beta)
+            self.tape.append(entry)
+            if not hasattr(self, "pending_gn"):
+                self.pending_gn, self.pending_entry = {}, {}
+            self.pending_gn[self._act_key(res)] = ap
+            self.pending_entry = getattr(self, "pending_entry", {})
+            self.pending_entry[self._act_key(res)] = entry
+            return res
         aux_ap = self._aux_take(aux)
         if aux_ap is not None:
             self._aux_apply(aux_ap)
         self.ops.append(ap)
         self.tape.append(dict(kind="gn", norm=norm, raw=act, out=res, aux=aux, flags=flags, table=table,
                               gamma=gamma, beta=beta))
+        return res
+
+    def _train_materialise(self, pend, act):
+        """A GroupNorm apply deferred in a training plan whose consumer cannot apply it on load: run it as a pass into a buffer of
+        its own (the raw conv output stays: the backward pass reads it) and continue with that activation."""
+        t, H, W, C, ld, off = act
+        out = self.alloc(self.B * H * W * C)
+        pend.out, pend.ld_out = out.data_ptr(), C
+        self.ops.append(pend)
+        res = (out, H, W, C, C, 0)
+        entry = getattr(self, "pending_entry", {}).pop(self._act_key(act), None)
+        if entry is not None:
+            entry["out"] = res
         return res
 
     def wino_tile(self, act, conv):
@@ -793,7 +834,10 @@ class _Plan:
             op.flags = CONV_SPLIT_BF16 | (CONV_SPLIT_IL if split_il else 0)
         if deferred is not None:                      # the producer's GroupNorm(+ReLU) is applied while gathering
             op.flags |= deferred.flags
-            self.deferred_gn_consumers = getattr(self, "deferred_gn_consumers", []) + [len(self.ops)]
+            if self.train:
+                op.aux2 = deferred.aux2               # (training plans: the producer's own coefficient table)
+            else:
+                self.deferred_gn_consumers = getattr(self, "deferred_gn_consumers", []) + [len(self.ops)]
         if fold is not None:                          # ... and, fold: the activation `act` is written by this transform
             fap, raw = fold["ap"], fold["raw"]
             op.in_, op.ld_in = raw[0].data_ptr() + 4 * raw[5], raw[4]
@@ -873,8 +917,8 @@ class _Plan:
                 self.kept_v_bytes += 4 * V.numel()
             else:
                 self.free.setdefault(V.numel(), []).append(V)
-            self.tape.append(dict(kind="conv", conv=conv, x=act, raw=y, v=kept_v, wm=m))
-            return self.gn(y, norm, flags, aux, pre_stats=(stats_t, nchunks), out=dst)
+            self.tape.append(dict(kind="conv", conv=conv, x=act, raw=y, v=kept_v, wm=m, xnorm=deferred))
+            return self.gn(y, norm, flags, aux, pre_stats=(stats_t, nchunks), out=dst, defer=defer)
         self.max_stats = max(self.max_stats, B * nchunks * G * 2)
         self.stats_ops.append(len(self.ops))
         self.ops.append(op)
@@ -928,7 +972,9 @@ class _Plan:
         fold = getattr(self, "pending_fold", {}).pop(self._act_key(act), None)
         m = self.wino_tile(act, conv)
         if out is not None and not m:                  # no Winograd form for this layer: direct conv, then the apply into `out`
-            if pend is not None:
+            if pend is not None and self.train:
+                act = self._train_materialise(pend, act)
+            elif pend is not None:
                 self.stats_ops.append(len(self.ops))
                 self.ops.append(pend)
             if fold is not None:
@@ -946,7 +992,18 @@ class _Plan:
         #  group - still runs on the split pipe in inference plans, followed by a statistics pass over its output)
         split_1x1 = self.split_1x1_ok(act, conv) and (cpg == 16 or self.separate_stats or not self.train)
         absorbs = (split_1x1 and act[3] <= 512 and act[1] * act[2] >= 256 and not os.environ.get("XL_NO_NORM_ON_LOAD"))
-        if pend is not None and m not in (4, 6) and not self.norm_on_load_ok(act, conv) and not stem and not absorbs:
+        if pend is not None and self.train:
+            # training plans: absorbed by a Winograd layer (V is kept normalised) or by a 1x1 layer whose forward AND
+            # weight-gradient kernels normalise on load; anything else gets the activation materialised
+            t_ok = (m in (4, 6) and self.wino_wgrad_ok(conv, act[1], act[2], act[3], m)) or \
+                   (split_1x1 and absorbs and cpg == 16 and self.wgrad_split_ok(act[3], conv.out_channels)
+                    and act[4] % 4 == 0 and act[5] % 4 == 0)
+            if not t_ok:
+                act = self._train_materialise(pend, act)
+                pend = None
+            else:
+                getattr(self, "pending_entry", {}).pop(self._act_key(act), None)
+        if pend is not None and not self.train and m not in (4, 6) and not self.norm_on_load_ok(act, conv) and not stem and not absorbs:
             self.stats_ops.append(len(self.ops))       # consumer cannot absorb it: materialise now
             self.ops.append(pend)
             pend = None
@@ -986,11 +1043,11 @@ class _Plan:
             stats_t = torch.zeros(self.B * nchunks * G * 2, dtype=torch.float64, device=self.device)
             self.keep.append(stats_t)
             cop.stats, cop.groups, cop.nchunks = stats_t.data_ptr(), G, nchunks
-            return self.gn(y, norm, flags, aux, pre_stats=(stats_t, nchunks), stat_tile=tile)
+            return self.gn(y, norm, flags, aux, pre_stats=(stats_t, nchunks), stat_tile=tile, defer=defer)
         if not self.train:
             return self.gn(y, norm, flags, aux, defer=defer and flags == GN_RELU_IN and aux is None
                            and not os.environ.get("XL_NO_DEFERRED_GN"), share=share)
-        r = self.gn(y, norm, flags, aux)
+        r = self.gn(y, norm, flags, aux, defer=defer)
         if r[0] is not y[0]:
             self.release(y[0])
         return r
@@ -1346,6 +1403,9 @@ class _Plan:
             self.tape.append(dict(kind="duc_head", fc3=dec.fc3, x=d, w3=w3, cout=nc, n_task=op.n_task))
             return
         pend = getattr(self, "pending_gn", {}).pop(self._act_key(b), None)
+        if pend is not None and self.train:              # (the head's backward pass reads the normalised activation)
+            b = self._train_materialise(pend, b)
+            pend = None
         t, H, W, C, ld, off = b
         nout = dec.num_task_channel + dec.num_pos_channel
         if pend is not None and not (C == 512 and nout <= 4):
@@ -1539,6 +1599,8 @@ class _Plan:
                         wi.type, wi.ksize = XL_OP_WINO_IN, wm
                         wi.B, wi.Hi, wi.Wi, wi.Cin, wi.Ho, wi.Wo, wi.ld_in = B, H, W, C, Th, Tw, ld
                         wi.in_, wi.out = t.data_ptr() + 4 * off, Vb.data_ptr()
+                        if e.get("xnorm") is not None:                # x is a raw conv output whose GroupNorm was left to its consumers
+                            wi.aux2, wi.flags = e["xnorm"].aux2, e["xnorm"].flags & GN_RELU_IN
                         bops.append(wi)
                     dMb = self.alloc(nfw * Tw4 * Cout)
                     wd = XlOp()
@@ -1598,6 +1660,11 @@ class _Plan:
                 if k == 1 and s == 1 and not wino_w and self.wgrad_split_ok(C, Cout) and ld % 4 == 0 and off % 4 == 0:
                     op.flags = CONV_SPLIT_BF16
                     splits = self.wgrad_splits((Cout // 256) * (C // 256), M)
+                    if e.get("xnorm") is not None:                    # x is a raw conv output: normalise on load
+                        op.flags |= CONV_NORM_IN | (CONV_NORM_RELU if e["xnorm"].flags & GN_RELU_IN else 0)
+                        op.aux2 = e["xnorm"].aux2
+                else:
+                    assert e.get("xnorm") is None or wino_w, "a deferred GroupNorm reached a weight-gradient form that cannot apply it"
                 op.nchunks2 = splits
                 op.in_, op.aux = t.data_ptr() + 4 * off, dy.data_ptr()
                 if not wino_w:
