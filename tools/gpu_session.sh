@@ -1,7 +1,10 @@
 #!/bin/bash
-O=$GRAFT_REPO_ROOT/gpurun_out/r4n; mkdir -p $O
-timeout 900 python -m pytest tests/test_cnn_bwd_gpu.py tests/test_train_gpu.py tests/test_reference_fixtures.py tests/test_full_size_gpu.py tests/test_semantics_gpu.py -m gpu -q -x > $O/t.log 2>&1; echo "rc=$?"; grep -E "^FAILED|^ERROR|passed|failed" $O/t.log | tail; grep -E "^E " $O/t.log | head -20
-python tools/train_step_bench.py --full --steps 8 2>&1 | tail -1
-XL_NO_TRAIN_DEFER=1 python tools/train_step_bench.py --full --steps 8 2>&1 | tail -1
-python tools/train_step_bench.py --full --steps 8 2>&1 | tail -1
-XL_NO_TRAIN_DEFER=1 python tools/train_step_bench.py --full --steps 8 2>&1 | tail -1
+# scratch script of the current gpurun call (overwritten per call)
+O=$GRAFT_REPO_ROOT/gpurun_out/sess; mkdir -p $O
+python -m pytest tests -m gpu -q > $O/gputest.log 2>&1; echo "pytest rc=$?" >> $O/gputest.log
+grep -E "^FAILED|^ERROR|passed|failed|rc=" $O/gputest.log | tail -8; grep -E "^E " $O/gputest.log | head -12
+B="python bench.py --no-secondary --no-cpu-baseline"
+for i in 1 2; do
+  $B 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('1 stream', d['value'], d['ms_per_step'])"
+  $B --cnn-streams 2 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('2 streams', d['value'], d['ms_per_step'])"
+done
