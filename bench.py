@@ -274,11 +274,12 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=None,
-                    help="images per step per GPU.  The two persistent GEMM kernels walk 256 x 256 tiles with one workgroup "
-                         "per CU, so what matters is how evenly the tiles divide over 256 CUs: 47 frames = 3584 tiles (14.0 "
-                         "rounds) for the 64 batched Winograd GEMMs of a 512-channel layer and 1984 tiles (7.75 rounds) for a "
-                         "1x1 layer (44 frames: 13.0 / 7.26 rounds - profiles/r3_bench_b44.json beside profiles/r3_bench.json).  "
-                         "Default 47; 24 with --mlr 3")
+                    help="images per step per GPU.  The persistent GEMM kernels walk 256 x 256 tiles with one workgroup per CU, so "
+                         "what matters is how evenly the tiles divide over 256 CUs, and every kernel of the ~100 per forward has a "
+                         "fixed start-up / tail cost (~0.5 ms per forward in total).  95 frames = 7168 tiles (28.0 rounds) for the 64 "
+                         "batched Winograd GEMMs of a 512-channel layer - the 56 row tiles hold 14336 rows, 95 x 150 = 14250 - and 4008 "
+                         "tiles (15.7 rounds) for a 1x1 layer; 47 frames (the default until round 4: 14.0 / 7.75 rounds) measures "
+                         "1.8-2 %% lower (profiles/r4_bench_b47.json).  Default 95; 47 with --mlr 3 (24 until round 4: -7 %%)")
     ap.add_argument("--hyps", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cnn-streams", type=int, default=1,
@@ -293,7 +294,7 @@ def main():
                          "eager, configs[4] 3-encoder network) that N=1 runs report outside the timed region")
     args = ap.parse_args()
     if args.batch is None:
-        args.batch = 24 if args.mlr else 47
+        args.batch = 47 if args.mlr else 95
 
     stub = bool(os.environ.get("XL_BENCH_STUB"))       # tests only: the rank / collective / timing plumbing on CPU (gloo)
     # XL_BENCH_SHARED_GPU=1 (tests/test_multiprocess_gpu.py): the multi-process preflight on a ONE-GPU box.  Every rank runs the
@@ -451,7 +452,7 @@ def main():
         del pipe, plan
         net.invalidate()
         torch.cuda.empty_cache()
-        secondary = secondary_configs(dev, NH)
+        secondary = secondary_configs(dev, NH, batch=B)
 
     if rank == 0:
         value = total_imgs / elapsed
@@ -629,7 +630,7 @@ def _eager_coord_loss(sc, unc, poses, gt, focal=480.0, W=720, H=480):
     return (lu * g + lr).sum() / g.numel()
 
 
-def inference_leg(dev, env, n_hyp, batch=47, steps=5, warmup=2):
+def inference_leg(dev, env, n_hyp, batch=95, steps=5, warmup=2):
     """The headline step (CNN forward + solver through PipelinedLocalizer, 480x720, `batch` frames) under the environment
     switches `env` (read when a plan is lowered), outside the headline's timed region: wall clock over `steps` steps between
     synchronisations, and the launches of the 3x3 512 -> 512 layers timed by HIP events on their own stream like the headline.
@@ -684,7 +685,7 @@ def inference_leg(dev, env, n_hyp, batch=47, steps=5, warmup=2):
                 os.environ[k] = v
 
 
-def gemm_error_leg(dev, frames=47):
+def gemm_error_leg(dev, frames=95):
     """What justifies `dtype: f32` for the split-bf16 GEMMs, measured on the bench box: the 64 batched [7050 x 512] x [512 x 512]
     products of a Winograd layer at `frames` frames on random fp32 operands, through the split kernel (six bf16-MFMA passes) and
     through the fp32-MFMA kernel, both against a float64 product of the SAME fp32 operands (torch.matmul in float64 on the GPU - a
@@ -720,7 +721,7 @@ def gemm_error_leg(dev, frames=47):
     return out["split"], out["f32"]
 
 
-def secondary_configs(dev, n_hyp, train_batch=16, mlr_batch=24, steps=5):
+def secondary_configs(dev, n_hyp, train_batch=16, mlr_batch=47, steps=5, batch=95):
     """Outside the timed region of the headline, N=1 only - the other single-GPU BASELINE configurations, so that their
     figures are driver-visible:
       configs[1]  batch-16 480x720 coord network forward + MLE coordinate loss + backward (train_single_task.py:245-301
@@ -865,14 +866,14 @@ def secondary_configs(dev, n_hyp, train_batch=16, mlr_batch=24, steps=5):
 
     # ---- the strict fp32-MFMA form of the headline (every GEMM on v_mfma_f32_32x32x2_f32, XL_GEMM_SPLIT_BF16=0) and the GEMM
     # error figures that justify calling the split-bf16 form f32: driver-visible, not builder-run files
-    ips, dom_ms, n_dom, z = inference_leg(dev, {"XL_GEMM_SPLIT_BF16": "0"}, n_hyp)
+    ips, dom_ms, n_dom, z = inference_leg(dev, {"XL_GEMM_SPLIT_BF16": "0"}, n_hyp, batch=batch)
     out["f32_mfma_images_per_s"] = round(ips, 1)
     if dom_ms:
-        flop = (z * 2.0 * (47 * 150) * 512 * 512) if z else 2.0 * (47 * 5400) * 512 * 4608
+        flop = (z * 2.0 * (batch * 150) * 512 * 512) if z else 2.0 * (batch * 5400) * 512 * 4608
         out["f32_mfma_dominant_kernel"] = {"avg_launch_ms": round(dom_ms, 4), "launches_timed": n_dom,
                                            "tflops": round(flop / (dom_ms * 1e-3) / 1e12, 2), "peak": PEAK_F32_MFMA_TFLOPS,
                                            "frac": round(flop / (dom_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)}
-    esp, e32 = gemm_error_leg(dev)
+    esp, e32 = gemm_error_leg(dev, frames=batch)
     out["split_gemm_err_vs_f64"] = float("%.3e" % esp)
     out["f32_mfma_err_vs_f64"] = float("%.3e" % e32)
     out["split_gemm_err_over_f32_mfma_err"] = round(esp / max(e32, 1e-30), 2)

@@ -12,9 +12,9 @@ cd $GRAFT_REPO_ROOT
 python tools/pmc_summary.py $OUT/pmc $OUT/pmc_summary.csv
 python tools/pmc_derive.py $OUT/pmc_summary.csv $OUT/pmc_derived.csv > /dev/null
 rm -f profiles/traffic.json
-python tools/traffic_record.py $OUT/pmc_derived.csv 47 "profiles/r4_pmc_summary.csv (rocprofv3 -i tools/pmc_r2.txt over bench.py --steps 2)" > /dev/null
+python tools/traffic_record.py $OUT/pmc_derived.csv 95 "profiles/r4_pmc_summary.csv (rocprofv3 -i tools/pmc_r2.txt over bench.py --steps 2)" > /dev/null
 rm -rf $OUT/pmc
-for nb in 24 44; do                                                  # HBM-side bytes of the dominant launch at other batch sizes
+for nb in 47 24; do                                                  # HBM-side bytes of the dominant launch at other batch sizes
   cd /tmp
   rocprofv3 -i $GRAFT_REPO_ROOT/tools/pmc_hbm2.txt --kernel-trace --output-format csv -d $OUT/pmc$nb -- $B --batch $nb --steps 2 --warmup 1 > $OUT/pmc$nb.log 2>&1
   cd $GRAFT_REPO_ROOT
@@ -31,8 +31,8 @@ import json
 def bad(c): raise ValueError(c)
 d = json.loads(open('$OUT/bench.json').read(), parse_constant=bad)
 print('strict JSON ok', d['value'], d['roofline']['traffic'], d['config']['dsac_pmc'])"
+python bench.py --no-secondary --no-cpu-baseline --batch 47 > $OUT/bench_b47.json 2>/dev/null
 python bench.py --no-secondary --no-cpu-baseline --batch 24 > $OUT/bench_b24.json 2>/dev/null
-python bench.py --no-secondary --no-cpu-baseline --batch 44 > $OUT/bench_b44.json 2>/dev/null
 python bench.py --no-secondary --no-cpu-baseline --cnn-streams 2 > $OUT/bench_streams2.json 2>/dev/null
 python bench.py --no-secondary --no-cpu-baseline --mlr 3 > $OUT/bench_mlr3.json 2>/dev/null
 cd /tmp
@@ -62,7 +62,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ktm -- $B --mlr 3 -
 cd $GRAFT_REPO_ROOT
 cp $(ls $OUT/ktm/*/*kernel_stats.csv | head -1) $OUT/mlr3_kernel_stats.csv
 rm -rf $OUT/ktm
-# output transform: tiles per workgroup (default at 47 frames: 15)
+# output transform: tiles per workgroup
 for t in 3 5 8 16; do
   XL_WINO_OUT_TPB=$t python bench.py --no-secondary --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('tpb $t', d['value'], d['ms_per_step'])"
 done | tee $OUT/wino_out_tpb.txt
