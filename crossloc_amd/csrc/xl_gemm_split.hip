@@ -634,6 +634,8 @@ struct SplitConvArgs {
     int Z; long long zIn, zOut;                      // Z > 1: Z independent products in one launch (the frequencies of a Winograd
                                                      // layer: in / out advance by zIn / zOut floats, the weights by N rows; no bias)
     int tile0, ntiles;                               // the launch's range of the (z, m-tile, n-tile) order
+    const float *res; int ldRes;                     // RES (with NORM): a residual added behind the normalisation, then ReLU - the
+                                                     // producer's whole GroupNorm(+ReLU, +residual, +ReLU) epilogue applied on load
 };
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -664,10 +666,12 @@ __device__ __forceinline__ void split_pair(f32x2 v, unsigned &w1, unsigned &w2, 
 // of a persistent kernel is the CU count whatever the problem, so the NAME is the only key a dispatch table has.
 // BN = tile columns: 256 x 256 (NW 8, BN 256), 256 x 128 (NW 8, BN 128: 4 x 2 waves of 64 x 64 - launches that would run a
 // last round of 256 x 256 tiles mostly empty) or 128 x 128 (NW 4, BN 128).
-template <bool NORM, bool ACC = false, int NW = 8, int ZB = 0, int BN = (NW == 8 ? 256 : 128)>  // ACC: out += result
+template <bool NORM, bool ACC = false, int NW = 8, int ZB = 0, int BN = (NW == 8 ? 256 : 128), bool RES = false>  // ACC: out += result
 __global__ __launch_bounds__(64 * NW)
 void split_conv1x1_kernel(SplitConvArgs a)
 {
+    static_assert(!RES || NORM, "the residual form is a normalise-on-load form");
+    constexpr int NLD = RES ? 4 : 2;                                          // activation loads per thread and K-step
     extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
     typedef __attribute__((address_space(3))) void lds_void;
     constexpr int NTH = 64 * NW, BM = NTH / 2;                                // threads; tile rows (a thread = 8 channels of a row)
@@ -727,8 +731,9 @@ void split_conv1x1_kernel(SplitConvArgs a)
     // into registers (row tid >> 1, channels 8 (tid & 1) .. + 7 of the step; two register sets, by the parity of the step)
     __amdgpu_buffer_rsrc_t srdU = __builtin_amdgcn_make_buffer_rsrc((void *)a.u, 0, (int)(a.N * rowU), 0x00020000);
     __amdgpu_buffer_rsrc_t srdIn = __builtin_amdgcn_make_buffer_rsrc((void *)a.in, 0, 0, 0x00020000);
+    __amdgpu_buffer_rsrc_t srdRes = __builtin_amdgcn_make_buffer_rsrc((void *)a.in, 0, 0, 0x00020000);
     const int arow = tid >> 1, ahalf = tid & 1;
-    unsigned gB[3], gA = OOB;
+    unsigned gB[3], gA = OOB, gR = OOB;
     int dTile = 0, dK = 0;
     auto set_dma_tile = [&](int i) {
         if (i < myCount) {
@@ -739,6 +744,10 @@ void split_conv1x1_kernel(SplitConvArgs a)
             srdIn = __builtin_amdgcn_make_buffer_rsrc((void *)(a.in + z * a.zIn + (long long)m0 * a.ldIn), 0, rows * a.ldIn * 4, 0x00020000);
             if (a.Z > 1) srdU = __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)a.u + z * (a.N * rowU)), 0, (int)(a.N * rowU), 0x00020000);
             gA = (unsigned)(arow * a.ldIn * 4 + ahalf * 32);              // rows past M fall outside the descriptor
+            if constexpr (RES) {
+                srdRes = __builtin_amdgcn_make_buffer_rsrc((void *)(a.res + (long long)m0 * a.ldRes), 0, rows * a.ldRes * 4, 0x00020000);
+                gR = (unsigned)(arow * a.ldRes * 4 + ahalf * 32);
+            }
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
                 const int sl = (wave * 3 + q) * 64 + lane;
@@ -748,7 +757,7 @@ void split_conv1x1_kernel(SplitConvArgs a)
                 gB[q] = dmaWave ? (unsigned)((long long)(n0 + row) * rowU + logical * 16) : OOB;
             }
         } else {
-            gA = OOB;
+            gA = OOB; gR = OOB;
 #pragma unroll
             for (int q = 0; q < 3; ++q) gB[q] = OOB;
         }
@@ -758,10 +767,15 @@ void split_conv1x1_kernel(SplitConvArgs a)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(srdU, (lds_void *)(dsm + dst), 16, (int)gB[q], dK * kIUnit, 0, 0);
     };
     u32x4 rA[2][2];                                                    // [K-step parity][half of my 8 channels]
+    u32x4 rR[2][RES ? 2 : 1];                                          // ... of the residual
     auto load_a = [&](auto parTag) {
         constexpr int P = decltype(parTag)::value;
         rA[P][0] = __builtin_amdgcn_raw_buffer_load_b128(srdIn, (int)gA, dK * 64, 0);
         rA[P][1] = __builtin_amdgcn_raw_buffer_load_b128(srdIn, (int)(gA + 16u), dK * 64, 0);
+        if constexpr (RES) {
+            rR[P][0] = __builtin_amdgcn_raw_buffer_load_b128(srdRes, (int)gR, dK * 64, 0);
+            rR[P][1] = __builtin_amdgcn_raw_buffer_load_b128(srdRes, (int)(gR + 16u), dK * 64, 0);
+        }
     };
     auto advance_dma = [&]() {
         if (++dK == nk) { dK = 0; ++dTile; set_dma_tile(dTile); }
@@ -801,6 +815,10 @@ void split_conv1x1_kernel(SplitConvArgs a)
                 const f32x2 lo = f32x2{ fmaf(x[0], c0[0], c0[1]), fmaf(x[1], c0[2], c0[3]) };
                 const f32x2 hi = f32x2{ fmaf(x[2], c1[0], c1[1]), fmaf(x[3], c1[2], c1[3]) };
                 x = f32x4{ fmaxf(lo[0], a.normLo), fmaxf(lo[1], a.normLo), fmaxf(hi[0], a.normLo), fmaxf(hi[1], a.normLo) };
+                if constexpr (RES) {                                   // gn_apply's epilogue: v += residual; v = max(v, 0)
+                    const f32x4 r = __builtin_bit_cast(f32x4, rR[P][h]);
+                    x = f32x4{ fmaxf(x[0] + r[0], 0.f), fmaxf(x[1] + r[1], 0.f), fmaxf(x[2] + r[2], 0.f), fmaxf(x[3] + r[3], 0.f) };
+                }
             }
             split_pair(f32x2{ x[0], x[1] }, w[0][2 * h], w[1][2 * h], w[2][2 * h]);
             split_pair(f32x2{ x[2], x[3] }, w[0][2 * h + 1], w[1][2 * h + 1], w[2][2 * h + 1]);
@@ -895,7 +913,7 @@ void split_conv1x1_kernel(SplitConvArgs a)
     load_a(P1{});                                                     // (the order of a steady-state step)
     dma_instr(0, 1); dma_instr(1, 1); dma_instr(2, 1);
     advance_dma();
-    __builtin_amdgcn_s_waitcnt(0x0070 | 5);                           // my writes of step 0; stage 0 of the ring landed before
+    __builtin_amdgcn_s_waitcnt(0x0070 | (3 + NLD));                   // my writes of step 0; stage 0 of the ring landed before
     __builtin_amdgcn_s_barrier();
     int sc = 0, sd = 2;
     {
@@ -939,7 +957,7 @@ void split_conv1x1_kernel(SplitConvArgs a)
         convert(std::integral_constant<int, sa ^ 1>{});           // (the compiler counts vmcnt for rA)
         mma_term(0, 1);
         {
-            constexpr int nM = 4 * RI, groups = nM < 12 ? nM : 12, valu = 72 / groups;    // MFMAs of the two terms; 12 x 6 / 8 x 9 VALU
+            constexpr int nM = 4 * RI, groups = nM < 12 ? nM : 12, valu = (RES ? 88 : 72) / groups;    // MFMAs of the two terms; 12 x 6 / 8 x 9 VALU
 #pragma unroll
             for (int g = 0; g < groups; ++g) {
                 if constexpr (NORM) { if (g == 0 || g == groups / 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); }  // coefficient reads of 4 channels
@@ -953,8 +971,8 @@ void split_conv1x1_kernel(SplitConvArgs a)
         advance_conv();
         // the weights of step kk + 1 have landed: younger are 2 DMAs and 2 loads of step kk + 2 - and, in the first
         // step of a tile, the 32 stores of the tile before (vmcnt(36)); lgkmcnt(0): my activation writes are done
-        if constexpr (decltype(firstTag)::value) __builtin_amdgcn_s_waitcnt(0x0070 | ((4 + NS) & 15) | (((4 + NS) >> 4) << 14));
-        else __builtin_amdgcn_s_waitcnt(0x0070 | 4);
+        if constexpr (decltype(firstTag)::value) __builtin_amdgcn_s_waitcnt(0x0070 | ((2 + NLD + NS) & 15) | (((2 + NLD + NS) >> 4) << 14));
+        else __builtin_amdgcn_s_waitcnt(0x0070 | (2 + NLD));
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         mma_term(0, 0); dma_instr(2, sd);
@@ -1104,15 +1122,17 @@ static int launch_split_conv1x1(const xl_op &op, SplitConvArgs a, bool norm, int
     a.nbn = (op.Cout + BN - 1) / BN;
     const size_t lds = 3 * BN * kIUnit + 2 * BM * kIUnit + 2 * 16 * (64 * NW) + 16384 + 4096 + 1024;
     const bool accumulate = (op.flags & XL_CONV_ACCUMULATE) != 0;
+    const bool resid = norm && a.res != nullptr;
     const bool dominant = Z > 1 && op.Cin == 512 && op.Cout == 512 && !accumulate && !norm;     // the 512 -> 512 Winograd layers
     const void *fn = accumulate ? reinterpret_cast<const void *>(split_conv1x1_kernel<false, true, NW, 0, BN>)
+                   : resid ? reinterpret_cast<const void *>(split_conv1x1_kernel<true, false, NW, 0, BN, true>)
                    : norm ? reinterpret_cast<const void *>(split_conv1x1_kernel<true, false, NW, 0, BN>)
                    : dominant ? reinterpret_cast<const void *>(split_conv1x1_kernel<false, false, NW, 2, BN>)
                    : Z > 1 ? reinterpret_cast<const void *>(split_conv1x1_kernel<false, false, NW, 1, BN>)
                            : reinterpret_cast<const void *>(split_conv1x1_kernel<false, false, NW, 0, BN>);
-    static XlLdsLimit configured[5];
+    static XlLdsLimit configured[6];
     int cfgDev;
-    const int slot = accumulate ? 2 : (norm ? 1 : (dominant ? 4 : (Z > 1 ? 3 : 0)));
+    const int slot = accumulate ? 2 : (resid ? 5 : (norm ? 1 : (dominant ? 4 : (Z > 1 ? 3 : 0))));
     if (configured[slot].needs(lds, &cfgDev)) {
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return XL_ERR_HIP;
         configured[slot].done(lds, cfgDev);
@@ -1122,6 +1142,7 @@ static int launch_split_conv1x1(const xl_op &op, SplitConvArgs a, bool norm, int
     int grid = 256;                                   // persistent: one workgroup per CU
     if (grid > ((nwg + 7) & ~7)) grid = (nwg + 7) & ~7;
     if (accumulate) hipLaunchKernelGGL((split_conv1x1_kernel<false, true, NW, 0, BN>), dim3(grid), dim3(64 * NW), lds, st, a);
+    else if (resid) hipLaunchKernelGGL((split_conv1x1_kernel<true, false, NW, 0, BN, true>), dim3(grid), dim3(64 * NW), lds, st, a);
     else if (norm) hipLaunchKernelGGL((split_conv1x1_kernel<true, false, NW, 0, BN>), dim3(grid), dim3(64 * NW), lds, st, a);
     else if (dominant) hipLaunchKernelGGL((split_conv1x1_kernel<false, false, NW, 2, BN>), dim3(grid), dim3(64 * NW), lds, st, a);
     else if (Z > 1) hipLaunchKernelGGL((split_conv1x1_kernel<false, false, NW, 1, BN>), dim3(grid), dim3(64 * NW), lds, st, a);
@@ -1157,6 +1178,12 @@ static int xl_run_split_conv1x1(const xl_op &op, hipStream_t st)
     a.stats = (double *)op.stats; a.HW = HW; a.G = op.groups; a.nchunks = op.nchunks; a.B = op.B;
     a.M = (int)M; a.C = op.Cin; a.N = op.Cout; a.ldIn = op.ld_in; a.ldOut = op.ld_out;
     a.Z = Z; a.zIn = M * op.ld_in; a.zOut = M * op.ld_out;
+    a.res = nullptr; a.ldRes = 0;
+    if (op.flags & XL_CONV_NORM_ADD) {                // the producer's GroupNorm + ReLU + residual (aux, ld_aux) + ReLU applied on load
+        if (!norm || !(op.flags & XL_CONV_NORM_RELU) || !op.aux || op.ld_aux < op.Cin || (op.ld_aux & 3) || ((uintptr_t)op.aux & 15) || Z > 1 ||
+            256LL * op.ld_aux * 4 >= 0x7fffffffLL) return XL_ERR_ARG;
+        a.res = (const float *)op.aux; a.ldRes = op.ld_aux;
+    }
     if (op.flags & XL_CONV_M_TILE_MAJOR) {            // result [row][Z][Cout]: a row of product z starts Z*Cout floats after the one before
         if (Z < 2 || op.ld_out != op.Cout || 256LL * Z * op.Cout * 4 >= 0x7fffffffLL) return XL_ERR_ARG;
         a.zOut = op.Cout; a.ldOut = Z * op.Cout;

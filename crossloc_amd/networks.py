@@ -36,6 +36,7 @@ CONV_NORM_IN, CONV_NORM_RELU = 128, 256
 CONV_SPLIT_IL = 512
 CONV_SPLIT_ACT = 1024
 CONV_M_TILE_MAJOR = 2048
+CONV_NORM_ADD = 4096
 XL_ERR_UNSUPPORTED = -4            # include/crossloc_dsac.h
 
 
@@ -281,6 +282,14 @@ class _Plan:
             self.held[id(x)] = [x, x is raw[0]]           # the raw conv output has no other owner: released with the fold
         self.pending_fold[self._act_key(res)] = dict(ap=ap, raw=raw, tensors=tensors, aux_ap=self._aux_take(aux))
         return res
+
+    def _unhold(self, t):
+        """End of a hold on a tensor (see `held`): release it now if its owner released it meanwhile."""
+        if t is None:
+            return
+        entry = getattr(self, "held", {}).pop(id(t), None)
+        if entry is not None and entry[1]:
+            self.release(t)
 
     def _fold_end(self, fold):
         for x in fold["tensors"]:
@@ -664,6 +673,10 @@ class _Plan:
             op.reserved_i = -256 if self.separate_stats else self.split_tile_form(self.B * Ho * Wo, cout, 1, Ho * Wo)
         if norm_in is not None:                       # the producer's deferred GroupNorm apply, folded into the operand load
             op.flags |= CONV_NORM_IN | (CONV_NORM_RELU if norm_in.flags & GN_RELU_IN else 0)
+            if norm_in.flags & GN_ADD:                # ... + residual + ReLU (XL_CONV_NORM_ADD, split 1x1 kernel only)
+                assert split and k == 1 and (norm_in.flags & GN_RELU_OUT) and (norm_in.flags & GN_RELU_IN)
+                op.flags |= CONV_NORM_ADD
+                op.aux, op.ld_aux = norm_in.aux, norm_in.ld_aux
             if self.train:
                 op.aux2 = norm_in.aux2                # (training plans: the producer's own coefficient table)
             else:
@@ -963,7 +976,7 @@ class _Plan:
     def fold_ok(self):
         return not self.train and not os.environ.get("XL_NO_DEFERRED_GN") and not os.environ.get("XL_NO_FOLD_GN")
 
-    def cgr(self, act, conv, norm, flags=GN_RELU_IN, aux=None, defer=False, share=False, out=None):
+    def cgr(self, act, conv, norm, flags=GN_RELU_IN, aux=None, defer=False, share=False, out=None, defer_add=False):
         """conv -> GroupNorm -> epilogue.  `defer`: the caller promises that the next cgr() is the only consumer of the
         result; when that consumer is an F(4x4,3x3) layer its input transform applies the normalisation and the separate
         GN_APPLY pass (one read + one write of the activation) disappears.  `out` = (tensor, ld, channel offset): the
@@ -1003,10 +1016,18 @@ class _Plan:
                 pend = None
             else:
                 getattr(self, "pending_entry", {}).pop(self._act_key(act), None)
-        if pend is not None and not self.train and m not in (4, 6) and not self.norm_on_load_ok(act, conv) and not stem and not absorbs:
+        pend_add = pend is not None and bool(pend.flags & GN_ADD)
+        if pend is not None and not self.train and ((m not in (4, 6) and not self.norm_on_load_ok(act, conv) and not stem and not absorbs)
+                                                    or (pend_add and not absorbs)):
             self.stats_ops.append(len(self.ops))       # consumer cannot absorb it: materialise now
             self.ops.append(pend)
             pend = None
+        held_res = None
+        if pend_add:                                   # the residual is dead once the consumer (or the apply pass) is emitted
+            held_res = getattr(self, "pending_res", {}).pop(self._act_key(act), None)
+            if pend is None:                           # (materialised just above)
+                self._unhold(held_res)
+                held_res = None
         if fold is not None:
             # the fold form of the input transform writes V as fp32 (F(6x6,3x3) layers whose GEMMs read fp32 activations)
             sp, _, sp_act = self.wino_gemm_form(act[3], conv.out_channels, m, self.B * -(-act[1] // 6) * -(-act[2] // 6)) if m == 6 else (0, 0, 0)
@@ -1023,15 +1044,20 @@ class _Plan:
                            and not os.environ.get("XL_NO_DEFERRED_GN"), share=share)
         split = split_1x1 and (pend is None or absorbs)
         y = self.conv(act, conv, norm_in=pend, split=split)
+        self._unhold(held_res)
         bn = 128 if conv.out_channels % 128 == 0 else 64
         # a conv tile's columns cover whole groups, and the statistics epilogue sums 2- or 4-channel pieces
         whole_groups = bn % cpg == 0 and (cpg == 2 or cpg % 4 == 0)
         if (not self.train and y[1] * y[2] >= 128 and whole_groups and (not split or cpg == 16)
                 and (not self.separate_stats or (split and cpg == 16))):
             # inference: the conv epilogue produces the GroupNorm statistics, the separate stats pass is dropped
+            # defer_add (round 4): the caller promises that the only consumer is a 1x1 layer on the split pipe - it applies the whole
+            # GroupNorm + ReLU + residual + ReLU epilogue while it loads its operand (XL_CONV_NORM_ADD), no apply pass
+            add_on_load = (defer_add and flags == (GN_RELU_IN | GN_ADD | GN_RELU_OUT) and aux is not None and split
+                           and not os.environ.get("XL_NO_DEFERRED_GN") and not os.environ.get("XL_NO_ADD_ON_LOAD"))
             return self.gn_fused(y, norm, flags, aux, len(self.ops) - 1,
-                                 defer=defer and flags == GN_RELU_IN and aux is None
-                                 and not os.environ.get("XL_NO_DEFERRED_GN"), share=share)
+                                 defer=(defer and flags == GN_RELU_IN and aux is None
+                                        and not os.environ.get("XL_NO_DEFERRED_GN")) or add_on_load, share=share)
         if (self.train and y[1] * y[2] >= 128 and whole_groups and not self.separate_stats
                 and self.ops[-1].type == XL_OP_CONV):
             # training: same epilogue statistics, written to a buffer of the layer's own (they are inputs of the
@@ -1088,6 +1114,12 @@ class _Plan:
             if not hasattr(self, "pending_gn"):
                 self.pending_gn = {}
             self.pending_gn[self._act_key(res)] = ap
+            if aux is not None:                        # (the residual must outlive the caller's release until the consumer is emitted)
+                if not hasattr(self, "held"):
+                    self.pending_fold, self.held = getattr(self, "pending_fold", {}), {}
+                self.held[id(aux[0])] = [aux[0], False]
+                self.pending_res = getattr(self, "pending_res", {})
+                self.pending_res[self._act_key(res)] = aux[0]
             return res
         if share and out is None and self.fold_ok():
             return self._fold_begin(ap, act, aux)
@@ -1376,7 +1408,8 @@ class _Plan:
             res = self.res_block(res, block)
         a = self.cgr(res, dec.res3_conv1, dec.res3_norm1, defer=True)
         b = self.cgr(a, dec.res3_conv2, dec.res3_norm2, defer=True); self.release(a[0])
-        c = self.cgr(b, dec.res3_conv3, dec.res3_norm3, GN_RELU_IN | GN_ADD | GN_RELU_OUT, aux=res)
+        # (res3's output has ONE consumer, fc1 - a 1x1 layer: its GroupNorm + ReLU + residual + ReLU is applied by fc1's operand load)
+        c = self.cgr(b, dec.res3_conv3, dec.res3_norm3, GN_RELU_IN | GN_ADD | GN_RELU_OUT, aux=res, defer_add=True)
         self.release(b[0]); self.release(res[0])
         res = c
         a = self.cgr(res, dec.fc1, dec.fc1_norm, defer=True); self.release(res[0])

@@ -113,6 +113,9 @@ enum {
                                   GroupNorm is applied while the operand is loaded (aux2 = {scale, shift} pairs
                                   [B][Cin][2] written by XL_OP_GN_FINAL): x -> x*scale + shift, no separate apply pass */
 #define XL_CONV_NORM_RELU 256  /* ... followed by ReLU */
+#define XL_CONV_NORM_ADD 4096  /* 1x1 layers on the split pipe, with XL_CONV_NORM_IN | XL_CONV_NORM_RELU: ... then `aux` (pixel stride
+                                  ld_aux) is added and ReLU applied again - the producer's whole GroupNorm + ReLU + residual + ReLU
+                                  epilogue happens while the operand is loaded (no apply pass, the activation is never written) */
 /* extra xl_op.flags for XL_OP_GNB_* */
 #define XL_GN_ACC_AUX 8        /* d(residual) is accumulated into out2 instead of written */
 #define XL_GN_NO_CONV_BIAS 16  /* no conv precedes this GroupNorm: skip the bias gradient */

@@ -1040,3 +1040,27 @@ def test_fused_stem_is_bitwise_the_two_kernel_path(B, H, W, monkeypatch):
     assert networks.XL_OP_STEM12 in ops_new and networks.XL_OP_STEM12 not in ops_old
     assert torch.isfinite(y_new).all()
     assert torch.equal(y_new, y_old), (y_new - y_old).abs().max()
+
+
+def test_residual_epilogue_applied_by_the_consuming_1x1_layer_is_bitwise_the_apply_pass(monkeypatch):
+    """Round 4: the GroupNorm + ReLU + residual + ReLU of the decoder's res3 block has ONE consumer, the 1x1 layer fc1, which applies
+    it while loading its operand (XL_CONV_NORM_ADD) instead of a pass of its own (XL_NO_ADD_ON_LOAD=1).  Same arithmetic in the same
+    order (fmaf, max, add, max): the network output is equal to the bit, at 480 x 720 and on a ragged small map."""
+    for B, H, W in ((2, 480, 720), (3, 136, 200)):
+        x = torch.rand(B, 3, H, W, generator=torch.Generator().manual_seed(H)).cuda()
+
+        def run():
+            net = networks.TransPoseNet(MEAN, False, False, 1, 1, 3, 1)
+            net.load_state_dict(seeded_state_dict(net, seed=9))
+            net = net.cuda().eval()
+            with torch.no_grad():
+                y = net(x)
+            plan = list(net._plans.values())[0]
+            return y.cpu(), sum(1 for op in plan.ops if op.type == networks.XL_OP_CONV and op.flags & networks.CONV_NORM_ADD), \
+                sum(1 for op in plan.ops if op.type == networks.XL_OP_GN_APPLY)
+        y_new, n_add, n_apply = run()
+        monkeypatch.setenv("XL_NO_ADD_ON_LOAD", "1")
+        y_old, n_add_old, n_apply_old = run()
+        monkeypatch.delenv("XL_NO_ADD_ON_LOAD")
+        assert n_add == 1 and n_add_old == 0 and n_apply == n_apply_old - 1
+        assert torch.equal(y_new, y_old), (y_new - y_old).abs().max()

@@ -1,8 +1,6 @@
 #!/bin/bash
-B="python bench.py --no-secondary --no-cpu-baseline"
-for b in 24 32 47 64 24 47; do
-  $B --mlr 3 --batch $b --steps 5 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('mlr3 batch $b', d['value'], d['ms_per_step'], d['config']['median_err_cm'])"
-done
-for b in 95 96 111 127; do
-  $B --batch $b --steps 6 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('batch $b', d['value'], d['ms_per_step'], d['roofline']['avg_launch_ms'])"
-done
+O=$GRAFT_REPO_ROOT/gpurun_out/sess; mkdir -p $O
+timeout 600 python -m pytest tests/test_cnn_gpu.py -m gpu -q -k "residual_epilogue or fused_stem" 2>&1 | tail -15
+python -m pytest tests -m gpu -q > $O/gputest.log 2>&1; echo "pytest rc=$?" >> $O/gputest.log
+grep -E "^FAILED|^ERROR|passed|failed|rc=" $O/gputest.log | tail -8; grep -E "^E " $O/gputest.log | head -12
+python -m pytest tests -q -m "not gpu" -x 2>&1 | tail -2
