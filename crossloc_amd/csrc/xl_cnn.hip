@@ -1683,7 +1683,7 @@ __global__ void gn_stats_kernel(const float *__restrict__ x, double *__restrict_
 __global__ __launch_bounds__(256)
 void gn_final_kernel(const double *__restrict__ stats, const float *__restrict__ gamma, const float *__restrict__ beta,
                      float *__restrict__ coeff, int HW, int C, int G, int nchunks, float eps, int statTile,
-                     float *__restrict__ murs)
+                     float *__restrict__ murs, int perTile)
 {
     __shared__ double sG[2 * 64];
     const int n = blockIdx.x, tid = threadIdx.x;
@@ -1693,6 +1693,7 @@ void gn_final_kernel(const double *__restrict__ stats, const float *__restrict__
         valid = (int)((((long long)(n + 1) * HW - 1) / statTile) - (((long long)n * HW) / statTile)) + 1;
     else if (statTile < 0)     // ... from a conv whose tiles start at image boundaries (batch-invariant plans)
         valid = (HW - statTile - 1) / -statTile;
+    valid *= perTile;          // (the stride-2 stem convolutions write one entry per tile and row block of waves)
     // P = 256 / (G rounded up to a power of two) threads per group (8 for 32 groups, 128 for the 2 groups of conv1) each sum
     // a contiguous slice of the chunks, then the P slices are added as a fixed binary tree.  P depends on the layer only.
     __shared__ double sP[256 * 2];
@@ -2448,7 +2449,7 @@ int run_op(const xl_op &op, hipStream_t st)
             if (op.groups > 32 || op.Cin % op.groups != 0) return XL_ERR_ARG;
             hipLaunchKernelGGL(gn_final_kernel, dim3(op.B), dim3(256), 0, st, (const double *)op.stats, (const float *)op.w,
                                (const float *)op.bias, (float *)op.out, op.Hi * op.Wi, op.Cin, op.groups, op.nchunks, op.eps,
-                               op.reserved_i, (float *)op.out2);
+                               op.reserved_i, (float *)op.out2, op.reserved_i != 0 && op.stride > 1 ? op.stride : 1);
             return XL_OK;
         }
         case XL_OP_HEAD: {

@@ -24,3 +24,29 @@ struct XlLdsLimit {
         while (cur < lds && !bytes[device].compare_exchange_weak(cur, lds, std::memory_order_release)) {}
     }
 };
+
+// Sum over the 32 lanes of a half wave (lanes 0-31 / 32-63) as a fixed fp32 tree on the DPP path, one v_add_f32 per level, no
+// LDS traffic: pairs, quads (quad_perm), half rows (row_half_mirror), rows (row_mirror), then lane 15 of rows 0 / 2 broadcast
+// into rows 1 / 3 (row_bcast:15).  The total is valid in the UPPER 16 lanes of the half only (lanes 16-31 / 48-63).
+// xl_wave_sum_top adds the lower half's total (lane 31, row_bcast:31): valid in lanes 48-63.  Used by the GroupNorm-statistics
+// epilogues of the stem kernels, whose groups of 2 - 8 channels lie within one lane / one or both halves.
+template <int CTRL, int ROWS = 0xF>
+__device__ __forceinline__ float xl_dpp_f32(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROWS, 0xF, false));
+}
+__device__ __forceinline__ float xl_half_wave_sum(float v)
+{
+    v += xl_dpp_f32<0xB1>(v);                            // quad_perm [1,0,3,2]
+    v += xl_dpp_f32<0x4E>(v);                            // quad_perm [2,3,0,1]
+    v += xl_dpp_f32<0x141>(v);                           // row_half_mirror
+    v += xl_dpp_f32<0x140>(v);                           // row_mirror
+    v += xl_dpp_f32<0x142, 0xA>(v);                      // row_bcast:15 into rows 1 and 3 (rows 0 and 2 add 0)
+    return v;
+}
+__device__ __forceinline__ float xl_wave_sum_top(float v)
+{
+    v = xl_half_wave_sum(v);
+    v += xl_dpp_f32<0x143, 0xC>(v);                      // row_bcast:31 into rows 2 and 3
+    return v;
+}

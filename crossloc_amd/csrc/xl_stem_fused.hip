@@ -95,7 +95,11 @@ struct Stem12Args {
     float normLo;                // 0 (ReLU) or -inf
     int *queue;                  // [2] = {next tile, workgroups done}: tiles are handed out dynamically (both zero before and after a launch)
     long long *clk;              // diagnostics (XL_STEM12_CLK=1): per-wave shader-clock sums of the phases of a tile, else NULL
+    // GroupNorm partial sums of the output (stats == nullptr: none), 32 groups of 2 channels: [B][nchunks][32][2] fp64 {sum, sum of
+    // squares}; chunk = (tile within the image) * (TH / 2) + (the wave's 32-pixel block): one writer per entry, every entry written
+    double *stats; int nchunks;
 };
+
 
 template <int TH>
 __global__ __launch_bounds__(256, TH == 8 ? 1 : 2)
@@ -290,6 +294,36 @@ void stem12_kernel(Stem12Args a)
         stamp(4);                                                      // conv2
         // ---- 4. store: pixel (oy0 + oyl, ox0 + oxl), channels 32 j + 8 q + 4 kh + {0..3}
         const int oy = oy0 + oyl, ox = ox0 + oxl;
+        if (a.stats != nullptr) {
+            // GroupNorm partial sums of conv2's output (round 4: no statistics pass over the 64-channel half-resolution tensor):
+            // 32 groups of 2 channels - accumulator registers (2 u, 2 u + 1) of a lane are group 16 (jb + j) + 4 (u >> 1) + 2 kh +
+            // (u & 1); fp32 over the pair, the fp32 tree of xl_half_wave_sum over the 32 pixels, one fp64 entry per (tile, block)
+            const bool live = oy < a.Ho && ox < a.Wo;
+            double *o = a.stats + ((long long)n * a.nchunks + tt * kPB + pxb) * 64;
+            typedef double f64x2 __attribute__((ext_vector_type(2)));
+            // (all the trees first - DPP only, no LDS traffic - then ONE predicated block of stores by a lane that holds the totals)
+            float s1[kNJ][8], s2[kNJ][8];
+#pragma unroll
+            for (int j = 0; j < kNJ; ++j)
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const float v0 = acc2[j][2 * u], v1 = acc2[j][2 * u + 1];
+                    s1[j][u] = xl_half_wave_sum(live ? v0 + v1 : 0.f);
+                    s2[j][u] = xl_half_wave_sum(live ? fmaf(v1, v1, v0 * v0) : 0.f);
+                }
+            // lanes 16-23 / 48-55 hold the totals of their half: lane 16 + u (48 + u) stores group-pair u - one 16-byte store
+            // instruction per column block instead of one per group (the per-lane choice is 7 selects per value)
+            if ((fr >> 3) == 2) {
+                const int us = fr & 7;
+#pragma unroll
+                for (int j = 0; j < kNJ; ++j) {
+                    float p1 = s1[j][0], p2 = s2[j][0];
+#pragma unroll
+                    for (int u = 1; u < 8; ++u) { p1 = us == u ? s1[j][u] : p1; p2 = us == u ? s2[j][u] : p2; }
+                    *reinterpret_cast<f64x2 *>(o + 2 * (16 * (jb + j) + 4 * (us >> 1) + 2 * kh + (us & 1))) = f64x2{ (double)p1, (double)p2 };
+                }
+            }
+        }
         if (oy < a.Ho && ox < a.Wo) {
             float *o = a.out + (((long long)n * a.Ho + oy) * a.Wo + ox) * a.ldOut + 4 * kh;
 #pragma unroll
@@ -317,24 +351,28 @@ void stem12_kernel(Stem12Args a)
 
 // XL_OP_STEM12: in = image [B,3,Hi,Wi] NCHW; w = conv1 weight fragments; bias = conv1 bias[32]; aux2 = {scale, shift} pairs
 // [B][32][2] of conv1's GroupNorm; aux = conv2 weight fragments [18][3][2][64][8] bf16; stats2 = conv2 bias[64] (read only);
-// out = raw conv2 output [B,Ho,Wo,64] NHWC (ld_out); flags & XL_GN_RELU_IN: ReLU after the GroupNorm; stats = two ints, zero (the
-// tile queue of the launch; left zero again - one buffer per op and stream).
+// out = raw conv2 output [B,Ho,Wo,64] NHWC (ld_out); flags & XL_GN_RELU_IN: ReLU after the GroupNorm; out2 = two ints, zero (the
+// tile queue of the launch; left zero again - one buffer per op and stream); stats (optional; groups = 32, nchunks = tiles per
+// image * tile rows / 2): GroupNorm partial sums of the output, [B][nchunks][32][2] fp64, every entry written (XL_OP_GN_FINAL
+// with reserved_i = 0 sums all nchunks of them).
 int xl_run_stem12(const xl_op &op, hipStream_t st)
 {
     if (op.Cin != 3 || op.Cout != 64 || op.Ho != (op.Hi - 1) / 2 + 1 || op.Wo != (op.Wi - 1) / 2 + 1 || op.ld_out < 64 || (op.ld_out & 3) ||
-        !op.in || !op.w || !op.bias || !op.aux || !op.aux2 || !op.stats2 || !op.stats || !op.out || op.B < 1 ||
-        (((uintptr_t)op.out | (uintptr_t)op.w | (uintptr_t)op.aux | (uintptr_t)op.aux2) & 15))
+        !op.in || !op.w || !op.bias || !op.aux || !op.aux2 || !op.stats2 || !op.out2 || !op.out || op.B < 1 ||
+        (((uintptr_t)op.out | (uintptr_t)op.w | (uintptr_t)op.aux | (uintptr_t)op.aux2 | (uintptr_t)op.stats) & 15) ||
+        (op.stats && op.groups != 32))
         return XL_ERR_ARG;
     Stem12Args a;
     a.img = (const float *)op.in; a.w1 = (const u32x4 *)op.w; a.b1 = (const float *)op.bias; a.coef = (const float *)op.aux2;
-    a.w2 = (const u32x4 *)op.aux; a.b2 = (const float *)op.stats2; a.out = (float *)op.out; a.queue = (int *)op.stats;
+    a.w2 = (const u32x4 *)op.aux; a.b2 = (const float *)op.stats2; a.out = (float *)op.out; a.queue = (int *)op.out2;
+    a.stats = (double *)op.stats; a.nchunks = op.nchunks;
     a.B = op.B; a.H = op.Hi; a.W = op.Wi; a.Ho = op.Ho; a.Wo = op.Wo; a.ldOut = op.ld_out;
     // tile rows: 4 (two workgroups per CU, 71 KB each - default) or 8 (one of 133 KB; XL_STEM12_TILE=8)
     static const int tileRows = getenv("XL_STEM12_TILE") && atoi(getenv("XL_STEM12_TILE")) == 8 ? 8 : 4;
     a.tilesX = (op.Wo + kTW - 1) / kTW; a.tilesY = (op.Ho + tileRows - 1) / tileRows;
     a.normLo = (op.flags & XL_GN_RELU_IN) ? 0.f : -__builtin_inff();
     const long long total = (long long)op.B * a.tilesX * a.tilesY;
-    if (total >= 0x7fffffffLL) return XL_ERR_ARG;
+    if (total >= 0x7fffffffLL || (op.stats && op.nchunks != a.tilesX * a.tilesY * (tileRows / 2))) return XL_ERR_ARG;
     const size_t lds = (tileRows == 8 ? S12<8>::kPatchBytes + S12<8>::kHaloBytes : S12<4>::kPatchBytes + S12<4>::kHaloBytes) + 1024;
     const void *fn = tileRows == 8 ? reinterpret_cast<const void *>(stem12_kernel<8>) : reinterpret_cast<const void *>(stem12_kernel<4>);
     static XlLdsLimit configured[2];

@@ -21,7 +21,7 @@
 // waves 2 and 3 read out of range and write their zeros into a scratch KB of LDS.  Everything the buffer instructions take as
 // scalars (descriptor, scalar offsets, the LDS base in M0) is passed through readfirstlane where the compiler would otherwise
 // carry it in vector registers across the loop and wrap each load in a readfirstlane loop.
-// The GroupNorm statistics of the output are NOT produced here (XL_OP_GN_STATS follows: one read of the output tensor).
+// The GroupNorm statistics of the output come from the epilogue (round 4; until then XL_OP_GN_STATS re-read the output).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -64,7 +64,12 @@ struct StemArgs {
     const float *coef; float normLo;                 // NORM: [B][Cin][2] {scale, shift}; lower clamp (0 = ReLU, -inf = none)
     int B, Hi, Wi, Cin, Ho, Wo, ldIn, ldOut, M, nbm;
     int nbn;                                         // column tiles of NT channels (1, or 2 when Cout = 256 runs on 128-wide tiles)
+    // GroupNorm partial sums of the output (stats == nullptr: none), G = Cout / 2 (Cout 64), / 4 (128), / 8 (256) groups: [B][nchunks][G][2] fp64
+    // {sum, sum of squares}; chunk = (tile index within the image) * WM + (the wave's row block wm): one writer per entry,
+    // every entry of a tile that overlaps the image is written.  nchunks >= (ceil(Ho*Wo / BM) + 1) * WM.
+    double *stats; int G, nchunks;
 };
+
 
 // CPT = channels of a K-step a thread converts: 8 (two threads per row, tiles of 32 NW rows) or 16 (one thread per row, tiles of
 // 64 NW rows: a wave then owns 64 rows - twice the MFMAs per byte of LDS traffic, what the 64-column layer is bound by)
@@ -313,6 +318,7 @@ void split_conv3x3s2_kernel(StemArgs a)
     __builtin_amdgcn_s_waitcnt(0x0070 | (3 + NL));                    // my writes of step 0; stage 0 of the ring landed before
     __builtin_amdgcn_s_barrier();
     int sc = 0, sd = 2;
+    int statStores = 0;                                               // statistics stores of the last epilogue (uniform)
     init_acc(tile_n0(0));
     // one K-step; FIRST: the first step of a tile that follows another one (NS stores of its epilogue are in flight)
     auto step = [&](auto firstTag, auto parTag) __attribute__((always_inline)) {
@@ -359,7 +365,14 @@ void split_conv3x3s2_kernel(StemArgs a)
         __builtin_amdgcn_sched_barrier(0);
         // the weights of step kk + 1 have landed: younger are 2 DMAs and the NL loads of step kk + 2 - and, in the first step
         // of a tile, the NS stores of the tile before; lgkmcnt(0): my activation writes are done
-        if constexpr (decltype(firstTag)::value) __builtin_amdgcn_s_waitcnt(0x0070 | ((2 + NL + NS) & 15) | (((2 + NL + NS) >> 4) << 14));
+        if constexpr (decltype(firstTag)::value) {
+            constexpr int S1 = NT == 64 ? 16 : 8;                      // statistics stores per slot (2 column blocks x 16 / NR groups)
+            constexpr int W0 = 2 + NL + NS, W1 = W0 + S1, W2 = W0 + 2 * S1;
+            static_assert(W2 < 64, "vmcnt is a 6-bit counter");
+            if (statStores == 0) __builtin_amdgcn_s_waitcnt(0x0070 | (W0 & 15) | ((W0 >> 4) << 14));
+            else if (statStores == S1) __builtin_amdgcn_s_waitcnt(0x0070 | (W1 & 15) | ((W1 >> 4) << 14));
+            else __builtin_amdgcn_s_waitcnt(0x0070 | (W2 & 15) | ((W2 >> 4) << 14));
+        }
         else __builtin_amdgcn_s_waitcnt(0x0070 | (2 + NL));
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
@@ -394,6 +407,80 @@ void split_conv3x3s2_kernel(StemArgs a)
                     const f32x4 v = f32x4{ acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3] };
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), srdO, (int)off, 0, 0);
                 }
+        }
+        if (a.stats != nullptr) {
+            // GroupNorm partial sums of the output (round 4: the statistics passes over the stem tensors are gone).  Groups
+            // of CPG = Cout / G channels (32 groups: 2, 4, 8 channels for conv2..conv4).  A lane's
+            // accumulator r holds channel 8 (r >> 2) + 4 kh + (r & 3) of its 32-column block: a group of 2 / 4 channels lies
+            // within one lane, one of 8 / 16 spans the two halves of the wave.  A tile touches at most two images (Ho*Wo >=
+            // 256 >= BM): slot 0 = rows before `split`, slot 1 = the rest.  Fixed order: per lane fp32 over the group's
+            // channels and its RI rows, the fp32 DPP tree of xl_half_wave_sum / xl_wave_sum_top over the 32 rows (x 2 halves), one fp64 entry
+            // per (image, tile, wm, group) - one writer, every entry of a tile that overlaps the image written.
+            // Its stores come AFTER the tile's NS output stores (the trees run under those) and are counted by the vmcnt wait of
+            // the next tile's first step (statStores: 0, S1 or 2 S1 more instructions in flight) - issued before them they were
+            // the OLDEST thing that wait covers, i.e. a store acknowledgement per tile on the critical path (+12 % on conv3).
+            const int nLo = m0 / HWo;
+            const int split = (nLo + 1) * HWo - m0;
+            const bool two = split < BM && nLo + 1 < a.B;              // (uniform)
+            const int kT = m0 / BM - (int)(((long long)nLo * HWo) / BM);
+            double *oLo = a.stats + ((long long)nLo * a.nchunks + kT * WM + wm) * a.G * 2;
+            double *oHi = a.stats + ((long long)(nLo + 1) * a.nchunks + wm) * a.G * 2;
+            typedef double f64x2 __attribute__((ext_vector_type(2)));
+            auto sums = [&](auto cpgTag) __attribute__((always_inline)) {
+                constexpr int CPG = decltype(cpgTag)::value;
+                constexpr int NR = CPG >= 16 ? 8 : (CPG >= 4 ? 4 : 2);   // accumulator registers per group and lane
+                constexpr bool FULL = CPG >= 8;                          // the group spans both halves of the wave
+                // (all the trees first, then one predicated block of stores)
+                constexpr int NU = 16 / NR;
+                float s0[2][NU], q0[2][NU], s1[2][NU], q1[2][NU];
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int u = 0; u < NU; ++u) {
+                        float a0 = 0.f, b0 = 0.f, a1 = 0.f, b1 = 0.f;
+#pragma unroll
+                        for (int i = 0; i < RI; ++i) {
+                            const int row = wm * (32 * RI) + i * 32 + fr;
+                            float t = 0.f, tt = 0.f;
+#pragma unroll
+                            for (int e = 0; e < NR; ++e) {
+                                const float v = acc[i][j][NR * u + e];
+                                t += v;
+                                tt = fmaf(v, v, tt);
+                            }
+                            const bool hi = row >= split, live = m0 + row < a.M;
+                            a0 += (live && !hi) ? t : 0.f; b0 += (live && !hi) ? tt : 0.f;
+                            a1 += (live && hi) ? t : 0.f;  b1 += (live && hi) ? tt : 0.f;
+                        }
+                        s0[j][u] = FULL ? xl_wave_sum_top(a0) : xl_half_wave_sum(a0);
+                        q0[j][u] = FULL ? xl_wave_sum_top(b0) : xl_half_wave_sum(b0);
+                        if (two) {
+                            a1 = FULL ? xl_wave_sum_top(a1) : xl_half_wave_sum(a1);
+                            b1 = FULL ? xl_wave_sum_top(b1) : xl_half_wave_sum(b1);
+                        }
+                        s1[j][u] = a1; q1[j][u] = b1;
+                    }
+                statStores = two ? 4 * NU : 2 * NU;
+                if (FULL ? lane == 63 : fr == 31) {                    // (a lane that holds the totals)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int u = 0; u < NU; ++u) {
+                            const int cb = n0 + wn * 64 + j * 32;
+                            const int g = CPG >= 16 ? (cb >> 4) + u : CPG == 8 ? (cb >> 3) + u : CPG == 4 ? (cb >> 2) + 2 * u + kh
+                                                                                               : (cb >> 1) + 4 * (u >> 1) + 2 * kh + (u & 1);
+                            *reinterpret_cast<f64x2 *>(oLo + 2 * g) = f64x2{ (double)s0[j][u], (double)q0[j][u] };
+                            if (two) *reinterpret_cast<f64x2 *>(oHi + 2 * g) = f64x2{ (double)s1[j][u], (double)q1[j][u] };
+                        }
+                }
+            };
+            // (only the group sizes the stem has - 32 groups: Cout 64 -> 2, 128 -> 4, 256 -> 8, also as two 128-column tiles - are
+            //  instantiated: each one costs registers in a kernel that has none to spare; the launcher rejects the rest)
+            const int cpg = a.nbn * NT / a.G;
+            if constexpr (NT == 64) sums(std::integral_constant<int, 2>{});
+            else if constexpr (NT == 256) sums(std::integral_constant<int, 8>{});
+            else if (cpg == 4) sums(std::integral_constant<int, 4>{});
+            else sums(std::integral_constant<int, 8>{});
         }
         if (ti + 1 < myCount) init_acc(tile_n0(ti + 1));
         __builtin_amdgcn_sched_barrier(0);
@@ -430,6 +517,8 @@ int launch_stem(StemArgs a, bool norm, hipStream_t st)
         configured[norm].done(lds, cfgDev);
     }
     a.nbm = (a.M + BM - 1) / BM;
+    constexpr int WM = NW / (NT / 64);
+    if (a.stats && (a.nchunks < ((a.Ho * a.Wo + BM - 1) / BM + 1) * WM || a.G * (NT == 64 ? 2 : NT == 256 || a.nbn == 2 ? 8 : 4) != a.nbn * NT)) return XL_ERR_ARG;
     int grid = 256 * PER_CU;                                          // persistent: PER_CU workgroups per CU (LDS- and register-bound)
     if (grid > ((a.nbm * a.nbn + 7) & ~7)) grid = (a.nbm * a.nbn + 7) & ~7;
     if (norm) hipLaunchKernelGGL((split_conv3x3s2_kernel<NT, true, NW, WPS, CPT>), dim3(grid), dim3(64 * NW), lds, st, a);
@@ -442,7 +531,9 @@ int launch_stem(StemArgs a, bool norm, hipStream_t st)
 // XL_OP_CONV with ksize 3, stride 2 and XL_CONV_SPLIT_BF16 | XL_CONV_SPLIT_IL: in fp32 NHWC [B,Hi,Wi,Cin] (ld_in), out fp32 NHWC
 // [B,Ho,Wo,Cout] (ld_out), w = [Cout][9 Cin / 16][3][16] bf16 (K = tap * Cin + c, tap = 3 ky + kx), bias; optionally
 // XL_CONV_NORM_IN (aux2 = [B][Cin][2] coefficients, XL_CONV_NORM_RELU).  Cin in {32, 64, 128}, Cout in {64, 128, 256},
-// Ho*Wo >= 256.  No statistics epilogue (stats must be null).
+// Ho*Wo >= 256.  stats (optional, groups = 32, nchunks): GroupNorm partial sums of the output, see StemArgs - chunk =
+// tile * WM + wm with (rows per tile, WM) = (128, 4) for Cout 64, (128, 2) for Cout 128, (256, 2) for Cout 256 and (128, 2)
+// for its latency form; XL_OP_GN_FINAL sums them with reserved_i = rows per tile, stride = WM.
 int xl_run_split_stem(const xl_op &op, hipStream_t st)
 {
     const long long M = (long long)op.B * op.Ho * op.Wo;
@@ -450,7 +541,7 @@ int xl_run_split_stem(const xl_op &op, hipStream_t st)
     if (op.ksize != 3 || op.stride != 2 || (op.Cin != 32 && op.Cin != 64 && op.Cin != 128) ||
         (op.Cout != 64 && op.Cout != 128 && op.Cout != 256) || op.Ho != (op.Hi - 1) / 2 + 1 || op.Wo != (op.Wi - 1) / 2 + 1 ||
         op.Ho * op.Wo < 256 || op.ld_in < op.Cin || op.ld_out < op.Cout || (op.ld_in & 3) || (op.ld_out & 3) || !op.bias ||
-        op.stats || (op.flags & (XL_CONV_ACCUMULATE | XL_CONV_DGRAD)) || !op.in || !op.w || !op.out ||
+        (op.flags & (XL_CONV_ACCUMULATE | XL_CONV_DGRAD)) || !op.in || !op.w || !op.out || (op.stats && ((uintptr_t)op.stats & 15)) ||
         (((uintptr_t)op.in | (uintptr_t)op.out | (uintptr_t)op.w) & 15) || M >= 0x7fffffffLL - 256 ||
         2LL * op.Hi * op.Wi * op.ld_in * 4 >= 0x7fffffffLL || 256LL * op.ld_out * 4 >= 0x7fffffffLL || (norm && !op.aux2))
         return XL_ERR_ARG;
@@ -460,6 +551,7 @@ int xl_run_split_stem(const xl_op &op, hipStream_t st)
     a.normLo = (op.flags & XL_CONV_NORM_RELU) ? 0.f : -__builtin_inff();
     a.B = op.B; a.Hi = op.Hi; a.Wi = op.Wi; a.Cin = op.Cin; a.Ho = op.Ho; a.Wo = op.Wo;
     a.ldIn = op.ld_in; a.ldOut = op.ld_out; a.M = (int)M; a.nbm = 0; a.nbn = 1;
+    a.stats = (double *)op.stats; a.G = op.groups; a.nchunks = op.nchunks;
     static const char *form = getenv("XL_STEM_FORM");                // measurement switch: "8x2" = 8-wave workgroups, two per CU
     if (op.Cout == 64) return form && !strcmp(form, "8x2") ? launch_stem<64, 8, 2>(a, norm, st)
                             : form && !strcmp(form, "c16") ? launch_stem<64, 4, 2, 16>(a, norm, st) : launch_stem<64, 4, 3>(a, norm, st);

@@ -197,7 +197,11 @@ void wgrad_split_kernel(WgSplitArgs a)
             __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
             __builtin_amdgcn_sched_barrier(0);
             if (kk + 2 < nk) load_regs(kk + 2);                        // (the registers are free again)
-            __syncthreads();
+            // my LDS writes are done, every wave has read this step's stage - but NOT vmcnt(0): __syncthreads() would hold
+            // all eight waves until the loads just issued are back, a memory latency per K-step with nothing under it;
+            // their wait belongs to the conversion one step later (the compiler counts it there)
+            __builtin_amdgcn_s_waitcnt(0x0070 | 0xC00F);               // lgkmcnt(0)
+            __builtin_amdgcn_s_barrier();
             mma_term(0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }

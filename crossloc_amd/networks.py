@@ -1040,8 +1040,14 @@ class _Plan:
             # conv on the split pipe with the producer's GroupNorm applied on load; statistics pass; the apply is left to the
             # consumer (the next stem layer, or - conv4 - the input transform of res1_conv1)
             y = self.conv(act, conv, norm_in=pend, split=True)
-            return self.gn(y, norm, flags, aux, defer=defer and flags == GN_RELU_IN and aux is None
-                           and not os.environ.get("XL_NO_DEFERRED_GN"), share=share)
+            dfr = defer and flags == GN_RELU_IN and aux is None and not os.environ.get("XL_NO_DEFERRED_GN")
+            if self.stem_stats_ok(norm, conv.out_channels):
+                # round 4: the statistics come from the convolution's epilogue (one entry per tile and row block of waves)
+                cop = self.ops[-1]
+                bm, wm = (128, 2) if cop.reserved_i == 128 else {64: (128, 4), 128: (128, 2), 256: (256, 2)}[conv.out_channels]
+                return self.gn_fused(y, norm, flags, aux, len(self.ops) - 1, defer=dfr, share=share,
+                                     stat=(bm, wm, (-(-(y[1] * y[2]) // bm) + 1) * wm))
+            return self.gn(y, norm, flags, aux, defer=dfr, share=share)
         split = split_1x1 and (pend is None or absorbs)
         y = self.conv(act, conv, norm_in=pend, split=split)
         self._unhold(held_res)
@@ -1082,13 +1088,19 @@ class _Plan:
     def _act_key(act):
         return (act[0].data_ptr(), act[5], act[3])
 
-    def gn_fused(self, act, norm, flags, aux, conv_index, out=None, defer=False, share=False):
-        """GroupNorm apply (in place) consuming statistics emitted by the epilogue of the conv op `conv_index`."""
+    def gn_fused(self, act, norm, flags, aux, conv_index, out=None, defer=False, share=False, stat=None):
+        """GroupNorm apply (in place) consuming statistics emitted by the epilogue of the conv op `conv_index`.
+        stat = (rows per tile, entries per tile, nchunks) when the producer is not the 1x1 / direct kernel (the stride-2 stem
+        kernels: one entry per tile and row block of waves; rows per tile 0: all nchunks entries are written)."""
         t, H, W, C, ld, off = act
         G, HW = norm.num_groups, H * W
         cop = self.ops[conv_index]
-        tile = cop.reserved_i if cop.reserved_i in (64, 256, -256) else (256 if cop.reserved_i in (192, 384) else 128)
-        nchunks = (HW + abs(tile) - 1) // abs(tile) + 1
+        mult = 1
+        if stat is not None:
+            tile, mult, nchunks = stat
+        else:
+            tile = cop.reserved_i if cop.reserved_i in (64, 256, -256) else (256 if cop.reserved_i in (192, 384) else 128)
+            nchunks = (HW + abs(tile) - 1) // abs(tile) + 1
         self.max_stats = max(self.max_stats, self.B * nchunks * G * 2)
         cop.groups, cop.nchunks = G, nchunks
         ap = XlOp()
@@ -1099,7 +1111,7 @@ class _Plan:
         gamma, beta = self.dev(norm.weight), self.dev(norm.bias)
         ap.w, ap.bias = gamma.data_ptr(), beta.data_ptr()
         self.stats_ops.append(conv_index)
-        self._emit_final(ap, gamma, beta, tile)
+        self._emit_final(ap, gamma, beta, tile, mult=mult)
         if aux is not None:
             ap.aux = aux[0].data_ptr() + 4 * aux[5]
             ap.ld_aux = aux[4]
@@ -1130,7 +1142,7 @@ class _Plan:
         self.ops.append(ap)
         return res
 
-    def _emit_final(self, ap, gamma, beta, stat_tile, table=None):
+    def _emit_final(self, ap, gamma, beta, stat_tile, table=None, mult=1):
         """GN_FINAL op: one tiny launch turns the partial sums into per-(image, channel) scale/shift so the
         streaming apply kernel does no redundant reduction per workgroup.  Inference: shared statistics and
         coefficient buffers, patched in once their sizes are known.  Training (`table`): the layer's own statistics
@@ -1138,7 +1150,7 @@ class _Plan:
         fin = XlOp()
         fin.type = XL_OP_GN_FINAL
         fin.B, fin.Hi, fin.Wi, fin.Cin, fin.groups, fin.nchunks = ap.B, ap.Hi, ap.Wi, ap.Cin, ap.groups, ap.nchunks
-        fin.eps, fin.reserved_i = ap.eps, stat_tile
+        fin.eps, fin.reserved_i, fin.stride = ap.eps, stat_tile, mult
         fin.w, fin.bias = gamma.data_ptr(), beta.data_ptr()
         if table is None:
             self.max_coeff = max(getattr(self, "max_coeff", 0), self.B * ap.Cin * 2)
@@ -1228,6 +1240,12 @@ class _Plan:
                 and not os.environ.get("XL_NO_SPLIT_STEM") and not os.environ.get("XL_NO_STEM12")
                 and not os.environ.get("XL_CONV1_VALU") and not os.environ.get("XL_NO_DEFERRED_GN"))
 
+    def stem_stats_ok(self, norm, cout):
+        """Inference plans: the stride-2 stem kernels (split pipe) sum the GroupNorm statistics of their output in the epilogue.
+        Not for batch-invariant plans (the partial sums are grouped by tile, i.e. by the frame's position in the batch)."""
+        return (not self.train and not self.separate_stats and norm.num_groups == 32 and cout in (64, 128, 256)
+                and not os.environ.get("XL_STEM_FORM") and not os.environ.get("XL_NO_STEM_STATS"))
+
     def _stem12(self, enc, image):
         """conv1 statistics (one evaluation of conv1, nothing written), GN_FINAL, then the fused kernel: raw conv2 output.  The
         32-channel full-resolution activation (2 GB at 47 frames) is never allocated.  Returns conv2's GroupNorm'ed activation
@@ -1261,12 +1279,17 @@ class _Plan:
         op.stats2 = self.dev(enc.conv2.bias).data_ptr()
         queue = torch.zeros(4, dtype=torch.int32, device=self.device)      # the launch's tile queue (zero before and after)
         self.keep.append(queue)
-        op.stats = queue.data_ptr()
+        op.out2 = queue.data_ptr()
         op.out = y.data_ptr()
         self.deferred_gn_consumers = getattr(self, "deferred_gn_consumers", []) + [len(self.ops)]
         self.image_op_indices.append(len(self.ops))
         self.ops.append(op)
         raw2 = (y, Ho, Wo, c2, c2, 0)
+        if self.stem_stats_ok(enc.norm2, c2) and enc.norm2.num_groups == 32:   # conv2's statistics from the fused kernel's epilogue
+            th = 8 if os.environ.get("XL_STEM12_TILE") == "8" else 4
+            return self.gn_fused(raw2, enc.norm2, GN_RELU_IN, None, len(self.ops) - 1,
+                                 defer=not os.environ.get("XL_NO_DEFERRED_GN"),
+                                 stat=(0, 1, -(-Wo // 16) * -(-Ho // th) * (th // 2)))
         return self.gn(raw2, enc.norm2, GN_RELU_IN, None, defer=not os.environ.get("XL_NO_DEFERRED_GN"))
 
     def _conv1_fused(self, enc, image, t1):

@@ -881,12 +881,29 @@ def test_stride2_stem_conv_on_the_split_bf16_pipe(cin, cout, B, H, W, norm, relu
         op.flags |= networks.CONV_NORM_IN | (networks.CONV_NORM_RELU if relu else 0)
         op.aux2 = cd.data_ptr()
     op.in_, op.w, op.bias, op.out = xd.data_ptr() + 4 * pad, wd.data_ptr(), bd.data_ptr(), out.data_ptr()
+    # round 4: the GroupNorm statistics of the output (32 groups) from the epilogue - one fp64 {sum, sum of squares} entry per
+    # (image, tile overlapping it, row block of waves, group)
+    bm, wm = {64: (128, 4), 128: (128, 2), 256: (256, 2)}[cout]
+    HWo = Ho * Wo
+    nchunks = (-(-HWo // bm) + 1) * wm
+    stats = torch.full((B, nchunks, 32, 2), float("nan"), dtype=torch.float64, device="cuda")
+    op.stats, op.groups, op.nchunks = stats.data_ptr(), 32, nchunks
     _run([op, op])                                        # twice: the second launch must overwrite, not accumulate
     got = out.cpu()
     if pad:
         assert torch.isnan(got[..., cout:]).all()
     got = got[..., :cout].permute(0, 3, 1, 2).double()
     _close(got, ref)
+    st = stats.cpu()
+    grouped = got.reshape(B, 32, cout // 32, HWo)
+    for n in range(B):
+        valid = (((n + 1) * HWo - 1) // bm - (n * HWo) // bm + 1) * wm
+        assert torch.isfinite(st[n, :valid]).all() and torch.isnan(st[n, valid:]).all(), (n, valid)
+        s1, s2 = st[n, :valid, :, 0].sum(0), st[n, :valid, :, 1].sum(0)
+        r1, r2 = grouped[n].sum((1, 2)), (grouped[n] ** 2).sum((1, 2))
+        # fp32 partial sums (<= 8 channels x 4 rows per lane, a 32- or 64-lane tree), fp64 across entries
+        assert ((s1 - r1).abs() <= 2e-6 * grouped[n].abs().sum((1, 2))).all(), (n, (s1 - r1).abs().max())
+        assert torch.allclose(s2, r2, rtol=2e-6, atol=0), (n, ((s2 - r2) / r2).abs().max())
     # the same layer through the fp32-MFMA kernel (operand normalised on the host)
     xfd = _nhwc(xn.float()).cuda()
     wsrc = conv.weight.detach().cuda().contiguous()
@@ -1025,6 +1042,7 @@ def test_fused_stem_is_bitwise_the_two_kernel_path(B, H, W, monkeypatch):
     K order, same conversion instructions: the network outputs are equal to the bit.  70 x 100 / 41 x 57: ragged tiles of 8 x 16
     conv2 outputs, odd image sizes (the last conv1 row / column is conv2's zero padding, not a convolution over padding)."""
     x = torch.rand(B, 3, H, W, generator=torch.Generator().manual_seed(H + W)).cuda()
+    monkeypatch.setenv("XL_NO_STEM_STATS", "1")    # (conv2's statistics by the same pass on both sides: the kernels are what is compared)
 
     def run():
         net = networks.TransPoseNet(MEAN, False, False, 1, 1, 3, 1)
@@ -1064,3 +1082,33 @@ def test_residual_epilogue_applied_by_the_consuming_1x1_layer_is_bitwise_the_app
         monkeypatch.delenv("XL_NO_ADD_ON_LOAD")
         assert n_add == 1 and n_add_old == 0 and n_apply == n_apply_old - 1
         assert torch.equal(y_new, y_old), (y_new - y_old).abs().max()
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 480, 720), (3, 136, 200), (5, 130, 260)])
+def test_stem_statistics_from_the_conv_epilogues_vs_the_statistics_pass(B, H, W, monkeypatch):
+    """Round 4: conv2 (inside the fused stem kernel), conv3 and conv4 sum the GroupNorm statistics of their outputs in their
+    epilogues - per lane fp32 over 8 channels x its rows, fp64 over the wave, one fp64 entry per tile and row block of waves -
+    instead of XL_OP_GN_STATS passes over the tensors (XL_NO_STEM_STATS=1).  Only the summation order differs: the network output
+    agrees to a few fp32 steps, the three statistics passes are gone, and repeated runs are equal to the bit (fixed order, one
+    writer per entry although the fused stem hands its tiles out dynamically).  136 x 200 / 130 x 260: tiles that straddle two
+    frames, ragged last tiles, a batch whose tile boundaries fall differently in every frame."""
+    x = torch.rand(B, 3, H, W, generator=torch.Generator().manual_seed(B + H)).cuda()
+
+    def run():
+        net = networks.TransPoseNet(MEAN, False, False, 1, 1, 3, 1)
+        net.load_state_dict(seeded_state_dict(net, seed=21))
+        net = net.cuda().eval()
+        with torch.no_grad():
+            y = net(x).clone()
+            y2 = net(x)
+        assert torch.equal(y, y2)
+        plan = list(net._plans.values())[0]
+        return y.cpu(), sum(1 for op in plan.ops if op.type == networks.XL_OP_GN_STATS)
+    y_new, n_new = run()
+    monkeypatch.setenv("XL_NO_STEM_STATS", "1")
+    y_old, n_old = run()
+    assert n_new == n_old - 3, (n_new, n_old)
+    # the coordinates are stored around the scene mean (|y| ~ 500: one fp32 step is 3e-5): 4 steps; the uncertainty channel 2e-4 (30 layers
+    # of an untrained net amplify the 1e-7 of the statistics; tests/...stride2_stem_conv... pins the sums themselves to 2e-6)
+    assert (y_new[:, :3] - y_old[:, :3]).abs().max() <= 4 * 3.06e-5
+    assert torch.allclose(y_new[:, 3], y_old[:, 3], rtol=2e-4, atol=1e-9)
