@@ -686,7 +686,7 @@ class _Plan:
         self.tape.append(dict(kind="conv", conv=conv, x=act, raw=res, xnorm=norm_in if self.train else None))
         return res
 
-    def gn(self, act, norm, flags, aux=None, out=None, pre_stats=None, stat_tile=0, defer=False, share=False):
+    def gn(self, act, norm, flags, aux=None, out=None, pre_stats=None, stat_tile=0, defer=False, share=False, stat_mult=1):
         """GroupNorm (+fused epilogue) of `act`; in place unless `out` (tensor, ld, off) is given or training.
         pre_stats = (stats tensor, nchunks): the partial sums were already produced (Winograd output transform or conv
         epilogue of a training plan; stat_tile = rows per conv tile in the latter case), no statistics pass is emitted.
@@ -726,7 +726,7 @@ class _Plan:
         if self.train:
             table = torch.zeros(self.B * C * 4, dtype=torch.float32, device=self.device)
             self.keep.append(table)
-        self._emit_final(ap, gamma, beta, stat_tile, table)
+        self._emit_final(ap, gamma, beta, stat_tile, table, mult=stat_mult)
         if aux is not None:
             ap.aux = aux[0].data_ptr() + 4 * aux[5]
             ap.ld_aux = aux[4]
@@ -1047,6 +1047,16 @@ class _Plan:
                 bm, wm = (128, 2) if cop.reserved_i == 128 else {64: (128, 4), 128: (128, 2), 256: (256, 2)}[conv.out_channels]
                 return self.gn_fused(y, norm, flags, aux, len(self.ops) - 1, defer=dfr, share=share,
                                      stat=(bm, wm, (-(-(y[1] * y[2]) // bm) + 1) * wm))
+            if self.train and self.stem_stats_ok(norm, conv.out_channels, train=True):
+                # training: the same epilogue statistics in a buffer of the layer's own (GN_FINAL turns them into the table the
+                # apply and the backward passes read)
+                cop = self.ops[-1]
+                bm, wm = (128, 2) if cop.reserved_i == 128 else {64: (128, 4), 128: (128, 2), 256: (256, 2)}[conv.out_channels]
+                nchunks = (-(-(y[1] * y[2]) // bm) + 1) * wm
+                stats_t = torch.zeros(self.B * nchunks * norm.num_groups * 2, dtype=torch.float64, device=self.device)
+                self.keep.append(stats_t)
+                cop.stats, cop.groups, cop.nchunks = stats_t.data_ptr(), norm.num_groups, nchunks
+                return self.gn(y, norm, flags, aux, pre_stats=(stats_t, nchunks), stat_tile=bm, stat_mult=wm, defer=dfr)
             return self.gn(y, norm, flags, aux, defer=dfr, share=share)
         split = split_1x1 and (pend is None or absorbs)
         y = self.conv(act, conv, norm_in=pend, split=split)
@@ -1240,10 +1250,10 @@ class _Plan:
                 and not os.environ.get("XL_NO_SPLIT_STEM") and not os.environ.get("XL_NO_STEM12")
                 and not os.environ.get("XL_CONV1_VALU") and not os.environ.get("XL_NO_DEFERRED_GN"))
 
-    def stem_stats_ok(self, norm, cout):
-        """Inference plans: the stride-2 stem kernels (split pipe) sum the GroupNorm statistics of their output in the epilogue.
+    def stem_stats_ok(self, norm, cout, train=False):
+        """The stride-2 stem kernels (split pipe) sum the GroupNorm statistics of their output in the epilogue.
         Not for batch-invariant plans (the partial sums are grouped by tile, i.e. by the frame's position in the batch)."""
-        return (not self.train and not self.separate_stats and norm.num_groups == 32 and cout in (64, 128, 256)
+        return (self.train == train and not self.separate_stats and norm.num_groups == 32 and cout in (64, 128, 256)
                 and not os.environ.get("XL_STEM_FORM") and not os.environ.get("XL_NO_STEM_STATS"))
 
     def _stem12(self, enc, image):
