@@ -538,19 +538,43 @@ __global__ void gnb_stats_kernel(GnbArgs a)
     int p1 = p0 + per; if (p1 > a.HW) p1 = a.HW;
     double sA[4] = { 0, 0, 0, 0 }, sB[4] = { 0, 0, 0, 0 }, sX[4] = { 0, 0, 0, 0 };
     const int c = 4 * c4;
-    for (int p = p0 + prow; p < p1; p += rows) {
+    // the thread's channel quad is fixed: its coefficients live in registers; four pixels per trip with all their loads issued
+    // before the first use (round 4: one pixel per trip left 2 - 3 loads in flight per thread, 3.8 TB/s).  The sums are
+    // accumulated pixel by pixel in the same order as before.
+    f32x4 cMu, cRs, cSc, cSh;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { cMu[j] = sCo[c + j]; cRs[j] = sCo[a.C + c + j]; cSc[j] = sCo[2 * a.C + c + j]; cSh[j] = sCo[3 * a.C + c + j]; }
+    const bool hasOut = (a.flags & XL_GN_RELU_OUT) != 0;
+    auto accumulate = [&](const f32x4 &xv, const f32x4 &dv4, const f32x4 &ov) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float v = xv[j] * cSc[j] + cSh[j];
+            const float xh = (xv[j] - cMu[j]) * cRs[j];
+            const float dv = gnb_dv(dv4[j], ov[j], v, a.flags);
+            sA[j] += (double)dv; sB[j] += (double)dv * (double)xh; sX[j] += (double)xh;
+        }
+    };
+    int p = p0 + prow;
+    for (; p + 3 * rows < p1; p += 4 * rows) {
+        f32x4 xv[4], dv4[4], ov[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const long long pix = (long long)n * a.HW + p + k * rows;
+            xv[k] = *reinterpret_cast<const f32x4 *>(a.x + pix * a.ldX + c);
+            dv4[k] = *reinterpret_cast<const f32x4 *>(a.dout + pix * a.ldD + c);
+            ov[k] = f32x4{ 1.f, 1.f, 1.f, 1.f };
+            if (hasOut) ov[k] = *reinterpret_cast<const f32x4 *>(a.outAct + pix * a.ldO + c);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) accumulate(xv[k], dv4[k], ov[k]);
+    }
+    for (; p < p1; p += rows) {
         const long long pix = (long long)n * a.HW + p;
         const f32x4 xv = *reinterpret_cast<const f32x4 *>(a.x + pix * a.ldX + c);
         const f32x4 dv4 = *reinterpret_cast<const f32x4 *>(a.dout + pix * a.ldD + c);
         f32x4 ov = { 1.f, 1.f, 1.f, 1.f };
-        if (a.flags & XL_GN_RELU_OUT) ov = *reinterpret_cast<const f32x4 *>(a.outAct + pix * a.ldO + c);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float v = xv[j] * sCo[2 * a.C + c + j] + sCo[3 * a.C + c + j];
-            const float xh = (xv[j] - sCo[c + j]) * sCo[a.C + c + j];
-            const float dv = gnb_dv(dv4[j], ov[j], v, a.flags);
-            sA[j] += (double)dv; sB[j] += (double)dv * (double)xh; sX[j] += (double)xh;
-        }
+        if (hasOut) ov = *reinterpret_cast<const f32x4 *>(a.outAct + pix * a.ldO + c);
+        accumulate(xv, dv4, ov);
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) { smemD[tid * 12 + j] = sA[j]; smemD[tid * 12 + 4 + j] = sB[j]; smemD[tid * 12 + 8 + j] = sX[j]; }
@@ -639,6 +663,65 @@ void gnb_apply_kernel(GnbArgs a)
     const int p0 = blockIdx.x * per;
     int p1 = p0 + per; if (p1 > a.HW) p1 = a.HW;
     const long long nElem4 = (long long)(p1 - p0) * C4;
+    if (C4 <= 256 && 256 % C4 == 0) {
+        // the usual case (C = 32 ... 1024, a power of two): a thread keeps ONE channel quad - its seven coefficients in
+        // registers, no 64-bit division per element - and walks the pixels, four per trip with all loads issued first
+        // (round 4: 4.5 -> TB/s).  Element by element the same arithmetic as the general loop below.
+        const int c = 4 * (tid % C4), rows = 256 / C4;
+        f32x4 kMu, kRs, kSc, kSh, k1, k2, k3;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            kMu[j] = sK[c + j]; kRs[j] = sK[C + c + j]; kSc[j] = sK[2 * C + c + j]; kSh[j] = sK[3 * C + c + j];
+            k1[j] = sK[4 * C + c + j]; k2[j] = sK[5 * C + c + j]; k3[j] = sK[6 * C + c + j];
+        }
+        const bool hasOut = (a.flags & XL_GN_RELU_OUT) != 0, reluIn = (a.flags & XL_GN_RELU_IN) != 0;
+        const bool add = (a.flags & XL_GN_ADD) != 0, accAux = (a.flags & XL_GN_ACC_AUX) != 0;
+        auto one = [&](long long pix, const f32x4 &xv, const f32x4 &d4, const f32x4 &ov, const f32x4 &old) {
+            f32x4 dx, t4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float v = xv[j] * kSc[j] + kSh[j];
+                const float xh = (xv[j] - kMu[j]) * kRs[j];
+                float t = d4[j];
+                if (hasOut && !(ov[j] > 0.f)) t = 0.f;
+                t4[j] = t;
+                const float dv = (reluIn && !(v > 0.f)) ? 0.f : t;
+                dx[j] = k1[j] * dv - k2[j] - xh * k3[j];
+            }
+            if (add) {
+                if (accAux) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) t4[j] += old[j];
+                }
+                *reinterpret_cast<f32x4 *>(a.daux + pix * a.ldAux + c) = t4;
+            }
+            *reinterpret_cast<f32x4 *>(a.dx + pix * a.ldDx + c) = dx;
+        };
+        const f32x4 ones = { 1.f, 1.f, 1.f, 1.f };
+        int p = p0 + tid / C4;
+        for (; p + 3 * rows < p1; p += 4 * rows) {
+            f32x4 xv[4], d4[4], ov[4], old[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const long long pix = (long long)n * a.HW + p + k * rows;
+                xv[k] = *reinterpret_cast<const f32x4 *>(a.x + pix * a.ldX + c);
+                d4[k] = *reinterpret_cast<const f32x4 *>(a.dout + pix * a.ldD + c);
+                ov[k] = hasOut ? *reinterpret_cast<const f32x4 *>(a.outAct + pix * a.ldO + c) : ones;
+                old[k] = (add && accAux) ? *reinterpret_cast<const f32x4 *>(a.daux + pix * a.ldAux + c) : ones;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) one((long long)n * a.HW + p + k * rows, xv[k], d4[k], ov[k], old[k]);
+        }
+        for (; p < p1; p += rows) {
+            const long long pix = (long long)n * a.HW + p;
+            const f32x4 xv = *reinterpret_cast<const f32x4 *>(a.x + pix * a.ldX + c);
+            const f32x4 d4 = *reinterpret_cast<const f32x4 *>(a.dout + pix * a.ldD + c);
+            const f32x4 ov = hasOut ? *reinterpret_cast<const f32x4 *>(a.outAct + pix * a.ldO + c) : ones;
+            const f32x4 old = (add && accAux) ? *reinterpret_cast<const f32x4 *>(a.daux + pix * a.ldAux + c) : ones;
+            one(pix, xv, d4, ov, old);
+        }
+        return;
+    }
     for (long long f = tid; f < nElem4; f += 256) {
         const int p = p0 + (int)(f / C4);
         const int c = (int)(f - (long long)(p - p0) * C4) * 4;
