@@ -73,16 +73,22 @@ enum {
                                bias = conv1 bias[32]; aux2 = {scale, shift} pairs [B][32][2] of conv1's GroupNorm (XL_OP_GN_FINAL on
                                the statistics of a statistics-only XL_OP_CONV1); aux = conv2 weight fragments
                                [18 K-steps][3 planes][2 column blocks][64 lanes][8] bf16 (networks._Plan.conv2_fragments);
-                               stats2 = conv2 bias[64] (read only); stats = two int32, zero (tile queue, zero
+                               stats2 = conv2 bias[64] (read only); out2 = two int32, zero (tile queue, zero
                                again after the launch); out = RAW conv2 output [B,Ho,Wo,64] NHWC (ld_out),
-                               Ho = (Hi-1)/2+1; flags & XL_GN_RELU_IN: ReLU behind the GroupNorm */
+                               Ho = (Hi-1)/2+1; flags & XL_GN_RELU_IN: ReLU behind the GroupNorm.
+                               stats (optional, groups = 32, nchunks = ceil(Wo/16) * ceil(Ho/4) * 2): GroupNorm partial sums of
+                               the output, fp64 [B][nchunks][32][2] {sum, sum of squares}, every entry written - XL_OP_GN_FINAL
+                               with reserved_i = 0 sums them */
     XL_OP_S2_DGRAD = 20,    /* data gradient of a 3x3 stride-2 stem convolution (conv2 / conv3 of training plans) on the bf16 matrix pipe,
                                csrc/xl_stem_dgrad.hip: in = dY [B,Hi,Wi,Cin] (Cin = the layer's output channels, 64 or 128), w = weight
                                fragments [9 taps][Cin/16][3 planes][Cout/32][64 lanes][8] bf16 (networks._Plan.s2_dgrad_fragments),
                                out = dX [B,Ho,Wo,Cout] (Cout = 32 or 64, overwritten), stats = two int32, zero (tile queue) */
     XL_OP_GN_FINAL = 11  /* per-(image, channel) GroupNorm scale/shift [B][C][2] from the partial sums (out);
                             GN_APPLY with aux2 = that buffer skips its own finalisation.  out2 (training plans):
-                            [B][C][2] {mean, rstd} for the GroupNorm backward ops */
+                            [B][C][2] {mean, rstd} for the GroupNorm backward ops.  reserved_i = rows per producer tile (0: all
+                            nchunks entries are valid; > 0: one entry per tile overlapping the image; < 0: tiles start at
+                            image boundaries), stride > 1 with reserved_i != 0: that many entries per tile (the stride-2 stem
+                            convolutions write one per row block of waves) */
 };
 
 /* xl_op.flags for XL_OP_CONV / XL_OP_WINO_IN (opt-in split-bf16 GEMMs, csrc/xl_gemm_split.hip): the batched GEMM reads
@@ -97,6 +103,11 @@ enum {
                                   `bias` is added, XL_CONV_NORM_IN applies (Cin <= 512) and `stats` receives the GroupNorm
                                   partial sums of the output per 256-row tile (nchunks >= ceil(Ho*Wo / 256) + 1, 16 channels
                                   per group, Ho*Wo >= 256); XL_OP_GN_FINAL / XL_OP_GN_APPLY take reserved_i = 256 for them */
+/* ksize 3, stride 2 with both flags (csrc/xl_stem_split.hip: conv2..conv4 of the stem, Cout 64 / 128 / 256): `stats`
+ * (optional, groups = 32) receives the GroupNorm partial sums of the output, fp64 [B][nchunks][32][2], one entry per (tile
+ * overlapping the image, row block of waves): (rows per tile, entries per tile) = (128, 4) / (128, 2) / (256, 2) for Cout
+ * 64 / 128 / 256 and (128, 2) for the 128-column latency form (reserved_i = 128); nchunks >= (ceil(Ho*Wo / rows) + 1) *
+ * entries; XL_OP_GN_FINAL takes reserved_i = rows, stride = entries. */
 #define XL_CONV_SPLIT_ACT 1024 /* with both flags above and nchunks2 = Z > 1: the Z batched GEMMs of a Winograd layer whose
                                   activation operand V arrives as plain fp32 [Z][rows][Cin] (XL_OP_WINO_IN without the split
                                   flags) and is split into its three bf16 terms inside the GEMM kernel on its way into LDS, like
