@@ -279,7 +279,7 @@ def main():
                          "fixed start-up / tail cost (~0.5 ms per forward in total).  95 frames = 7168 tiles (28.0 rounds) for the 64 "
                          "batched Winograd GEMMs of a 512-channel layer - the 56 row tiles hold 14336 rows, 95 x 150 = 14250 - and 4008 "
                          "tiles (15.7 rounds) for a 1x1 layer; 47 frames (the default until round 4: 14.0 / 7.75 rounds) measures "
-                         "1.8-2 %% lower (profiles/r4_bench_b47.json).  Default 95; 47 with --mlr 3 (24 until round 4: -7 %%)")
+                         "1.8-2 %% lower (profiles/r4_bench_b47.json).  Default 95, also with --mlr 3 (47 there: -2.6 %%; 24 until round 4: -9 %%)")
     ap.add_argument("--hyps", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cnn-streams", type=int, default=1,
@@ -294,7 +294,7 @@ def main():
                          "eager, configs[4] 3-encoder network) that N=1 runs report outside the timed region")
     args = ap.parse_args()
     if args.batch is None:
-        args.batch = 47 if args.mlr else 95
+        args.batch = 95
 
     stub = bool(os.environ.get("XL_BENCH_STUB"))       # tests only: the rank / collective / timing plumbing on CPU (gloo)
     # XL_BENCH_SHARED_GPU=1 (tests/test_multiprocess_gpu.py): the multi-process preflight on a ONE-GPU box.  Every rank runs the
@@ -721,7 +721,7 @@ def gemm_error_leg(dev, frames=95):
     return out["split"], out["f32"]
 
 
-def secondary_configs(dev, n_hyp, train_batch=16, mlr_batch=47, steps=5, batch=95):
+def secondary_configs(dev, n_hyp, train_batch=16, mlr_batch=95, steps=5, batch=95):
     """Outside the timed region of the headline, N=1 only - the other single-GPU BASELINE configurations, so that their
     figures are driver-visible:
       configs[1]  batch-16 480x720 coord network forward + MLE coordinate loss + backward (train_single_task.py:245-301
