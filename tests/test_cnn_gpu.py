@@ -199,6 +199,69 @@ def test_conv1x1_on_the_split_bf16_pipe(cin, cout, B, H, W, norm, relu, stats, p
         assert torch.allclose(sums[:, :, 1], (grp * grp).sum(2), rtol=1e-5)
 
 
+@pytest.mark.parametrize("cin,cout,B,H,W,pad,stats,form", [
+    (512, 512, 2, 60, 90, 0, True, 0),        # fc1 behind the decoder's res3 block: the shape the plans use
+    (512, 512, 3, 24, 37, 32, True, 0),       # tiles straddle images, ragged last tile, operands inside wider tensors
+    (256, 512, 9, 60, 90, 0, False, 0),       # 190 tiles on 256 workgroups... several K-step counts
+    (512, 256, 1, 60, 90, 0, True, 128),      # single-frame forms: 128 x 128 tiles
+    (512, 512, 1, 60, 90, 0, True, 192)])     # ... 256 x 128
+def test_conv1x1_residual_epilogue_on_load_vs_float64(cin, cout, B, H, W, pad, stats, form):
+    """XL_CONV_NORM_ADD (round 4, split_conv1x1_res_kernel): the 1x1 layer consumes the RAW output x of a convolution and the
+    residual r of its block and applies the block's whole epilogue while loading its operand -
+    v = max(max(fmaf(x, scale, shift), 0) + r, 0) - so that GroupNorm + ReLU + residual + ReLU has no pass of its own.  Against a
+    float64 convolution of the float64 epilogue, and EQUAL TO THE BIT to the plain NORM-less kernel fed with the epilogue computed
+    in fp32 on the host in the same order (fmaf, max, add, max)."""
+    g = torch.Generator().manual_seed(cin + cout + B + H)
+    x = torch.randn(B, cin, H, W, generator=g) * 2.0 + 0.5
+    r = torch.randn(B, cin, H, W, generator=g).clamp(min=0) * 1.5             # (a residual is itself behind a ReLU)
+    coef = torch.stack([torch.rand(B, cin, generator=g) + 0.5, torch.randn(B, cin, generator=g)], 2)
+    conv = nn.Conv2d(cin, cout, 1)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) * (2.0 / cin) ** 0.5)
+        conv.bias.copy_(torch.randn(cout, generator=g))
+        sc, sh = coef[:, :, 0, None, None], coef[:, :, 1, None, None]
+        v64 = ((x.double() * sc.double() + sh.double()).clamp(min=0) + r.double()).clamp(min=0)
+        ref = F.conv2d(v64, conv.weight.double(), conv.bias.double())
+        # the kernel's arithmetic in fp32: one fused multiply-add (float64 product and sum rounded once = fmaf for these magnitudes)
+        v32 = ((x.double() * sc.double() + sh.double()).float().clamp(min=0) + r).clamp(min=0)
+
+    def wide(t):
+        w = torch.full((B, H, W, cin + pad), float("nan"))
+        w[..., pad:] = _nhwc(t)
+        return w.cuda()
+    xd, rd, vd = wide(x), wide(r), wide(v32)
+    wd = networks._Plan.split_bf16_interleaved(conv.weight.detach().reshape(cout, cin).cuda(), cin)
+    bd, cd = conv.bias.detach().cuda(), coef.contiguous().cuda()
+    G, tile = cout // 16, 128 if form == 128 else 256
+    nchunks = (H * W + tile - 1) // tile + 1
+
+    def run(res_form):
+        out = torch.full((B, H, W, cout), float("nan"), device="cuda")
+        st = torch.zeros(B * nchunks * G * 2, dtype=torch.float64, device="cuda")
+        op = networks.XlOp()
+        op.type = networks.XL_OP_CONV
+        op.B, op.Hi, op.Wi, op.Cin, op.Ho, op.Wo, op.Cout = B, H, W, cin, H, W, cout
+        op.ksize, op.stride, op.ld_in, op.ld_out, op.reserved_i = 1, 1, cin + pad, cout, form
+        op.flags = networks.CONV_SPLIT_BF16 | networks.CONV_SPLIT_IL
+        op.w, op.bias, op.out = wd.data_ptr(), bd.data_ptr(), out.data_ptr()
+        if res_form:
+            op.flags |= networks.CONV_NORM_IN | networks.CONV_NORM_RELU | networks.CONV_NORM_ADD
+            op.in_, op.aux, op.ld_aux, op.aux2 = xd.data_ptr() + 4 * pad, rd.data_ptr() + 4 * pad, cin + pad, cd.data_ptr()
+        else:
+            op.in_ = vd.data_ptr() + 4 * pad
+        if stats:
+            op.stats, op.groups, op.nchunks = st.data_ptr(), G, nchunks
+        _run([op, op])
+        return out.cpu(), st.cpu()
+    got, st_res = run(True)
+    plain, st_plain = run(False)
+    assert torch.equal(got, plain), (got - plain).abs().max()
+    assert torch.equal(st_res, st_plain)
+    _close(got.permute(0, 3, 1, 2).double(), ref)
+    esp = (got.permute(0, 3, 1, 2).double() - ref).abs().max().item() / ref.abs().max().item()
+    assert esp < 2e-6, esp
+
+
 @pytest.mark.parametrize("cin,cout,B,H,W,norm", [(512, 512, 8, 60, 90, True), (96, 256, 1, 60, 90, False), (64, 1024, 3, 17, 23, True)])
 def test_conv1x1_split_tile_forms_give_the_same_bits(cin, cout, B, H, W, norm):
     """reserved_i = 256 / 192 / 128: 256 x 256, 256 x 128 and 128 x 128 tiles of the same kernel.  Every output element

@@ -1,21 +1,18 @@
-"""Print the op list of the inference plan of the single-task network (batch given, 480 x 720): type, shape, flags, tile form."""
-import os
-import sys
-
+"""Op list of the inference plan of the single-task net: python tools/plan_dump.py [frames]"""
+import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import torch  # noqa: E402
-
-from crossloc_amd import networks, synth  # noqa: E402
-from crossloc_amd.weights import seeded_state_dict  # noqa: E402
-
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 47
+import torch
+from crossloc_amd import networks, synth
+from crossloc_amd.weights import seeded_state_dict
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 net = networks.TransPoseNet(torch.tensor(synth.SCENE_MEAN, dtype=torch.float32), False, False, 2, 2, 3, 1)
 net.load_state_dict(seeded_state_dict(net, seed=2021))
 net = net.cuda().eval()
 with torch.no_grad():
-    net(torch.rand(B, 3, 480, 720).cuda())
+    net(torch.rand(B, 3, 480, 720, device="cuda"))
 plan = list(net._plans.values())[0]
-names = {getattr(networks, k): k[6:] for k in dir(networks) if k.startswith("XL_OP_")}
+names = {0: "conv1", 1: "conv", 2: "gn_stats", 3: "gn_apply", 4: "head", 11: "gn_final", 12: "wino_in", 13: "wino_out", 19: "stem12"}
 for i, op in enumerate(plan.ops):
-    print("%3d %-10s B%d %dx%d Cin %4d -> %dx%d Cout %4d k%d s%d flags 0x%x nchunks2 %d form %d" % (
-        i, names.get(op.type, op.type), op.B, op.Hi, op.Wi, op.Cin, op.Ho, op.Wo, op.Cout, op.ksize, op.stride, op.flags, op.nchunks2, op.reserved_i))
+    if op.type == 11:
+        continue
+    print("%3d %-9s k%d s%d %4d->%4d %3dx%3d flags %#06x z %d" % (i, names.get(op.type, op.type), op.ksize, op.stride, op.Cin, op.Cout, op.Hi, op.Wi, op.flags, op.nchunks2))
