@@ -1,2 +1,3 @@
 #!/bin/bash
-timeout 900 python -m pytest tests/test_cnn_gpu.py -m gpu -q -k "residual_epilogue" 2>&1 | grep -E "^E   |passed|failed|Error" | cut -c1-300 | head -20
+python -m pytest tests/test_semantics_gpu.py tests/test_cnn_bwd_gpu.py tests/test_train_gpu.py -m gpu -q 2>&1 | grep -E "passed|failed"
+XL_TRAIN_STEM_STATS=1 python -m pytest tests/test_semantics_gpu.py tests/test_cnn_bwd_gpu.py tests/test_train_gpu.py tests/test_reference_fixtures.py -m gpu -q 2>&1 | grep -E "passed|failed|^FAILED"
