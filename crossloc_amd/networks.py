@@ -1043,10 +1043,8 @@ class _Plan:
             dfr = defer and flags == GN_RELU_IN and aux is None and not os.environ.get("XL_NO_DEFERRED_GN")
             if self.stem_stats_ok(norm, conv.out_channels):
                 # round 4: the statistics come from the convolution's epilogue (one entry per tile and row block of waves)
-                cop = self.ops[-1]
-                bm, wm = (128, 2) if cop.reserved_i == 128 else {64: (128, 4), 128: (128, 2), 256: (256, 2)}[conv.out_channels]
-                return self.gn_fused(y, norm, flags, aux, len(self.ops) - 1, defer=dfr, share=share,
-                                     stat=(bm, wm, (-(-(y[1] * y[2]) // bm) + 1) * wm))
+                bm, wm, nchunks = self._stem_stat_shape(self.ops[-1], y)
+                return self.gn_fused(y, norm, flags, aux, len(self.ops) - 1, defer=dfr, share=share, stat=(bm, wm, nchunks))
             if self.train and os.environ.get("XL_TRAIN_STEM_STATS") and self.stem_stats_ok(norm, conv.out_channels, train=True):
                 # training (opt-in, XL_TRAIN_STEM_STATS=1): the same epilogue statistics in a buffer of the layer's own (GN_FINAL
                 # turns them into the table the apply and the backward passes read).  Not the default: the step time does not
@@ -1054,8 +1052,7 @@ class _Plan:
                 # enough to flip ReLUs at the kinks and move the small-map gradient test against float64 autograd
                 # (tests/test_semantics_gpu.py) from 0.047 to 0.063 of the max-norm
                 cop = self.ops[-1]
-                bm, wm = (128, 2) if cop.reserved_i == 128 else {64: (128, 4), 128: (128, 2), 256: (256, 2)}[conv.out_channels]
-                nchunks = (-(-(y[1] * y[2]) // bm) + 1) * wm
+                bm, wm, nchunks = self._stem_stat_shape(cop, y)
                 stats_t = torch.zeros(self.B * nchunks * norm.num_groups * 2, dtype=torch.float64, device=self.device)
                 self.keep.append(stats_t)
                 cop.stats, cop.groups, cop.nchunks = stats_t.data_ptr(), norm.num_groups, nchunks
@@ -1252,6 +1249,13 @@ class _Plan:
                 and self.split_train_ok() and os.environ.get("XL_GEMM_SPLIT_BF16", self.SPLIT_DEFAULT) not in ("", "0", "1")
                 and not os.environ.get("XL_NO_SPLIT_STEM") and not os.environ.get("XL_NO_STEM12")
                 and not os.environ.get("XL_CONV1_VALU") and not os.environ.get("XL_NO_DEFERRED_GN"))
+
+    @staticmethod
+    def _stem_stat_shape(cop, y):
+        """(rows per tile, statistics entries per tile, nchunks) of a stride-2 stem convolution on the split pipe
+        (csrc/xl_stem_split.hip: one fp64 entry per tile and row block of waves; include/crossloc_cnn.h)."""
+        bm, wm = (128, 2) if cop.reserved_i == 128 else {64: (128, 4), 128: (128, 2), 256: (256, 2)}[y[3]]
+        return bm, wm, (-(-(y[1] * y[2]) // bm) + 1) * wm
 
     def stem_stats_ok(self, norm, cout, train=False):
         """The stride-2 stem kernels (split pipe) sum the GroupNorm statistics of their output in the epilogue.

@@ -1,3 +1,7 @@
 #!/bin/bash
-python -m pytest tests/test_semantics_gpu.py tests/test_cnn_bwd_gpu.py tests/test_train_gpu.py -m gpu -q 2>&1 | grep -E "passed|failed"
-XL_TRAIN_STEM_STATS=1 python -m pytest tests/test_semantics_gpu.py tests/test_cnn_bwd_gpu.py tests/test_train_gpu.py tests/test_reference_fixtures.py -m gpu -q 2>&1 | grep -E "passed|failed|^FAILED"
+# One gpurun call: the GPU test suite, the smoke entry point and the bench line (scratch script of the round; edit per session).
+O=$GRAFT_REPO_ROOT/gpurun_out/sess; mkdir -p $O
+python -m pytest tests -m gpu -q > $O/gputest.log 2>&1; echo "pytest rc=$?" >> $O/gputest.log
+grep -E "^FAILED|^ERROR|passed|failed|rc=" $O/gputest.log | tail -8; grep -E "^E " $O/gputest.log | head -12
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
+python bench.py 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline']['traffic'])"
