@@ -1722,11 +1722,18 @@ class _Plan:
                 # E.g. 3x3 512->512 at batch 16: 144 tiles x 7 = 1008 workgroups = 1.97 rounds of 386 steps.
                 steps_total = -(-M // 32)
                 best, splits = None, 1
-                for cand in range(1, 65):
+                # (round 4: resident workgroups by the tile form's LDS - 2 stages x 32 pixels x (bo + bc) floats: the 64 x 32 form of
+                #  conv2's weight gradient, 9 tiles, fits six per CU, and 56 splits = 504 two-wave workgroups had left the chip at one
+                #  wave per SIMD: 0.99 -> 0.54 ms; 128 x 64 fits three)
+                per_cu = max(2, min(6, (160 * 1024) // (2 * 32 * (bo + bc) * 4)))
+                if os.environ.get("XL_WGRAD_SMALL_SPLITS_OLD"):
+                    per_cu = 2
+                resident, max_splits = 256 * per_cu, 32 * per_cu
+                for cand in range(1, max_splits + 1):
                     if cand > max(1, M // 256):
                         break
                     n_wg = tiles * cand
-                    rounds = -(-n_wg // 512)
+                    rounds = -(-n_wg // resident)
                     cost = rounds * (-(-steps_total // cand) + 8) + (cand + 1) * tiles * bo * bc * 4 / 4e12 / 1.8e-6
                     if best is None or cost < best - 1e-9:
                         best, splits = cost, cand

@@ -1,7 +1,14 @@
 #!/bin/bash
-# One gpurun call: the GPU test suite, the smoke entry point and the bench line (scratch script of the round; edit per session).
-O=$GRAFT_REPO_ROOT/gpurun_out/sess; mkdir -p $O
-python -m pytest tests -m gpu -q > $O/gputest.log 2>&1; echo "pytest rc=$?" >> $O/gputest.log
-grep -E "^FAILED|^ERROR|passed|failed|rc=" $O/gputest.log | tail -8; grep -E "^E " $O/gputest.log | head -12
-python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
-python bench.py 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline']['traffic'])"
+O=$GRAFT_REPO_ROOT/gpurun_out/sess; rm -rf $O; mkdir -p $O
+timeout 900 python -m pytest tests/test_cnn_bwd_gpu.py tests/test_train_gpu.py -m gpu -q 2>&1 | grep -E "passed|failed|rc="; echo "tests done"
+cd /tmp; export TMPDIR=/tmp
+for v in new old; do
+  [ $v = old ] && export XL_WGRAD_SMALL_SPLITS_OLD=1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_$v -o r -- python $GRAFT_REPO_ROOT/tools/train_step_bench.py --full --steps 5 2>&1 | grep "HIP path"
+  python - $v <<'PY'
+import csv,glob,os,sys
+f=glob.glob(os.environ['GRAFT_REPO_ROOT']+'/gpurun_out/sess/kt_%s/**/*kernel_stats.csv'%sys.argv[1],recursive=True)[0]
+for r in csv.DictReader(open(f)):
+    if 'wgrad_kernel' in r['Name'] or 'wgrad_reduce' in r['Name']: print(sys.argv[1], '%-80s %5s %10.1f'%(r['Name'][:80], r['Calls'], float(r['AverageNs'])/1e3))
+PY
+done
