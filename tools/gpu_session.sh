@@ -1,9 +1,7 @@
 #!/bin/bash
-O=$GRAFT_REPO_ROOT/gpurun_out/sess; rm -rf $O; mkdir -p $O
-export TMPDIR=/tmp
-cd /tmp
-rocprofv3 -i $GRAFT_REPO_ROOT/tools/pmc_r2.txt --kernel-trace --output-format csv -d $O/pmc -- python $GRAFT_REPO_ROOT/tools/train_step_bench.py --full --steps 2 > $O/pmc.log 2>&1
-cd $GRAFT_REPO_ROOT
-python tools/pmc_summary.py $O/pmc $O/sum.csv > /dev/null
-python tools/pmc_derive.py $O/sum.csv $O/der.csv > /dev/null
-rm -rf $O/pmc
+# One gpurun call: the GPU test suite, the smoke entry point and the bench line (scratch script of the round; edit per session).
+O=$GRAFT_REPO_ROOT/gpurun_out/sess; mkdir -p $O
+python -m pytest tests -m gpu -q > $O/gputest.log 2>&1; echo "pytest rc=$?" >> $O/gputest.log
+grep -E "^FAILED|^ERROR|passed|failed|rc=" $O/gputest.log | tail -8; grep -E "^E " $O/gputest.log | head -12
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
+python bench.py 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline']['traffic'])"
