@@ -1224,7 +1224,7 @@ struct WinoFold { const float *res; float *side; int ldRes, ldSide, flags; const
 template <int DEFER, int SPLIT = 0, int FOLD = 0>
 __global__ __launch_bounds__(256, (SPLIT == 2 ? 3 : 1))
 void wino6_in_kernel(const float *__restrict__ in, float *__restrict__ V, int B, int H, int W, int C, int ldIn, int Th, int Tw,
-                     const float *__restrict__ coeff, WinoFold fold)
+                     const float *__restrict__ coeff, WinoFold fold, const float *__restrict__ pairScale)
 {
     static_assert(!FOLD || DEFER == 1, "the fold form takes its ReLU / residual flags at run time");
     const int C2 = C >> 1;
@@ -1321,6 +1321,28 @@ void wino6_in_kernel(const float *__restrict__ in, float *__restrict__ V, int B,
                     typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
                     const u32x3 v3 = u32x3{ row[3 * lane], row[3 * lane + 1], row[3 * lane + 2] };
                     *reinterpret_cast<u32x3 *>(op + (8 * i + j) * zw) = v3;
+                }
+            }
+            continue;
+        }
+        if constexpr (SPLIT == 3) {
+            // fp16 pairs (round 5, XL_CONV_PAIR_F16, csrc/xl_gemm_pair.hip): V[xi][t][c / 16][2][16] fp16 = {hi, (v - hi) 2^11} of
+            // v = V * scale.  A row is C words of 4 bytes like the fp32 form; a lane's channel pair is one word of the chunk's hi
+            // half and one word 32 bytes on: two dword stores per frequency, together the same contiguous 512 bytes per wave
+            typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+            const float sc = pairScale[0];
+            unsigned *op = reinterpret_cast<unsigned *>(V) + t * C + (c2 >> 3) * 16 + (c2 & 7);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                f32x2 o[8];
+                wino6_bt(w[i], o);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const f32x2 x = o[j] * sc;
+                    const f16x2 h = __builtin_convertvector(x, f16x2);
+                    const f16x2 l = __builtin_convertvector((x - __builtin_convertvector(h, f32x2)) * 2048.f, f16x2);
+                    unsigned *q = op + (8 * i + j) * zs;
+                    q[0] = __builtin_bit_cast(unsigned, h); q[8] = __builtin_bit_cast(unsigned, l);
                 }
             }
             continue;
@@ -2356,12 +2378,14 @@ int run_op(const xl_op &op, hipStream_t st)
                     fold.side = (float *)op.out2; fold.ldRes = op.ld_aux; fold.ldSide = op.ld_out;
                     fold.flags = op.flags & (XL_GN_RELU_IN | XL_GN_RELU_OUT);
                     fold.resCoef = (op.flags & XL_GN_ADD) ? (const float *)op.w : nullptr;
-                    if (op.flags & XL_CONV_SPLIT_BF16) return XL_ERR_UNSUPPORTED;     // the fold form writes V as fp32
-                    kin = wino6_in_kernel<1, 0, 1>;
-                }
+                    if ((op.flags & XL_CONV_SPLIT_BF16) && !(op.flags & XL_CONV_PAIR_F16)) return XL_ERR_UNSUPPORTED;   // fp32 or fp16 pairs
+                    kin = (op.flags & XL_CONV_PAIR_F16) ? wino6_in_kernel<1, 3, 1> : wino6_in_kernel<1, 0, 1>;
+                } else if (op.flags & XL_CONV_PAIR_F16)
+                    kin = !op.aux2 ? wino6_in_kernel<0, 3> : (op.flags & XL_GN_RELU_IN) ? wino6_in_kernel<2, 3> : wino6_in_kernel<1, 3>;
+                if ((op.flags & XL_CONV_PAIR_F16) && (!op.scale || op.Cin % 16 != 0)) return XL_ERR_ARG;
                 hipLaunchKernelGGL(kin, dim3((unsigned)blocks6), dim3(256), 0, st, (const float *)op.in,
                                    (float *)op.out, op.B, op.Hi, op.Wi, op.Cin, op.ld_in, op.Ho, op.Wo,
-                                   (const float *)op.aux2, fold);
+                                   (const float *)op.aux2, fold, (const float *)op.scale);
                 return XL_OK;
             }
             if (op.ksize == 4) {                    // F(4x4,3x3): Ho x Wo tiles of 4x4 outputs, partial tiles allowed

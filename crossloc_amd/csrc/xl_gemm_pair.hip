@@ -1,0 +1,843 @@
+// crossloc_hip: the split-pipe GEMMs with HALF the matrix-pipe work (round 5): fp16 pairs and triples, three passes.
+//
+//   M_z[t][o] = sum_c V_z[t][c] * U_z[o][c]
+//
+// csrc/xl_gemm_split.hip writes an fp32 operand as three bf16 terms and multiplies six term pairs.  fp16 carries 11
+// significand bits against bf16's 8, so TWO fp16 terms hold 22 bits and the products that matter are three:
+//
+//     a = ah + al,   b = bh + bl,        a b  =  ah bh  +  ah bl  +  al bh   ( + al bl, below 2^-22 of ah bh: dropped )
+//
+// on v_mfma_f32_32x32x16_f16 - the same 2.5 PFLOP/s pipe as the bf16 instruction, an fp16 x fp16 product is exact in fp32,
+// accumulation in fp32.  What fp16 lacks is bf16's exponent range, and the two operands deal with that differently:
+//   * weights (static, packed once per weight version, csrc/xl_pack.hip): every matrix is scaled by the power of two that
+//     puts its largest element into [2^14, 2^15) and stored as the TRIPLE {hi = fp16(w), lo = fp16(w - hi), hs = hi * 2^-11};
+//   * activations are scaled by ONE power of two per plan (xl_op.scale, chosen from a bound on the network's activations
+//     so that nothing can overflow) and stored as the PAIR {hi = fp16(a), lo' = fp16((a - hi) * 2^11)}: the low term is kept
+//     2^11 times too large, i.e. in fp16's normal range whenever hi is - its 11 bits survive for any |a| in [2^-13, 65504],
+//     so a loose bound (and with it a small scale) costs no accuracy - and its product is taken with `hs`, the weight's
+//     high term scaled down by the same 2^11:      a b  =  hi * bh  +  hi * bl  +  lo' * hs.
+// Measured error of the dominant launch against a float64 product of the same fp32 operands: see bench.py
+// (`split_gemm_err_vs_f64`, beside the fp32-MFMA kernel's own).
+//
+// Layouts (K-step = 16 channels = one k-depth of the MFMA):
+//     activations  [Z][rows][C/16][2][16] fp16     64 bytes per row and K-step  (4 bytes per element: what fp32 costs)
+//     weights      [Z][rows][C/16][3][16] fp16     96 bytes per row and K-step, then 2 Z floats: scratch, inverse scales
+// Kernels:
+//   pair_gemm_kernel      - both operands arrive in that form (V written by the Winograd input transform) and reach LDS by
+//                           DMA: no conversion, no register staging, no LDS writes from the ALU side;
+//   pair_conv1x1_kernel   - activations arrive as fp32 (1x1 layers; normalise-on-load, residual-on-load), the pairs are
+//                           formed on the way into LDS as csrc/xl_gemm_split.hip forms its bf16 terms.
+// Both are the 256 x 256 persistent loops of csrc/xl_gemm_split.hip (one workgroup per CU, 8 waves of 128 x 64, LDS-DMA
+// ring of 3 stages two K-steps ahead, ONE bare s_barrier per K-step behind a counted vmcnt wait) with half the MFMAs.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <type_traits>
+
+#include "../../include/crossloc_cnn.h"
+#include "../../include/crossloc_dsac.h"   // status codes
+#include "xl_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kPA = 64;                                  // bytes per activation row and K-step: {hi, lo'} x 16 fp16
+constexpr int kPB = 96;                                  // bytes per weight row and K-step: {hi, lo, hs} x 16 fp16
+constexpr unsigned OOB = 0x80000000u;
+
+// LDS rows of the activation stages are 4 slots of 16 bytes (hi k0-7, hi k8-15, lo' k0-7, lo' k8-15), slot s of row r at
+// physical slot s ^ swz(r).  ds_read_b128 is serviced in four groups of 16 lanes ({0-3, 12-15, 20-27}, ...); the 16 rows of a
+// group must hit 16 different 16-byte columns of the 256-byte bank row: (4 r + slot) mod 16, i.e. rows equal mod 4 need
+// different swz - bits 2-3 of the row.  Bit 1 is folded into the upper slot bit for the converting kernel's ds_write_b128
+// (groups of 8 consecutive lanes = 4 rows x 2 halves over 128 bytes of banks: rows r and r + 2 would collide).
+__device__ __forceinline__ int swz(int row) { return ((row >> 2) & 3) ^ (((row >> 1) & 1) << 1); }
+
+struct PairArgs {
+    const unsigned char *v, *u;  // [Z][T][C/16][2][16] fp16, [Z][N][C/16][3][16] fp16
+    float *out;                  // [Z][T][N] fp32
+    const float *uInv;           // [Z] inverse weight scales
+    const float *aScale;         // {s, 1 / s} of the activations
+    int T, C, N, Z, nbm, nbn;
+};
+
+// vmcnt bookkeeping (in order, per wave): a wave issues 5 DMA instructions per K-step (2 of the activations, 3 of the weights),
+// four of them in front of the step's barrier.  At the barrier of step s the operands of step s + 1 must have landed; younger
+// than those are the 4 DMAs of step s + 2 issued so far - and, in the first step of a tile, the 32 stores of the tile before.
+template <int CT>                                                      // compile-time channel count (0: a.C)
+__global__ __launch_bounds__(512)
+void pair_gemm_kernel(PairArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+    typedef __attribute__((address_space(3))) void lds_void;
+    constexpr int kOpA = 256 * kPA, kOpB = 256 * kPB, kStage = kOpA + kOpB;     // 16 + 24 = 40 KB per stage
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;                          // 2 x 4 waves of 128 x 64
+
+    // tiles of this workgroup: XCD x (= block % 8) owns a contiguous run of the (z, m-tile, n-tile) order, its workgroups
+    // take every nloc-th tile of the run, so the workgroups of an XCD work on neighbouring tiles at any time
+    const int total = a.nbm * a.nbn * a.Z;
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3, nloc = gridDim.x >> 3;
+    const int q8 = total >> 3, r8 = total & 7;
+    const int runStart = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+    const int runLen = q8 + (xcd < r8 ? 1 : 0);
+    const int myCount = runLen > local ? (runLen - local + nloc - 1) / nloc : 0;
+    if (myCount == 0) return;
+
+    const long long rowA = (long long)a.C * 4, rowB = (long long)a.C * 6;     // bytes per operand row
+    const int nk = CT ? CT / 16 : a.C / 16;
+
+    // ---- operand stream
+    __amdgpu_buffer_rsrc_t srdV, srdU;
+    unsigned gA[2], gB[3];
+    int dTile = 0, dK = 0;                                            // position of the stream: tile of my list, K-step
+    auto set_dma_tile = [&](int i) {
+        if (i < myCount) {
+            int t = runStart + local + i * nloc;
+            const int z = t / (a.nbm * a.nbn);
+            t -= z * (a.nbm * a.nbn);
+            const int mt = t / a.nbn, nt = t - mt * a.nbn;
+            const int m0 = mt * 256, n0 = nt * 256;
+            srdV = __builtin_amdgcn_make_buffer_rsrc((void *)(a.v + (long long)z * a.T * rowA), 0, (int)(a.T * rowA), 0x00020000);
+            srdU = __builtin_amdgcn_make_buffer_rsrc((void *)(a.u + (long long)z * a.N * rowB), 0, (int)(a.N * rowB), 0x00020000);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {                             // 16 rows x 4 slots per instruction
+                const int row = (wave * 2 + q) * 16 + (lane >> 2);
+                const int logical = (lane & 3) ^ swz(row);
+                gA[q] = (m0 + row < a.T) ? (unsigned)((long long)(m0 + row) * rowA + logical * 16) : OOB;
+            }
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {                             // 6 slots per row, rotated by one on rows with bit 3 set
+                const int sl = (wave * 3 + q) * 64 + lane;
+                const int row = sl / 6, phys = sl - row * 6;
+                int logical = phys - ((row >> 3) & 1);
+                if (logical < 0) logical += 6;
+                gB[q] = (n0 + row < a.N) ? (unsigned)((long long)(n0 + row) * rowB + logical * 16) : OOB;
+            }
+        } else {                                                      // past my last tile: zero-fill, same instruction count
+            gA[0] = OOB; gA[1] = OOB;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) gB[q] = OOB;
+        }
+    };
+    auto dma_instr = [&](int q, int stage) {                          // instruction q of 5 of the stream's current step
+        unsigned char *base = dsm + stage * kStage;
+        if (q < 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(srdV, (lds_void *)(base + (wave * 2 + q) * 1024), 16, (int)gA[q], dK * kPA, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(srdU, (lds_void *)(base + kOpA + (wave * 3 + q - 2) * 1024), 16, (int)gB[q - 2], dK * kPB, 0, 0);
+    };
+    auto advance_dma = [&]() {
+        if (++dK == nk) { dK = 0; ++dTile; set_dma_tile(dTile); }
+    };
+
+    // ---- fragments: lane -> row lane & 31 of a 32-row block, k-half lane >> 5 (8 fp16 = one 16-byte slot)
+    const int fr = lane & 31, kh = lane >> 5;
+    unsigned slotA[2], slotB[3];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) slotA[p] = (unsigned)(((2 * p + kh) ^ swz(fr)) * 16);
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        int ph = 2 * p + kh + ((fr >> 3) & 1);
+        if (ph >= 6) ph -= 6;
+        slotB[p] = (unsigned)(ph * 16);
+    }
+    const unsigned frA = (unsigned)((wm * 128 + fr) * kPA), frB = (unsigned)(kOpA + (wn * 64 + fr) * kPB);
+    f16x8 fa[2][4], fb[3][2];                                         // [hi, lo'][row block], [hi, lo, hs][column block]
+    f16x8 faN[4], fbN[2];
+    f32x16 acc[4][2];
+    auto ldA = [&](const unsigned char *sb, int p, int i) { return *reinterpret_cast<const f16x8 *>(sb + frA + i * 32 * kPA + slotA[p]); };
+    auto ldB = [&](const unsigned char *sb, int p, int j) { return *reinterpret_cast<const f16x8 *>(sb + frB + j * 32 * kPB + slotB[p]); };
+    auto mma_term = [&](int pu, int pv) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[pu][j], fa[pv][i], acc[i][j], 0, 0, 0);
+    };
+
+    // ---- prologue: steps 0 and 1 of the stream
+    set_dma_tile(0);
+#pragma unroll
+    for (int q = 0; q < 5; ++q) dma_instr(q, 0);
+    advance_dma();
+#pragma unroll
+    for (int q = 0; q < 5; ++q) dma_instr(q, 1);
+    advance_dma();
+    __builtin_amdgcn_s_waitcnt(0x0F70 | 5);
+    // (a bare s_barrier: the workgroup fence of __syncthreads() makes the compiler wait for EVERY outstanding LDS-DMA)
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int j = 0; j < 2; ++j) fbN[j] = ldB(dsm, 2, j);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) faN[i] = ldA(dsm, 1, i);
+    int sc = 0, sd = 2;                                               // stage being multiplied / being filled
+    const int rhalf = (lane >> 5) * 4;
+    const float aInv = a.aScale[1];
+    for (int ti = 0; ti < myCount; ++ti) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int kk = 0; kk < nk; ++kk) {
+            const unsigned char *sb = dsm + sc * kStage;
+            const int next = sc == 2 ? 0 : sc + 1;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[2][j] = fbN[j];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[1][i] = faN[i];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[1][j] = ldB(sb, 1, j);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[0][i] = ldA(sb, 0, i);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[0][j] = ldB(sb, 0, j);
+            mma_term(2, 1); dma_instr(0, sd); dma_instr(1, sd);        // lo' x hs
+            mma_term(1, 0); dma_instr(2, sd); dma_instr(3, sd);        // hi x lo
+            __builtin_amdgcn_sched_barrier(0);
+            if (kk == 0 && ti > 0) __builtin_amdgcn_s_waitcnt(0x8F70 | 4);      // vmcnt(36): + the 32 stores of the tile before
+            else __builtin_amdgcn_s_waitcnt(0x0F70 | 4);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned char *sn = dsm + next * kStage;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fbN[j] = ldB(sn, 2, j);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) faN[i] = ldA(sn, 1, i);
+            mma_term(0, 0); dma_instr(4, sd);                           // hi x hi
+            advance_dma();
+            sc = next;
+            sd = sd == 2 ? 0 : sd + 1;
+        }
+        // ---- epilogue of tile ti (swapped operands): row = lane & 31, channels (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+        int t = runStart + local + ti * nloc;
+        const int z = t / (a.nbm * a.nbn);
+        t -= z * (a.nbm * a.nbn);
+        const int mt = t / a.nbn, nt = t - mt * a.nbn;
+        const int m0 = mt * 256, n0 = nt * 256;
+        const float inv = aInv * a.uInv[z];                              // (powers of two: the un-scaling is exact)
+        const __amdgpu_buffer_rsrc_t srdO = __builtin_amdgcn_make_buffer_rsrc((void *)(a.out + (long long)z * a.T * a.N), 0, (int)((long long)a.T * a.N * 4), 0x00020000);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            // (exactly 32 stores per wave and tile, counted by the vmcnt arithmetic above: rows past T fall outside the
+            //  descriptor, N is a multiple of 256)
+            const int m = m0 + wm * 128 + i * 32 + (lane & 31);
+            const unsigned rowOff = (unsigned)((long long)m * a.N * 4);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int n = n0 + wn * 64 + j * 32 + rhalf + 8 * q;
+                    const unsigned off = rowOff + (unsigned)n * 4u;
+                    const f32x4 v = f32x4{ acc[i][j][4 * q] * inv, acc[i][j][4 * q + 1] * inv, acc[i][j][4 * q + 2] * inv, acc[i][j][4 * q + 3] * inv };
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), srdO, (int)off, 0, 0);
+                }
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);                             // vmcnt(0)
+}
+
+// ---------------------------------------------------------------------------------------------- fp32 activations, pairs formed in the kernel
+//
+// out[m][n] = bias[n] + sum_c f(in[m][c]) * W[n][c] - the 1x1 layers (f = identity, the producer's deferred GroupNorm(+ReLU), or
+// its whole GroupNorm + ReLU + residual + ReLU epilogue), the GroupNorm partial sums of the output in the epilogue, and the batched
+// GEMMs of a Winograd layer whose V arrives as fp32 (XL_CONV_SPLIT_ACT).  split_conv1x1_body of csrc/xl_gemm_split.hip with two
+// activation planes instead of three and three term groups instead of six: a thread loads 8 channels of one row two K-steps
+// ahead, applies scale (folded into the {scale, shift} table for the normalising forms), forms {hi, lo'} with v_cvt_pk_f16_f32
+// (the residual a - hi is exact in fp32) and writes 2 x 16 bytes into the activation stage of the next K-step under the MFMAs of
+// the second term group.  LDS: weights 3 x BN x 96 | activations 2 x BM x 64 | statistics staging 64 NTH (overlaps activation
+// stage 1) | fp64 partials 16 NTH | coefficient tables 2 x 8 KB | bias 4 KB | 1 KB scratch.
+struct PairConvArgs {
+    const float *in; const unsigned char *u; const float *bias; float *out;
+    const float *coef; float normLo;                 // NORM: [B][C][2] {scale, shift}; lower clamp (0 = ReLU, -inf = none)
+    double *stats; int HW, G, nchunks, B;            // statistics of the output (stats == nullptr: none); 16 channels per group
+    int M, C, N, ldIn, ldOut, nbm, nbn;
+    int tpi;                                         // > 0: tiles start at image boundaries, tpi = ceil(HW / BM) per image; 0: dense
+    int Z; long long zIn, zOut;                      // Z > 1: Z independent products (in / out advance by zIn / zOut floats, the weights by N rows)
+    int tile0, ntiles;                               // the launch's range of the (z, m-tile, n-tile) order
+    const float *res; int ldRes;                     // RES (with NORM): a residual added behind the normalisation, then ReLU
+    const float *uInv; const float *aScale;          // [Z] inverse weight scales; {s, 1 / s} of the activations
+};
+
+template <bool NORM, bool ACC, int NW, int ZB, int BN, bool RES>               // ACC: out += result
+__device__ __forceinline__ void pair_conv1x1_body(const PairConvArgs &a)
+{
+    static_assert(!RES || NORM, "the residual form is a normalise-on-load form");
+    constexpr int NLD = RES ? 4 : 2;                                          // activation loads per thread and K-step
+    extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+    typedef __attribute__((address_space(3))) void lds_void;
+    constexpr int NTH = 64 * NW, BM = NTH / 2;                                // threads; tile rows (a thread = 8 channels of a row)
+    constexpr int WN = BN / 64, WM = NW / WN, RI = BM / WM / 32;              // waves across columns / rows; 32-row blocks per wave
+    static_assert(RI >= 1 && RI * WM * 32 == BM && WN * WM == NW, "tile shape");
+    constexpr int NDMA = BN * kPB / 1024;                                     // DMA instructions per weight stage
+    constexpr int PARTS = NTH * 8 / BN;                                       // statistics: threads per (group, slot)
+    constexpr int kW = BN * kPB, kAS = BM * kPA;                              // one weight stage / one activation stage
+    constexpr int kCvA = 3 * kW, kCvStage1 = kCvA + kAS;                      // activation stages; statistics staging: 64 NTH bytes from stage 1
+    constexpr int kCvPart = kCvStage1 + 64 * NTH;                             // fp64 partials [NTH / 16][16][2]
+    constexpr int kCvCoef = kCvPart + 16 * NTH;                               // coefficient tables of two tiles, 8 KB each (C <= 512)
+    constexpr int kCvBias = kCvCoef + 16384;                                  // bias[N <= 1024]
+    constexpr int NS = 8 * RI;                                                // stores per wave and tile
+    static_assert(64 * NTH >= kAS, "the statistics staging covers activation stage 1");
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    // every wave issues three DMA instructions per K-step (straight-line code, the same counted waits in all waves); with 8 waves
+    // on 128 columns those of waves 4 .. 7 read out of range and write their zeros into a scratch KB
+    constexpr bool ALLDMA = NDMA >= 3 * NW;
+    constexpr int kCvScratch = kCvBias + 4096;
+    const bool dmaWave = ALLDMA || wave * 3 < NDMA;
+    const int dmaBase = __builtin_amdgcn_readfirstlane(dmaWave ? wave * 3 * 1024 : kCvScratch);
+    const int dmaStage = __builtin_amdgcn_readfirstlane(dmaWave ? kW : 0), dmaQ = __builtin_amdgcn_readfirstlane(dmaWave ? 1024 : 0);
+
+    const int total = a.ntiles;
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3, nloc = gridDim.x >> 3;
+    const int q8 = total >> 3, r8 = total & 7;
+    const int runStart = a.tile0 + (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8);
+    const int runLen = q8 + (xcd < r8 ? 1 : 0);
+    const int myCount = runLen > local ? (runLen - local + nloc - 1) / nloc : 0;
+    if (myCount == 0) return;
+    auto tile_z = [&](int i) { return (runStart + local + i * nloc) / (a.nbm * a.nbn); };
+    auto tile_at = [&](int i, int &m0, int &n0) {
+        int t = runStart + local + i * nloc;
+        t -= (t / (a.nbm * a.nbn)) * (a.nbm * a.nbn);
+        const int mt = t / a.nbn;
+        n0 = (t - mt * a.nbn) * BN;
+        if (a.tpi) {
+            const int n = mt / a.tpi;
+            m0 = n * a.HW + (mt - n * a.tpi) * BM;
+        } else m0 = mt * BM;
+    };
+    auto tile_rows = [&](int m0) {
+        int rows = a.M - m0;
+        if (a.tpi) rows = (m0 / a.HW + 1) * a.HW - m0;
+        return rows < BM ? rows : BM;
+    };
+
+    const long long rowU = (long long)a.C * 6;
+    const int nk = ZB == 2 ? 32 : a.C / 16;
+    const float aS = a.aScale[0], aInv = a.aScale[1];
+
+    // ---- stream two K-steps ahead of the multiplies: weights by LDS-DMA (3 instructions per wave and step), activations into
+    // registers (row tid >> 1, channels 8 (tid & 1) .. + 7 of the step; two register sets, by the parity of the step)
+    __amdgpu_buffer_rsrc_t srdU = __builtin_amdgcn_make_buffer_rsrc((void *)a.u, 0, (int)(a.N * rowU), 0x00020000);
+    __amdgpu_buffer_rsrc_t srdIn = __builtin_amdgcn_make_buffer_rsrc((void *)a.in, 0, 0, 0x00020000);
+    __amdgpu_buffer_rsrc_t srdRes = __builtin_amdgcn_make_buffer_rsrc((void *)a.in, 0, 0, 0x00020000);
+    const int arow = tid >> 1, ahalf = tid & 1;
+    unsigned gB[3], gA = OOB, gR = OOB;
+    int dTile = 0, dK = 0;
+    auto set_dma_tile = [&](int i) {
+        if (i < myCount) {
+            int m0, n0;
+            tile_at(i, m0, n0);
+            const int rows = tile_rows(m0);
+            const int z = tile_z(i);
+            srdIn = __builtin_amdgcn_make_buffer_rsrc((void *)(a.in + z * a.zIn + (long long)m0 * a.ldIn), 0, rows * a.ldIn * 4, 0x00020000);
+            if (a.Z > 1) srdU = __builtin_amdgcn_make_buffer_rsrc((void *)(a.u + z * (a.N * rowU)), 0, (int)(a.N * rowU), 0x00020000);
+            gA = (unsigned)(arow * a.ldIn * 4 + ahalf * 32);              // rows past M fall outside the descriptor
+            if constexpr (RES) {
+                srdRes = __builtin_amdgcn_make_buffer_rsrc((void *)(a.res + (long long)m0 * a.ldRes), 0, rows * a.ldRes * 4, 0x00020000);
+                gR = (unsigned)(arow * a.ldRes * 4 + ahalf * 32);
+            }
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int sl = (wave * 3 + q) * 64 + lane;
+                const int row = sl / 6, phys = sl - row * 6;
+                int logical = phys - ((row >> 3) & 1);
+                if (logical < 0) logical += 6;
+                gB[q] = dmaWave ? (unsigned)((long long)(n0 + row) * rowU + logical * 16) : OOB;
+            }
+        } else {
+            gA = OOB; gR = OOB;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) gB[q] = OOB;
+        }
+    };
+    auto dma_instr = [&](int q, int stage) {
+        const int dst = ALLDMA ? stage * kW + (wave * 3 + q) * 1024 : dmaBase + stage * dmaStage + q * dmaQ;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(srdU, (lds_void *)(dsm + dst), 16, (int)gB[q], dK * kPB, 0, 0);
+    };
+    u32x4 rA[2][2];                                                    // [K-step parity][half of my 8 channels]
+    u32x4 rR[2][RES ? 2 : 1];                                          // ... of the residual
+    auto load_a = [&](auto parTag) {
+        constexpr int P = decltype(parTag)::value;
+        rA[P][0] = __builtin_amdgcn_raw_buffer_load_b128(srdIn, (int)gA, dK * 64, 0);
+        rA[P][1] = __builtin_amdgcn_raw_buffer_load_b128(srdIn, (int)(gA + 16u), dK * 64, 0);
+        if constexpr (RES) {
+            rR[P][0] = __builtin_amdgcn_raw_buffer_load_b128(srdRes, (int)gR, dK * 64, 0);
+            rR[P][1] = __builtin_amdgcn_raw_buffer_load_b128(srdRes, (int)(gR + 16u), dK * 64, 0);
+        }
+    };
+    auto advance_dma = [&]() {
+        if (++dK == nk) { dK = 0; ++dTile; set_dma_tile(dTile); }
+    };
+
+    // ---- conversion, one K-step ahead of the multiplies
+    unsigned wOff[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) wOff[p] = (unsigned)(kCvA + arow * kPA + (((2 * p + ahalf) ^ swz(arow)) * 16));
+    int cTile = 0, cK = 0;
+    unsigned cCoef = 0;                                              // LDS offset of my row's {scale, shift} run
+    auto set_conv_tile = [&](int i) {
+        if (NORM && i < myCount) {
+            int m0, n0;
+            tile_at(i, m0, n0);
+            const int nLo = m0 / a.HW;
+            const int split = (nLo + 1) * a.HW - m0;                 // first tile row of the second image
+            cCoef = (unsigned)(kCvCoef + (i & 1) * 8192 + (arow >= split ? a.C * 8 : 0) + ahalf * 64);
+        }
+    };
+    auto convert = [&](auto parTag) {                                  // registers of parity P -> activation stage P
+        constexpr int P = decltype(parTag)::value;
+        unsigned w[2][4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            f32x4 x = __builtin_bit_cast(f32x4, rA[P][h]);
+            if constexpr (NORM) {
+                // (the table in LDS holds {scale, shift} * s: fmaf(x, scale s, shift s) = s fmaf(x, scale, shift) to the bit, s a power of two)
+                const f32x4 c0 = *reinterpret_cast<const f32x4 *>(dsm + cCoef + cK * 128 + h * 32);
+                const f32x4 c1 = *reinterpret_cast<const f32x4 *>(dsm + cCoef + cK * 128 + h * 32 + 16);
+                x = f32x4{ fmaxf(fmaf(x[0], c0[0], c0[1]), a.normLo), fmaxf(fmaf(x[1], c0[2], c0[3]), a.normLo),
+                           fmaxf(fmaf(x[2], c1[0], c1[1]), a.normLo), fmaxf(fmaf(x[3], c1[2], c1[3]), a.normLo) };
+                if constexpr (RES) {                                   // gn_apply's epilogue: v += residual; v = max(v, 0)
+                    const f32x4 r = __builtin_bit_cast(f32x4, rR[P][h]);
+                    x = f32x4{ fmaxf(fmaf(r[0], aS, x[0]), 0.f), fmaxf(fmaf(r[1], aS, x[1]), 0.f), fmaxf(fmaf(r[2], aS, x[2]), 0.f), fmaxf(fmaf(r[3], aS, x[3]), 0.f) };
+                }
+            } else x *= aS;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const f32x2 v = f32x2{ x[2 * e], x[2 * e + 1] };
+                const f16x2 hi = __builtin_convertvector(v, f16x2);
+                const f16x2 lo = __builtin_convertvector((v - __builtin_convertvector(hi, f32x2)) * 2048.f, f16x2);
+                w[0][2 * h + e] = __builtin_bit_cast(unsigned, hi);
+                w[1][2 * h + e] = __builtin_bit_cast(unsigned, lo);
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+            *reinterpret_cast<u32x4 *>(dsm + P * kAS + wOff[p]) = u32x4{ w[p][0], w[p][1], w[p][2], w[p][3] };
+    };
+    auto advance_conv = [&]() {
+        if (++cK == nk) { cK = 0; ++cTile; set_conv_tile(cTile); }
+    };
+    // coefficient table of tile i: the {scale, shift} pairs of its (at most two) images, 4 C floats, into table i & 1 - times s
+    const __amdgpu_buffer_rsrc_t srdCoef = __builtin_amdgcn_make_buffer_rsrc((void *)a.coef, 0, NORM ? a.B * a.C * 8 : 0, 0x00020000);
+    constexpr int TPT = 512 / NTH;                                     // 16-byte table entries per thread (C <= 512)
+    struct Tab { u32x4 v[TPT]; };
+    auto load_table = [&](int i) -> Tab {
+        Tab t;
+#pragma unroll
+        for (int e = 0; e < TPT; ++e) {
+            const int idx = tid + e * NTH;
+            unsigned off = OOB;
+            if (i < myCount && idx < a.C) {
+                int m0, n0;
+                tile_at(i, m0, n0);
+                off = (unsigned)(((long long)(m0 / a.HW) * a.C * 2 + idx * 4) * 4);
+            }
+            t.v[e] = __builtin_amdgcn_raw_buffer_load_b128(srdCoef, (int)off, 0, 0);
+        }
+        return t;
+    };
+    auto store_table = [&](int i, const Tab &t) {
+#pragma unroll
+        for (int e = 0; e < TPT; ++e) {
+            const int idx = tid + e * NTH;
+            if (idx < a.C) *reinterpret_cast<f32x4 *>(dsm + kCvCoef + (i & 1) * 8192 + idx * 16) = __builtin_bit_cast(f32x4, t.v[e]) * aS;
+        }
+    };
+
+    // ---- fragments
+    const int fr = lane & 31, kh = lane >> 5;
+    unsigned slotA[2], slotB[3];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) slotA[p] = (unsigned)(((2 * p + kh) ^ swz(fr)) * 16);
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        int ph = 2 * p + kh + ((fr >> 3) & 1);
+        if (ph >= 6) ph -= 6;
+        slotB[p] = (unsigned)(ph * 16);
+    }
+    const unsigned frA = (unsigned)(kCvA + (wm * (32 * RI) + fr) * kPA), frB = (unsigned)((wn * 64 + fr) * kPB);
+    f16x8 fa[2][RI], fb[3][2];
+    f32x16 acc[RI][2];
+    auto ldA = [&](int stage, int p, int i) { return *reinterpret_cast<const f16x8 *>(dsm + stage * kAS + frA + i * 32 * kPA + slotA[p]); };
+    auto ldB = [&](int stage, int p, int j) { return *reinterpret_cast<const f16x8 *>(dsm + stage * kW + frB + j * 32 * kPB + slotB[p]); };
+    auto mma_term = [&](int pu, int pv) {
+#pragma unroll
+        for (int i = 0; i < RI; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[pu][j], fa[pv][i], acc[i][j], 0, 0, 0);
+    };
+    const int rhalf = kh * 4;
+    // accumulators start at the bias, in the scaled domain: bias * s * (weight scale) - powers of two, so the sum is s sW times
+    // what the unscaled order of operations gives, to the bit
+    const float biasMul = a.Z > 1 ? 0.f : aS * (1.f / a.uInv[0]);
+    auto init_acc = [&](int n0) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 b = *reinterpret_cast<const f32x4 *>(dsm + kCvBias + (n0 + wn * 64 + j * 32 + rhalf + 8 * q) * 4);
+#pragma unroll
+                for (int i = 0; i < RI; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[i][j][4 * q + e] = b[e];
+            }
+    };
+
+    // ---- prologue: bias and the first two coefficient tables into LDS, steps 0 and 1 of the stream, step 0 converted
+    for (int i = tid; i < a.nbn * BN; i += NTH) reinterpret_cast<float *>(dsm + kCvBias)[i] = (a.bias && i < a.N) ? a.bias[i] * biasMul : 0.f;
+    if constexpr (NORM) {
+        const Tab t0 = load_table(0), t1 = load_table(1);
+        store_table(0, t0);
+        store_table(1, t1);
+    }
+    set_dma_tile(0);
+    set_conv_tile(0);
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    load_a(P0{});
+    dma_instr(0, 0); dma_instr(1, 0); dma_instr(2, 0);
+    advance_dma();
+    __builtin_amdgcn_s_waitcnt(0x0070);                               // everything landed
+    __syncthreads();                                                  // tables and bias visible
+    convert(P0{});
+    advance_conv();
+    load_a(P1{});                                                     // (the order of a steady-state step)
+    dma_instr(0, 1); dma_instr(1, 1); dma_instr(2, 1);
+    advance_dma();
+    __builtin_amdgcn_s_waitcnt(0x0070 | (3 + NLD));                   // my writes of step 0; stage 0 of the ring landed before
+    __builtin_amdgcn_s_barrier();
+    int sc = 0, sd = 2;
+    {
+        int m0, n0;
+        tile_at(0, m0, n0);
+        init_acc(n0);
+    }
+    // one K-step; FIRST: the first step of a tile that follows another one (NS stores of its epilogue are in flight)
+    auto step = [&](auto firstTag, auto parTag) __attribute__((always_inline)) {
+        constexpr int sa = decltype(parTag)::value;                   // parity of the K-step
+        const int next = sc == 2 ? 0 : sc + 1;
+        load_a(parTag);                                               // step kk + 2: two steps until its conversion
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fb[2][j] = ldB(sc, 2, j);
+#pragma unroll
+        for (int i = 0; i < RI; ++i) fa[1][i] = ldA(sa, 1, i);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fb[1][j] = ldB(sc, 1, j);
+#pragma unroll
+        for (int i = 0; i < RI; ++i) fa[0][i] = ldA(sa, 0, i);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fb[0][j] = ldB(sc, 0, j);
+        mma_term(2, 1); dma_instr(0, sd);                              // lo' x hs
+        __builtin_amdgcn_sched_barrier(0);
+        // hi x lo with the conversion of step kk + 1 threaded through it: one MFMA (8 passes, 32 cycles of the pipe) covers the issue
+        // of a few VALU instructions of the same wave; the LDS writes go out before the last MFMAs of the group
+        mma_term(1, 0);
+        convert(std::integral_constant<int, sa ^ 1>{});               // (the compiler counts vmcnt for rA)
+        {
+            constexpr int nM = 2 * RI, valu = (RES ? 64 : (NORM ? 48 : 40)) / nM;
+#pragma unroll
+            for (int g = 0; g < nM; ++g) {
+                if constexpr (NORM) { if (g == 0 || g == nM / 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); }  // coefficient reads of 4 channels
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, valu, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);                      // the two LDS writes
+        }
+        dma_instr(1, sd);
+        __builtin_amdgcn_sched_barrier(0);
+        advance_conv();
+        // the weights of step kk + 1 have landed: younger are 2 DMAs and NLD loads of step kk + 2 - and, in the first
+        // step of a tile, the NS stores of the tile before; lgkmcnt(0): my activation writes are done
+        if constexpr (decltype(firstTag)::value) __builtin_amdgcn_s_waitcnt(0x0070 | ((2 + NLD + NS) & 15) | (((2 + NLD + NS) >> 4) << 14));
+        else __builtin_amdgcn_s_waitcnt(0x0070 | (2 + NLD));
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        mma_term(0, 0); dma_instr(2, sd);                              // hi x hi
+        advance_dma();
+        sc = next;
+        sd = sd == 2 ? 0 : sd + 1;
+        __builtin_amdgcn_sched_barrier(0);                            // (the vmcnt arithmetic above assumes this issue order)
+    };
+    auto epilogue = [&](int ti) __attribute__((always_inline)) {
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- tile ti (swapped operands): row = lane & 31, channels (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+        int m0, n0;
+        tile_at(ti, m0, n0);
+        {
+            const float inv = aInv * a.uInv[a.Z > 1 ? tile_z(ti) : 0];    // un-scale (exact)
+#pragma unroll
+            for (int i = 0; i < RI; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] *= inv;
+        }
+        if (a.stats != nullptr) {
+            // GroupNorm partial sums of the output, as split_conv1x1_body: slot 0 = rows before `split`, slot 1 = the rest; per lane
+            // fp32 over its rows x 8 channels of a group, fp64 over the lanes holding the group; one writer per (image, tile, group)
+            const int nLo = m0 / a.HW;
+            const int split = (nLo + 1) * a.HW - m0;
+            f32x2 *sS = reinterpret_cast<f32x2 *>(dsm + kCvStage1);    // [4 pieces][2 slots][NTH threads]
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int gh = 0; gh < 2; ++gh) {
+                    float s[2] = { 0.f, 0.f }, ss[2] = { 0.f, 0.f };
+#pragma unroll
+                    for (int i = 0; i < RI; ++i) {
+                        const int row = wm * (32 * RI) + i * 32 + fr;
+                        float t = 0.f, tt = 0.f;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float v = acc[i][j][8 * gh + e];
+                            t += v;
+                            tt = fmaf(v, v, tt);
+                        }
+                        const bool hi = row >= split, live = m0 + row < a.M && !(a.tpi && hi);
+                        s[0] += (live && !hi) ? t : 0.f; ss[0] += (live && !hi) ? tt : 0.f;
+                        s[1] += (live && hi) ? t : 0.f;  ss[1] += (live && hi) ? tt : 0.f;
+                    }
+#pragma unroll
+                    for (int sl = 0; sl < 2; ++sl) sS[((j * 2 + gh) * 2 + sl) * NTH + tid] = f32x2{ s[sl], ss[sl] };
+                }
+            __builtin_amdgcn_s_waitcnt(0x0070 | 0xC00F);               // lgkmcnt(0)
+            __builtin_amdgcn_s_barrier();
+            {
+                const int gs = tid / PARTS, part = tid % PARTS;        // (group of the tile, slot) x PARTS parts (8 lane blocks x WM)
+                const int gt = gs >> 1, sl = gs & 1;
+                const int src = ((part >> 3) * WN + (gt >> 2)) * 64 + (part & 7) * 8;
+                const f32x2 *o = sS + ((gt & 3) * 2 + sl) * NTH + src;
+                double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { s1 += (double)o[e][0]; s2 += (double)o[e][1]; }
+                double *sC = reinterpret_cast<double *>(dsm + kCvPart);
+                sC[tid * 2] = s1; sC[tid * 2 + 1] = s2;
+            }
+            __builtin_amdgcn_s_waitcnt(0x0070 | 0xC00F);
+            __builtin_amdgcn_s_barrier();
+            if (tid < 2 * (BN / 16)) {
+                const int gt = tid >> 1, sl = tid & 1;
+                const int n = nLo + sl;
+                const int firstRow = sl ? split : 0;
+                const int g = (n0 >> 4) + gt;
+                if (n < a.B && m0 + firstRow < a.M && (sl == 0 || (split < BM && !a.tpi)) && g < a.G) {
+                    const double *sC = reinterpret_cast<const double *>(dsm + kCvPart) + tid * (2 * PARTS);
+                    double s1 = 0.0, s2 = 0.0;
+                    for (int e = 0; e < PARTS; ++e) { s1 += sC[2 * e]; s2 += sC[2 * e + 1]; }
+                    const int k = a.tpi ? (m0 - n * a.HW) / BM                            // tile index within the image
+                                        : m0 / BM - (int)(((long long)n * a.HW) / BM);
+                    double *o = a.stats + (((long long)n * a.nchunks + k) * a.G + g) * 2;
+                    o[0] = s1; o[1] = s2;
+                }
+            }
+        }
+        if constexpr (NORM) {                                          // (waits for everything older than the table)
+            const Tab tab = load_table(ti + 2);
+            store_table(ti + 2, tab);
+        }
+        // (every wave issues exactly NS stores per tile - the vmcnt arithmetic of the next step counts them)
+        const __amdgpu_buffer_rsrc_t srdO = __builtin_amdgcn_make_buffer_rsrc((void *)(a.out + tile_z(ti) * a.zOut + (long long)m0 * a.ldOut), 0,
+                                                                              tile_rows(m0) * a.ldOut * 4, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < RI; ++i) {
+            const unsigned rowOff = (unsigned)((wm * (32 * RI) + i * 32 + fr) * a.ldOut * 4);
+            f32x4 old[2][4];
+            if constexpr (ACC) {                                       // (8 loads in flight per 32-row block; rows past the tile read 0)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        old[j][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                            srdO, (int)(rowOff + (unsigned)(n0 + wn * 64 + j * 32 + rhalf + 8 * q) * 4u), 0, 0));
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int n = n0 + wn * 64 + j * 32 + rhalf + 8 * q;
+                    const unsigned off = rowOff + (unsigned)n * 4u;
+                    f32x4 v = f32x4{ acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3] };
+                    if constexpr (ACC) v += old[j][q];
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), srdO, (int)off, 0, 0);
+                }
+        }
+        if (ti + 1 < myCount) {
+            tile_at(ti + 1, m0, n0);
+            init_acc(n0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto tile_steps = [&](auto firstTag) __attribute__((always_inline)) {
+        step(firstTag, P0{});
+        step(std::false_type{}, P1{});
+        for (int kk = 2; kk < nk; kk += 2) {
+            step(std::false_type{}, P0{});
+            step(std::false_type{}, P1{});
+        }
+    };
+    tile_steps(std::false_type{});
+    for (int ti = 1; ti < myCount; ++ti) {
+        epilogue(ti - 1);
+        tile_steps(std::true_type{});
+    }
+    epilogue(myCount - 1);
+    __builtin_amdgcn_s_waitcnt(0x0F70);                             // vmcnt(0)
+}
+
+template <bool NORM, bool ACC = false, int NW = 8, int ZB = 0, int BN = (NW == 8 ? 256 : 128)>
+__global__ __launch_bounds__(64 * NW)
+void pair_conv1x1_kernel(PairConvArgs a)
+{
+    pair_conv1x1_body<NORM, ACC, NW, ZB, BN, false>(a);
+}
+
+template <int NW = 8, int BN = (NW == 8 ? 256 : 128)>
+__global__ __launch_bounds__(64 * NW)
+void pair_conv1x1_res_kernel(PairConvArgs a)
+{
+    pair_conv1x1_body<true, false, NW, 0, BN, true>(a);
+}
+
+}  // namespace
+
+// XL_OP_CONV with XL_CONV_SPLIT_BF16 | XL_CONV_SPLIT_IL | XL_CONV_PAIR_F16, nchunks2 = Z > 1, no XL_CONV_SPLIT_ACT: in = V as
+// activation pairs [Z][T][Cin/16][2][16] fp16, w = weight triples [Z][Cout][Cin/16][3][16] fp16 + 2 Z floats, out = M fp32
+// [Z][T][Cout], scale = {s, 1 / s}.
+static int xl_run_pair_gemm(const xl_op &op, hipStream_t st)
+{
+    const int T = op.B * op.Ho * op.Wo, Z = op.nchunks2;
+    if (op.ksize != 1 || op.stride != 1 || Z < 1 || op.Cin % 16 != 0 || op.Cout % 256 != 0 || op.ld_in != op.Cin || op.ld_out != op.Cout ||
+        op.bias || op.stats || (op.flags & (XL_CONV_ACCUMULATE | XL_CONV_NORM_IN | XL_CONV_M_TILE_MAJOR)) || !op.in || !op.w || !op.out || !op.scale ||
+        (((uintptr_t)op.in | (uintptr_t)op.w | (uintptr_t)op.out) & 15))
+        return XL_ERR_ARG;
+    // 32-bit offsets inside one GEMM's operands / result (each z has its own buffer descriptor)
+    if ((long long)(T + 256) * op.Cout * 4 >= 0xffffffffLL || (long long)T * op.Cin * 4 >= 0x7fffffffLL || (long long)op.Cout * op.Cin * 6 >= 0x7fffffffLL ||
+        (long long)T * op.Cout * 4 >= 0x7fffffffLL) return XL_ERR_ARG;
+    PairArgs a;
+    a.v = (const unsigned char *)op.in; a.u = (const unsigned char *)op.w; a.out = (float *)op.out;
+    a.uInv = reinterpret_cast<const float *>(a.u + (long long)Z * op.Cout * op.Cin * 6) + Z;
+    a.aScale = (const float *)op.scale;
+    a.T = T; a.C = op.Cin; a.N = op.Cout; a.Z = Z;
+    a.nbm = (T + 255) / 256; a.nbn = op.Cout / 256;
+    const size_t lds = 3 * (size_t)(256 * kPA + 256 * kPB);         // 120 KB: one workgroup per CU
+    auto kernel = op.Cin == 512 ? pair_gemm_kernel<512> : pair_gemm_kernel<0>;
+    static XlLdsLimit configured[2];
+    int cfgDev;
+    const int slot = op.Cin == 512 ? 1 : 0;
+    if (configured[slot].needs(lds, &cfgDev)) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return XL_ERR_HIP;
+        configured[slot].done(lds, cfgDev);
+    }
+    const int nwg = a.nbm * a.nbn * Z;
+    int grid = 256;
+    if (grid > ((nwg + 7) & ~7)) grid = (nwg + 7) & ~7;
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(512), lds, st, a);
+    return XL_OK;
+}
+
+
+// fp32 activations: the launcher of csrc/xl_gemm_split.hip's 1x1 / XL_CONV_SPLIT_ACT forms with the pair kernels (same tile forms,
+// same statistics rows: op.reserved_i as there)
+template <int NW, int BN>
+static int launch_pair_conv1x1(const xl_op &op, PairConvArgs a, bool norm, int Z, hipStream_t st, int tileFrom = 0, int tileCount = -1)
+{
+    constexpr int BM = 32 * NW;
+    const long long M = a.M;
+    const bool perImage = op.reserved_i < 0;         // tiles start at image boundaries (reserved_i = -256 / -128)
+    a.tpi = perImage ? (a.HW + BM - 1) / BM : 0;
+    a.nbm = perImage ? op.B * a.tpi : (int)((M + BM - 1) / BM);
+    a.nbn = (op.Cout + BN - 1) / BN;
+    const size_t lds = 3 * BN * kPB + BM * kPA + 64 * (64 * NW) + 16 * (64 * NW) + 16384 + 4096 + 1024;
+    const bool accumulate = (op.flags & XL_CONV_ACCUMULATE) != 0;
+    const bool resid = norm && a.res != nullptr;
+    const bool dominant = Z > 1 && op.Cin == 512 && op.Cout == 512 && !accumulate && !norm;
+    const void *fn = accumulate ? reinterpret_cast<const void *>(pair_conv1x1_kernel<false, true, NW, 0, BN>)
+                   : resid ? reinterpret_cast<const void *>(pair_conv1x1_res_kernel<NW, BN>)
+                   : norm ? reinterpret_cast<const void *>(pair_conv1x1_kernel<true, false, NW, 0, BN>)
+                   : dominant ? reinterpret_cast<const void *>(pair_conv1x1_kernel<false, false, NW, 2, BN>)
+                   : Z > 1 ? reinterpret_cast<const void *>(pair_conv1x1_kernel<false, false, NW, 1, BN>)
+                           : reinterpret_cast<const void *>(pair_conv1x1_kernel<false, false, NW, 0, BN>);
+    static XlLdsLimit configured[6];
+    int cfgDev;
+    const int slot = accumulate ? 2 : (resid ? 5 : (norm ? 1 : (dominant ? 4 : (Z > 1 ? 3 : 0))));
+    if (configured[slot].needs(lds, &cfgDev)) {
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return XL_ERR_HIP;
+        configured[slot].done(lds, cfgDev);
+    }
+    const int nwg = tileCount < 0 ? a.nbm * a.nbn * Z : tileCount;
+    a.tile0 = tileFrom; a.ntiles = nwg;
+    int grid = 256;                                   // persistent: one workgroup per CU
+    if (grid > ((nwg + 7) & ~7)) grid = (nwg + 7) & ~7;
+    if (accumulate) hipLaunchKernelGGL((pair_conv1x1_kernel<false, true, NW, 0, BN>), dim3(grid), dim3(64 * NW), lds, st, a);
+    else if (resid) hipLaunchKernelGGL((pair_conv1x1_res_kernel<NW, BN>), dim3(grid), dim3(64 * NW), lds, st, a);
+    else if (norm) hipLaunchKernelGGL((pair_conv1x1_kernel<true, false, NW, 0, BN>), dim3(grid), dim3(64 * NW), lds, st, a);
+    else if (dominant) hipLaunchKernelGGL((pair_conv1x1_kernel<false, false, NW, 2, BN>), dim3(grid), dim3(64 * NW), lds, st, a);
+    else if (Z > 1) hipLaunchKernelGGL((pair_conv1x1_kernel<false, false, NW, 1, BN>), dim3(grid), dim3(64 * NW), lds, st, a);
+    else hipLaunchKernelGGL((pair_conv1x1_kernel<false, false, NW, 0, BN>), dim3(grid), dim3(64 * NW), lds, st, a);
+    return XL_OK;
+}
+
+static int xl_run_pair_conv1x1(const xl_op &op, hipStream_t st)
+{
+    const long long M = (long long)op.B * op.Ho * op.Wo;
+    const int HW = op.Ho * op.Wo;
+    const bool norm = (op.flags & XL_CONV_NORM_IN) != 0;
+    const bool small = op.reserved_i == 128 || op.reserved_i == -128;
+    const int BM = small ? 128 : 256;
+    const int Z = op.nchunks2 > 1 ? op.nchunks2 : 1;
+    if (Z > 1 && (op.bias || op.stats || norm || op.reserved_i < 0 || op.ld_in != op.Cin || op.ld_out != op.Cout)) return XL_ERR_ARG;
+    if (op.ksize != 1 || op.stride != 1 || op.Cin % 32 != 0 || op.Cout % 256 != 0 || op.Cout > 1024 || op.ld_in < op.Cin ||
+        op.ld_out < op.Cout || (op.ld_in & 3) || (op.ld_out & 3) || ((op.flags & XL_CONV_ACCUMULATE) && (norm || Z > 1 || op.stats)) || !op.in ||
+        !op.w || !op.out || !op.scale || (((uintptr_t)op.in | (uintptr_t)op.out | (uintptr_t)op.w) & 15) || M >= 0x7fffffffLL ||
+        (long long)op.Cout * op.Cin * 6 >= 0x7fffffffLL || 256LL * op.ld_in * 4 >= 0x7fffffffLL || 256LL * op.ld_out * 4 >= 0x7fffffffLL)
+        return XL_ERR_ARG;
+    if (norm && (!op.aux2 || op.Cin > 512 || HW < BM)) return XL_ERR_ARG;
+    if (op.stats && (op.groups <= 0 || op.Cout != 16 * op.groups || HW < BM || op.nchunks < (HW + BM - 1) / BM + 1)) return XL_ERR_ARG;
+    if (op.reserved_i < 0 && HW < BM) return XL_ERR_ARG;
+    PairConvArgs a;
+    a.in = (const float *)op.in; a.u = (const unsigned char *)op.w; a.bias = (const float *)op.bias; a.out = (float *)op.out;
+    a.coef = (const float *)op.aux2;
+    a.normLo = (op.flags & XL_CONV_NORM_RELU) ? 0.f : -__builtin_inff();
+    a.stats = (double *)op.stats; a.HW = HW; a.G = op.groups; a.nchunks = op.nchunks; a.B = op.B;
+    a.M = (int)M; a.C = op.Cin; a.N = op.Cout; a.ldIn = op.ld_in; a.ldOut = op.ld_out;
+    a.Z = Z; a.zIn = M * op.ld_in; a.zOut = M * op.ld_out;
+    a.res = nullptr; a.ldRes = 0;
+    a.uInv = reinterpret_cast<const float *>(a.u + (long long)Z * op.Cout * op.Cin * 6) + Z;
+    a.aScale = (const float *)op.scale;
+    if (op.flags & XL_CONV_NORM_ADD) {
+        if (!norm || !(op.flags & XL_CONV_NORM_RELU) || !op.aux || op.ld_aux < op.Cin || (op.ld_aux & 3) || ((uintptr_t)op.aux & 15) || Z > 1 ||
+            256LL * op.ld_aux * 4 >= 0x7fffffffLL) return XL_ERR_ARG;
+        a.res = (const float *)op.aux; a.ldRes = op.ld_aux;
+    }
+    if (op.flags & XL_CONV_M_TILE_MAJOR) {
+        if (Z < 2 || op.ld_out != op.Cout || 256LL * Z * op.Cout * 4 >= 0x7fffffffLL) return XL_ERR_ARG;
+        a.zOut = op.Cout; a.ldOut = Z * op.Cout;
+    }
+    a.tpi = 0; a.nbm = 0; a.nbn = 0;
+    if (small) return launch_pair_conv1x1<4, 128>(op, a, norm, Z, st);
+    if (op.reserved_i == 192) return launch_pair_conv1x1<8, 128>(op, a, norm, Z, st);
+    if (op.reserved_i == 384) {
+        const int nbig = (int)((M + 255) / 256) * (op.Cout / 256) * Z, full = nbig / 256 * 256, rem = nbig - full;
+        if (full > 0 && rem > 0 && 2 * rem <= 256) {
+            const int rc = launch_pair_conv1x1<8, 256>(op, a, norm, Z, st, 0, full);
+            return rc != XL_OK ? rc : launch_pair_conv1x1<8, 128>(op, a, norm, Z, st, 2 * full, 2 * rem);
+        }
+        if (full == 0 && 2 * rem <= 256) return launch_pair_conv1x1<8, 128>(op, a, norm, Z, st);
+    }
+    return launch_pair_conv1x1<8, 256>(op, a, norm, Z, st);
+}
+
+int xl_run_pair(const xl_op &op, hipStream_t st)
+{
+    if (!(op.flags & XL_CONV_SPLIT_IL)) return XL_ERR_ARG;
+    if (op.nchunks2 > 1 && !(op.flags & XL_CONV_SPLIT_ACT)) return xl_run_pair_gemm(op, st);
+    return xl_run_pair_conv1x1(op, st);
+}

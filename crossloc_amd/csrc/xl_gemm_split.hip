@@ -1219,8 +1219,11 @@ static int xl_run_split_conv1x1(const xl_op &op, hipStream_t st)
     return launch_split_conv1x1<8, 256>(op, a, norm, Z, st);
 }
 
+int xl_run_pair(const xl_op &op, hipStream_t st);       // csrc/xl_gemm_pair.hip
+
 int xl_run_split_gemm(const xl_op &op, hipStream_t st)
 {
+    if (op.flags & XL_CONV_PAIR_F16) return xl_run_pair(op, st);
     if ((op.flags & XL_CONV_SPLIT_IL) && (op.nchunks2 <= 1 || (op.flags & XL_CONV_SPLIT_ACT))) return xl_run_split_conv1x1(op, st);
     const int T = op.B * op.Ho * op.Wo, Z = op.nchunks2;
     if (op.ksize != 1 || op.stride != 1 || Z < 1 || op.Cin % kBK != 0 || op.Cout % 4 != 0 || op.ld_in != op.Cin ||

@@ -95,6 +95,169 @@ void split_weight_kernel(const float *__restrict__ src, uint16_t *__restrict__ d
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------- fp16 pair / triple operands (round 5)
+// XL_CONV_PAIR_F16 (csrc/xl_gemm_pair.hip): a weight w, scaled by the power of two 2^e of its matrix (max|w| 2^e in [2^14, 2^15)),
+// is stored as {hi = fp16(x), lo = fp16(x - hi), hs = fp16(hi * 2^-11)}; layout [Z][rows][K/16][3][16] fp16, then 2 Z floats:
+// the maxima of the matrices as float bits (pass 1, atomicMax on the bits of |w| - non-negative floats order like their bits)
+// and the inverse scales 2^-e (pass 2).
+__device__ __forceinline__ float pair_scale_of_max(unsigned maxBits)
+{
+    if (maxBits == 0u || (maxBits >> 23) == 0u) return 1.f;                       // all zero (or subnormal): no scaling
+    const int E = (int)(maxBits >> 23) - 127;                                    // floor(log2(max))
+    int e = 14 - E;
+    if (e > 100) e = 100;
+    if (e < -100) e = -100;
+    return __builtin_bit_cast(float, (unsigned)(e + 127) << 23);
+}
+__device__ __forceinline__ void pair_triple(float x, uint16_t &hi, uint16_t &lo, uint16_t &hs)
+{
+    const _Float16 h = (_Float16)x;
+    const _Float16 l = (_Float16)(x - (float)h);
+    const _Float16 s = (_Float16)((float)h * 0.00048828125f);
+    hi = __builtin_bit_cast(uint16_t, h); lo = __builtin_bit_cast(uint16_t, l); hs = __builtin_bit_cast(uint16_t, s);
+}
+
+template <int M>
+__device__ __forceinline__ void wino_u_of(const float *__restrict__ w, int Cin, int o, int c, int dgrad, float (&u)[(M + 2) * (M + 2)])
+{
+    constexpr int N = M + 2;
+    const float *src = w + ((long long)o * Cin + c) * 9;
+    double g[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) g[a][b] = (double)(dgrad ? src[(2 - a) * 3 + (2 - b)] : src[a * 3 + b]);
+    double t[N][3];
+#pragma unroll
+    for (int x = 0; x < N; ++x)
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+            t[x][b] = WinoG<M>::g[x][0] * g[0][b] + WinoG<M>::g[x][1] * g[1][b] + WinoG<M>::g[x][2] * g[2][b];
+#pragma unroll
+    for (int x = 0; x < N; ++x)
+#pragma unroll
+        for (int y = 0; y < N; ++y)
+            u[x * N + y] = (float)(t[x][0] * WinoG<M>::g[y][0] + t[x][1] * WinoG<M>::g[y][1] + t[x][2] * WinoG<M>::g[y][2]);
+}
+
+// PASS 0: the maxima per frequency; PASS 1: scale, split, store (and the inverse scales)
+template <int M, int PASS>
+__global__ __launch_bounds__(256)
+void wino_weight_pair_kernel(const float *__restrict__ w, uint16_t *__restrict__ dst, unsigned *__restrict__ maxBits,
+                             float *__restrict__ invScale, int Cout, int Cin, int dgrad)
+{
+    constexpr int N = M + 2, Z = N * N;
+    __shared__ unsigned sMax[Z];
+    const int rows = dgrad ? Cin : Cout, K = dgrad ? Cout : Cin;
+    const long long total = (long long)rows * K;
+    if (PASS == 0) {
+        for (int i = threadIdx.x; i < Z; i += 256) sMax[i] = 0u;
+        __syncthreads();
+    }
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int r = (int)(i / K), k = (int)(i - (long long)r * K);
+        float u[Z];
+        wino_u_of<M>(w, Cin, dgrad ? k : r, dgrad ? r : k, dgrad, u);
+        if (PASS == 0) {
+#pragma unroll
+            for (int z = 0; z < Z; ++z) atomicMax(&sMax[z], __builtin_bit_cast(unsigned, fabsf(u[z])));
+        } else {
+#pragma unroll
+            for (int z = 0; z < Z; ++z) {
+                const float sc = pair_scale_of_max(maxBits[z]);
+                uint16_t hi, lo, hs;
+                pair_triple(u[z] * sc, hi, lo, hs);
+                const long long b0 = (((long long)z * rows + r) * (K >> 4) + (k >> 4)) * 48 + (k & 15);
+                dst[b0] = hi; dst[b0 + 16] = lo; dst[b0 + 32] = hs;
+                if (i == 0) invScale[z] = 1.f / sc;
+            }
+        }
+    }
+    if (PASS == 0) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < Z; i += 256) if (sMax[i]) atomicMax(&maxBits[i], sMax[i]);
+    }
+}
+
+template <int PASS>
+__global__ __launch_bounds__(256)
+void pair_weight_kernel(const float *__restrict__ src, uint16_t *__restrict__ dst, unsigned *__restrict__ maxBits, float *__restrict__ invScale,
+                        int rows, int K, int taps)
+{
+    const long long total = (long long)rows * K;
+    const int Cin = taps > 0 ? K / taps : K;
+    unsigned m = 0u;
+    const float sc = PASS ? pair_scale_of_max(maxBits[0]) : 1.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int r = (int)(i / K), k = (int)(i - (long long)r * K);
+        float v;
+        if (taps == 1) v = src[i];
+        else if (taps == 0) v = src[(long long)k * rows + r];
+        else { const int tap = k / Cin, c = k - tap * Cin; v = src[((long long)r * Cin + c) * taps + tap]; }
+        if (PASS == 0) { const unsigned b = __builtin_bit_cast(unsigned, fabsf(v)); m = b > m ? b : m; }
+        else {
+            uint16_t hi, lo, hs;
+            pair_triple(v * sc, hi, lo, hs);
+            const long long b0 = ((long long)r * (K >> 4) + (k >> 4)) * 48 + (k & 15);
+            dst[b0] = hi; dst[b0 + 16] = lo; dst[b0 + 32] = hs;
+            if (i == 0) invScale[0] = 1.f / sc;
+        }
+    }
+    if (PASS == 0 && m) atomicMax(maxBits, m);
+}
+
+// activation pairs [rows][K/16][2][16] fp16 {hi, (x - hi) * 2^11} of x = src * scale[0]
+__global__ __launch_bounds__(256)
+void pair_activation_kernel(const float *__restrict__ src, uint16_t *__restrict__ dst, long long rows, int K, const float *__restrict__ scale)
+{
+    const long long total = rows * K;
+    const float sc = scale[0];
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long r = i / K;
+        const int k = (int)(i - r * K);
+        const float x = src[i] * sc;
+        const _Float16 h = (_Float16)x;
+        const _Float16 l = (_Float16)((x - (float)h) * 2048.f);
+        const long long b0 = (r * (K >> 4) + (k >> 4)) * 32 + (k & 15);
+        dst[b0] = __builtin_bit_cast(uint16_t, h); dst[b0 + 16] = __builtin_bit_cast(uint16_t, l);
+    }
+}
+
+// one workgroup: bound = sum_i (sqrtN_i max|gamma_i| + max|beta_i|); s = the largest power of two with s * bound <= 2^14
+// (kernel arguments hold 128 layers: longer lists run as a chain of launches that carry the sum in out[4..5] as a double)
+struct PairGnList { const float *gamma[128]; const float *beta[128]; int C[128]; float sqrtN[128]; int n; };
+__global__ __launch_bounds__(256)
+void pair_scales_kernel(PairGnList L, float *__restrict__ out, int first, int last)
+{
+    __shared__ float sG[256], sB[256];
+    __shared__ double sBound;
+    if (threadIdx.x == 0) sBound = first ? 0.0 : *reinterpret_cast<double *>(out + 4);
+    for (int i = 0; i < L.n; ++i) {
+        float g = 0.f, b = 0.f;
+        for (int c = threadIdx.x; c < L.C[i]; c += 256) { g = fmaxf(g, fabsf(L.gamma[i][c])); b = fmaxf(b, fabsf(L.beta[i][c])); }
+        sG[threadIdx.x] = g; sB[threadIdx.x] = b;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if ((int)threadIdx.x < s) { sG[threadIdx.x] = fmaxf(sG[threadIdx.x], sG[threadIdx.x + s]); sB[threadIdx.x] = fmaxf(sB[threadIdx.x], sB[threadIdx.x + s]); }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) sBound += (double)L.sqrtN[i] * (double)sG[0] + (double)sB[0];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *reinterpret_cast<double *>(out + 4) = sBound;
+    if (threadIdx.x == 0 && last) {
+        double bound = sBound;
+        if (!(bound > 1e-30)) bound = 1.0;
+        if (!(bound < 1e30)) bound = 1e30;                  // (a non-finite parameter: the results are garbage whatever the scale)
+        int e;
+        const double m = frexp(bound, &e);                   // bound = m 2^e, m in [0.5, 1): 2^(14 - e) bound <= 2^14
+        (void)m;
+        const float s = ldexpf(1.f, 14 - e), sv = ldexpf(1.f, 14 - e - 8);
+        out[0] = s; out[1] = 1.f / s; out[2] = sv; out[3] = 1.f / sv;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -121,6 +284,68 @@ int xl_cnn_split_weight(const float *src, void *dst, int rows, int K, int taps, 
     long long blocks = (total + 255) / 256;
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(split_weight_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, (uint16_t *)dst, rows, K, taps);
+    return hipGetLastError() == hipSuccess ? XL_OK : XL_ERR_HIP;
+}
+
+int xl_cnn_pack_wino_weight_pair(const float *w, void *dst, int Cout, int Cin, int m, int dgrad, void *stream)
+{
+    if (!w || !dst || Cout < 1 || Cin < 1 || (m != 4 && m != 6)) return XL_ERR_ARG;
+    const int K = dgrad ? Cout : Cin, Z = (m + 2) * (m + 2);
+    if (K % 16 != 0) return XL_ERR_ARG;
+    const long long total = (long long)Cout * Cin;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipStream_t st = (hipStream_t)stream;
+    uint16_t *d = (uint16_t *)dst;
+    unsigned *maxBits = reinterpret_cast<unsigned *>(d + (long long)Z * total * 3);
+    float *inv = reinterpret_cast<float *>(maxBits + Z);
+    if (hipMemsetAsync(maxBits, 0, sizeof(unsigned) * Z, st) != hipSuccess) return XL_ERR_HIP;
+    if (m == 4) {
+        hipLaunchKernelGGL((wino_weight_pair_kernel<4, 0>), dim3((unsigned)blocks), dim3(256), 0, st, w, d, maxBits, inv, Cout, Cin, dgrad ? 1 : 0);
+        hipLaunchKernelGGL((wino_weight_pair_kernel<4, 1>), dim3((unsigned)blocks), dim3(256), 0, st, w, d, maxBits, inv, Cout, Cin, dgrad ? 1 : 0);
+    } else {
+        hipLaunchKernelGGL((wino_weight_pair_kernel<6, 0>), dim3((unsigned)blocks), dim3(256), 0, st, w, d, maxBits, inv, Cout, Cin, dgrad ? 1 : 0);
+        hipLaunchKernelGGL((wino_weight_pair_kernel<6, 1>), dim3((unsigned)blocks), dim3(256), 0, st, w, d, maxBits, inv, Cout, Cin, dgrad ? 1 : 0);
+    }
+    return hipGetLastError() == hipSuccess ? XL_OK : XL_ERR_HIP;
+}
+
+int xl_cnn_pair_weight(const float *src, void *dst, int rows, int K, int taps, void *stream)
+{
+    if (!src || !dst || rows < 1 || K < 16 || K % 16 != 0 || (taps != 0 && taps != 1 && taps != 9) || (taps > 0 && K % taps != 0)) return XL_ERR_ARG;
+    const long long total = (long long)rows * K;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipStream_t st = (hipStream_t)stream;
+    uint16_t *d = (uint16_t *)dst;
+    unsigned *maxBits = reinterpret_cast<unsigned *>(d + total * 3);
+    float *inv = reinterpret_cast<float *>(maxBits + 1);
+    if (hipMemsetAsync(maxBits, 0, sizeof(unsigned), st) != hipSuccess) return XL_ERR_HIP;
+    hipLaunchKernelGGL(pair_weight_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, st, src, d, maxBits, inv, rows, K, taps);
+    hipLaunchKernelGGL(pair_weight_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, src, d, maxBits, inv, rows, K, taps);
+    return hipGetLastError() == hipSuccess ? XL_OK : XL_ERR_HIP;
+}
+
+int xl_cnn_pair_activation(const float *src, void *dst, long long rows, int K, const float *scale, void *stream)
+{
+    if (!src || !dst || !scale || rows < 1 || K < 16 || K % 16 != 0) return XL_ERR_ARG;
+    long long blocks = (rows * K + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(pair_activation_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, (uint16_t *)dst, rows, K, scale);
+    return hipGetLastError() == hipSuccess ? XL_OK : XL_ERR_HIP;
+}
+
+int xl_cnn_pair_scales(const float *const *gamma, const float *const *beta, const int *C, const float *sqrtN, int n, float *out, void *stream)
+{
+    if (!out || n < 0 || (((uintptr_t)out) & 7) || (n > 0 && (!gamma || !beta || !C || !sqrtN))) return XL_ERR_ARG;
+    for (int i = 0; i < n; ++i)
+        if (!gamma[i] || !beta[i] || C[i] < 1 || !(sqrtN[i] >= 0.f)) return XL_ERR_ARG;
+    for (int i0 = 0; i0 == 0 || i0 < n; i0 += 128) {
+        PairGnList L;
+        L.n = n - i0 < 128 ? n - i0 : 128;
+        for (int i = 0; i < L.n; ++i) { L.gamma[i] = gamma[i0 + i]; L.beta[i] = beta[i0 + i]; L.C[i] = C[i0 + i]; L.sqrtN[i] = sqrtN[i0 + i]; }
+        hipLaunchKernelGGL(pair_scales_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, L, out, i0 == 0 ? 1 : 0, i0 + 128 >= n ? 1 : 0);
+    }
     return hipGetLastError() == hipSuccess ? XL_OK : XL_ERR_HIP;
 }
 

@@ -37,6 +37,7 @@ CONV_SPLIT_IL = 512
 CONV_SPLIT_ACT = 1024
 CONV_M_TILE_MAJOR = 2048
 CONV_NORM_ADD = 4096
+CONV_PAIR_F16 = 8192
 XL_ERR_UNSUPPORTED = -4            # include/crossloc_dsac.h
 
 
@@ -45,7 +46,7 @@ class XlOp(ctypes.Structure):
                 ("type", "B", "Hi", "Wi", "Cin", "Ho", "Wo", "Cout", "ksize", "stride", "groups", "nchunks",
                  "flags", "ld_in", "ld_out", "ld_aux", "n_task", "n_pos", "nchunks2", "reserved_i")] + \
                [(n, ctypes.c_float) for n in ("eps", "clamp_lo", "clamp_hi", "reserved")] + \
-               [(n, ctypes.c_void_p) for n in ("in_", "w", "bias", "aux", "stats", "out", "aux2", "out2", "stats2")]
+               [(n, ctypes.c_void_p) for n in ("in_", "w", "bias", "aux", "stats", "out", "aux2", "out2", "stats2", "scale")]
 
 
 def _bind():
@@ -63,6 +64,15 @@ def _bind():
         L.xl_cnn_pack_wino_weight.argtypes = [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 5 + [ctypes.c_void_p]
         L.xl_cnn_split_weight.restype = ctypes.c_int
         L.xl_cnn_split_weight.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+        L.xl_cnn_pack_wino_weight_pair.restype = ctypes.c_int
+        L.xl_cnn_pack_wino_weight_pair.argtypes = [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 4 + [ctypes.c_void_p]
+        L.xl_cnn_pair_weight.restype = ctypes.c_int
+        L.xl_cnn_pair_weight.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+        L.xl_cnn_pair_activation.restype = ctypes.c_int
+        L.xl_cnn_pair_activation.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        L.xl_cnn_pair_scales.restype = ctypes.c_int
+        L.xl_cnn_pair_scales.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                         ctypes.c_void_p, ctypes.c_void_p]
         L.xl_cnn_graph_capture.restype = ctypes.c_int
         L.xl_cnn_graph_capture.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]
         L.xl_cnn_graph_launch.restype = ctypes.c_int
@@ -219,7 +229,13 @@ class _Plan:
         self.out_op_index = None
         self.image_op_indices = []
         self.tape = []
+        # round 5: the activation scales of the fp16-pair GEMMs (csrc/xl_gemm_pair.hip): {s, 1/s} for GroupNorm outputs and sums of
+        # them, {s/256, 256/s} for their Winograd transforms; written by _update_pair_scales() once the plan's GroupNorm layers are
+        # known, and again whenever the parameters change
+        self.packed_pair = {}
+        self.pair_scales = torch.zeros(8, dtype=torch.float32, device=device)
         self._lower(net)
+        self._update_pair_scales()
         self.op_array = (XlOp * len(self.ops))(*self.ops)
         self.stats = torch.zeros(max(self.max_stats, 1), dtype=torch.float64, device=device)
         for i in self.stats_ops:
@@ -401,6 +417,78 @@ class _Plan:
         else:
             _check(_bind().xl_cnn_split_weight(src.data_ptr(), planes.data_ptr(), src.shape[0], src.shape[1] * taps, taps, stream))
 
+
+    # -- fp16 pair / triple operands (round 5, XL_CONV_PAIR_F16): half the matrix-pipe passes of the split-bf16 GEMMs
+    def pair_ok(self):
+        """The GEMMs of inference plans run as three fp16 passes instead of six bf16 ones (csrc/xl_gemm_pair.hip) unless
+        XL_GEMM_PAIR=0.  Every convolution this applies to reads GroupNorm outputs (and sums of them): their magnitude is
+        bounded by the GroupNorm parameters, which is what makes ONE static power-of-two scale per plan safe for fp16."""
+        return (not self.train and os.environ.get("XL_GEMM_PAIR", "1") not in ("", "0")
+                and os.environ.get("XL_GEMM_SPLIT_BF16", self.SPLIT_DEFAULT) not in ("", "0", "1"))
+
+    def _gn_layers(self):
+        """(gamma, beta, C, sqrt(N)) of every GroupNorm of the network: N = the elements of a group, from the op that applies
+        the layer in this plan, or - layers the plan does not run - from the image size (no map is larger)."""
+        seen = {}
+        for op in self.ops:
+            if op.type in (XL_OP_GN_FINAL, XL_OP_GN_APPLY) and op.w and op.bias and op.groups > 0:
+                n = (op.Cin // op.groups) * op.Hi * op.Wi
+                seen[op.w] = max(seen.get(op.w, 0), n)
+        out = []
+        for mod in self.net.modules():
+            if isinstance(mod, nn.GroupNorm) and mod.weight is not None:
+                g, b = self.dev(mod.weight), self.dev(mod.bias)
+                n = seen.get(g.data_ptr(), (mod.num_channels // mod.num_groups) * self.H * self.W)
+                out.append((g, b, mod.num_channels, float(n) ** 0.5))
+        return out
+
+    def _update_pair_scales(self):
+        """s = the largest power of two with s * sum over the GroupNorm layers of (sqrt(N) max|gamma| + max|beta|) <= 2^14:
+        |gn(x)| <= sqrt(N - 1) |gamma| + |beta|, an activation is a GroupNorm output plus residuals that are activations
+        themselves (the sum over ALL layers bounds any chain), and |B^T d B| <= 225 max|d| for F(6x6,3x3).  One tiny launch
+        reading the live parameters - no host synchronisation, so a training loop can call it every step."""
+        if not self.packed_pair and not getattr(self, "pair_ops", 0):
+            return
+        if not hasattr(self, "_pair_gn"):
+            layers = self._gn_layers()
+            n = len(layers)
+            self._pair_gn = ((ctypes.c_void_p * n)(*[g.data_ptr() for g, _, _, _ in layers]),
+                             (ctypes.c_void_p * n)(*[b.data_ptr() for _, b, _, _ in layers]),
+                             (ctypes.c_int * n)(*[c for _, _, c, _ in layers]),
+                             (ctypes.c_float * n)(*[r for _, _, _, r in layers]), n)
+        g, b, c, r, n = self._pair_gn
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        _check(_bind().xl_cnn_pair_scales(g, b, c, r, n, self.pair_scales.data_ptr(), stream))
+
+    def pack_conv_wino_pair(self, conv, m):
+        """The transformed weights of pack_conv_wino as fp16 triples [(m+2)^2][Cout][Cin/16][3][16], each frequency scaled by its
+        own power of two, + 2 (m+2)^2 floats (scratch, inverse scales)."""
+        key = (id(conv.weight), "wino%d_pair" % m)
+        if key not in self.packed_pair:
+            src = conv.weight.detach().to(device=self.device, dtype=torch.float32).contiguous()   # aliases the live parameter
+            nf = (m + 2) ** 2
+            planes = torch.empty(3 * nf * src.shape[0] * src.shape[1] + 4 * nf, dtype=torch.int16, device=self.device)
+            self.packed_pair[key] = (planes, src, m)
+            self._pack_pair(planes, src, m)
+        return self.packed_pair[key][0]
+
+    def pack_conv_1x1_pair(self, conv):
+        """[Cout][Cin/16][3][16] fp16 triples of a 1x1 convolution's weight (one power-of-two scale) + 2 floats."""
+        key = (id(conv.weight), "1x1_pair")
+        if key not in self.packed_pair:
+            src = conv.weight.detach().to(device=self.device, dtype=torch.float32).contiguous()   # aliases the live parameter
+            planes = torch.empty(3 * src.numel() + 4, dtype=torch.int16, device=self.device)
+            self.packed_pair[key] = (planes, src, 0)
+            self._pack_pair(planes, src, 0)
+        return self.packed_pair[key][0]
+
+    def _pack_pair(self, planes, src, m):
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        if m:
+            _check(_bind().xl_cnn_pack_wino_weight_pair(src.data_ptr(), planes.data_ptr(), src.shape[0], src.shape[1], m, 0, stream))
+        else:
+            _check(_bind().xl_cnn_pair_weight(src.data_ptr(), planes.data_ptr(), src.shape[0], src.shape[1], 1, stream))
+
     def wino_pick(self, H, W, chan_max, allowed=(6, 4)):
         """Output tile m of F(m x m, 3x3) for an H x W map: the allowed size (capped by XL_WINOGRAD) with the fewest
         multiplies, (m+2)^2 * ceil(H/m) * ceil(W/m); 0 if none.  The transformed tensors V / M hold (m+2)^2 independent
@@ -468,6 +556,9 @@ class _Plan:
             self._pack_wino_split(*entry)
         for entry in self.packed_1x1.values():
             self._split_weight(*entry)
+        for entry in self.packed_pair.values():
+            self._pack_pair(*entry)
+        self._update_pair_scales()
         for key, (planes, src) in self.packed_c1.items():
             kind = key[1] if isinstance(key, tuple) else "c1"
             planes.copy_(self.s2_dgrad_fragments(src) if kind == "s2dgrad" else self.conv2_fragments(src) if kind == "c2frag"
@@ -665,6 +756,12 @@ class _Plan:
             op.reserved_i = 0
             if (cout == 256 and -(-self.B * Ho * Wo // 256) < 128 and not os.environ.get("XL_NO_SMALL_TILES")):
                 op.reserved_i = 128                  # latency form: 128 x 128 tiles when 256-row tiles leave the chip idle
+        elif split and self.pair_ok():
+            # round 5: three fp16 passes instead of six bf16 ones; the operand is a GroupNorm output (or normalised on load)
+            op.flags |= CONV_SPLIT_BF16 | CONV_SPLIT_IL | CONV_PAIR_F16
+            op.w = self.pack_conv_1x1_pair(conv).data_ptr()
+            op.scale = self.pair_scales.data_ptr()
+            op.reserved_i = -256 if self.separate_stats else self.split_tile_form(self.B * Ho * Wo, cout, 1, Ho * Wo)
         elif split:
             op.flags |= CONV_SPLIT_BF16 | CONV_SPLIT_IL
             op.w = self.pack_conv_1x1_split(conv).data_ptr()
@@ -843,6 +940,15 @@ class _Plan:
         op.ksize = m
         op.B, op.Hi, op.Wi, op.Cin, op.Ho, op.Wo, op.ld_in = B, H, W, C, Th, Tw, ld
         op.in_, op.out = t.data_ptr() + 4 * off, V.data_ptr()
+        # round 5: fp16 pairs (XL_CONV_PAIR_F16).  With full 256 x 256 tiles V is written as pairs by the input transform and both
+        # operands of the GEMM arrive by DMA (pair_gemm_kernel); the small-batch tile forms keep V in fp32 and form the pairs in
+        # the GEMM (pair_conv1x1_kernel with XL_CONV_SPLIT_ACT)
+        pair = split_act and m == 6 and self.pair_ok()
+        tile_form = self.split_tile_form(T, cout, nf) if split_act else 0
+        pair_dma = pair and tile_form == 256 and not os.environ.get("XL_PAIR_NO_DMA")
+        if pair_dma:
+            op.flags = CONV_PAIR_F16
+            op.scale = self.pair_scales.data_ptr() + 8
         if split and not split_act:
             op.flags = CONV_SPLIT_BF16 | (CONV_SPLIT_IL if split_il else 0)
         if deferred is not None:                      # the producer's GroupNorm(+ReLU) is applied while gathering
@@ -873,17 +979,24 @@ class _Plan:
         # XL_WINO_M_TILE_MAJOR=1: the product M as [tiles][64][C], so that the block the output transform reads per tile is one
         # contiguous piece.  Measured at 47 frames: output transforms 3.21 -> 3.05 ms per step, GEMM epilogues +0.17 ms: no net
         # gain, so [64][tiles][C] (what every other form reads and writes) stays the default
-        m_tile_major = CONV_M_TILE_MAJOR if (split_act and m == 6 and os.environ.get("XL_WINO_M_TILE_MAJOR")) else 0
+        m_tile_major = CONV_M_TILE_MAJOR if (split_act and m == 6 and os.environ.get("XL_WINO_M_TILE_MAJOR") and not pair_dma) else 0
         if split:
             op.flags = (CONV_SPLIT_BF16 | (CONV_SPLIT_IL if split_il else 0) | (CONV_SPLIT_ACT if split_act else 0)
                         | m_tile_major)
-            op.w = self.pack_conv_wino_split(conv, m, split_il).data_ptr()
+            if pair:
+                op.flags |= CONV_PAIR_F16
+                if pair_dma:
+                    op.flags &= ~CONV_SPLIT_ACT
+                op.w = self.pack_conv_wino_pair(conv, m).data_ptr()
+                op.scale = self.pair_scales.data_ptr() + 8
+            else:
+                op.w = self.pack_conv_wino_split(conv, m, split_il).data_ptr()
         else:
             op.w = self.pack_conv_wino(conv, m).data_ptr()
         if -(-T // 128) * (cout // 128) * nf <= 256:
             op.reserved_i = 64
         if split_act:
-            op.reserved_i = self.split_tile_form(T, cout, nf)
+            op.reserved_i = tile_form
         self.ops.append(op)
         self.wino_gemm_indices = getattr(self, "wino_gemm_indices", []) + [len(self.ops) - 1]
         self.release(V)

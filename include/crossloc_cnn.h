@@ -116,6 +116,21 @@ enum {
 #define XL_CONV_M_TILE_MAJOR 2048 /* on the batched GEMM op (with XL_CONV_SPLIT_ACT) and on the XL_OP_WINO_OUT (ksize 6) that
                                   consumes its result: the product M is laid out [tiles][Z][Cout] instead of [Z][tiles][Cout], so
                                   the Z x Cout block the output transform reads per tile is one contiguous piece */
+#define XL_CONV_PAIR_F16 8192   /* round 5, with XL_CONV_SPLIT_BF16 | XL_CONV_SPLIT_IL: the same GEMMs with HALF the matrix-pipe work
+                                  (csrc/xl_gemm_pair.hip): an activation a (times the power of two *scale, see xl_op.scale) is the fp16 pair
+                                  {hi = fp16(a), lo = fp16((a - hi) * 2^11)} - 22 significand bits, lo in fp16's NORMAL range whatever
+                                  the magnitude of a - and a weight w (times a per-matrix power of two that brings max|w| into
+                                  [2^14, 2^15)) is the triple {hi, lo = fp16(w - hi), hs = hi * 2^-11}; the three products hi*hi,
+                                  hi*lo and lo*hs are exact in fp32 (v_mfma_f32_32x32x16_f16, fp32 accumulate), what is dropped
+                                  (lo*lo) is below 2^-22 of the leading product; the epilogue un-scales (exact).  Layouts:
+                                  activations [Z][rows][C/16][2][16] fp16 (4 bytes per element, what an fp32 V costs), weights
+                                  [Z][rows][C/16][3][16] fp16 followed by 2 Z floats (xl_cnn_pack_wino_weight_pair /
+                                  xl_cnn_pair_weight).  On XL_OP_WINO_IN (ksize 6): V is written in the activation layout;
+                                  on XL_OP_CONV with nchunks2 = Z > 1 and without XL_CONV_SPLIT_ACT: `in` is that V (both operands
+                                  reach LDS by DMA, no conversion in the GEMM); with XL_CONV_SPLIT_ACT or nchunks2 <= 1: `in` is
+                                  fp32 and the kernel forms the pairs on the operand's way into LDS (1x1 layers, normalise-on-load).
+                                  xl_op.scale must be set; |a * scale| <= 65504 is the caller's contract (crossloc_amd/networks.py
+                                  derives the scale from the GroupNorm bound |gn(x)| <= sqrt(N - 1) |gamma| + |beta|) */
 /* xl_op.flags for XL_OP_CONV */
 #define XL_CONV_DGRAD 1        /* data gradient: `in` is dY (Hi x Wi x Cin = forward output), result is dX; weights
                                   packed with xl_cnn_pack_conv_weight_dgrad; `stride` is the forward stride */
@@ -165,6 +180,9 @@ typedef struct xl_op {
     void *out2;                    /* GNB_APPLY: d(residual), pixel stride in Cout (0: ld_out); GNB_PARAMS: d beta;
                                       HEAD_BWD: d weight */
     void *stats2;                  /* GNB_*: fp64 backward sums; WGRAD: fp32 split-K partials; GNB_PARAMS out3 = d bias */
+    const void *scale;             /* XL_CONV_PAIR_F16: device float[2] {s, 1 / s}, s a power of two: the activation operand is
+                                      multiplied by s before it is split into its fp16 pair, the result by 1 / s (and by the
+                                      weights' own inverse scale) in the epilogue */
 } xl_op;
 
 /* Execute ops[0..n_ops) in order on `stream` (hipStream_t; NULL = default). Asynchronous.
@@ -206,6 +224,25 @@ int xl_cnn_pack_wino_weight(const float *w_oihw_dev, void *dst_dev, int Cout, in
  *   taps = 9: src = OIHW [rows][K/9][3][3], K ordered tap-major: k = (3 ky + kx) * Cin + c (csrc/xl_stem_split.hip);
  *   taps = 0: src = [K][rows], i.e. the transpose - the operand of a 1x1 layer's data gradient, dX = dY W. */
 int xl_cnn_split_weight(const float *src_dev, void *dst_dev, int rows, int K, int taps, void *stream);
+
+/* ---- fp16 pair / triple operands (XL_CONV_PAIR_F16, csrc/xl_gemm_pair.hip, csrc/xl_pack.hip)
+ * xl_cnn_pack_wino_weight_pair: U = G g G^T of F(6x6,3x3) / F(4x4,3x3) (float64 inside) per frequency z, scaled by the power of two
+ * 2^e_z with max|U_z| 2^e_z in [2^14, 2^15), as triples [Z][rows][K/16][3][16] fp16 {hi, lo, hi * 2^-11}, followed by 2 Z floats:
+ * [Z] scratch (the maxima, as float bits) and [Z] inverse scales 2^-e_z - dst holds Z*rows*K*6 + 8 Z bytes.  dgrad as
+ * xl_cnn_pack_wino_weight.
+ * xl_cnn_pair_weight: a plain [rows][K] matrix (taps as xl_cnn_split_weight), one scale: rows*K*6 + 8 bytes. */
+int xl_cnn_pack_wino_weight_pair(const float *w_oihw_dev, void *dst_dev, int Cout, int Cin, int m, int dgrad, void *stream);
+int xl_cnn_pair_weight(const float *src_dev, void *dst_dev, int rows, int K, int taps, void *stream);
+/* fp32 [rows][K] -> activation pairs [rows][K/16][2][16] fp16 of src * scale[0] (tests, tools; K % 16 == 0) */
+int xl_cnn_pair_activation(const float *src_dev, void *dst_dev, long long rows, int K, const float *scale_dev, void *stream);
+/* The activation scale of a plan: out[0..1] = {s, 1/s} for GroupNorm outputs, out[2..3] = {s/256, 256/s} for their Winograd
+ * transforms (|B^T d B| <= 225 max|d| for F(6x6,3x3)), with s the largest power of two such that
+ *     s * sum over the n GroupNorm layers of (sqrtN[i] * max|gamma_i| + max|beta_i|)  <=  2^14
+ * - a bound on every activation of a network whose convolutions all read GroupNorm outputs and sums of them (residuals):
+ * |gn(x)| <= sqrt(N - 1) |gamma| + |beta| for a group of N elements.  gamma / beta: n device pointers each (host arrays),
+ * C[i] channels.  out: 6 floats, 8-byte aligned (out[4..5] is scratch).  Re-run whenever the parameters change. */
+int xl_cnn_pair_scales(const float *const *gamma_dev, const float *const *beta_dev, const int *C, const float *sqrtN, int n,
+                       float *out_dev, void *stream);
 
 /* Per-op HIP-event timing for measurement (bench.py): between prof_begin and prof_end every op launched by
  * xl_cnn_run is bracketed by two events on its own stream (up to max_records ops).  prof_end waits for the
