@@ -10,7 +10,8 @@
 // on v_mfma_f32_32x32x16_f16 - the same 2.5 PFLOP/s pipe as the bf16 instruction, an fp16 x fp16 product is exact in fp32,
 // accumulation in fp32.  What fp16 lacks is bf16's exponent range, and the two operands deal with that differently:
 //   * weights (static, packed once per weight version, csrc/xl_pack.hip): every matrix is scaled by the power of two that
-//     puts its largest element into [2^14, 2^15) and stored as the TRIPLE {hi = fp16(w), lo = fp16(w - hi), hs = hi * 2^-11};
+//     puts its largest element into [2^14, 2^15) and stored as the pair {hi = fp16(w), lo = fp16(w - hi)}; the kernels derive
+//     hs = hi * 2^-11 from the hi fragment in registers (v_pk_mul_f16, exact down to fp16's subnormals);
 //   * activations are scaled by ONE power of two per plan (xl_op.scale, chosen from a bound on the network's activations
 //     so that nothing can overflow) and stored as the PAIR {hi = fp16(a), lo' = fp16((a - hi) * 2^11)}: the low term is kept
 //     2^11 times too large, i.e. in fp16's normal range whenever hi is - its 11 bits survive for any |a| in [2^-13, 65504],
@@ -21,19 +22,21 @@
 //
 // Layouts (K-step = 16 channels = one k-depth of the MFMA):
 //     activations  [Z][rows][C/16][2][16] fp16     64 bytes per row and K-step  (4 bytes per element: what fp32 costs)
-//     weights      [Z][rows][C/16][3][16] fp16     96 bytes per row and K-step, then 2 Z floats: scratch, inverse scales
+//     weights      [Z][rows][C/16][2][16] fp16     the same, then 2 Z floats: scratch, inverse scales
 // Kernels:
 //   pair_gemm_kernel      - both operands arrive in that form (V written by the Winograd input transform) and reach LDS by
 //                           DMA: no conversion, no register staging, no LDS writes from the ALU side;
 //   pair_conv1x1_kernel   - activations arrive as fp32 (1x1 layers; normalise-on-load, residual-on-load), the pairs are
 //                           formed on the way into LDS as csrc/xl_gemm_split.hip forms its bf16 terms.
-// Both are the 256 x 256 persistent loops of csrc/xl_gemm_split.hip (one workgroup per CU, 8 waves of 128 x 64, LDS-DMA
-// ring of 3 stages two K-steps ahead, ONE bare s_barrier per K-step behind a counted vmcnt wait) with half the MFMAs.
+// Both are the 256 x 256 persistent loops of csrc/xl_gemm_split.hip (one workgroup per CU, 8 waves of 128 x 64, ONE bare
+// s_barrier per K-step behind a counted vmcnt wait) with half the MFMAs per K-step - and therefore half the time to hide a
+// memory access in: the LDS-DMA ring has FOUR stages of 32 KB (three K-steps ahead) where the bf16 kernels have three of 48.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <type_traits>
+#include <vector>
 
 #include "../../include/crossloc_cnn.h"
 #include "../../include/crossloc_dsac.h"   // status codes
@@ -49,10 +52,10 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kPA = 64;                                  // bytes per activation row and K-step: {hi, lo'} x 16 fp16
-constexpr int kPB = 96;                                  // bytes per weight row and K-step: {hi, lo, hs} x 16 fp16
+constexpr int kPB = 64;                                  // bytes per weight row and K-step: {hi, lo} x 16 fp16
 constexpr unsigned OOB = 0x80000000u;
 
-// LDS rows of the activation stages are 4 slots of 16 bytes (hi k0-7, hi k8-15, lo' k0-7, lo' k8-15), slot s of row r at
+// LDS rows of both operands are 4 slots of 16 bytes (hi k0-7, hi k8-15, lo k0-7, lo k8-15), slot s of row r at
 // physical slot s ^ swz(r).  ds_read_b128 is serviced in four groups of 16 lanes ({0-3, 12-15, 20-27}, ...); the 16 rows of a
 // group must hit 16 different 16-byte columns of the 256-byte bank row: (4 r + slot) mod 16, i.e. rows equal mod 4 need
 // different swz - bits 2-3 of the row.  Bit 1 is folded into the upper slot bit for the converting kernel's ds_write_b128
@@ -60,23 +63,30 @@ constexpr unsigned OOB = 0x80000000u;
 __device__ __forceinline__ int swz(int row) { return ((row >> 2) & 3) ^ (((row >> 1) & 1) << 1); }
 
 struct PairArgs {
-    const unsigned char *v, *u;  // [Z][T][C/16][2][16] fp16, [Z][N][C/16][3][16] fp16
+    const unsigned char *v, *u;  // [Z][T][C/16][2][16] fp16, [Z][N][C/16][2][16] fp16
     float *out;                  // [Z][T][N] fp32
     const float *uInv;           // [Z] inverse weight scales
     const float *aScale;         // {s, 1 / s} of the activations
     int T, C, N, Z, nbm, nbn;
+    long long *clk;              // diagnostics (XL_PAIR_CLK=1): per-wave shader-tick sums of the four phases of a K-step
 };
 
-// vmcnt bookkeeping (in order, per wave): a wave issues 5 DMA instructions per K-step (2 of the activations, 3 of the weights),
-// four of them in front of the step's barrier.  At the barrier of step s the operands of step s + 1 must have landed; younger
-// than those are the 4 DMAs of step s + 2 issued so far - and, in the first step of a tile, the 32 stores of the tile before.
-template <int CT>                                                      // compile-time channel count (0: a.C)
+__device__ __forceinline__ f16x8 scale_hs(f16x8 hi) { return hi * (_Float16)0.00048828125f; }      // hi * 2^-11: 4 x v_pk_mul_f16
+
+// vmcnt bookkeeping (in order, per wave): a wave issues 4 DMA instructions per K-step (2 per operand), all in front of the step's
+// barrier, into the stage that was multiplied in the step before.  At the barrier of step s the operands of step s + 1 must
+// have landed - issued in step s - 2; younger are the 4 DMAs of step s - 1 and the 4 of step s: vmcnt(8), and vmcnt(40) in the
+// first TWO steps of a tile that follows another one (the 32 stores of its epilogue lie between).
+// DBG (XL_PAIR_DBG, measurement only - the results are garbage): 1 = no DMA after the prologue, 2 = no fragment reads in the loop,
+// 4 = no barrier / vmcnt wait: what each piece costs under the chip's power limit.
+template <int CT, int DBG = 0>                                         // compile-time channel count (0: a.C)
 __global__ __launch_bounds__(512)
 void pair_gemm_kernel(PairArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
     typedef __attribute__((address_space(3))) void lds_void;
-    constexpr int kOpA = 256 * kPA, kOpB = 256 * kPB, kStage = kOpA + kOpB;     // 16 + 24 = 40 KB per stage
+    constexpr int kOpA = 256 * kPA, kOpB = 256 * kPB, kStage = kOpA + kOpB;     // 16 + 16 = 32 KB per stage
+    constexpr int NST = 4;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;                          // 2 x 4 waves of 128 x 64
@@ -91,46 +101,36 @@ void pair_gemm_kernel(PairArgs a)
     const int myCount = runLen > local ? (runLen - local + nloc - 1) / nloc : 0;
     if (myCount == 0) return;
 
-    const long long rowA = (long long)a.C * 4, rowB = (long long)a.C * 6;     // bytes per operand row
+    const long long rowB = (long long)a.C * 4;                        // bytes per operand row (both operands)
     const int nk = CT ? CT / 16 : a.C / 16;
 
-    // ---- operand stream
+    // ---- operand stream: an instruction moves 16 rows x 4 slots; wave w fills rows 32 w .. 32 w + 31 of both operands.  A lane's
+    // offset inside a tile never changes (row and slot of the 16 x 4 piece); the tile is the descriptor's base, and rows past the
+    // end of an operand - or a tile past the end of my list - fall outside the descriptor's extent and read as zero
     __amdgpu_buffer_rsrc_t srdV, srdU;
-    unsigned gA[2], gB[3];
+    unsigned lOff[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int row = (wave * 2 + q) * 16 + (lane >> 2);
+        lOff[q] = (unsigned)(row * (int)rowB + (((lane & 3) ^ swz(row)) * 16));
+    }
     int dTile = 0, dK = 0;                                            // position of the stream: tile of my list, K-step
     auto set_dma_tile = [&](int i) {
-        if (i < myCount) {
-            int t = runStart + local + i * nloc;
-            const int z = t / (a.nbm * a.nbn);
-            t -= z * (a.nbm * a.nbn);
-            const int mt = t / a.nbn, nt = t - mt * a.nbn;
-            const int m0 = mt * 256, n0 = nt * 256;
-            srdV = __builtin_amdgcn_make_buffer_rsrc((void *)(a.v + (long long)z * a.T * rowA), 0, (int)(a.T * rowA), 0x00020000);
-            srdU = __builtin_amdgcn_make_buffer_rsrc((void *)(a.u + (long long)z * a.N * rowB), 0, (int)(a.N * rowB), 0x00020000);
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {                             // 16 rows x 4 slots per instruction
-                const int row = (wave * 2 + q) * 16 + (lane >> 2);
-                const int logical = (lane & 3) ^ swz(row);
-                gA[q] = (m0 + row < a.T) ? (unsigned)((long long)(m0 + row) * rowA + logical * 16) : OOB;
-            }
-#pragma unroll
-            for (int q = 0; q < 3; ++q) {                             // 6 slots per row, rotated by one on rows with bit 3 set
-                const int sl = (wave * 3 + q) * 64 + lane;
-                const int row = sl / 6, phys = sl - row * 6;
-                int logical = phys - ((row >> 3) & 1);
-                if (logical < 0) logical += 6;
-                gB[q] = (n0 + row < a.N) ? (unsigned)((long long)(n0 + row) * rowB + logical * 16) : OOB;
-            }
-        } else {                                                      // past my last tile: zero-fill, same instruction count
-            gA[0] = OOB; gA[1] = OOB;
-#pragma unroll
-            for (int q = 0; q < 3; ++q) gB[q] = OOB;
-        }
+        int t = runStart + local + (i < myCount ? i : 0) * nloc;
+        const int z = t / (a.nbm * a.nbn);
+        t -= z * (a.nbm * a.nbn);
+        const int mt = t / a.nbn, nt = t - mt * a.nbn;
+        const int m0 = mt * 256, n0 = nt * 256;
+        const int rowsA = i < myCount ? (a.T - m0 < 256 ? a.T - m0 : 256) : 0, rowsB = i < myCount ? 256 : 0;
+        srdV = __builtin_amdgcn_make_buffer_rsrc((void *)(a.v + ((long long)z * a.T + m0) * rowB), 0, (int)(rowsA * rowB), 0x00020000);
+        srdU = __builtin_amdgcn_make_buffer_rsrc((void *)(a.u + ((long long)z * a.N + n0) * rowB), 0, (int)(rowsB * rowB), 0x00020000);
     };
-    auto dma_instr = [&](int q, int stage) {                          // instruction q of 5 of the stream's current step
-        unsigned char *base = dsm + stage * kStage;
-        if (q < 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(srdV, (lds_void *)(base + (wave * 2 + q) * 1024), 16, (int)gA[q], dK * kPA, 0, 0);
-        else __builtin_amdgcn_raw_ptr_buffer_load_lds(srdU, (lds_void *)(base + kOpA + (wave * 3 + q - 2) * 1024), 16, (int)gB[q - 2], dK * kPB, 0, 0);
+    bool dmaOn = true;
+    auto dma_instr = [&](int q, int stage) {                          // instruction q of 4 of the stream's current step
+        if ((DBG & 1) && !dmaOn) return;
+        unsigned char *base = dsm + stage * kStage + (wave * 2 + (q & 1)) * 1024;
+        if (q < 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(srdV, (lds_void *)base, 16, (int)lOff[q], dK * kPA, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(srdU, (lds_void *)(base + kOpA), 16, (int)lOff[q - 2], dK * kPB, 0, 0);
     };
     auto advance_dma = [&]() {
         if (++dK == nk) { dK = 0; ++dTile; set_dma_tile(dTile); }
@@ -138,47 +138,51 @@ void pair_gemm_kernel(PairArgs a)
 
     // ---- fragments: lane -> row lane & 31 of a 32-row block, k-half lane >> 5 (8 fp16 = one 16-byte slot)
     const int fr = lane & 31, kh = lane >> 5;
-    unsigned slotA[2], slotB[3];
+    unsigned slot[2];
 #pragma unroll
-    for (int p = 0; p < 2; ++p) slotA[p] = (unsigned)(((2 * p + kh) ^ swz(fr)) * 16);
-#pragma unroll
-    for (int p = 0; p < 3; ++p) {
-        int ph = 2 * p + kh + ((fr >> 3) & 1);
-        if (ph >= 6) ph -= 6;
-        slotB[p] = (unsigned)(ph * 16);
-    }
+    for (int p = 0; p < 2; ++p) slot[p] = (unsigned)(((2 * p + kh) ^ swz(fr)) * 16);
     const unsigned frA = (unsigned)((wm * 128 + fr) * kPA), frB = (unsigned)(kOpA + (wn * 64 + fr) * kPB);
-    f16x8 fa[2][4], fb[3][2];                                         // [hi, lo'][row block], [hi, lo, hs][column block]
+    f16x8 fa[2][4], fb[2][2], fbs[2];                                 // [hi, lo'][row block], [hi, lo][column block], hs
     f16x8 faN[4], fbN[2];
     f32x16 acc[4][2];
-    auto ldA = [&](const unsigned char *sb, int p, int i) { return *reinterpret_cast<const f16x8 *>(sb + frA + i * 32 * kPA + slotA[p]); };
-    auto ldB = [&](const unsigned char *sb, int p, int j) { return *reinterpret_cast<const f16x8 *>(sb + frB + j * 32 * kPB + slotB[p]); };
-    auto mma_term = [&](int pu, int pv) {
+    bool readOn = true;
+    auto ldA = [&](const unsigned char *sb, int p, int i) {
+        if ((DBG & 2) && !readOn) return faN[i];
+        return *reinterpret_cast<const f16x8 *>(sb + frA + i * 32 * kPA + slot[p]);
+    };
+    auto ldB = [&](const unsigned char *sb, int p, int j) {
+        if ((DBG & 2) && !readOn) return fbN[j];
+        return *reinterpret_cast<const f16x8 *>(sb + frB + j * 32 * kPB + slot[p]);
+    };
+    auto mma = [&](const f16x8 (&b)[2], const f16x8 (&v)[4]) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[pu][j], fa[pv][i], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[j], v[i], acc[i][j], 0, 0, 0);
     };
 
-    // ---- prologue: steps 0 and 1 of the stream
+    // ---- prologue: steps 0, 1 and 2 of the stream
     set_dma_tile(0);
 #pragma unroll
-    for (int q = 0; q < 5; ++q) dma_instr(q, 0);
-    advance_dma();
+    for (int st = 0; st < 3; ++st) {
 #pragma unroll
-    for (int q = 0; q < 5; ++q) dma_instr(q, 1);
-    advance_dma();
-    __builtin_amdgcn_s_waitcnt(0x0F70 | 5);
+        for (int q = 0; q < 4; ++q) dma_instr(q, st);
+        advance_dma();
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70 | 8);
     // (a bare s_barrier: the workgroup fence of __syncthreads() makes the compiler wait for EVERY outstanding LDS-DMA)
     __builtin_amdgcn_s_barrier();
 #pragma unroll
-    for (int j = 0; j < 2; ++j) fbN[j] = ldB(dsm, 2, j);
+    for (int j = 0; j < 2; ++j) fbN[j] = ldB(dsm, 0, j);
 #pragma unroll
     for (int i = 0; i < 4; ++i) faN[i] = ldA(dsm, 1, i);
-    int sc = 0, sd = 2;                                               // stage being multiplied / being filled
+    int sc = 0, sd = 3;                                               // stage being multiplied / being filled
     const int rhalf = (lane >> 5) * 4;
     const float aInv = a.aScale[1];
+    dmaOn = false; readOn = false;
+    long long cPre = 0, cVm = 0, cBar = 0, cTail = 0, cT = 0;
+    if (a.clk) cT = clock64();
     for (int ti = 0; ti < myCount; ++ti) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -188,33 +192,51 @@ void pair_gemm_kernel(PairArgs a)
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
         for (int kk = 0; kk < nk; ++kk) {
             const unsigned char *sb = dsm + sc * kStage;
-            const int next = sc == 2 ? 0 : sc + 1;
+            const int next = (sc + 1) & (NST - 1);
+            // The two waves of a SIMD (wm = 0: the older one, which wins the matrix pipe's arbitration) take their four DMA
+            // instructions at opposite ends of the phase: an LDS-DMA costs its wave 100-200 ticks of issue in which it multiplies
+            // nothing, and with both waves in the same order those windows coincide (measured, XL_PAIR_CLK: the phase took the
+            // younger waves 1837 ticks for 1024 of MFMA work per SIMD).  Now one wave multiplies while the other issues.
+            if (wm) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) fb[2][j] = fbN[j];
+                for (int q = 0; q < 4; ++q) dma_instr(q, sd);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) { fb[0][j] = fbN[j]; fbs[j] = scale_hs(fbN[j]); }
 #pragma unroll
             for (int i = 0; i < 4; ++i) fa[1][i] = faN[i];
 #pragma unroll
             for (int j = 0; j < 2; ++j) fb[1][j] = ldB(sb, 1, j);
 #pragma unroll
             for (int i = 0; i < 4; ++i) fa[0][i] = ldA(sb, 0, i);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) fb[0][j] = ldB(sb, 0, j);
-            mma_term(2, 1); dma_instr(0, sd); dma_instr(1, sd);        // lo' x hs
-            mma_term(1, 0); dma_instr(2, sd); dma_instr(3, sd);        // hi x lo
+            mma(fbs, fa[1]);                                            // hs x lo'
+            mma(fb[1], fa[0]);                                          // lo x hi
             __builtin_amdgcn_sched_barrier(0);
-            if (kk == 0 && ti > 0) __builtin_amdgcn_s_waitcnt(0x8F70 | 4);      // vmcnt(36): + the 32 stores of the tile before
-            else __builtin_amdgcn_s_waitcnt(0x0F70 | 4);
-            __builtin_amdgcn_s_barrier();
+            if (!wm) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) dma_instr(q, sd);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (a.clk) { const long long t = clock64(); cPre += t - cT; cT = t; }
+            if (!(DBG & 4)) {
+                if (kk < 2 && ti > 0) __builtin_amdgcn_s_waitcnt(0x8F70 | 8);   // vmcnt(40): + the 32 stores of the tile before
+                else __builtin_amdgcn_s_waitcnt(0x0F70 | 8);
+            }
+            if (a.clk) { const long long t = clock64(); cVm += t - cT; cT = t; }
+            if (!(DBG & 4)) __builtin_amdgcn_s_barrier();
+            if (a.clk) { const long long t = clock64(); cBar += t - cT; cT = t; }
             __builtin_amdgcn_sched_barrier(0);
             const unsigned char *sn = dsm + next * kStage;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) fbN[j] = ldB(sn, 2, j);
+            for (int j = 0; j < 2; ++j) fbN[j] = ldB(sn, 0, j);
 #pragma unroll
             for (int i = 0; i < 4; ++i) faN[i] = ldA(sn, 1, i);
-            mma_term(0, 0); dma_instr(4, sd);                           // hi x hi
+            mma(fb[0], fa[0]);                                          // hi x hi
             advance_dma();
             sc = next;
-            sd = sd == 2 ? 0 : sd + 1;
+            sd = (sd + 1) & (NST - 1);
+            if (a.clk) { const long long t = clock64(); cTail += t - cT; cT = t; }
         }
         // ---- epilogue of tile ti (swapped operands): row = lane & 31, channels (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
         int t = runStart + local + ti * nloc;
@@ -241,6 +263,10 @@ void pair_gemm_kernel(PairArgs a)
                 }
         }
     }
+    if (a.clk && lane == 0) {
+        long long *c = a.clk + ((long long)blockIdx.x * 8 + wave) * 8;
+        c[0] = cPre; c[1] = cVm; c[2] = cBar; c[3] = cTail; c[4] = (long long)myCount * nk;
+    }
     __builtin_amdgcn_s_waitcnt(0x0F70);                             // vmcnt(0)
 }
 
@@ -252,8 +278,9 @@ void pair_gemm_kernel(PairArgs a)
 // activation planes instead of three and three term groups instead of six: a thread loads 8 channels of one row two K-steps
 // ahead, applies scale (folded into the {scale, shift} table for the normalising forms), forms {hi, lo'} with v_cvt_pk_f16_f32
 // (the residual a - hi is exact in fp32) and writes 2 x 16 bytes into the activation stage of the next K-step under the MFMAs of
-// the second term group.  LDS: weights 3 x BN x 96 | activations 2 x BM x 64 | statistics staging 64 NTH (overlaps activation
-// stage 1) | fp64 partials 16 NTH | coefficient tables 2 x 8 KB | bias 4 KB | 1 KB scratch.
+// the second term group.  The weights run THREE K-steps ahead (ring of 4 stages by LDS-DMA), the activation loads two.
+// LDS: weights 4 x BN x 64 | activations 2 x BM x 64 | statistics staging 64 NTH (overlaps activation stage 1) | fp64 partials
+// 16 NTH | coefficient tables 2 x 8 KB | bias 4 KB | 1 KB scratch.
 struct PairConvArgs {
     const float *in; const unsigned char *u; const float *bias; float *out;
     const float *coef; float normLo;                 // NORM: [B][C][2] {scale, shift}; lower clamp (0 = ReLU, -inf = none)
@@ -264,6 +291,7 @@ struct PairConvArgs {
     int tile0, ntiles;                               // the launch's range of the (z, m-tile, n-tile) order
     const float *res; int ldRes;                     // RES (with NORM): a residual added behind the normalisation, then ReLU
     const float *uInv; const float *aScale;          // [Z] inverse weight scales; {s, 1 / s} of the activations
+    int var;                                         // measurement switches (XL_PAIR_VAR)
 };
 
 template <bool NORM, bool ACC, int NW, int ZB, int BN, bool RES>               // ACC: out += result
@@ -279,7 +307,8 @@ __device__ __forceinline__ void pair_conv1x1_body(const PairConvArgs &a)
     constexpr int NDMA = BN * kPB / 1024;                                     // DMA instructions per weight stage
     constexpr int PARTS = NTH * 8 / BN;                                       // statistics: threads per (group, slot)
     constexpr int kW = BN * kPB, kAS = BM * kPA;                              // one weight stage / one activation stage
-    constexpr int kCvA = 3 * kW, kCvStage1 = kCvA + kAS;                      // activation stages; statistics staging: 64 NTH bytes from stage 1
+    constexpr int NWS = 4;                                                    // weight stages
+    constexpr int kCvA = NWS * kW, kCvStage1 = kCvA + kAS;                    // activation stages; statistics staging: 64 NTH bytes from stage 1
     constexpr int kCvPart = kCvStage1 + 64 * NTH;                             // fp64 partials [NTH / 16][16][2]
     constexpr int kCvCoef = kCvPart + 16 * NTH;                               // coefficient tables of two tiles, 8 KB each (C <= 512)
     constexpr int kCvBias = kCvCoef + 16384;                                  // bias[N <= 1024]
@@ -288,12 +317,12 @@ __device__ __forceinline__ void pair_conv1x1_body(const PairConvArgs &a)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
-    // every wave issues three DMA instructions per K-step (straight-line code, the same counted waits in all waves); with 8 waves
+    // every wave issues two DMA instructions per K-step (straight-line code, the same counted waits in all waves); with 8 waves
     // on 128 columns those of waves 4 .. 7 read out of range and write their zeros into a scratch KB
-    constexpr bool ALLDMA = NDMA >= 3 * NW;
+    constexpr bool ALLDMA = NDMA >= 2 * NW;
     constexpr int kCvScratch = kCvBias + 4096;
-    const bool dmaWave = ALLDMA || wave * 3 < NDMA;
-    const int dmaBase = __builtin_amdgcn_readfirstlane(dmaWave ? wave * 3 * 1024 : kCvScratch);
+    const bool dmaWave = ALLDMA || wave * 2 < NDMA;
+    const int dmaBase = __builtin_amdgcn_readfirstlane(dmaWave ? wave * 2 * 1024 : kCvScratch);
     const int dmaStage = __builtin_amdgcn_readfirstlane(dmaWave ? kW : 0), dmaQ = __builtin_amdgcn_readfirstlane(dmaWave ? 1024 : 0);
 
     const int total = a.ntiles;
@@ -320,62 +349,61 @@ __device__ __forceinline__ void pair_conv1x1_body(const PairConvArgs &a)
         return rows < BM ? rows : BM;
     };
 
-    const long long rowU = (long long)a.C * 6;
+    const long long rowU = (long long)a.C * 4;
     const int nk = ZB == 2 ? 32 : a.C / 16;
     const float aS = a.aScale[0], aInv = a.aScale[1];
 
-    // ---- stream two K-steps ahead of the multiplies: weights by LDS-DMA (3 instructions per wave and step), activations into
-    // registers (row tid >> 1, channels 8 (tid & 1) .. + 7 of the step; two register sets, by the parity of the step)
+    // ---- streams: weights by LDS-DMA three K-steps ahead of the multiplies (2 instructions per wave and step), activations into
+    // registers two steps ahead (row tid >> 1, channels 8 (tid & 1) .. + 7 of the step; two register sets, by the parity of the step)
     __amdgpu_buffer_rsrc_t srdU = __builtin_amdgcn_make_buffer_rsrc((void *)a.u, 0, (int)(a.N * rowU), 0x00020000);
     __amdgpu_buffer_rsrc_t srdIn = __builtin_amdgcn_make_buffer_rsrc((void *)a.in, 0, 0, 0x00020000);
     __amdgpu_buffer_rsrc_t srdRes = __builtin_amdgcn_make_buffer_rsrc((void *)a.in, 0, 0, 0x00020000);
     const int arow = tid >> 1, ahalf = tid & 1;
-    unsigned gB[3], gA = OOB, gR = OOB;
-    int dTile = 0, dK = 0;
-    auto set_dma_tile = [&](int i) {
-        if (i < myCount) {
-            int m0, n0;
-            tile_at(i, m0, n0);
-            const int rows = tile_rows(m0);
-            const int z = tile_z(i);
-            srdIn = __builtin_amdgcn_make_buffer_rsrc((void *)(a.in + z * a.zIn + (long long)m0 * a.ldIn), 0, rows * a.ldIn * 4, 0x00020000);
-            if (a.Z > 1) srdU = __builtin_amdgcn_make_buffer_rsrc((void *)(a.u + z * (a.N * rowU)), 0, (int)(a.N * rowU), 0x00020000);
-            gA = (unsigned)(arow * a.ldIn * 4 + ahalf * 32);              // rows past M fall outside the descriptor
-            if constexpr (RES) {
-                srdRes = __builtin_amdgcn_make_buffer_rsrc((void *)(a.res + (long long)m0 * a.ldRes), 0, rows * a.ldRes * 4, 0x00020000);
-                gR = (unsigned)(arow * a.ldRes * 4 + ahalf * 32);
-            }
+    // (a lane's offsets inside a tile never change: the tile is the descriptor's base, and a tile past the end of my list gets
+    //  an empty descriptor - every load of it reads zero)
+    unsigned gB[2];
 #pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                const int sl = (wave * 3 + q) * 64 + lane;
-                const int row = sl / 6, phys = sl - row * 6;
-                int logical = phys - ((row >> 3) & 1);
-                if (logical < 0) logical += 6;
-                gB[q] = dmaWave ? (unsigned)((long long)(n0 + row) * rowU + logical * 16) : OOB;
-            }
-        } else {
-            gA = OOB; gR = OOB;
-#pragma unroll
-            for (int q = 0; q < 3; ++q) gB[q] = OOB;
-        }
+    for (int q = 0; q < 2; ++q) {                                     // 16 rows x 4 slots per instruction
+        const int row = (wave * 2 + q) * 16 + (lane >> 2);
+        gB[q] = dmaWave ? (unsigned)(row * (int)rowU + (((lane & 3) ^ swz(row)) * 16)) : OOB;
+    }
+    const unsigned gA = (unsigned)(arow * a.ldIn * 4 + ahalf * 32), gR = (unsigned)(arow * a.ldRes * 4 + ahalf * 32);
+    int dTile = 0, dK = 0;                                            // position of the weight stream: tile of my list, K-step
+    int aTile = 0, aK = 0;                                            // ... of the activation loads
+    auto set_w_tile = [&](int i) {
+        int m0, n0;
+        tile_at(i < myCount ? i : 0, m0, n0);
+        const int z = tile_z(i < myCount ? i : 0);
+        srdU = __builtin_amdgcn_make_buffer_rsrc((void *)(a.u + ((long long)z * a.N + n0) * rowU), 0, i < myCount ? (int)(BN * rowU) : 0, 0x00020000);
+    };
+    auto set_a_tile = [&](int i) {
+        int m0, n0;
+        tile_at(i < myCount ? i : 0, m0, n0);
+        const int rows = i < myCount ? tile_rows(m0) : 0;              // rows past the tile fall outside the descriptor
+        srdIn = __builtin_amdgcn_make_buffer_rsrc((void *)(a.in + tile_z(i < myCount ? i : 0) * a.zIn + (long long)m0 * a.ldIn), 0, rows * a.ldIn * 4, 0x00020000);
+        if constexpr (RES)
+            srdRes = __builtin_amdgcn_make_buffer_rsrc((void *)(a.res + (long long)m0 * a.ldRes), 0, rows * a.ldRes * 4, 0x00020000);
     };
     auto dma_instr = [&](int q, int stage) {
-        const int dst = ALLDMA ? stage * kW + (wave * 3 + q) * 1024 : dmaBase + stage * dmaStage + q * dmaQ;
+        const int dst = ALLDMA ? stage * kW + (wave * 2 + q) * 1024 : dmaBase + stage * dmaStage + q * dmaQ;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(srdU, (lds_void *)(dsm + dst), 16, (int)gB[q], dK * kPB, 0, 0);
     };
     u32x4 rA[2][2];                                                    // [K-step parity][half of my 8 channels]
     u32x4 rR[2][RES ? 2 : 1];                                          // ... of the residual
     auto load_a = [&](auto parTag) {
         constexpr int P = decltype(parTag)::value;
-        rA[P][0] = __builtin_amdgcn_raw_buffer_load_b128(srdIn, (int)gA, dK * 64, 0);
-        rA[P][1] = __builtin_amdgcn_raw_buffer_load_b128(srdIn, (int)(gA + 16u), dK * 64, 0);
+        rA[P][0] = __builtin_amdgcn_raw_buffer_load_b128(srdIn, (int)gA, aK * 64, 0);
+        rA[P][1] = __builtin_amdgcn_raw_buffer_load_b128(srdIn, (int)(gA + 16u), aK * 64, 0);
         if constexpr (RES) {
-            rR[P][0] = __builtin_amdgcn_raw_buffer_load_b128(srdRes, (int)gR, dK * 64, 0);
-            rR[P][1] = __builtin_amdgcn_raw_buffer_load_b128(srdRes, (int)(gR + 16u), dK * 64, 0);
+            rR[P][0] = __builtin_amdgcn_raw_buffer_load_b128(srdRes, (int)gR, aK * 64, 0);
+            rR[P][1] = __builtin_amdgcn_raw_buffer_load_b128(srdRes, (int)(gR + 16u), aK * 64, 0);
         }
     };
     auto advance_dma = [&]() {
-        if (++dK == nk) { dK = 0; ++dTile; set_dma_tile(dTile); }
+        if (++dK == nk) { dK = 0; ++dTile; set_w_tile(dTile); }
+    };
+    auto advance_a = [&]() {
+        if (++aK == nk) { aK = 0; ++aTile; set_a_tile(aTile); }
     };
 
     // ---- conversion, one K-step ahead of the multiplies
@@ -455,26 +483,24 @@ __device__ __forceinline__ void pair_conv1x1_body(const PairConvArgs &a)
 
     // ---- fragments
     const int fr = lane & 31, kh = lane >> 5;
-    unsigned slotA[2], slotB[3];
+    unsigned slot[2];
 #pragma unroll
-    for (int p = 0; p < 2; ++p) slotA[p] = (unsigned)(((2 * p + kh) ^ swz(fr)) * 16);
-#pragma unroll
-    for (int p = 0; p < 3; ++p) {
-        int ph = 2 * p + kh + ((fr >> 3) & 1);
-        if (ph >= 6) ph -= 6;
-        slotB[p] = (unsigned)(ph * 16);
-    }
+    for (int p = 0; p < 2; ++p) slot[p] = (unsigned)(((2 * p + kh) ^ swz(fr)) * 16);
     const unsigned frA = (unsigned)(kCvA + (wm * (32 * RI) + fr) * kPA), frB = (unsigned)((wn * 64 + fr) * kPB);
-    f16x8 fa[2][RI], fb[3][2];
+    f16x8 fa[2][RI], fb[2][2], fbs[2];
     f32x16 acc[RI][2];
-    auto ldA = [&](int stage, int p, int i) { return *reinterpret_cast<const f16x8 *>(dsm + stage * kAS + frA + i * 32 * kPA + slotA[p]); };
-    auto ldB = [&](int stage, int p, int j) { return *reinterpret_cast<const f16x8 *>(dsm + stage * kW + frB + j * 32 * kPB + slotB[p]); };
-    auto mma_term = [&](int pu, int pv) {
+    auto ldA = [&](int stage, int p, int i) { return *reinterpret_cast<const f16x8 *>(dsm + stage * kAS + frA + i * 32 * kPA + slot[p]); };
+    auto ldB = [&](int stage, int p, int j) { return *reinterpret_cast<const f16x8 *>(dsm + stage * kW + frB + j * 32 * kPB + slot[p]); };
+    auto mma = [&](const f16x8 (&b)[2], const f16x8 (&v)[RI]) {
 #pragma unroll
         for (int i = 0; i < RI; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[pu][j], fa[pv][i], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[j], v[i], acc[i][j], 0, 0, 0);
+    };
+    auto mma_col = [&](const f16x8 &b, const f16x8 (&v)[RI], int j) {   // one 32-column block
+#pragma unroll
+        for (int i = 0; i < RI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b, v[i], acc[i][j], 0, 0, 0);
     };
     const int rhalf = kh * 4;
     // accumulators start at the bias, in the scaled domain: bias * s * (weight scale) - powers of two, so the sum is s sW times
@@ -500,48 +526,63 @@ __device__ __forceinline__ void pair_conv1x1_body(const PairConvArgs &a)
         store_table(0, t0);
         store_table(1, t1);
     }
-    set_dma_tile(0);
+    set_w_tile(0);
+    set_a_tile(0);
     set_conv_tile(0);
     using P0 = std::integral_constant<int, 0>;
     using P1 = std::integral_constant<int, 1>;
     load_a(P0{});
-    dma_instr(0, 0); dma_instr(1, 0); dma_instr(2, 0);
+    advance_a();
+    dma_instr(0, 0); dma_instr(1, 0);
     advance_dma();
     __builtin_amdgcn_s_waitcnt(0x0070);                               // everything landed
     __syncthreads();                                                  // tables and bias visible
     convert(P0{});
     advance_conv();
-    load_a(P1{});                                                     // (the order of a steady-state step)
-    dma_instr(0, 1); dma_instr(1, 1); dma_instr(2, 1);
+    load_a(P1{});
+    advance_a();
+    dma_instr(0, 1); dma_instr(1, 1);
     advance_dma();
-    __builtin_amdgcn_s_waitcnt(0x0070 | (3 + NLD));                   // my writes of step 0; stage 0 of the ring landed before
+    dma_instr(0, 2); dma_instr(1, 2);
+    advance_dma();
+    // (once per launch: everything issued so far has landed, so the counted waits of the first steps - which assume the steady
+    //  state's issue order - cannot under-wait; lgkmcnt(0): my writes of step 0)
+    __builtin_amdgcn_s_waitcnt(0x0070);
     __builtin_amdgcn_s_barrier();
-    int sc = 0, sd = 2;
+    fb[0][0] = ldB(0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < RI; ++i) fa[1][i] = ldA(0, 1, i);
+    int sc = 0, sd = 3;
     {
         int m0, n0;
         tile_at(0, m0, n0);
         init_acc(n0);
     }
-    // one K-step; FIRST: the first step of a tile that follows another one (NS stores of its epilogue are in flight)
+    // one K-step; FIRST: one of the first two steps of a tile that follows another one (NS stores of its epilogue are in flight).
+    // The weights of step kk + 1 were issued in step kk - 2; younger at the barrier of step kk are the NLD loads and 2 DMAs of
+    // step kk - 1 and of step kk
     auto step = [&](auto firstTag, auto parTag) __attribute__((always_inline)) {
         constexpr int sa = decltype(parTag)::value;                   // parity of the K-step
-        const int next = sc == 2 ? 0 : sc + 1;
-        load_a(parTag);                                               // step kk + 2: two steps until its conversion
-#pragma unroll
-        for (int j = 0; j < 2; ++j) fb[2][j] = ldB(sc, 2, j);
-#pragma unroll
-        for (int i = 0; i < RI; ++i) fa[1][i] = ldA(sa, 1, i);
+        const int next = (sc + 1) & (NWS - 1);
+        // (hs x lo' first, column block 0 first: its operands - the weights' hi fragment of block 0 and the activations' lo' fragments
+        //  of this step - were read behind the barrier of the step before, into registers that were dead by then, so the matrix
+        //  pipe has work while this step's other fragments arrive)
+        fb[0][1] = ldB(sc, 0, 1);
 #pragma unroll
         for (int j = 0; j < 2; ++j) fb[1][j] = ldB(sc, 1, j);
 #pragma unroll
         for (int i = 0; i < RI; ++i) fa[0][i] = ldA(sa, 0, i);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) fb[0][j] = ldB(sc, 0, j);
-        mma_term(2, 1); dma_instr(0, sd);                              // lo' x hs
+        fbs[0] = scale_hs(fb[0][0]);
+        mma_col(fbs[0], fa[1], 0);                                     // hs x lo'
+        fbs[1] = scale_hs(fb[0][1]);
+        mma_col(fbs[1], fa[1], 1);
+        load_a(parTag);                                               // step kk + 2: two steps until its conversion
+        advance_a();
+        dma_instr(0, sd);
         __builtin_amdgcn_sched_barrier(0);
-        // hi x lo with the conversion of step kk + 1 threaded through it: one MFMA (8 passes, 32 cycles of the pipe) covers the issue
+        // lo x hi with the conversion of step kk + 1 threaded through it: one MFMA (8 passes, 32 cycles of the pipe) covers the issue
         // of a few VALU instructions of the same wave; the LDS writes go out before the last MFMAs of the group
-        mma_term(1, 0);
+        mma(fb[1], fa[0]);
         convert(std::integral_constant<int, sa ^ 1>{});               // (the compiler counts vmcnt for rA)
         {
             constexpr int nM = 2 * RI, valu = (RES ? 64 : (NORM ? 48 : 40)) / nM;
@@ -556,16 +597,19 @@ __device__ __forceinline__ void pair_conv1x1_body(const PairConvArgs &a)
         dma_instr(1, sd);
         __builtin_amdgcn_sched_barrier(0);
         advance_conv();
-        // the weights of step kk + 1 have landed: younger are 2 DMAs and NLD loads of step kk + 2 - and, in the first
-        // step of a tile, the NS stores of the tile before; lgkmcnt(0): my activation writes are done
-        if constexpr (decltype(firstTag)::value) __builtin_amdgcn_s_waitcnt(0x0070 | ((2 + NLD + NS) & 15) | (((2 + NLD + NS) >> 4) << 14));
-        else __builtin_amdgcn_s_waitcnt(0x0070 | (2 + NLD));
+        constexpr int YOUNG = 2 * NLD + 4 + (decltype(firstTag)::value ? NS : 0);
+        __builtin_amdgcn_s_waitcnt(0x0070 | (YOUNG & 15) | ((YOUNG >> 4) << 14));     // + lgkmcnt(0): my activation writes are done
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        mma_term(0, 0); dma_instr(2, sd);                              // hi x hi
+        mma_col(fb[0][0], fa[0], 0);                                   // hi x hi, column block 0 ...
+        __builtin_amdgcn_sched_barrier(0);
+        fb[0][0] = ldB(next, 0, 0);                                    // ... whose weight fragment then makes room for the next step's
+#pragma unroll
+        for (int i = 0; i < RI; ++i) fa[1][i] = ldA(sa ^ 1, 1, i);
+        mma_col(fb[0][1], fa[0], 1);
         advance_dma();
         sc = next;
-        sd = sd == 2 ? 0 : sd + 1;
+        sd = (sd + 1) & (NWS - 1);
         __builtin_amdgcn_sched_barrier(0);                            // (the vmcnt arithmetic above assumes this issue order)
     };
     auto epilogue = [&](int ti) __attribute__((always_inline)) {
@@ -677,7 +721,7 @@ __device__ __forceinline__ void pair_conv1x1_body(const PairConvArgs &a)
     };
     auto tile_steps = [&](auto firstTag) __attribute__((always_inline)) {
         step(firstTag, P0{});
-        step(std::false_type{}, P1{});
+        step(firstTag, P1{});
         for (int kk = 2; kk < nk; kk += 2) {
             step(std::false_type{}, P0{});
             step(std::false_type{}, P1{});
@@ -709,7 +753,7 @@ void pair_conv1x1_res_kernel(PairConvArgs a)
 }  // namespace
 
 // XL_OP_CONV with XL_CONV_SPLIT_BF16 | XL_CONV_SPLIT_IL | XL_CONV_PAIR_F16, nchunks2 = Z > 1, no XL_CONV_SPLIT_ACT: in = V as
-// activation pairs [Z][T][Cin/16][2][16] fp16, w = weight triples [Z][Cout][Cin/16][3][16] fp16 + 2 Z floats, out = M fp32
+// activation pairs [Z][T][Cin/16][2][16] fp16, w = weight pairs [Z][Cout][Cin/16][2][16] fp16 + 2 Z floats, out = M fp32
 // [Z][T][Cout], scale = {s, 1 / s}.
 static int xl_run_pair_gemm(const xl_op &op, hipStream_t st)
 {
@@ -719,19 +763,24 @@ static int xl_run_pair_gemm(const xl_op &op, hipStream_t st)
         (((uintptr_t)op.in | (uintptr_t)op.w | (uintptr_t)op.out) & 15))
         return XL_ERR_ARG;
     // 32-bit offsets inside one GEMM's operands / result (each z has its own buffer descriptor)
-    if ((long long)(T + 256) * op.Cout * 4 >= 0xffffffffLL || (long long)T * op.Cin * 4 >= 0x7fffffffLL || (long long)op.Cout * op.Cin * 6 >= 0x7fffffffLL ||
+    if ((long long)(T + 256) * op.Cout * 4 >= 0xffffffffLL || (long long)T * op.Cin * 4 >= 0x7fffffffLL || (long long)op.Cout * op.Cin * 4 >= 0x7fffffffLL ||
         (long long)T * op.Cout * 4 >= 0x7fffffffLL) return XL_ERR_ARG;
     PairArgs a;
     a.v = (const unsigned char *)op.in; a.u = (const unsigned char *)op.w; a.out = (float *)op.out;
-    a.uInv = reinterpret_cast<const float *>(a.u + (long long)Z * op.Cout * op.Cin * 6) + Z;
+    a.uInv = reinterpret_cast<const float *>(a.u + (long long)Z * op.Cout * op.Cin * 4) + Z;
     a.aScale = (const float *)op.scale;
     a.T = T; a.C = op.Cin; a.N = op.Cout; a.Z = Z;
     a.nbm = (T + 255) / 256; a.nbn = op.Cout / 256;
-    const size_t lds = 3 * (size_t)(256 * kPA + 256 * kPB);         // 120 KB: one workgroup per CU
+    a.clk = nullptr;
+    const size_t lds = 4 * (size_t)(256 * kPA + 256 * kPB);         // 128 KB: one workgroup per CU
     auto kernel = op.Cin == 512 ? pair_gemm_kernel<512> : pair_gemm_kernel<0>;
-    static XlLdsLimit configured[2];
+    static const int dbg = getenv("XL_PAIR_DBG") ? atoi(getenv("XL_PAIR_DBG")) : 0;
+    if (dbg && op.Cin == 512)
+        kernel = dbg == 1 ? pair_gemm_kernel<512, 1> : dbg == 2 ? pair_gemm_kernel<512, 2> : dbg == 3 ? pair_gemm_kernel<512, 3> : dbg == 4 ? pair_gemm_kernel<512, 4>
+               : dbg == 7 ? pair_gemm_kernel<512, 7> : pair_gemm_kernel<512, 5>;
+    static XlLdsLimit configured[3];
     int cfgDev;
-    const int slot = op.Cin == 512 ? 1 : 0;
+    const int slot = dbg ? 2 : op.Cin == 512 ? 1 : 0;
     if (configured[slot].needs(lds, &cfgDev)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return XL_ERR_HIP;
         configured[slot].done(lds, cfgDev);
@@ -739,7 +788,21 @@ static int xl_run_pair_gemm(const xl_op &op, hipStream_t st)
     const int nwg = a.nbm * a.nbn * Z;
     int grid = 256;
     if (grid > ((nwg + 7) & ~7)) grid = (nwg + 7) & ~7;
+    static const bool clkDbg = getenv("XL_PAIR_CLK") != nullptr;
+    if (clkDbg && hipMalloc(&a.clk, sizeof(long long) * 64 * grid) != hipSuccess) return XL_ERR_HIP;
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(512), lds, st, a);
+    if (clkDbg) {
+        std::vector<long long> h((size_t)64 * grid);
+        if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(h.data(), a.clk, sizeof(long long) * 64 * grid, hipMemcpyDeviceToHost) == hipSuccess) {
+            double v[2][4] = { { 0 } }; double steps = 0;
+            for (int i = 0; i < 8 * grid; ++i) { const int r = (i & 7) < 4 ? 0 : 1; for (int c = 0; c < 4; ++c) v[r][c] += h[8 * (size_t)i + c]; steps += h[8 * (size_t)i + 4]; }
+            steps /= 2;                                         // per wave group
+            for (int r = 0; r < 2; ++r)
+                fprintf(stderr, "[pair clk] waves %d-%d, ticks per K-step: reads + terms 0-1 + DMA issue %.0f, wait for DMAs %.0f, barrier %.0f, prefetch + term 2 %.0f\n",
+                        4 * r, 4 * r + 3, v[r][0] / steps, v[r][1] / steps, v[r][2] / steps, v[r][3] / steps);
+        }
+        (void)hipFree(a.clk);
+    }
     return XL_OK;
 }
 
@@ -755,7 +818,7 @@ static int launch_pair_conv1x1(const xl_op &op, PairConvArgs a, bool norm, int Z
     a.tpi = perImage ? (a.HW + BM - 1) / BM : 0;
     a.nbm = perImage ? op.B * a.tpi : (int)((M + BM - 1) / BM);
     a.nbn = (op.Cout + BN - 1) / BN;
-    const size_t lds = 3 * BN * kPB + BM * kPA + 64 * (64 * NW) + 16 * (64 * NW) + 16384 + 4096 + 1024;
+    const size_t lds = 4 * BN * kPB + BM * kPA + 64 * (64 * NW) + 16 * (64 * NW) + 16384 + 4096 + 1024;
     const bool accumulate = (op.flags & XL_CONV_ACCUMULATE) != 0;
     const bool resid = norm && a.res != nullptr;
     const bool dominant = Z > 1 && op.Cin == 512 && op.Cout == 512 && !accumulate && !norm;
@@ -797,7 +860,7 @@ static int xl_run_pair_conv1x1(const xl_op &op, hipStream_t st)
     if (op.ksize != 1 || op.stride != 1 || op.Cin % 32 != 0 || op.Cout % 256 != 0 || op.Cout > 1024 || op.ld_in < op.Cin ||
         op.ld_out < op.Cout || (op.ld_in & 3) || (op.ld_out & 3) || ((op.flags & XL_CONV_ACCUMULATE) && (norm || Z > 1 || op.stats)) || !op.in ||
         !op.w || !op.out || !op.scale || (((uintptr_t)op.in | (uintptr_t)op.out | (uintptr_t)op.w) & 15) || M >= 0x7fffffffLL ||
-        (long long)op.Cout * op.Cin * 6 >= 0x7fffffffLL || 256LL * op.ld_in * 4 >= 0x7fffffffLL || 256LL * op.ld_out * 4 >= 0x7fffffffLL)
+        (long long)op.Cout * op.Cin * 4 >= 0x7fffffffLL || 256LL * op.ld_in * 4 >= 0x7fffffffLL || 256LL * op.ld_out * 4 >= 0x7fffffffLL)
         return XL_ERR_ARG;
     if (norm && (!op.aux2 || op.Cin > 512 || HW < BM)) return XL_ERR_ARG;
     if (op.stats && (op.groups <= 0 || op.Cout != 16 * op.groups || HW < BM || op.nchunks < (HW + BM - 1) / BM + 1)) return XL_ERR_ARG;
@@ -810,8 +873,10 @@ static int xl_run_pair_conv1x1(const xl_op &op, hipStream_t st)
     a.M = (int)M; a.C = op.Cin; a.N = op.Cout; a.ldIn = op.ld_in; a.ldOut = op.ld_out;
     a.Z = Z; a.zIn = M * op.ld_in; a.zOut = M * op.ld_out;
     a.res = nullptr; a.ldRes = 0;
-    a.uInv = reinterpret_cast<const float *>(a.u + (long long)Z * op.Cout * op.Cin * 6) + Z;
+    a.uInv = reinterpret_cast<const float *>(a.u + (long long)Z * op.Cout * op.Cin * 4) + Z;
     a.aScale = (const float *)op.scale;
+    static const int var = getenv("XL_PAIR_VAR") ? atoi(getenv("XL_PAIR_VAR")) : 0;
+    a.var = var;
     if (op.flags & XL_CONV_NORM_ADD) {
         if (!norm || !(op.flags & XL_CONV_NORM_RELU) || !op.aux || op.ld_aux < op.Cin || (op.ld_aux & 3) || ((uintptr_t)op.aux & 15) || Z > 1 ||
             256LL * op.ld_aux * 4 >= 0x7fffffffLL) return XL_ERR_ARG;

@@ -98,7 +98,7 @@ void split_weight_kernel(const float *__restrict__ src, uint16_t *__restrict__ d
 
 // ---------------------------------------------------------------------------------------------- fp16 pair / triple operands (round 5)
 // XL_CONV_PAIR_F16 (csrc/xl_gemm_pair.hip): a weight w, scaled by the power of two 2^e of its matrix (max|w| 2^e in [2^14, 2^15)),
-// is stored as {hi = fp16(x), lo = fp16(x - hi), hs = fp16(hi * 2^-11)}; layout [Z][rows][K/16][3][16] fp16, then 2 Z floats:
+// is stored as {hi = fp16(x), lo = fp16(x - hi)}; layout [Z][rows][K/16][2][16] fp16, then 2 Z floats:
 // the maxima of the matrices as float bits (pass 1, atomicMax on the bits of |w| - non-negative floats order like their bits)
 // and the inverse scales 2^-e (pass 2).
 __device__ __forceinline__ float pair_scale_of_max(unsigned maxBits)
@@ -110,12 +110,11 @@ __device__ __forceinline__ float pair_scale_of_max(unsigned maxBits)
     if (e < -100) e = -100;
     return __builtin_bit_cast(float, (unsigned)(e + 127) << 23);
 }
-__device__ __forceinline__ void pair_triple(float x, uint16_t &hi, uint16_t &lo, uint16_t &hs)
+__device__ __forceinline__ void pair_hi_lo(float x, uint16_t &hi, uint16_t &lo)
 {
     const _Float16 h = (_Float16)x;
     const _Float16 l = (_Float16)(x - (float)h);
-    const _Float16 s = (_Float16)((float)h * 0.00048828125f);
-    hi = __builtin_bit_cast(uint16_t, h); lo = __builtin_bit_cast(uint16_t, l); hs = __builtin_bit_cast(uint16_t, s);
+    hi = __builtin_bit_cast(uint16_t, h); lo = __builtin_bit_cast(uint16_t, l);
 }
 
 template <int M>
@@ -166,10 +165,10 @@ void wino_weight_pair_kernel(const float *__restrict__ w, uint16_t *__restrict__
 #pragma unroll
             for (int z = 0; z < Z; ++z) {
                 const float sc = pair_scale_of_max(maxBits[z]);
-                uint16_t hi, lo, hs;
-                pair_triple(u[z] * sc, hi, lo, hs);
-                const long long b0 = (((long long)z * rows + r) * (K >> 4) + (k >> 4)) * 48 + (k & 15);
-                dst[b0] = hi; dst[b0 + 16] = lo; dst[b0 + 32] = hs;
+                uint16_t hi, lo;
+                pair_hi_lo(u[z] * sc, hi, lo);
+                const long long b0 = (((long long)z * rows + r) * (K >> 4) + (k >> 4)) * 32 + (k & 15);
+                dst[b0] = hi; dst[b0 + 16] = lo;
                 if (i == 0) invScale[z] = 1.f / sc;
             }
         }
@@ -197,10 +196,10 @@ void pair_weight_kernel(const float *__restrict__ src, uint16_t *__restrict__ ds
         else { const int tap = k / Cin, c = k - tap * Cin; v = src[((long long)r * Cin + c) * taps + tap]; }
         if (PASS == 0) { const unsigned b = __builtin_bit_cast(unsigned, fabsf(v)); m = b > m ? b : m; }
         else {
-            uint16_t hi, lo, hs;
-            pair_triple(v * sc, hi, lo, hs);
-            const long long b0 = ((long long)r * (K >> 4) + (k >> 4)) * 48 + (k & 15);
-            dst[b0] = hi; dst[b0 + 16] = lo; dst[b0 + 32] = hs;
+            uint16_t hi, lo;
+            pair_hi_lo(v * sc, hi, lo);
+            const long long b0 = ((long long)r * (K >> 4) + (k >> 4)) * 32 + (k & 15);
+            dst[b0] = hi; dst[b0 + 16] = lo;
             if (i == 0) invScale[0] = 1.f / sc;
         }
     }
@@ -297,7 +296,7 @@ int xl_cnn_pack_wino_weight_pair(const float *w, void *dst, int Cout, int Cin, i
     if (blocks > 4096) blocks = 4096;
     hipStream_t st = (hipStream_t)stream;
     uint16_t *d = (uint16_t *)dst;
-    unsigned *maxBits = reinterpret_cast<unsigned *>(d + (long long)Z * total * 3);
+    unsigned *maxBits = reinterpret_cast<unsigned *>(d + (long long)Z * total * 2);
     float *inv = reinterpret_cast<float *>(maxBits + Z);
     if (hipMemsetAsync(maxBits, 0, sizeof(unsigned) * Z, st) != hipSuccess) return XL_ERR_HIP;
     if (m == 4) {
@@ -318,7 +317,7 @@ int xl_cnn_pair_weight(const float *src, void *dst, int rows, int K, int taps, v
     if (blocks > 4096) blocks = 4096;
     hipStream_t st = (hipStream_t)stream;
     uint16_t *d = (uint16_t *)dst;
-    unsigned *maxBits = reinterpret_cast<unsigned *>(d + total * 3);
+    unsigned *maxBits = reinterpret_cast<unsigned *>(d + total * 2);
     float *inv = reinterpret_cast<float *>(maxBits + 1);
     if (hipMemsetAsync(maxBits, 0, sizeof(unsigned), st) != hipSuccess) return XL_ERR_HIP;
     hipLaunchKernelGGL(pair_weight_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, st, src, d, maxBits, inv, rows, K, taps);

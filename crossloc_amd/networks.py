@@ -461,23 +461,23 @@ class _Plan:
         _check(_bind().xl_cnn_pair_scales(g, b, c, r, n, self.pair_scales.data_ptr(), stream))
 
     def pack_conv_wino_pair(self, conv, m):
-        """The transformed weights of pack_conv_wino as fp16 triples [(m+2)^2][Cout][Cin/16][3][16], each frequency scaled by its
+        """The transformed weights of pack_conv_wino as fp16 pairs {hi, lo} [(m+2)^2][Cout][Cin/16][2][16], each frequency scaled by its
         own power of two, + 2 (m+2)^2 floats (scratch, inverse scales)."""
         key = (id(conv.weight), "wino%d_pair" % m)
         if key not in self.packed_pair:
             src = conv.weight.detach().to(device=self.device, dtype=torch.float32).contiguous()   # aliases the live parameter
             nf = (m + 2) ** 2
-            planes = torch.empty(3 * nf * src.shape[0] * src.shape[1] + 4 * nf, dtype=torch.int16, device=self.device)
+            planes = torch.empty(2 * nf * src.shape[0] * src.shape[1] + 4 * nf, dtype=torch.int16, device=self.device)
             self.packed_pair[key] = (planes, src, m)
             self._pack_pair(planes, src, m)
         return self.packed_pair[key][0]
 
     def pack_conv_1x1_pair(self, conv):
-        """[Cout][Cin/16][3][16] fp16 triples of a 1x1 convolution's weight (one power-of-two scale) + 2 floats."""
+        """[Cout][Cin/16][2][16] fp16 pairs {hi, lo} of a 1x1 convolution's weight (one power-of-two scale) + 2 floats."""
         key = (id(conv.weight), "1x1_pair")
         if key not in self.packed_pair:
             src = conv.weight.detach().to(device=self.device, dtype=torch.float32).contiguous()   # aliases the live parameter
-            planes = torch.empty(3 * src.numel() + 4, dtype=torch.int16, device=self.device)
+            planes = torch.empty(2 * src.numel() + 4, dtype=torch.int16, device=self.device)
             self.packed_pair[key] = (planes, src, 0)
             self._pack_pair(planes, src, 0)
         return self.packed_pair[key][0]

@@ -120,11 +120,11 @@ enum {
                                   (csrc/xl_gemm_pair.hip): an activation a (times the power of two *scale, see xl_op.scale) is the fp16 pair
                                   {hi = fp16(a), lo = fp16((a - hi) * 2^11)} - 22 significand bits, lo in fp16's NORMAL range whatever
                                   the magnitude of a - and a weight w (times a per-matrix power of two that brings max|w| into
-                                  [2^14, 2^15)) is the triple {hi, lo = fp16(w - hi), hs = hi * 2^-11}; the three products hi*hi,
-                                  hi*lo and lo*hs are exact in fp32 (v_mfma_f32_32x32x16_f16, fp32 accumulate), what is dropped
-                                  (lo*lo) is below 2^-22 of the leading product; the epilogue un-scales (exact).  Layouts:
-                                  activations [Z][rows][C/16][2][16] fp16 (4 bytes per element, what an fp32 V costs), weights
-                                  [Z][rows][C/16][3][16] fp16 followed by 2 Z floats (xl_cnn_pack_wino_weight_pair /
+                                  [2^14, 2^15)) is the pair {hi, lo = fp16(w - hi)}, from whose hi the kernels derive hs = hi * 2^-11 in
+                                  registers; the three products hi*hi, hi*lo and lo*hs are exact in fp32
+                                  (v_mfma_f32_32x32x16_f16, fp32 accumulate), what is dropped (lo*lo) is below 2^-22 of the
+                                  leading product; the epilogue un-scales (exact).  Layouts, 4 bytes per element (what fp32 costs):
+                                  activations [Z][rows][C/16][2][16] fp16, weights the same followed by 2 Z floats (xl_cnn_pack_wino_weight_pair /
                                   xl_cnn_pair_weight).  On XL_OP_WINO_IN (ksize 6): V is written in the activation layout;
                                   on XL_OP_CONV with nchunks2 = Z > 1 and without XL_CONV_SPLIT_ACT: `in` is that V (both operands
                                   reach LDS by DMA, no conversion in the GEMM); with XL_CONV_SPLIT_ACT or nchunks2 <= 1: `in` is
@@ -227,10 +227,10 @@ int xl_cnn_split_weight(const float *src_dev, void *dst_dev, int rows, int K, in
 
 /* ---- fp16 pair / triple operands (XL_CONV_PAIR_F16, csrc/xl_gemm_pair.hip, csrc/xl_pack.hip)
  * xl_cnn_pack_wino_weight_pair: U = G g G^T of F(6x6,3x3) / F(4x4,3x3) (float64 inside) per frequency z, scaled by the power of two
- * 2^e_z with max|U_z| 2^e_z in [2^14, 2^15), as triples [Z][rows][K/16][3][16] fp16 {hi, lo, hi * 2^-11}, followed by 2 Z floats:
- * [Z] scratch (the maxima, as float bits) and [Z] inverse scales 2^-e_z - dst holds Z*rows*K*6 + 8 Z bytes.  dgrad as
+ * 2^e_z with max|U_z| 2^e_z in [2^14, 2^15), as pairs [Z][rows][K/16][2][16] fp16 {hi, lo}, followed by 2 Z floats:
+ * [Z] scratch (the maxima, as float bits) and [Z] inverse scales 2^-e_z - dst holds Z*rows*K*4 + 8 Z bytes.  dgrad as
  * xl_cnn_pack_wino_weight.
- * xl_cnn_pair_weight: a plain [rows][K] matrix (taps as xl_cnn_split_weight), one scale: rows*K*6 + 8 bytes. */
+ * xl_cnn_pair_weight: a plain [rows][K] matrix (taps as xl_cnn_split_weight), one scale: rows*K*4 + 8 bytes. */
 int xl_cnn_pack_wino_weight_pair(const float *w_oihw_dev, void *dst_dev, int Cout, int Cin, int m, int dgrad, void *stream);
 int xl_cnn_pair_weight(const float *src_dev, void *dst_dev, int rows, int K, int taps, void *stream);
 /* fp32 [rows][K] -> activation pairs [rows][K/16][2][16] fp16 of src * scale[0] (tests, tools; K % 16 == 0) */

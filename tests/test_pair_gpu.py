@@ -1,4 +1,4 @@
-"""GPU parity of the fp16 pair / triple GEMMs (round 5, XL_CONV_PAIR_F16, csrc/xl_gemm_pair.hip + csrc/xl_pack.hip): the same
+"""GPU parity of the fp16 pair GEMMs (round 5, XL_CONV_PAIR_F16, csrc/xl_gemm_pair.hip + csrc/xl_pack.hip): the same
 products as the split-bf16 kernels with three matrix-pipe passes instead of six.  Every GEMM is held against a float64 product
 of the same fp32 operands AND against the fp32-MFMA kernel's own error on that product (the bar: fp32-class, <= 1.5x), over
 operand magnitudes from 1e-8 to 1e4 and with activation scales far looser than necessary - the layout keeps the low term in
@@ -35,35 +35,34 @@ def _scale_for(maxabs, slack=0):
 
 
 def _pair_weight(w2d):
-    """[rows][K] fp32 (device) -> triples + 2 floats, as the plan packs a 1x1 layer."""
+    """[rows][K] fp32 (device) -> pairs {hi, lo} + 2 floats, as the plan packs a 1x1 layer."""
     rows, K = w2d.shape
-    dst = torch.zeros(3 * rows * K + 4, dtype=torch.int16, device="cuda")
+    dst = torch.zeros(2 * rows * K + 4, dtype=torch.int16, device="cuda")
     src = w2d.contiguous()
     networks._check(networks._bind().xl_cnn_pair_weight(src.data_ptr(), dst.data_ptr(), rows, K, 1, None))
     torch.cuda.synchronize()
     return dst
 
 
-def _triples(dst, Z, rows, K):
-    body = dst[:3 * Z * rows * K].view(torch.float16).view(Z, rows, K // 16, 3, 16).float()
-    tail = dst[3 * Z * rows * K:].view(torch.float32)
-    hi, lo, hs = (body[:, :, :, p].reshape(Z, rows, K) for p in range(3))
-    return hi, lo, hs, tail[Z:2 * Z]
+def _pairs(dst, Z, rows, K):
+    body = dst[:2 * Z * rows * K].view(torch.float16).view(Z, rows, K // 16, 2, 16).float()
+    tail = dst[2 * Z * rows * K:].view(torch.float32)
+    hi, lo = (body[:, :, :, p].reshape(Z, rows, K) for p in range(2))
+    return hi, lo, tail[Z:2 * Z]
 
 
 @pytest.mark.parametrize("mag", [1.0, 3e-6, 2e3])
-def test_pair_weight_is_the_scaled_triple(mag):
+def test_pair_weight_is_the_scaled_pair(mag):
     g = torch.Generator().manual_seed(7)
     w = (torch.randn(256, 96, generator=g) * mag).cuda()
     w[3, 5] = 0.0
-    hi, lo, hs, inv = _triples(_pair_weight(w), 1, 256, 96)
+    hi, lo, inv = _pairs(_pair_weight(w), 1, 256, 96)
     s = 1.0 / inv.item()
     assert math.frexp(s)[0] == 0.5                                  # a power of two
     x = w.double() * s
     assert 2.0 ** 14 <= x.abs().max().item() < 2.0 ** 15
     assert torch.equal(hi[0], (w * s).half().float())
     assert torch.equal(lo[0], ((w * s) - hi[0]).half().float())
-    assert torch.equal(hs[0], (hi[0] * 2.0 ** -11).half().float())
     # 22 significand bits: |x - hi - lo| <= 2^-22 |x| (or the fp16 subnormal spacing for the smallest elements)
     err = (x - hi[0].double() - lo[0].double()).abs()
     assert (err <= x.abs() * 2.0 ** -22 + 2.0 ** -25).all()
@@ -75,10 +74,10 @@ def test_winograd_pair_pack_vs_float64(m):
     cout, cin = 256, 128
     w = (torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (9 * cin)) ** 0.5).cuda()
     nf = (m + 2) ** 2
-    dst = torch.zeros(3 * nf * cout * cin + 4 * nf, dtype=torch.int16, device="cuda")
+    dst = torch.zeros(2 * nf * cout * cin + 4 * nf, dtype=torch.int16, device="cuda")
     networks._check(networks._bind().xl_cnn_pack_wino_weight_pair(w.data_ptr(), dst.data_ptr(), cout, cin, m, 0, None))
     torch.cuda.synchronize()
-    hi, lo, hs, inv = _triples(dst, nf, cout, cin)
+    hi, lo, inv = _pairs(dst, nf, cout, cin)
     G = torch.tensor(networks._Plan._WINO_G[m], dtype=torch.float64, device="cuda")
     U = torch.einsum("xa,ocab,yb->xyoc", G, w.double(), G).reshape(nf, cout, cin)
     for z in range(nf):
@@ -88,7 +87,6 @@ def test_winograd_pair_pack_vs_float64(m):
         assert 2.0 ** 14 <= x.abs().max().item() < 2.0 ** 15, (z, x.abs().max().item())
         # U rounded to fp32 once, then 22 bits of it
         assert ((hi[z].double() + lo[z].double()) - x).abs().max().item() <= 2.0 ** 15 * (2.0 ** -22 + 2.0 ** -24)
-        assert torch.equal(hs[z], (hi[z] * 2.0 ** -11).half().float())
 
 
 def _fp32_mfma_gemm(V, U, Z, T, cin, cout):
@@ -113,7 +111,7 @@ def _fp32_mfma_gemm(V, U, Z, T, cin, cout):
     (2, 257, 1536, 1024, 1.0, 1.0, 3),         # one ragged second row tile, four column tiles, 96 K-steps
     (2, 9000, 32, 256, 1.0, 1.0, 0)])          # two K-steps per tile: the operand stream runs a tile ahead
 def test_pair_gemm_vs_float64_and_the_fp32_mfma_kernel(Z, T, cin, cout, vmag, umag, slack):
-    """pair_gemm_kernel: V as activation pairs, U as weight triples, both by LDS-DMA; M against float64."""
+    """pair_gemm_kernel: V as activation pairs, U as weight pairs, both by LDS-DMA; M against float64."""
     g = torch.Generator().manual_seed(Z * 31 + T + cin)
     V = (torch.randn(Z, T, cin, generator=g) * vmag).cuda()
     V[:, :, ::7] *= 1e-3                                        # a wide spread inside every row
@@ -124,11 +122,11 @@ def test_pair_gemm_vs_float64_and_the_fp32_mfma_kernel(Z, T, cin, cout, vmag, um
     L = networks._bind()
     Vp = torch.zeros(Z * T * cin * 2, dtype=torch.int16, device="cuda")
     networks._check(L.xl_cnn_pair_activation(V.data_ptr(), Vp.data_ptr(), Z * T, cin, scale.data_ptr(), None))
-    Up = torch.zeros(3 * Z * cout * cin + 4 * Z, dtype=torch.int16, device="cuda")
+    Up = torch.zeros(2 * Z * cout * cin + 4 * Z, dtype=torch.int16, device="cuda")
     for z in range(Z):                                          # (one scale per matrix: pack them one by one, gather the tails)
         one = _pair_weight(U[z])
-        Up[3 * z * cout * cin:3 * (z + 1) * cout * cin] = one[:3 * cout * cin]
-        Up[3 * Z * cout * cin:].view(torch.float32)[Z + z] = one[3 * cout * cin:].view(torch.float32)[1]
+        Up[2 * z * cout * cin:2 * (z + 1) * cout * cin] = one[:2 * cout * cin]
+        Up[2 * Z * cout * cin:].view(torch.float32)[Z + z] = one[2 * cout * cin:].view(torch.float32)[1]
     Mb = torch.full((Z * T * cout,), float("nan"), device="cuda")
     gm = networks.XlOp()
     gm.type = networks.XL_OP_CONV
