@@ -1981,7 +1981,7 @@ class _Plan:
 
     def _graph_wanted(self, stream):
         env = os.environ.get("XL_CNN_GRAPH")
-        if self.train or stream == 0 or env == "0":
+        if self.train or env == "0":
             return False
         return env == "1" or self.B <= self.GRAPH_MAX_BATCH
 
@@ -2005,18 +2005,34 @@ class _Plan:
         # streams pass distinct plan_slots).  A call from any other stream than the capturing one runs eagerly.
         if self.graph_stream is not None and stream != self.graph_stream:
             return None
+        # round 5: the caller is on the DEFAULT stream - what the reference's unchanged loop uses (test_single_task.py:347,
+        # `network(image.cuda())`), and a stream HIP cannot capture on.  The graph then lives on a private stream of the plan,
+        # bracketed by events: copy-in on the caller's stream, graph behind it, the result copy back on the caller's stream
+        # behind the graph.  Same kernels, same order, same bits as the eager op list.
+        private = None
+        if stream == 0:
+            if not hasattr(self, "graph_private"):
+                self.graph_private = torch.cuda.Stream(device=self.device)
+            private = self.graph_private
         for i in self.image_op_indices:
             self.op_array[i].in_ = self.graph_in.data_ptr()
         self.op_array[self.out_op_index].out = self.graph_out.data_ptr()
         if self.graph is None:
             h = ctypes.c_void_p()
-            rc = L.xl_cnn_graph_capture(self.op_array, len(self.op_array), ctypes.c_void_p(stream), ctypes.byref(h))
+            rc = L.xl_cnn_graph_capture(self.op_array, len(self.op_array),
+                                        ctypes.c_void_p(private.cuda_stream if private is not None else stream), ctypes.byref(h))
             if rc != 0:
                 return self._graph_give_up("capture", rc)
             self.graph, self.graph_stream = h, stream
             weakref.finalize(self, L.xl_cnn_graph_destroy, h)
         self.graph_in.copy_(image)
-        rc = L.xl_cnn_graph_launch(self.graph, ctypes.c_void_p(stream))
+        if private is not None:
+            caller = torch.cuda.current_stream()
+            private.wait_stream(caller)                     # the copy-in (and whatever produced the image) before the graph
+            rc = L.xl_cnn_graph_launch(self.graph, ctypes.c_void_p(private.cuda_stream))
+            caller.wait_stream(private)                     # the caller's next operation - the result copy - behind the graph
+        else:
+            rc = L.xl_cnn_graph_launch(self.graph, ctypes.c_void_p(stream))
         if rc == XL_ERR_UNSUPPORTED:                        # per-op profiling is on: this call runs eagerly
             return None
         if rc != 0:

@@ -1078,6 +1078,39 @@ def test_small_batch_forward_as_a_hip_graph_and_small_tile_form(monkeypatch):
         assert torch.equal(net(xs[1]), y2) and not torch.equal(y2, want[1])
 
 
+@pytest.mark.skipif(os.environ.get("XL_GEMM_SPLIT_BF16") in ("0", "1") or os.environ.get("XL_CNN_GRAPH") == "0", reason="graph path switched off")
+def test_default_stream_calls_replay_the_graph_on_a_private_stream(monkeypatch):
+    """Round 5 (the reference's unchanged loop, test_single_task.py:347: `network(image.cuda())` on the DEFAULT stream): HIP
+    cannot capture on the default stream, so the plan captures and replays its graph on a private stream bracketed by events.
+    Bitwise the eager op list, new images picked up, the result usable at once by default-stream work and by `.cpu()`; a call
+    from a created stream afterwards falls back to the eager list (one stream per plan)."""
+    net = networks.TransPoseNet(MEAN, False, False, 1, 1, 3, 1)
+    net.load_state_dict(seeded_state_dict(net, seed=23))
+    net = net.cuda().eval()
+    xs = [torch.rand(1, 3, 480, 720, generator=torch.Generator().manual_seed(s)).cuda() for s in (4, 5, 6)]
+    monkeypatch.setenv("XL_CNN_GRAPH", "0")
+    with torch.no_grad():
+        want = [net(x).clone() for x in xs]
+    monkeypatch.delenv("XL_CNN_GRAPH")
+    net.invalidate()
+    torch.cuda.synchronize()
+    assert torch.cuda.current_stream().cuda_stream == 0
+    with torch.no_grad():
+        got = []
+        for x in xs + [xs[0]]:
+            y = net(x)
+            got.append((y * 2.0).cpu())                      # consumed on the default stream straight away, then on the host
+    plan = list(net._plans.values())[0]
+    assert plan.graph is not None and plan.graph_runs == 4 and plan.graph_stream == 0 and hasattr(plan, "graph_private")
+    for g, w in zip(got, want + [want[0]]):
+        assert torch.equal(g, (w * 2.0).cpu())
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st), torch.no_grad():
+        y = net(xs[1])
+    st.synchronize()
+    assert torch.equal(y, want[1]) and plan.graph_runs == 5
+
+
 @pytest.mark.skipif(bool(os.environ.get("XL_WINO_V_SPLIT")) or os.environ.get("XL_GEMM_SPLIT_BF16") in ("0", "1"),
                     reason="the tile-major product belongs to the GEMM form that reads an fp32 V")
 def test_tile_major_winograd_product_is_bitwise_the_plane_major_form(monkeypatch):
