@@ -35,6 +35,21 @@ def grad_inputs():
     return x, poses, delta
 
 
+def grad_full_inputs():
+    """Inputs of the 480x720 gradient fixture (grads_full.npz, BASELINE configs[1] frame size, batch 1): the 'single' frame, one
+    camera pose above the label mean looking down, focal length 480, an offset field `delta` [1,3,60,90] (labels = reference
+    prediction + delta, a block of cells NODATA, a few cells beyond the 50 m init tolerance)."""
+    rng = np.random.default_rng(480720)
+    x = full_size_image("single")
+    T = np.eye(4)
+    T[:3, :3] = synth._rot_xyz(*rng.uniform(-0.1, 0.1, size=3)) @ np.array([[1.0, 0, 0], [0, -1.0, 0], [0, 0, -1.0]])
+    T[:3, 3] = synth.SCENE_MEAN + np.array([rng.uniform(-20, 20), rng.uniform(-20, 20), 240.0])
+    poses = T[None].astype(np.float32)
+    delta = rng.normal(0.0, 4.0, size=(1, 3, FULL_H // 8, FULL_W // 8)).astype(np.float32)
+    delta[0, :, 10:12, 20:24] += np.array([70.0, 0.0, 0.0], np.float32)[:, None, None]
+    return x, poses, delta
+
+
 B16 = 16
 
 

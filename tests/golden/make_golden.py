@@ -18,6 +18,7 @@ Round 4 - the BASELINE sizes and the backward pass (inputs regenerated from seed
                   on the reference module, 64x96 batch 2 - loss, rate, dL/dprediction, and for each of the 114 parameters
                   the L2 norm, the sum and a strided sample of .grad (network evaluated in float64: the fixture holds
                   no ReLU-mask flips of its own; the fp32 run's loss is stored beside it)
+  grads_full.npz  (round 5) the same step at 480x720, batch 1, float64 network
   losses_b16.npz  loss/coord.py:87-188, loss/depth.py:7-76, loss/normal.py:8-127 at [16,*,60,90]: value, rate, gradient
                   moments and strided samples
 """
@@ -265,6 +266,11 @@ def grad_goldens():
         out["loss_" + tag] = np.array(loss.item(), np.float64)
         out["rate_" + tag] = np.array(float(rate))
         if tag == "f32":
+            # round 5: the reference's OWN fp32 gradients (sample + norm per tensor): how far fp32 arithmetic sits from the
+            # float64 result on this graph - the yardstick the tests hold the HIP path to
+            out["param_grad_sample_f32"] = np.stack([np.pad(golden_inputs.strided(p.grad.double().numpy()), (0, 256 - golden_inputs.strided(p.grad.numpy()).size))
+                                                     for _, p in net.named_parameters()]).astype(np.float32)
+            out["param_grad_l2_f32"] = np.array([float(np.sqrt((p.grad.double().numpy() ** 2).sum())) for _, p in net.named_parameters()])
             continue
         out["y"] = pred.detach().float().numpy()
         out["dpred"] = pred32.grad.numpy().copy()
@@ -284,6 +290,56 @@ def grad_goldens():
     np.savez_compressed(os.path.join(HERE, "grads.npz"), **out)
     _print("grads.npz", {k: v.shape for k, v in out.items()}, "loss f64-net %.6f fp32 %.6f rate %.4f" % (
         out["loss_f64"], out["loss_f32"], out["rate_f64"]))
+
+
+def grad_full_goldens():
+    """Round 5: the same training step (train_single_task.py:262-298) on the reference module at the BASELINE frame size,
+    480x720, batch 1, network in float64 (no ReLU-mask flips of its own): loss, rate, dL/dprediction and for each of the 114
+    parameters the L2 norm, the sum and a strided 256-element sample of .grad."""
+    mean = torch.tensor([-455.934, 417.50, 520.31])
+    x, poses, delta = golden_inputs.grad_full_inputs()
+    pixel_grid = get_pixel_grid(8)
+    cam_mat = get_cam_mat(golden_inputs.FULL_W, golden_inputs.FULL_H, 480.0)
+    net = quiet(TransPoseNet, mean, False, False, 2, 2, 3, 1, 32, 0, 0, False)
+    net.load_state_dict(seeded_state_dict(net, seed=2021), strict=True)
+    net = net.to(torch.float64).train()
+    pred = net(torch.from_numpy(x).to(torch.float64))
+    gt = (pred.detach()[:, :3].float() + torch.from_numpy(delta)).numpy()
+    gt[0, :, 30:33, 40:45] = -1.0
+    pred32 = pred.float()
+    pred32.retain_grad()
+    sc, unc = torch.split(pred32, [3, 1], dim=1)
+    loss, rate = quiet(scene_coords_regression_loss, 0.1, 100.0, 1000.0, 50.0, "MLE", pixel_grid, -1, cam_mat,
+                       sc, unc, torch.from_numpy(poses), torch.from_numpy(gt), 'mean')
+    loss.backward()
+    out = dict(loss_f64=np.array(loss.item(), np.float64), rate_f64=np.array(float(rate)), y=pred.detach().float().numpy(),
+               dpred=pred32.grad.numpy().copy(), gt=gt)
+    names, norms, sums, samples = [], [], [], []
+    for name, p in net.named_parameters():
+        g = p.grad.double().numpy()
+        names.append("%s:%s" % (name, "x".join(map(str, p.shape))))
+        norms.append(np.sqrt((g * g).sum()))
+        sums.append(g.sum())
+        s = golden_inputs.strided(g)
+        samples.append(np.pad(s, (0, 256 - s.size)))
+    out.update(param_names=np.array(names), param_grad_l2=np.array(norms), param_grad_sum=np.array(sums),
+               param_grad_sample=np.stack(samples).astype(np.float32),
+               x_checksum=np.array(golden_inputs.checksum(x)), poses_checksum=np.array(golden_inputs.checksum(poses)))
+    # the reference's own fp32 run of the same step (same labels): its distance from the float64 gradients is the yardstick
+    net32 = quiet(TransPoseNet, mean, False, False, 2, 2, 3, 1, 32, 0, 0, False)
+    net32.load_state_dict(seeded_state_dict(net32, seed=2021), strict=True)
+    net32 = net32.train()
+    p32 = net32(torch.from_numpy(x))
+    sc, unc = torch.split(p32, [3, 1], dim=1)
+    loss32, _ = quiet(scene_coords_regression_loss, 0.1, 100.0, 1000.0, 50.0, "MLE", pixel_grid, -1, cam_mat,
+                      sc, unc, torch.from_numpy(poses), torch.from_numpy(gt), 'mean')
+    loss32.backward()
+    out["loss_f32"] = np.array(loss32.item(), np.float64)
+    out["param_grad_sample_f32"] = np.stack([np.pad(golden_inputs.strided(p.grad.double().numpy()), (0, 256 - golden_inputs.strided(p.grad.numpy()).size))
+                                             for _, p in net32.named_parameters()]).astype(np.float32)
+    out["param_grad_l2_f32"] = np.array([float(np.sqrt((p.grad.double().numpy() ** 2).sum())) for _, p in net32.named_parameters()])
+    np.savez_compressed(os.path.join(HERE, "grads_full.npz"), **out)
+    _print("grads_full.npz", {k: v.shape for k, v in out.items()}, "loss %.6f rate %.4f" % (out["loss_f64"], out["rate_f64"]))
 
 
 def loss_b16_goldens():
@@ -334,7 +390,9 @@ def loss_b16_goldens():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["net", "net4", "loss", "semantics", "full", "grads", "loss16"]
+    which = sys.argv[1:] or ["net", "net4", "loss", "semantics", "full", "grads", "loss16", "gradsfull"]
+    if "gradsfull" in which:
+        grad_full_goldens()
     if "net" in which:
         net_goldens()
     if "net4" in which:

@@ -175,30 +175,76 @@ def test_hip_training_step_gradients_vs_reference_fixture():
     dref = GRADS["dpred"].astype(np.float64)
     dgot = pred.grad.double().cpu().numpy()
     assert np.linalg.norm(dgot - dref) <= 2e-3 * np.linalg.norm(dref)
-    names = [n.split(":")[0] for n in GRADS["param_names"]]
+    _check_param_grads(net, GRADS, "64x96 x 2")
+
+
+def _check_param_grads(net, G, tag):
+    """All 114 parameter gradients of `net` against the fixture `G` - the reference module's autograd gradients with the network
+    in float64.  Per tensor: relative L2 error of a strided 256-element sample and relative error of the L2 norm.  The yardstick
+    is the reference's OWN fp32 run of the same step, stored beside the float64 one (round 5): fp32 arithmetic through 29
+    GroupNorm layers sits 1e-3 (64x96: 96-pixel maps) / 3e-5 (480x720) from the float64 gradients in the median, and the HIP
+    path adds the rounding of its F(6x6,3x3) transforms (~1e-5 per layer where a direct fp32 convolution has 2e-7).  Asserted:
+      median over the tensors  <= max(1e-3, 5 x the reference's fp32 median);
+      every tensor             <= max(1e-2, 5 x that tensor's own fp32 error) on the sample, <= 2e-2 on the norm."""
+    names = [n.split(":")[0] for n in G["param_names"]]
     params = dict(net.named_parameters())
     assert names == list(params.keys()) and len(names) == 114
-    gmax = float(np.abs(GRADS["param_grad_sample"]).max())
-    worst = []
+    gmax = float(np.abs(G["param_grad_sample"]).max())
+    table, ref32 = [], []
     for i, name in enumerate(names):
         g = params[name].grad
         assert g is not None, name
         g = g.double().cpu().numpy()
         s = golden_inputs.strided(g)
-        ref = GRADS["param_grad_sample"][i, :s.size].astype(np.float64)
+        ref = G["param_grad_sample"][i, :s.size].astype(np.float64)
         if name == "encoder.conv1.bias":
             # GroupNorm(32, 32) is an instance norm: d/d(conv1.bias) is exactly 0; the reference holds rounding noise
-            assert np.abs(g).max() <= 1e-4 * gmax and float(GRADS["param_grad_l2"][i]) <= 1e-4 * gmax
+            assert np.abs(g).max() <= 1e-4 * gmax and float(G["param_grad_l2"][i]) <= 1e-4 * gmax
             continue
         floor = 1e-4 * gmax * np.sqrt(s.size)
-        e2 = np.linalg.norm(s - ref) / max(np.linalg.norm(ref), floor)
+        den = max(np.linalg.norm(ref), floor)
+        e2 = np.linalg.norm(s - ref) / den
+        r2 = np.linalg.norm(G["param_grad_sample_f32"][i, :s.size].astype(np.float64) - ref) / den
         l2 = np.sqrt((g * g).sum())
-        en = abs(l2 - float(GRADS["param_grad_l2"][i])) / max(float(GRADS["param_grad_l2"][i]), 1e-4 * gmax * np.sqrt(g.size))
-        worst.append((max(e2, en), e2, en, name))
-    worst.sort(reverse=True)
-    print("parameter gradients vs the reference module: worst sample L2 %.2e / norm %.2e (%s), median %.2e" % (
-        worst[0][1], worst[0][2], worst[0][3], worst[len(worst) // 2][0]))
-    assert worst[0][1] <= 5e-2 and worst[0][2] <= 2e-2, worst[:5]
+        en = abs(l2 - float(G["param_grad_l2"][i])) / max(float(G["param_grad_l2"][i]), 1e-4 * gmax * np.sqrt(g.size))
+        table.append((e2, en, r2, name))
+        ref32.append(r2)
+    table.sort(reverse=True)
+    median, med32 = table[len(table) // 2][0], sorted(ref32)[len(ref32) // 2]
+    print("%s: parameter gradients vs the reference module in float64: median %.2e (the reference's own fp32 run: %.2e), worst "
+          "sample %.2e / norm %.2e, %d tensors above 1e-3" % (tag, median, med32, table[0][0], max(t[1] for t in table),
+                                                              sum(1 for t in table if t[0] > 1e-3)))
+    for t in table[:6]:
+        print("   %-40s sample %.2e (reference fp32 %.2e) norm %.2e" % (t[3], t[0], t[2], t[1]))
+    assert median <= max(1e-3, 5.0 * med32), (median, med32)
+    for e2, en, r2, name in table:
+        assert e2 <= max(1e-2, 5.0 * r2) and en <= 2e-2, (name, e2, r2, en)
+
+
+@pytest.mark.gpu
+def test_hip_training_step_gradients_at_480x720_vs_reference_fixture():
+    """Round 5: the same step at the BASELINE configs[1] frame size - 480x720, batch 1 - against gradients autograd produced on
+    the reference module in float64 (tests/golden/make_golden.py gradsfull; train_single_task.py:262-300)."""
+    from crossloc_amd import loss as xl_loss
+    GF = np.load(os.path.join(os.path.dirname(__file__), "golden", "grads_full.npz"))
+    x, poses, _ = golden_inputs.grad_full_inputs()
+    assert golden_inputs.checksum(x) == pytest.approx(float(GF["x_checksum"]), rel=1e-12)
+    net = _net().cuda().train()
+    pred = net(torch.from_numpy(x).cuda())
+    _check_forward(pred.detach().cpu(), GF["y"], tol_range=1e-3)
+    pred.retain_grad()
+    sc, unc = torch.split(pred, [3, 1], dim=1)
+    loss, rate = xl_loss.scene_coords_regression_loss(0.1, 100.0, 1000.0, 50.0, "MLE", xl_loss.get_pixel_grid(8), -1,
+                                                      xl_loss.get_cam_mat(golden_inputs.FULL_W, golden_inputs.FULL_H, 480.0), sc, unc,
+                                                      torch.from_numpy(poses).cuda(), torch.from_numpy(GF["gt"]).cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    assert loss.item() == pytest.approx(float(GF["loss_f64"]), rel=2e-4)
+    assert float(rate) == pytest.approx(float(GF["rate_f64"]), abs=1e-6)
+    dref = GF["dpred"].astype(np.float64)
+    dgot = pred.grad.double().cpu().numpy()
+    assert np.linalg.norm(dgot - dref) <= 2e-3 * np.linalg.norm(dref)
+    _check_param_grads(net, GF, "480x720 x 1")
 
 
 @pytest.mark.gpu
