@@ -239,15 +239,22 @@ def timed_steps(dist, sync, run_steps):
     t0 = time.perf_counter()
     run_steps()
     sync()
+    own = time.perf_counter() - t0
     if dist is not None:
         dist.barrier()
     sync()
     elapsed = time.perf_counter() - t0
+    timed_steps.per_rank_s = (own, own)
     if dist is not None:
         dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+        # each rank's own time for its K steps (before the closing barrier): a straggler shows in the first real multi-GPU line
+        lo, hi = torch.tensor([own], dtype=torch.float64, device=dev), torch.tensor([own], dtype=torch.float64, device=dev)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        timed_steps.per_rank_s = (float(lo.item()), float(hi.item()))
     return elapsed
 
 
@@ -524,6 +531,8 @@ def main():
                        "hypotheses": NH, "batch_per_gpu": B, "global_batch": B * world,
                        "parallelism": "images sharded over %d GPU(s), no data-path collective" % world,
                        "rccl_ranks": rccl_ranks, "rows_gathered": n_rows,
+                       "per_rank_ms_per_step": {"min": round(timed_steps.per_rank_s[0] / K * 1e3, 3),
+                                                "max": round(timed_steps.per_rank_s[1] / K * 1e3, 3)},
                        **({"preflight": "XL_BENCH_SHARED_GPU=1: %d ranks share cuda:0 (RCCL refuses two ranks on one device): gloo "
                                         "all-gather / max-over-ranks on CPU tensors, real kernels; not a scaling measurement" % world}
                           if shared else {}),
