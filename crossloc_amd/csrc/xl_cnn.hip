@@ -35,6 +35,7 @@
 int xl_run_bwd_op(const xl_op &op, hipStream_t st);   // xl_cnn_bwd.hip
 int xl_run_split_gemm(const xl_op &op, hipStream_t st);   // xl_gemm_split.hip
 int xl_run_split_stem(const xl_op &op, hipStream_t st);   // xl_stem_split.hip
+int xl_run_pair_stem(const xl_op &op, hipStream_t st);    // xl_stem_pair.hip
 int xl_run_stem12(const xl_op &op, hipStream_t st);       // xl_stem_fused.hip
 int xl_run_s2_dgrad(const xl_op &op, hipStream_t st);     // xl_stem_dgrad.hip
 
@@ -2282,6 +2283,7 @@ int run_conv(const xl_op &op, hipStream_t st)
         return wide ? XL_FWD(3, 1, 128, 0, 128) : XL_FWD(3, 1, 64, 0, 128);
     }
     if (op.ksize == 3 && op.stride == 2) {
+        if (op.flags & XL_CONV_PAIR_F16) return xl_run_pair_stem(op, st);
         if (op.flags & XL_CONV_SPLIT_BF16) return xl_run_split_stem(op, st);
         if (small) return wide ? XL_FWD(3, 2, 128, 0, 64) : XL_FWD(3, 2, 64, 0, 64);
         return wide ? XL_FWD(3, 2, 128, 0, 128) : XL_FWD(3, 2, 64, 0, 128);

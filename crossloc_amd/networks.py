@@ -482,10 +482,22 @@ class _Plan:
             self._pack_pair(planes, src, 0)
         return self.packed_pair[key][0]
 
+    def pack_conv_stem_pair(self, conv):
+        """[Cout][9 Cin / 16][2][16] fp16 pairs {hi, lo} of a 3x3 convolution's weight, K ordered tap-major, + 2 floats."""
+        key = (id(conv.weight), "stem_pair")
+        if key not in self.packed_pair:
+            src = conv.weight.detach().to(device=self.device, dtype=torch.float32).contiguous()   # aliases the live parameter
+            planes = torch.empty(2 * src.numel() + 4, dtype=torch.int16, device=self.device)
+            self.packed_pair[key] = (planes, src, 0)
+            self._pack_pair(planes, src, 0)
+        return self.packed_pair[key][0]
+
     def _pack_pair(self, planes, src, m):
         stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         if m:
             _check(_bind().xl_cnn_pack_wino_weight_pair(src.data_ptr(), planes.data_ptr(), src.shape[0], src.shape[1], m, 0, stream))
+        elif src.dim() == 4 and src.shape[2] == 3:
+            _check(_bind().xl_cnn_pair_weight(src.data_ptr(), planes.data_ptr(), src.shape[0], src.shape[1] * 9, 9, stream))
         else:
             _check(_bind().xl_cnn_pair_weight(src.data_ptr(), planes.data_ptr(), src.shape[0], src.shape[1], 1, stream))
 
@@ -752,7 +764,13 @@ class _Plan:
             op.reserved_i = 64                        # (the normalise-on-load form exists with 128-row tiles only)
         if split and k == 3:                          # stride-2 stem layer on the split pipe (no statistics epilogue)
             op.flags |= CONV_SPLIT_BF16 | CONV_SPLIT_IL
-            op.w = self.pack_conv_stem_split(conv).data_ptr()
+            if self.pair_ok() and norm_in is not None and not os.environ.get("XL_NO_PAIR_STEM"):
+                # round 5: fp16 pairs, three passes (csrc/xl_stem_pair.hip); the operand is a GroupNorm output normalised on load
+                op.flags |= CONV_PAIR_F16
+                op.w = self.pack_conv_stem_pair(conv).data_ptr()
+                op.scale = self.pair_scales.data_ptr()
+            else:
+                op.w = self.pack_conv_stem_split(conv).data_ptr()
             op.reserved_i = 0
             if (cout == 256 and -(-self.B * Ho * Wo // 256) < 128 and not os.environ.get("XL_NO_SMALL_TILES")):
                 op.reserved_i = 128                  # latency form: 128 x 128 tiles when 256-row tiles leave the chip idle

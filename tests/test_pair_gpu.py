@@ -270,6 +270,74 @@ def test_pair_conv1x1_residual_on_load(cin, cout, B, H, W, pad, form):
     assert esp < 2e-6, esp
 
 
+@pytest.mark.parametrize("cin,cout,B,H,W,norm,relu,pad", [
+    (64, 128, 2, 60, 90, True, True, 0), (128, 256, 2, 60, 90, True, True, 0), (32, 64, 2, 40, 64, True, True, 0),
+    (64, 128, 3, 37, 53, True, False, 32), (128, 256, 5, 33, 41, False, False, 0), (128, 256, 1, 120, 180, True, True, 0),
+    (32, 64, 1, 97, 131, False, False, 0)])
+def test_stride2_stem_conv_as_fp16_pairs(cin, cout, B, H, W, norm, relu, pad):
+    """pair_conv3x3s2_kernel (csrc/xl_stem_pair.hip): the stride-2 3x3 stem layers with three fp16 passes - against a float64
+    convolution, beside the six-pass bf16 kernel, with the GroupNorm partial sums of the epilogue."""
+    g = torch.Generator().manual_seed(cin + cout + B + H)
+    x = torch.randn(B, cin, H, W, generator=g) * 3.0 + 1.0
+    coef = torch.stack([torch.rand(B, cin, generator=g) + 0.5, torch.randn(B, cin, generator=g)], 2)
+    conv = nn.Conv2d(cin, cout, 3, 2, 1)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) * (2.0 / (9 * cin)) ** 0.5)
+        conv.bias.copy_(torch.randn(cout, generator=g))
+        xn = x.double()
+        if norm:
+            xn = xn * coef[:, :, 0, None, None].double() + coef[:, :, 1, None, None].double()
+            if relu:
+                xn = xn.clamp(min=0)
+        ref = F.conv2d(xn, conv.weight.double(), conv.bias.double(), stride=2, padding=1)
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    wide_in = torch.full((B, H, W, cin + pad), float("nan"))
+    wide_in[..., pad:] = x.permute(0, 2, 3, 1)
+    xd = wide_in.cuda()
+    wsrc = conv.weight.detach().cuda().contiguous()
+    wp = torch.zeros(2 * wsrc.numel() + 4, dtype=torch.int16, device="cuda")
+    networks._check(networks._bind().xl_cnn_pair_weight(wsrc.data_ptr(), wp.data_ptr(), cout, 9 * cin, 9, None))
+    wb = networks._Plan.split_bf16_interleaved(networks._Plan._stem_rows(wsrc), 9 * cin)
+    bd, cd = conv.bias.detach().cuda(), coef.contiguous().cuda()
+    scale = _scale_for(xn.abs().max().item(), 5)
+    bm, wm = {64: (128, 4), 128: (128, 2), 256: (256, 2)}[cout]
+    HWo = Ho * Wo
+    nchunks = (-(-HWo // bm) + 1) * wm
+
+    def run(pair):
+        out = torch.full((B, Ho, Wo, cout + pad), float("nan"), device="cuda")
+        stats = torch.full((B, nchunks, 32, 2), float("nan"), dtype=torch.float64, device="cuda")
+        op = networks.XlOp()
+        op.type = networks.XL_OP_CONV
+        op.B, op.Hi, op.Wi, op.Cin, op.Ho, op.Wo, op.Cout = B, H, W, cin, Ho, Wo, cout
+        op.ksize, op.stride, op.ld_in, op.ld_out = 3, 2, cin + pad, cout + pad
+        op.flags = PAIR if pair else (networks.CONV_SPLIT_BF16 | networks.CONV_SPLIT_IL)
+        if norm:
+            op.flags |= networks.CONV_NORM_IN | (networks.CONV_NORM_RELU if relu else 0)
+            op.aux2 = cd.data_ptr()
+        op.in_, op.w, op.bias, op.out = xd.data_ptr() + 4 * pad, (wp if pair else wb).data_ptr(), bd.data_ptr(), out.data_ptr()
+        op.scale = scale.data_ptr()
+        op.stats, op.groups, op.nchunks = stats.data_ptr(), 32, nchunks
+        _run([op, op])
+        o = out.cpu()
+        if pad:
+            assert torch.isnan(o[..., cout:]).all()
+        return o[..., :cout].permute(0, 3, 1, 2).double(), stats.cpu()
+    got, st = run(True)
+    six, _ = run(False)
+    sc = ref.abs().max().item()
+    esp, e6 = (got - ref).abs().max().item() / sc, (six - ref).abs().max().item() / sc
+    assert esp < 2e-6 and esp <= 1.5 * e6 + 1e-7, (esp, e6)
+    grouped = got.reshape(B, 32, cout // 32, HWo)
+    for n in range(B):
+        valid = (((n + 1) * HWo - 1) // bm - (n * HWo) // bm + 1) * wm
+        assert torch.isfinite(st[n, :valid]).all() and torch.isnan(st[n, valid:]).all(), (n, valid)
+        s1, s2 = st[n, :valid, :, 0].sum(0), st[n, :valid, :, 1].sum(0)
+        r1, r2 = grouped[n].sum((1, 2)), (grouped[n] ** 2).sum((1, 2))
+        assert ((s1 - r1).abs() <= 2e-6 * grouped[n].abs().sum((1, 2))).all(), (n, (s1 - r1).abs().max())
+        assert torch.allclose(s2, r2, rtol=2e-6, atol=0), (n, ((s2 - r2) / r2).abs().max())
+
+
 @pytest.mark.parametrize("defer", [0, 1, 2])
 def test_winograd_input_transform_writes_the_pairs_of_its_fp32_result(defer):
     """XL_OP_WINO_IN with XL_CONV_PAIR_F16: V as activation pairs = the split of the fp32 transform's V, to the bit."""
