@@ -37,7 +37,10 @@ def main():
                     "%.3f" % (v("SQ_INSTS_SALU") / max(nv, 1.0)),
                     "%.4f" % (v("SQ_LDS_BANK_CONFLICT") / max(v("SQ_LDS_IDX_ACTIVE"), 1.0)),
                     "%.2f" % (v("SQ_INSTS_VALU_MFMA_MOPS_F32") * 512.0 / 1e9),
-                    "%.2f" % (v("SQ_INSTS_VALU_MFMA_MOPS_BF16") * 512.0 / 1e9)])
+                    # (16-bit matrix pipe: bf16 + fp16 MFMA operations - round 5's pair kernels are fp16; a pass that did not collect
+                    #  the F16 counter reads it as 0)
+                    "%.2f" % ((v("SQ_INSTS_VALU_MFMA_MOPS_BF16") + (v("SQ_INSTS_VALU_MFMA_MOPS_F16") if "SQ_INSTS_VALU_MFMA_MOPS_F16" in c else 0.0))
+                              * 512.0 / 1e9)])
     with open(dst, "w", newline="") as fh:
         w = csv.writer(fh)
         w.writerow(cols)

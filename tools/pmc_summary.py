@@ -30,7 +30,10 @@ def main():
             name = m.group(1).replace(" ", "")
             if name.startswith("split_conv1x1_kernel<false,false,") and name.split(",")[3] == "2":
                 pass                                  # ZB = 2: one launch shape by construction (Cin = Cout = 512, Z = 64)
-            elif "persist" in name or name.startswith(("split_conv1x1_kernel", "split_conv3x3s2_kernel")):
+            elif name.startswith("pair_gemm_kernel<512"):
+                pass                                  # round 5: Cin = 512 -> the 64 GEMMs of a 512 -> 512 layer, one launch shape
+            elif "persist" in name or name.startswith(("split_conv1x1_kernel", "split_conv3x3s2_kernel", "pair_conv1x1_kernel",
+                                                      "pair_conv1x1_res_kernel", "pair_conv3x3s2_kernel", "pair_gemm_kernel")):
                 name += "@%dus" % (4 ** round(math.log(max(d, 1.0), 4)))  # (reading aid only, see the header)
             key = (name, int(r["Grid_Size"]), int(r["VGPR_Count"]) + int(r["Accum_VGPR_Count"]),
                    int(r["LDS_Block_Size"]), r["Counter_Name"])

@@ -51,6 +51,13 @@ def main():
         r = cand[0]
         assert int(r["dispatches_per_pass"]) % 9 == 0, "9 layers of that shape per forward pass: %s dispatches" % r["dispatches_per_pass"]
         recs.append(record("splitact64", r["kernel"], r))
+    # round 5: the same launches as fp16 pairs, both operands by DMA (pair_gemm_kernel<512,0>: Cin = 512, one launch shape)
+    cand = [r for r in rows if r["kernel"].replace(" ", "") == "pair_gemm_kernel<512,0>"]
+    assert len(cand) <= 1, "the dominant kernel must be one row (one launch shape)"
+    if cand:
+        r = cand[0]
+        assert int(r["dispatches_per_pass"]) % 9 == 0, "9 layers of that shape per forward pass: %s dispatches" % r["dispatches_per_pass"]
+        recs.append(record("pair64", r["kernel"], r))
     solver = {}
     for r in rows:
         if r["kernel"].startswith("xl_dsac_forward_kernel"):
