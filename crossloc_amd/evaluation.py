@@ -5,6 +5,8 @@ localisation (CNN forward + HIP DSAC* per batch) and image-level sharding over t
 all-gather of the per-image errors (the median is not decomposable, hence gather not reduce).
 """
 import numpy as np
+import os
+
 import torch
 
 
@@ -222,7 +224,11 @@ class PipelinedLocalizer:
         self.net, self.n_hyp, self.focal = network, n_hyp, focal
         self.h, self.w = image_h, image_w
         self.thr, self.alpha, self.maxerr = threshold, inlier_alpha, max_pixel_error
-        self.side = torch.cuda.Stream()
+        # (round 5) the solver's stream has the HIGHER priority: its 95 workgroups (64.8 KB of LDS each) otherwise queue behind the
+        # persistent workgroups of the next batch's stem and GEMM kernels, and both stages run slow for 5 ms instead of the 2 ms
+        # the solver needs when it gets its CUs at once (XL_SOLVER_PRIORITY=0: equal priorities, the round-4 behaviour)
+        prio = -1 if os.environ.get("XL_SOLVER_PRIORITY", "1") not in ("", "0") else 0
+        self.side = torch.cuda.Stream(priority=prio)
         self.cnn = [torch.cuda.Stream() for _ in range(max(1, cnn_streams))]
 
     def forward_cnn(self, images, plant=None):
