@@ -1327,21 +1327,19 @@ void wino6_in_kernel(const float *__restrict__ in, float *__restrict__ V, int B,
             continue;
         }
         if constexpr (SPLIT == 3) {
-            // fp16 pairs (round 5, XL_CONV_PAIR_F16, csrc/xl_gemm_pair.hip): V[xi][t][c / 16][2][16] fp16 = {hi, (v - hi) 2^11} of
-            // v = V * scale.  A row is C words of 4 bytes like the fp32 form; the 64 lanes of a wave hold 128 consecutive channels
-            // of one tile = 8 chunks = one contiguous 512-byte piece per frequency, but a lane's two words (its channel pair's hi
-            // and lo halves) lie 32 bytes apart.  They are exchanged through a wave-private LDS row laid out like the memory
-            // piece, so that every lane stores 8 contiguous bytes: one dwordx2 store per frequency like the fp32 form (two
-            // scattered dword stores per frequency measured 0.66 against 0.51 ms per 512-channel launch at 95 frames).
-            // C % 128 == 0 and whole waves: checked by the launcher.
+            // fp16 pairs (round 5, XL_CONV_PAIR_F16, csrc/xl_gemm_pair.hip): V[xi][t][c / 8][2][8] fp16 = {hi, (v - hi) 2^11} of
+            // v = V * scale - a 16-byte slot of hi then one of lo' per 8 channels, so a K-step of 16 channels is the four slots
+            // hi(k 0-7) lo'(k 0-7) hi(k 8-15) lo'(k 8-15).  A row is C words of 4 bytes like the fp32 form, and the four lanes
+            // that hold 8 consecutive channels own the 32 bytes of their chunk: a lane's two words (hi and lo' of its channel pair)
+            // are exchanged inside the QUAD on the DPP path - neighbours trade one word (even lanes collect the hi pair, odd lanes
+            // the lo' pair), then lanes 1 and 2 swap - so that lane q stores bytes 8 q .. 8 q + 7: the same dwordx2 store, at the
+            // same address, as the fp32 form.  (Through a wave-private LDS row instead: 0.60 / 1.07 ms per 512-channel launch at 95
+            // frames, plain / fold form, against 0.51 / 0.83 for fp32.)
             typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
             typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-            __shared__ unsigned sP[4][2][128];
             const float sc = pairScale[0];
-            const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-            const int c = 2 * c2;
-            unsigned *op = reinterpret_cast<unsigned *>(V) + t * C + (c - 2 * lane) + 2 * lane;        // the wave's piece + 8 bytes per lane
-            const int wr = (lane >> 3) * 16 + (lane & 7);                                 // chunk, pair within the chunk
+            const bool odd = (threadIdx.x & 1) != 0, mid = ((threadIdx.x + 1) & 2) != 0;      // lanes 1 and 2 of a quad
+            unsigned *op = reinterpret_cast<unsigned *>(V) + t * C + 2 * c2;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 f32x2 o[8];
@@ -1351,10 +1349,13 @@ void wino6_in_kernel(const float *__restrict__ in, float *__restrict__ V, int B,
                     const f32x2 x = o[j] * sc;
                     const f16x2 h = __builtin_convertvector(x, f16x2);
                     const f16x2 l = __builtin_convertvector((x - __builtin_convertvector(h, f32x2)) * 2048.f, f16x2);
-                    unsigned *row = sP[wv][j & 1];
-                    row[wr] = __builtin_bit_cast(unsigned, h); row[wr + 8] = __builtin_bit_cast(unsigned, l);
-                    const u32x2 v2 = *reinterpret_cast<const u32x2 *>(row + 2 * lane);
-                    *reinterpret_cast<u32x2 *>(op + (8 * i + j) * zs) = v2;
+                    const int H = __builtin_bit_cast(int, h), L = __builtin_bit_cast(int, l);
+                    const int recv = __builtin_amdgcn_update_dpp(0, odd ? H : L, 0xB1, 0xF, 0xF, false);      // quad_perm [1,0,3,2]
+                    int p0 = odd ? recv : H, p1 = odd ? L : recv;                 // even lanes: (hi, hi'), odd lanes: (lo', lo'')
+                    const int s0 = __builtin_amdgcn_update_dpp(0, p0, 0xD8, 0xF, 0xF, false);                 // quad_perm [0,2,1,3]
+                    const int s1 = __builtin_amdgcn_update_dpp(0, p1, 0xD8, 0xF, 0xF, false);
+                    p0 = mid ? s0 : p0; p1 = mid ? s1 : p1;
+                    *reinterpret_cast<u32x2 *>(op + (8 * i + j) * zs) = u32x2{ (unsigned)p0, (unsigned)p1 };
                 }
             }
             continue;
@@ -2395,7 +2396,7 @@ int run_op(const xl_op &op, hipStream_t st)
                     kin = (op.flags & XL_CONV_PAIR_F16) ? wino6_in_kernel<1, 3, 1> : wino6_in_kernel<1, 0, 1>;
                 } else if (op.flags & XL_CONV_PAIR_F16)
                     kin = !op.aux2 ? wino6_in_kernel<0, 3> : (op.flags & XL_GN_RELU_IN) ? wino6_in_kernel<2, 3> : wino6_in_kernel<1, 3>;
-                if ((op.flags & XL_CONV_PAIR_F16) && (!op.scale || op.Cin % 128 != 0)) return XL_ERR_ARG;      // a wave = 128 channels of one tile
+                if ((op.flags & XL_CONV_PAIR_F16) && (!op.scale || op.Cin % 16 != 0)) return XL_ERR_ARG;       // (a quad = 8 channels of one tile)
                 hipLaunchKernelGGL(kin, dim3((unsigned)blocks6), dim3(256), 0, st, (const float *)op.in,
                                    (float *)op.out, op.B, op.Hi, op.Wi, op.Cin, op.ld_in, op.Ho, op.Wo,
                                    (const float *)op.aux2, fold, (const float *)op.scale);

@@ -21,7 +21,7 @@
 // (`split_gemm_err_vs_f64`, beside the fp32-MFMA kernel's own).
 //
 // Layouts (K-step = 16 channels = one k-depth of the MFMA):
-//     activations  [Z][rows][C/16][2][16] fp16     64 bytes per row and K-step  (4 bytes per element: what fp32 costs)
+//     activations  [Z][rows][C/8][2][8] fp16       64 bytes per row and K-step  (4 bytes per element: what fp32 costs)
 //     weights      [Z][rows][C/16][2][16] fp16     the same, then 2 Z floats: scratch, inverse scales
 // Kernels:
 //   pair_gemm_kernel      - both operands arrive in that form (V written by the Winograd input transform) and reach LDS by
@@ -138,9 +138,14 @@ void pair_gemm_kernel(PairArgs a)
 
     // ---- fragments: lane -> row lane & 31 of a 32-row block, k-half lane >> 5 (8 fp16 = one 16-byte slot)
     const int fr = lane & 31, kh = lane >> 5;
-    unsigned slot[2];
+    // (a K-step's four slots: activations hi(k 0-7) lo'(k 0-7) hi(k 8-15) lo'(k 8-15) - what the input transform's quads write -,
+    //  weights hi(k 0-7) hi(k 8-15) lo(k 0-7) lo(k 8-15))
+    unsigned slot[2], slotA[2];
 #pragma unroll
-    for (int p = 0; p < 2; ++p) slot[p] = (unsigned)(((2 * p + kh) ^ swz(fr)) * 16);
+    for (int p = 0; p < 2; ++p) {
+        slot[p] = (unsigned)(((2 * p + kh) ^ swz(fr)) * 16);
+        slotA[p] = (unsigned)(((2 * kh + p) ^ swz(fr)) * 16);
+    }
     const unsigned frA = (unsigned)((wm * 128 + fr) * kPA), frB = (unsigned)(kOpA + (wn * 64 + fr) * kPB);
     f16x8 fa[2][4], fb[2][2], fbs[2];                                 // [hi, lo'][row block], [hi, lo][column block], hs
     f16x8 faN[4], fbN[2];
@@ -148,7 +153,7 @@ void pair_gemm_kernel(PairArgs a)
     bool readOn = true;
     auto ldA = [&](const unsigned char *sb, int p, int i) {
         if ((DBG & 2) && !readOn) return faN[i];
-        return *reinterpret_cast<const f16x8 *>(sb + frA + i * 32 * kPA + slot[p]);
+        return *reinterpret_cast<const f16x8 *>(sb + frA + i * 32 * kPA + slotA[p]);
     };
     auto ldB = [&](const unsigned char *sb, int p, int j) {
         if ((DBG & 2) && !readOn) return fbN[j];

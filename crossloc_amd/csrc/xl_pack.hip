@@ -206,7 +206,7 @@ void pair_weight_kernel(const float *__restrict__ src, uint16_t *__restrict__ ds
     if (PASS == 0 && m) atomicMax(maxBits, m);
 }
 
-// activation pairs [rows][K/16][2][16] fp16 {hi, (x - hi) * 2^11} of x = src * scale[0]
+// activation pairs [rows][K/8][2][8] fp16 {hi, (x - hi) * 2^11} of x = src * scale[0] (the layout the Winograd input transform writes)
 __global__ __launch_bounds__(256)
 void pair_activation_kernel(const float *__restrict__ src, uint16_t *__restrict__ dst, long long rows, int K, const float *__restrict__ scale)
 {
@@ -218,8 +218,8 @@ void pair_activation_kernel(const float *__restrict__ src, uint16_t *__restrict_
         const float x = src[i] * sc;
         const _Float16 h = (_Float16)x;
         const _Float16 l = (_Float16)((x - (float)h) * 2048.f);
-        const long long b0 = (r * (K >> 4) + (k >> 4)) * 32 + (k & 15);
-        dst[b0] = __builtin_bit_cast(uint16_t, h); dst[b0 + 16] = __builtin_bit_cast(uint16_t, l);
+        const long long b0 = (r * (K >> 3) + (k >> 3)) * 16 + (k & 7);
+        dst[b0] = __builtin_bit_cast(uint16_t, h); dst[b0 + 8] = __builtin_bit_cast(uint16_t, l);
     }
 }
 

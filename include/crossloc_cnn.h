@@ -124,7 +124,7 @@ enum {
                                   registers; the three products hi*hi, hi*lo and lo*hs are exact in fp32
                                   (v_mfma_f32_32x32x16_f16, fp32 accumulate), what is dropped (lo*lo) is below 2^-22 of the
                                   leading product; the epilogue un-scales (exact).  Layouts, 4 bytes per element (what fp32 costs):
-                                  activations [Z][rows][C/16][2][16] fp16, weights the same followed by 2 Z floats (xl_cnn_pack_wino_weight_pair /
+                                  activations [Z][rows][C/8][2][8] fp16, weights [Z][rows][C/16][2][16] fp16 followed by 2 Z floats (xl_cnn_pack_wino_weight_pair /
                                   xl_cnn_pair_weight).  On XL_OP_WINO_IN (ksize 6): V is written in the activation layout;
                                   on XL_OP_CONV with nchunks2 = Z > 1 and without XL_CONV_SPLIT_ACT: `in` is that V (both operands
                                   reach LDS by DMA, no conversion in the GEMM); with XL_CONV_SPLIT_ACT or nchunks2 <= 1: `in` is
@@ -233,7 +233,7 @@ int xl_cnn_split_weight(const float *src_dev, void *dst_dev, int rows, int K, in
  * xl_cnn_pair_weight: a plain [rows][K] matrix (taps as xl_cnn_split_weight), one scale: rows*K*4 + 8 bytes. */
 int xl_cnn_pack_wino_weight_pair(const float *w_oihw_dev, void *dst_dev, int Cout, int Cin, int m, int dgrad, void *stream);
 int xl_cnn_pair_weight(const float *src_dev, void *dst_dev, int rows, int K, int taps, void *stream);
-/* fp32 [rows][K] -> activation pairs [rows][K/16][2][16] fp16 of src * scale[0] (tests, tools; K % 16 == 0) */
+/* fp32 [rows][K] -> activation pairs [rows][K/8][2][8] fp16 of src * scale[0] (tests, tools; K % 16 == 0) */
 int xl_cnn_pair_activation(const float *src_dev, void *dst_dev, long long rows, int K, const float *scale_dev, void *stream);
 /* The activation scale of a plan: out[0..1] = {s, 1/s} for GroupNorm outputs, out[2..3] = {s/256, 256/s} for their Winograd
  * transforms (|B^T d B| <= 225 max|d| for F(6x6,3x3)), with s the largest power of two such that
