@@ -140,19 +140,22 @@ __device__ __forceinline__ void wino_u_of(const float *__restrict__ w, int Cin, 
             u[x * N + y] = (float)(t[x][0] * WinoG<M>::g[y][0] + t[x][1] * WinoG<M>::g[y][1] + t[x][2] * WinoG<M>::g[y][2]);
 }
 
-// PASS 0: the maxima per frequency; PASS 1: scale, split, store (and the inverse scales)
+// PASS 0: the maxima per frequency; PASS 1: scale, split, store (and the inverse scales).  PASS 0 runs on few workgroups (a thread
+// keeps the running maxima of its elements in registers, the workgroup combines them through an LDS table - no atomics on
+// shared addresses - and issues one global atomicMax per frequency): a training loop re-packs every layer after every step.
 template <int M, int PASS>
 __global__ __launch_bounds__(256)
 void wino_weight_pair_kernel(const float *__restrict__ w, uint16_t *__restrict__ dst, unsigned *__restrict__ maxBits,
                              float *__restrict__ invScale, int Cout, int Cin, int dgrad)
 {
     constexpr int N = M + 2, Z = N * N;
-    __shared__ unsigned sMax[Z];
+    extern __shared__ unsigned sTab[];                                // PASS 0: [256 threads][Z]
     const int rows = dgrad ? Cin : Cout, K = dgrad ? Cout : Cin;
     const long long total = (long long)rows * K;
+    unsigned mx[Z];
     if (PASS == 0) {
-        for (int i = threadIdx.x; i < Z; i += 256) sMax[i] = 0u;
-        __syncthreads();
+#pragma unroll
+        for (int z = 0; z < Z; ++z) mx[z] = 0u;
     }
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const int r = (int)(i / K), k = (int)(i - (long long)r * K);
@@ -160,7 +163,7 @@ void wino_weight_pair_kernel(const float *__restrict__ w, uint16_t *__restrict__
         wino_u_of<M>(w, Cin, dgrad ? k : r, dgrad ? r : k, dgrad, u);
         if (PASS == 0) {
 #pragma unroll
-            for (int z = 0; z < Z; ++z) atomicMax(&sMax[z], __builtin_bit_cast(unsigned, fabsf(u[z])));
+            for (int z = 0; z < Z; ++z) { const unsigned b = __builtin_bit_cast(unsigned, fabsf(u[z])); mx[z] = b > mx[z] ? b : mx[z]; }
         } else {
 #pragma unroll
             for (int z = 0; z < Z; ++z) {
@@ -174,8 +177,14 @@ void wino_weight_pair_kernel(const float *__restrict__ w, uint16_t *__restrict__
         }
     }
     if (PASS == 0) {
+#pragma unroll
+        for (int z = 0; z < Z; ++z) sTab[threadIdx.x * Z + z] = mx[z];
         __syncthreads();
-        for (int i = threadIdx.x; i < Z; i += 256) if (sMax[i]) atomicMax(&maxBits[i], sMax[i]);
+        for (int z = threadIdx.x; z < Z; z += 256) {
+            unsigned m = 0u;
+            for (int t = 0; t < 256; ++t) { const unsigned b = sTab[((t + z) & 255) * Z + z]; m = b > m ? b : m; }   // (staggered: no bank conflicts)
+            if (m) atomicMax(&maxBits[z], m);
+        }
     }
 }
 
@@ -292,18 +301,22 @@ int xl_cnn_pack_wino_weight_pair(const float *w, void *dst, int Cout, int Cin, i
     const int K = dgrad ? Cout : Cin, Z = (m + 2) * (m + 2);
     if (K % 16 != 0) return XL_ERR_ARG;
     const long long total = (long long)Cout * Cin;
-    long long blocks = (total + 255) / 256;
+    long long blocks = (total + 255) / 256, blocks0 = blocks;
     if (blocks > 4096) blocks = 4096;
+    if (blocks0 > 256) blocks0 = 256;                             // PASS 0: one workgroup per CU, a few elements per thread
     hipStream_t st = (hipStream_t)stream;
     uint16_t *d = (uint16_t *)dst;
     unsigned *maxBits = reinterpret_cast<unsigned *>(d + (long long)Z * total * 2);
     float *inv = reinterpret_cast<float *>(maxBits + Z);
     if (hipMemsetAsync(maxBits, 0, sizeof(unsigned) * Z, st) != hipSuccess) return XL_ERR_HIP;
+    const size_t lds0 = sizeof(unsigned) * 256 * Z;
     if (m == 4) {
-        hipLaunchKernelGGL((wino_weight_pair_kernel<4, 0>), dim3((unsigned)blocks), dim3(256), 0, st, w, d, maxBits, inv, Cout, Cin, dgrad ? 1 : 0);
+        hipLaunchKernelGGL((wino_weight_pair_kernel<4, 0>), dim3((unsigned)blocks0), dim3(256), lds0, st, w, d, maxBits, inv, Cout, Cin, dgrad ? 1 : 0);
         hipLaunchKernelGGL((wino_weight_pair_kernel<4, 1>), dim3((unsigned)blocks), dim3(256), 0, st, w, d, maxBits, inv, Cout, Cin, dgrad ? 1 : 0);
     } else {
-        hipLaunchKernelGGL((wino_weight_pair_kernel<6, 0>), dim3((unsigned)blocks), dim3(256), 0, st, w, d, maxBits, inv, Cout, Cin, dgrad ? 1 : 0);
+        // (64 KB of dynamic LDS: set on every call - idempotent, and cheaper than tracking the attribute per device here)
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(wino_weight_pair_kernel<6, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds0) != hipSuccess) return XL_ERR_HIP;
+        hipLaunchKernelGGL((wino_weight_pair_kernel<6, 0>), dim3((unsigned)blocks0), dim3(256), lds0, st, w, d, maxBits, inv, Cout, Cin, dgrad ? 1 : 0);
         hipLaunchKernelGGL((wino_weight_pair_kernel<6, 1>), dim3((unsigned)blocks), dim3(256), 0, st, w, d, maxBits, inv, Cout, Cin, dgrad ? 1 : 0);
     }
     return hipGetLastError() == hipSuccess ? XL_OK : XL_ERR_HIP;

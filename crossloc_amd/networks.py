@@ -420,11 +420,15 @@ class _Plan:
 
     # -- fp16 pair / triple operands (round 5, XL_CONV_PAIR_F16): half the matrix-pipe passes of the split-bf16 GEMMs
     def pair_ok(self):
-        """The GEMMs of inference plans run as three fp16 passes instead of six bf16 ones (csrc/xl_gemm_pair.hip) unless
+        """The forward GEMMs of a plan run as three fp16 passes instead of six bf16 ones (csrc/xl_gemm_pair.hip) unless
         XL_GEMM_PAIR=0.  Every convolution this applies to reads GroupNorm outputs (and sums of them): their magnitude is
         bounded by the GroupNorm parameters, which is what makes ONE static power-of-two scale per plan safe for fp16."""
-        return (not self.train and os.environ.get("XL_GEMM_PAIR", "1") not in ("", "0")
-                and os.environ.get("XL_GEMM_SPLIT_BF16", self.SPLIT_DEFAULT) not in ("", "0", "1"))
+        # (training plans, round 5: the FORWARD GEMMs only - their operands are GroupNorm outputs like an inference plan's; the
+        #  gradients the backward GEMMs read have no such bound and stay on the six-pass bf16 kernels.  XL_TRAIN_PAIR=0: off)
+        if self.train and os.environ.get("XL_TRAIN_PAIR", "1") in ("", "0"):
+            return False
+        return (os.environ.get("XL_GEMM_PAIR", "1") not in ("", "0")
+                and os.environ.get("XL_GEMM_SPLIT_BF16", self.SPLIT_DEFAULT) not in ("", "0", "1") and self.split_train_ok())
 
     def _gn_layers(self):
         """(gamma, beta, C, sqrt(N)) of every GroupNorm of the network: N = the elements of a group, from the op that applies
@@ -963,7 +967,8 @@ class _Plan:
         # the GEMM (pair_conv1x1_kernel with XL_CONV_SPLIT_ACT)
         pair = split_act and m == 6 and self.pair_ok()
         tile_form = self.split_tile_form(T, cout, nf) if split_act else 0
-        pair_dma = pair and tile_form == 256 and not os.environ.get("XL_PAIR_NO_DMA")
+        # (training plans keep V in fp32: it is the left operand of the Winograd weight gradient)
+        pair_dma = pair and tile_form == 256 and not self.train and not os.environ.get("XL_PAIR_NO_DMA")
         if pair_dma:
             op.flags = CONV_PAIR_F16
             op.scale = self.pair_scales.data_ptr() + 8
