@@ -40,19 +40,23 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kTW = 16;                                // conv2 output columns per tile (rows: the template parameter TH)
 constexpr int kPW = 2 * kTW + 1;                       // conv1 output columns the tile needs: 33
 constexpr int kEven = kTW + 1;                         // even patch columns come first in a patch row (17 of them)
 constexpr int kHW = kPW + 3;                           // image halo columns: 36 (35 + the dx = 3 slot of the last pixel)
 constexpr int kPix = 208;                              // bytes per patch pixel: 3 planes x 64 B + 16
+constexpr int kPixPair = 144;                          // ... of the fp16-pair form (round 5): 2 planes x 64 B + 16 (9 x 16 as 13 x 16: odd)
 // TH = 8: 17 x 33 patch (116 688 B) + 19 x 36 halo (16 416 B): one workgroup per CU.  TH = 4: 9 x 33 patch (61 776 B) + 11 x 36
 // halo (9 504 B) = 71 KB: TWO workgroups per CU (8 waves: the conversion-heavy conv1 phase of one overlaps the MFMA-only conv2
 // phase of the other), or one beside a workgroup of the solver (64.8 KB), which runs on a side stream under the stem.
-template <int TH> struct S12 {
+template <int TH, bool PAIR = false> struct S12 {
     static constexpr int kPH = 2 * TH + 1, kHH = kPH + 2;
     static constexpr int kNPix = kPH * kPW, kBlocks = (kNPix + 31) / 32;
-    static constexpr int kPatchBytes = kNPix * kPix, kHaloPix = kHH * kHW, kHaloBytes = 3 * kHaloPix * 8;
+    static constexpr int kPixB = PAIR ? kPixPair : kPix;
+    static constexpr int kPatchBytes = kNPix * kPixB, kHaloPix = kHH * kHW, kHaloBytes = 3 * kHaloPix * 8;
     static constexpr int kE = (kHaloPix + 255) / 256;                // halo pixels per thread
     static constexpr int kPB = TH / 2;                               // 32-pixel blocks per tile (4 waves: kPB x 4 / kPB column blocks)
 };
@@ -88,7 +92,8 @@ struct Stem12Args {
     const u32x4 *w1;             // conv1 weight fragments [3 planes][3 window rows][64 lanes] x 16 B (networks._Plan.conv1_fragments)
     const float *b1;             // [32]
     const float *coef;           // [B][32][2] {scale, shift} of conv1's GroupNorm (XL_OP_GN_FINAL)
-    const u32x4 *w2;             // conv2 weight fragments [18 K-steps][3 planes][2 column blocks][64 lanes] x 16 B
+    const u32x4 *w2;             // conv2 weight fragments [18 K-steps][3 planes][2 column blocks][64 lanes] x 16 B (PAIR: 2 planes {hi, lo} fp16)
+    const float *aScale;         // PAIR: {s, 1 / s} of the activations (conv1's normalised output); conv2's inverse weight scale: one float behind w2
     const float *b2;             // [64]
     float *out;                  // [B][Ho][Wo][64], pixel stride ldOut
     int B, H, W, Ho, Wo, ldOut, tilesX, tilesY;
@@ -101,11 +106,16 @@ struct Stem12Args {
 };
 
 
-template <int TH>
+// PAIR (round 5): conv2 as three fp16 passes (csrc/xl_gemm_pair.hip's arithmetic, term for term that of pair_conv3x3s2_kernel<64>:
+// the raw conv2 output stays bitwise what the two-kernel path produces): conv1's normalised output times the plan's scale goes
+// into the patch as {hi, lo'} (144 bytes per pixel), conv2's weights arrive as {hi, lo} fragments of the scaled matrix, hs = hi 2^-11
+// in registers.  conv1 itself - its operand is the IMAGE, for which there is no bound - keeps the three bf16 terms.
+template <int TH, bool PAIR = false>
 __global__ __launch_bounds__(256, TH == 8 ? 1 : 2)
 void stem12_kernel(Stem12Args a)
 {
-    typedef S12<TH> K;
+    typedef S12<TH, PAIR> K;
+    constexpr int kPixB = K::kPixB, NPL = PAIR ? 2 : 3;
     constexpr int kTH = TH, kHH = K::kHH, kNPix = K::kNPix, kBlocks = K::kBlocks, kPatchBytes = K::kPatchBytes;
     constexpr int kHaloPix = K::kHaloPix, kE = K::kE, kPB = K::kPB, kNJ = kPB == 4 ? 2 : 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
@@ -128,7 +138,7 @@ void stem12_kernel(Stem12Args a)
     // accumulator element r of a lane: pixel lane & 31, channel 8 (r >> 2) + 4 kh + (r & 3) (+ 32 j for conv2's column block j)
     // conv2: wave -> (32-pixel block pxb: tile rows 2 pxb, 2 pxb + 1; first column block jb; kNJ column blocks of 32 channels)
     const int pxb = wave % kPB, jb = (wave / kPB) * kNJ;
-    if (tid < 64) sTab[64 + tid] = a.b2[tid];                         // (visible after the first barrier)
+    if (tid < 64) { if (!PAIR) sTab[64 + tid] = a.b2[tid]; }          // (visible after the first barrier)
     else if (tid < 96) sTab[64 + tid] = a.b1[tid - 64];               // conv1 bias[32] at sTab[128]
 
     // image halo of a tile: pixel i = tid + 256 e of the 19 x 36 window, three channels each, fetched one tile ahead
@@ -151,9 +161,17 @@ void stem12_kernel(Stem12Args a)
 
     // conv2: my output pixel inside the tile and the byte offset of its patch record (tap (0, 0), plane 0)
     const int oyl = 2 * pxb + (fr >> 4), oxl = fr & 15;
-    const unsigned aBase = (unsigned)(((2 * oyl) * kPW + oxl) * kPix + kh * 16);
+    const unsigned aBase = (unsigned)(((2 * oyl) * kPW + oxl) * kPixB + kh * 16);
+    float aS = 1.f, unscale = 1.f;
+    if constexpr (PAIR) {
+        aS = a.aScale[0];
+        const float uInv = reinterpret_cast<const float *>(a.w2 + 18 * 2 * 2 * 64)[0];     // (behind the fragments)
+        unscale = a.aScale[1] * uInv;
+        // biases of conv2 in the scaled domain (bias * s * weight scale: powers of two)
+        if (tid < 64) sTab[64 + tid] = a.b2[tid] * (aS * (1.f / uInv));
+    }
 
-    const __amdgpu_buffer_rsrc_t srdW2 = __builtin_amdgcn_make_buffer_rsrc((void *)a.w2, 0, 18 * 3 * 2 * 1024, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srdW2 = __builtin_amdgcn_make_buffer_rsrc((void *)a.w2, 0, 18 * NPL * 2 * 1024, 0x00020000);
     long long cPh[6] = { 0, 0, 0, 0, 0, 0 }, cT = 0, nTiles = 0;
     auto stamp = [&](int ph) { if (a.clk) { const long long now = clock64(); cPh[ph] += now - cT; cT = now; } };
     // Tiles come from a queue (one atomic per tile, fetched two tiles ahead), not from a static stride: the solver of the batch
@@ -188,7 +206,7 @@ void stem12_kernel(Stem12Args a)
         // {scale, shift} of the 32 conv1 channels for this image (a table in LDS: 32 registers fewer than per-lane copies)
         if (tid < 32) {
             const f32x2 c2 = *reinterpret_cast<const f32x2 *>(a.coef + ((long long)n * 32 + tid) * 2);
-            sTab[tid] = c2[0]; sTab[32 + tid] = c2[1];
+            sTab[tid] = c2[0] * aS; sTab[32 + tid] = c2[1] * aS;       // (PAIR: {scale, shift} s - fmaf(x, scale s, shift s) = s fmaf(x, scale, shift))
         }
         stamp(0);                                                      // halo split + coefficient loads
         __syncthreads();
@@ -196,13 +214,13 @@ void stem12_kernel(Stem12Args a)
         const int tAfter = sQ[0];
         // conv2's weight fragments of the first three K-steps: in flight under conv1
         constexpr int D = kNJ == 1 ? 6 : 3;                 // K-steps of weight fragments in flight (6 kNJ MFMAs = 192 kNJ cycles each)
-        u32x4 fbr[D][3][kNJ];
+        u32x4 fbr[D][NPL][kNJ];
         auto load_b = [&](int kk, int slot) {
 #pragma unroll
-            for (int p = 0; p < 3; ++p)
+            for (int p = 0; p < NPL; ++p)
 #pragma unroll
                 for (int j = 0; j < kNJ; ++j)          // (buffer load: one lane-offset register + a scalar offset per fragment)
-                    fbr[slot][p][j] = __builtin_amdgcn_raw_buffer_load_b128(srdW2, (int)(lane * 16), (int)(((kk * 3 + p) * 2 + jb + j) * 1024), 0);
+                    fbr[slot][p][j] = __builtin_amdgcn_raw_buffer_load_b128(srdW2, (int)(lane * 16), (int)(((kk * NPL + p) * 2 + jb + j) * 1024), 0);
         };
 #pragma unroll
         for (int kk = 0; kk < D; ++kk) load_b(kk, kk);
@@ -241,7 +259,7 @@ void stem12_kernel(Stem12Args a)
             const int iy = 2 * oy0 - 1 + pr, ix = 2 * ox0 - 1 + x;
             const bool inimg = ((unsigned)iy < (unsigned)a.H) & ((unsigned)ix < (unsigned)a.W);
             const float lo = inimg ? a.normLo : 0.f, hi = inimg ? __builtin_inff() : 0.f;
-            unsigned char *dst = sPatch + Lc * kPix + kh * 8;
+            unsigned char *dst = sPatch + Lc * kPixB + kh * 8;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const f32x4 sc4 = *reinterpret_cast<const f32x4 *>(sTab + 8 * q + 4 * kh), sh4 = *reinterpret_cast<const f32x4 *>(sTab + 32 + 8 * q + 4 * kh);
@@ -249,11 +267,19 @@ void stem12_kernel(Stem12Args a)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(fmaf(acc[4 * q + e], sc4[e], sh4[e]), lo, hi);
                 unsigned wa[3], wb[3];
-                s12_split_pair(f32x2{ v[0], v[1] }, wa[0], wa[1], wa[2]);
-                s12_split_pair(f32x2{ v[2], v[3] }, wb[0], wb[1], wb[2]);
+                if constexpr (PAIR) {
+                    const f32x2 va = f32x2{ v[0], v[1] }, vb = f32x2{ v[2], v[3] };
+                    const f16x2 ha = __builtin_convertvector(va, f16x2), hb = __builtin_convertvector(vb, f16x2);
+                    wa[0] = __builtin_bit_cast(unsigned, ha); wb[0] = __builtin_bit_cast(unsigned, hb);
+                    wa[1] = __builtin_bit_cast(unsigned, __builtin_convertvector((va - __builtin_convertvector(ha, f32x2)) * 2048.f, f16x2));
+                    wb[1] = __builtin_bit_cast(unsigned, __builtin_convertvector((vb - __builtin_convertvector(hb, f32x2)) * 2048.f, f16x2));
+                } else {
+                    s12_split_pair(f32x2{ v[0], v[1] }, wa[0], wa[1], wa[2]);
+                    s12_split_pair(f32x2{ v[2], v[3] }, wb[0], wb[1], wb[2]);
+                }
                 if (valid) {
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x2 *>(dst + p * 64 + q * 16) = u32x2{ wa[p], wb[p] };
+                    for (int p = 0; p < NPL; ++p) *reinterpret_cast<u32x2 *>(dst + p * 64 + q * 16) = u32x2{ wa[p], wb[p] };
                 }
             }
         }
@@ -275,22 +301,44 @@ void stem12_kernel(Stem12Args a)
 #pragma unroll
         for (int kk = 0; kk < 18; ++kk) {
             const int tap = kk >> 1, c = kk & 1, ky = tap / 3, kx = tap - 3 * ky;
-            const unsigned off = (unsigned)((ky * kPW + (kx & 1) * kEven + (kx >> 1)) * kPix + c * 32);
+            const unsigned off = (unsigned)((ky * kPW + (kx & 1) * kEven + (kx >> 1)) * kPixB + c * 32);
+            const int slot = kk % D;
+            if constexpr (PAIR) {
+                f16x8 fa[2];
+#pragma unroll
+                for (int p = 0; p < 2; ++p) fa[p] = *reinterpret_cast<const f16x8 *>(sPatch + aBase + off + p * 64);
+                // hs x lo', lo x hi, hi x hi: pair_conv3x3s2_kernel's terms and order
+#pragma unroll
+                for (int j = 0; j < kNJ; ++j) {
+                    const f16x8 hs = __builtin_bit_cast(f16x8, fbr[slot][0][j]) * (_Float16)0.00048828125f;
+                    acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hs, fa[1], acc2[j], 0, 0, 0);
+                }
+#pragma unroll
+                for (int j = 0; j < kNJ; ++j)
+                    acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fbr[slot][1][j]), fa[0], acc2[j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < kNJ; ++j)
+                    acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fbr[slot][0][j]), fa[0], acc2[j], 0, 0, 0);
+            } else {
             bf16x8 fa[3];
 #pragma unroll
             for (int p = 0; p < 3; ++p) fa[p] = *reinterpret_cast<const bf16x8 *>(sPatch + aBase + off + p * 64);
-            const int slot = kk % D;
             constexpr int PU[6] = { 2, 1, 0, 1, 0, 0 }, PV[6] = { 0, 1, 2, 0, 1, 0 };   // (weights, activations): split_conv3x3s2's order
 #pragma unroll
             for (int tm = 0; tm < 6; ++tm)
 #pragma unroll
                 for (int j = 0; j < kNJ; ++j)
                     acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fbr[slot][PU[tm]][j]), fa[PV[tm]], acc2[j], 0, 0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
             if (kk + D < 18) load_b(kk + D, slot);
             __builtin_amdgcn_sched_barrier(0);
         }
 
+        if constexpr (PAIR) {
+#pragma unroll
+            for (int j = 0; j < kNJ; ++j) acc2[j] *= unscale;         // (exact)
+        }
         stamp(4);                                                      // conv2
         // ---- 4. store: pixel (oy0 + oyl, ox0 + oxl), channels 32 j + 8 q + 4 kh + {0..3}
         const int oy = oy0 + oyl, ox = ox0 + oxl;
@@ -365,6 +413,9 @@ int xl_run_stem12(const xl_op &op, hipStream_t st)
     Stem12Args a;
     a.img = (const float *)op.in; a.w1 = (const u32x4 *)op.w; a.b1 = (const float *)op.bias; a.coef = (const float *)op.aux2;
     a.w2 = (const u32x4 *)op.aux; a.b2 = (const float *)op.stats2; a.out = (float *)op.out; a.queue = (int *)op.out2;
+    const bool pair = (op.flags & XL_CONV_PAIR_F16) != 0;             // aux = conv2 {hi, lo} fragments [18][2][2][64][8] fp16 + the inverse scale
+    if (pair && !op.scale) return XL_ERR_ARG;
+    a.aScale = (const float *)op.scale;
     a.stats = (double *)op.stats; a.nchunks = op.nchunks;
     a.B = op.B; a.H = op.Hi; a.W = op.Wi; a.Ho = op.Ho; a.Wo = op.Wo; a.ldOut = op.ld_out;
     // tile rows: 4 (two workgroups per CU, 71 KB each - default) or 8 (one of 133 KB; XL_STEM12_TILE=8)
@@ -373,21 +424,29 @@ int xl_run_stem12(const xl_op &op, hipStream_t st)
     a.normLo = (op.flags & XL_GN_RELU_IN) ? 0.f : -__builtin_inff();
     const long long total = (long long)op.B * a.tilesX * a.tilesY;
     if (total >= 0x7fffffffLL || (op.stats && op.nchunks != a.tilesX * a.tilesY * (tileRows / 2))) return XL_ERR_ARG;
-    const size_t lds = (tileRows == 8 ? S12<8>::kPatchBytes + S12<8>::kHaloBytes : S12<4>::kPatchBytes + S12<4>::kHaloBytes) + 1024;
-    const void *fn = tileRows == 8 ? reinterpret_cast<const void *>(stem12_kernel<8>) : reinterpret_cast<const void *>(stem12_kernel<4>);
-    static XlLdsLimit configured[2];
+    const size_t lds = (tileRows == 8 ? (pair ? S12<8, true>::kPatchBytes : S12<8>::kPatchBytes) + S12<8>::kHaloBytes
+                                      : (pair ? S12<4, true>::kPatchBytes : S12<4>::kPatchBytes) + S12<4>::kHaloBytes) + 1024;
+    const void *fn = tileRows == 8 ? (pair ? reinterpret_cast<const void *>(stem12_kernel<8, true>) : reinterpret_cast<const void *>(stem12_kernel<8>))
+                                   : (pair ? reinterpret_cast<const void *>(stem12_kernel<4, true>) : reinterpret_cast<const void *>(stem12_kernel<4>));
+    static XlLdsLimit configured[4];
     int cfgDev;
-    if (configured[tileRows == 8].needs(lds, &cfgDev)) {
+    const int cslot = (tileRows == 8 ? 1 : 0) + (pair ? 2 : 0);
+    if (configured[cslot].needs(lds, &cfgDev)) {
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return XL_ERR_HIP;
-        configured[tileRows == 8].done(lds, cfgDev);
+        configured[cslot].done(lds, cfgDev);
     }
     int grid = tileRows == 8 ? 256 : 512;                             // persistent: one / two workgroups per CU
     if (grid > total) grid = (int)total;
     static const bool clkDbg = getenv("XL_STEM12_CLK") != nullptr;
     a.clk = nullptr;
     if (clkDbg && hipMalloc(&a.clk, sizeof(long long) * 32 * grid) != hipSuccess) return XL_ERR_HIP;
-    if (tileRows == 8) hipLaunchKernelGGL(stem12_kernel<8>, dim3(grid), dim3(256), lds, st, a);
-    else hipLaunchKernelGGL(stem12_kernel<4>, dim3(grid), dim3(256), lds, st, a);
+    if (tileRows == 8) {
+        if (pair) hipLaunchKernelGGL((stem12_kernel<8, true>), dim3(grid), dim3(256), lds, st, a);
+        else hipLaunchKernelGGL((stem12_kernel<8, false>), dim3(grid), dim3(256), lds, st, a);
+    } else {
+        if (pair) hipLaunchKernelGGL((stem12_kernel<4, true>), dim3(grid), dim3(256), lds, st, a);
+        else hipLaunchKernelGGL((stem12_kernel<4, false>), dim3(grid), dim3(256), lds, st, a);
+    }
     if (clkDbg) {
         std::vector<long long> h((size_t)32 * grid);
         if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(h.data(), a.clk, sizeof(long long) * 32 * grid, hipMemcpyDeviceToHost) == hipSuccess) {

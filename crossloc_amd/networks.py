@@ -577,7 +577,8 @@ class _Plan:
         self._update_pair_scales()
         for key, (planes, src) in self.packed_c1.items():
             kind = key[1] if isinstance(key, tuple) else "c1"
-            planes.copy_(self.s2_dgrad_fragments(src) if kind == "s2dgrad" else self.conv2_fragments(src) if kind == "c2frag"
+            planes.copy_(self.conv2_pair_fragments(src) if kind == "c2pair" else      # (src: the conv module)
+                         self.s2_dgrad_fragments(src) if kind == "s2dgrad" else self.conv2_fragments(src) if kind == "c2frag"
                          else self.conv1_fragments(src))
 
     def dev(self, p):
@@ -728,6 +729,27 @@ class _Plan:
         if key not in self.packed_c1:
             src = conv.weight.detach().to(device=self.device, dtype=torch.float32).contiguous()   # aliases the live parameter
             self.packed_c1[key] = (self.s2_dgrad_fragments(src), src)
+        return self.packed_c1[key][0]
+
+    def conv2_pair_fragments(self, conv):
+        """[18 K-steps][2 planes {hi, lo}][2 column blocks][64 lanes][8] fp16 + the inverse weight scale (one float, then padding
+        to 16 bytes): the MFMA weight fragments of stem12_kernel<.., true> - the pair form of the 32 -> 64 stride-2 layer, cut
+        from the operand xl_cnn_pair_weight packs for pair_conv3x3s2_kernel (same scale, same split: the fused and the
+        two-kernel stem stay bitwise equal).  (int16 storage)"""
+        key = (id(conv.weight), "stem_pair")
+        if key in self.packed_pair:
+            self._pack_pair(*self.packed_pair[key])                             # (a refresh: the live weights first)
+        packed = self.pack_conv_stem_pair(conv)
+        n = 64 * 288
+        frag = packed[:2 * n].view(2, 32, 18, 2, 2, 8).permute(2, 3, 0, 4, 1, 5).contiguous().reshape(-1)   # [kk][p][j][kh][fr][8]
+        tail = torch.zeros(8, dtype=torch.int16, device=self.device)
+        tail[:2] = packed[2 * n + 2:2 * n + 4]                                   # the inverse scale (behind the maxima word)
+        return torch.cat([frag, tail])
+
+    def pack_conv2_pair_fragments(self, conv):
+        key = (id(conv.weight), "c2pair")
+        if key not in self.packed_c1:
+            self.packed_c1[key] = (self.conv2_pair_fragments(conv), conv)
         return self.packed_c1[key][0]
 
     def pack_conv2_fragments(self, conv):
@@ -1428,7 +1450,13 @@ class _Plan:
         op.B, op.Hi, op.Wi, op.Cin, op.Ho, op.Wo, op.Cout, op.ld_out = B, H, W, 3, Ho, Wo, c2, c2
         op.ksize, op.stride, op.flags = 3, 2, GN_RELU_IN
         op.in_, op.w, op.bias = image.data_ptr(), w1.data_ptr(), b1.data_ptr()
-        op.aux = self.pack_conv2_fragments(enc.conv2).data_ptr()
+        if self.pair_ok() and not os.environ.get("XL_NO_PAIR_STEM"):
+            # round 5: conv2 inside the fused kernel as three fp16 passes (conv1's normalised output is a GroupNorm output)
+            op.flags |= CONV_PAIR_F16
+            op.aux = self.pack_conv2_pair_fragments(enc.conv2).data_ptr()
+            op.scale = self.pair_scales.data_ptr()
+        else:
+            op.aux = self.pack_conv2_fragments(enc.conv2).data_ptr()
         op.stats2 = self.dev(enc.conv2.bias).data_ptr()
         queue = torch.zeros(4, dtype=torch.int32, device=self.device)      # the launch's tile queue (zero before and after)
         self.keep.append(queue)

@@ -78,7 +78,10 @@ enum {
                                Ho = (Hi-1)/2+1; flags & XL_GN_RELU_IN: ReLU behind the GroupNorm.
                                stats (optional, groups = 32, nchunks = ceil(Wo/16) * ceil(Ho/4) * 2): GroupNorm partial sums of
                                the output, fp64 [B][nchunks][32][2] {sum, sum of squares}, every entry written - XL_OP_GN_FINAL
-                               with reserved_i = 0 sums them */
+                               with reserved_i = 0 sums them.
+                               flags & XL_CONV_PAIR_F16 (round 5): conv2 as three fp16 passes - aux = its weight fragments as pairs
+                               [18 K-steps][2 planes {hi, lo}][2 column blocks][64 lanes][8] fp16 followed by the inverse weight
+                               scale (one float; networks._Plan.conv2_pair_fragments), scale = {s, 1 / s} of conv1's normalised output */
     XL_OP_S2_DGRAD = 20,    /* data gradient of a 3x3 stride-2 stem convolution (conv2 / conv3 of training plans) on the bf16 matrix pipe,
                                csrc/xl_stem_dgrad.hip: in = dY [B,Hi,Wi,Cin] (Cin = the layer's output channels, 64 or 128), w = weight
                                fragments [9 taps][Cin/16][3 planes][Cout/32][64 lanes][8] bf16 (networks._Plan.s2_dgrad_fragments),
