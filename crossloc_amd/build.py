@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INC = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libcrossloc_hip.so")
-SOURCES = ["xl_dsac.hip", "xl_cnn.hip", "xl_cnn_bwd.hip", "xl_gemm_split.hip", "xl_gemm_pair.hip", "xl_stem_split.hip", "xl_stem_pair.hip", "xl_stem_fused.hip", "xl_stem_dgrad.hip", "xl_wgrad_split.hip", "xl_pack.hip", "xl_loss.hip", "xl_optim.hip", "xl_data.hip"]
+SOURCES = ["xl_dsac.hip", "xl_cnn.hip", "xl_cnn_bwd.hip", "xl_gemm_split.hip", "xl_gemm_pair.hip", "xl_stem_split.hip", "xl_stem_pair.hip", "xl_stem_fused.hip", "xl_stem_dgrad.hip", "xl_wgrad_split.hip", "xl_wgrad_pair.hip", "xl_pack.hip", "xl_loss.hip", "xl_optim.hip", "xl_data.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wno-unused-result"]
 
 

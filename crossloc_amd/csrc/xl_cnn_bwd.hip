@@ -17,8 +17,10 @@
 
 #include "../../include/crossloc_cnn.h"
 #include "../../include/crossloc_dsac.h"
+#include "xl_common.h"
 
 int xl_run_wgrad_split(const xl_op &op, hipStream_t st);   // xl_wgrad_split.hip
+int xl_run_wgrad_pair(const xl_op &op, hipStream_t st);    // xl_wgrad_pair.hip
 
 namespace {
 
@@ -421,10 +423,18 @@ __device__ __forceinline__ void wino6_a(const V (&d)[6], V (&o)[8])
     o[7] = d[5];
 }
 
+// Round 5: the largest magnitude a gradient pass writes, for the fp16-pair GEMMs that consume its result (csrc/xl_gemm_pair.hip,
+// csrc/xl_wgrad_pair.hip: a gradient has no static bound, so its power-of-two scale comes from the data): every thread keeps a
+// running maximum, a wave combines its 64 with a DPP tree, at most one atomicMax per wave on the float's bits (xl_wave_max_commit,
+// csrc/xl_common.h).  The slot is zeroed by an XL_OP_FILL0 at the head of the backward op list.
+__device__ __forceinline__ void xl_amax_commit(float m, unsigned *slot) { xl_wave_max_commit(m, slot); }
+
 // dY [B,H,W,C] (pixel stride ld) -> dM [64][B*Th*Tw][C]; one tile x 2 channels per thread; pixels past H / W are zero
 __global__ __launch_bounds__(256)
-void wino6_dy_kernel(const float *__restrict__ dy, float *__restrict__ dM, int B, int H, int W, int C, int ld, int Th, int Tw)
+void wino6_dy_kernel(const float *__restrict__ dy, float *__restrict__ dM, int B, int H, int W, int C, int ld, int Th, int Tw,
+                     unsigned *__restrict__ amax)
 {
+    float mx = 0.f;
     const int C2 = C >> 1;
     const long long T = (long long)B * Th * Tw;
     const long long items = T * C2;
@@ -456,9 +466,13 @@ void wino6_dy_kernel(const float *__restrict__ dy, float *__restrict__ dM, int B
             f32x2 o[8];
             wino6_a(w[i], o);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) *reinterpret_cast<f32x2 *>(op + (8 * i + j) * zs) = o[j];
+            for (int j = 0; j < 8; ++j) {
+                *reinterpret_cast<f32x2 *>(op + (8 * i + j) * zs) = o[j];
+                mx = fmaxf(mx, fmaxf(fabsf(o[j][0]), fabsf(o[j][1])));
+            }
         }
     }
+    xl_amax_commit(mx, amax);
 }
 
 // dg[o][c][a][b] = sum_ij G[i][a] dU[8i+j][o][c] G[j][b]  (G of F(6x6,3x3)); one (o, c) per thread, OIHW output
@@ -505,6 +519,7 @@ struct GnbArgs {
     double *ncsums;          // [B][C][6]: A, Bc, Xh, S1, S2, rstd (gnb_final_kernel)
     float *bco;              // [B][C][3]: rstd*gamma, rstd*S1/m, rstd*S2/m (gnb_final_kernel)
     int B, HW, C, ldX, ldD, ldO, ldDx, ldAux, G, nchunks2, flags;
+    unsigned *amax;          // gnb_apply (optional): max |dx| of the pass, as float bits (xl_amax_commit)
 };
 
 // dv (gradient w.r.t. v = gn(x)) of one element
@@ -676,6 +691,7 @@ void gnb_apply_kernel(GnbArgs a)
         }
         const bool hasOut = (a.flags & XL_GN_RELU_OUT) != 0, reluIn = (a.flags & XL_GN_RELU_IN) != 0;
         const bool add = (a.flags & XL_GN_ADD) != 0, accAux = (a.flags & XL_GN_ACC_AUX) != 0;
+        float mx = 0.f;
         auto one = [&](long long pix, const f32x4 &xv, const f32x4 &d4, const f32x4 &ov, const f32x4 &old) {
             f32x4 dx, t4;
 #pragma unroll
@@ -696,6 +712,7 @@ void gnb_apply_kernel(GnbArgs a)
                 *reinterpret_cast<f32x4 *>(a.daux + pix * a.ldAux + c) = t4;
             }
             *reinterpret_cast<f32x4 *>(a.dx + pix * a.ldDx + c) = dx;
+            mx = fmaxf(fmaxf(mx, fmaxf(fabsf(dx[0]), fabsf(dx[1]))), fmaxf(fabsf(dx[2]), fabsf(dx[3])));
         };
         const f32x4 ones = { 1.f, 1.f, 1.f, 1.f };
         int p = p0 + tid / C4;
@@ -720,8 +737,10 @@ void gnb_apply_kernel(GnbArgs a)
             const f32x4 old = (add && accAux) ? *reinterpret_cast<const f32x4 *>(a.daux + pix * a.ldAux + c) : ones;
             one(pix, xv, d4, ov, old);
         }
+        xl_amax_commit(mx, a.amax);
         return;
     }
+    float mxs = 0.f;
     for (long long f = tid; f < nElem4; f += 256) {
         const int p = p0 + (int)(f / C4);
         const int c = (int)(f - (long long)(p - p0) * C4) * 4;
@@ -751,7 +770,9 @@ void gnb_apply_kernel(GnbArgs a)
             *reinterpret_cast<f32x4 *>(q) = t4;
         }
         *reinterpret_cast<f32x4 *>(a.dx + pix * a.ldDx + c) = dx;
+        mxs = fmaxf(fmaxf(mxs, fmaxf(fabsf(dx[0]), fabsf(dx[1]))), fmaxf(fabsf(dx[2]), fabsf(dx[3])));
     }
+    xl_amax_commit(mxs, a.amax);
 }
 
 // d gamma, d beta, d conv-bias from the per-(image, channel) sums; one thread per channel
@@ -1168,10 +1189,14 @@ int gnb_threads(int C)
 int xl_run_bwd_op(const xl_op &op, hipStream_t st)
 {
     switch (op.type) {
+        case XL_OP_FILL0: {
+            if (!op.out || op.Cin < 1) return XL_ERR_ARG;
+            return hipMemsetAsync(op.out, 0, (size_t)op.Cin, st) == hipSuccess ? XL_OK : XL_ERR_HIP;
+        }
         case XL_OP_WGRAD: {
             if (op.nchunks2 < 1 || op.ld_in % 4 != 0 || op.ld_aux % 4 != 0) return XL_ERR_ARG;
             if (op.flags & XL_CONV_SPLIT_BF16) {                      // 1x1 / batched Winograd products on the bf16 pipe
-                const int rc = xl_run_wgrad_split(op, st);
+                const int rc = (op.flags & XL_CONV_PAIR_F16) ? xl_run_wgrad_pair(op, st) : xl_run_wgrad_split(op, st);
                 if (rc != XL_OK) return rc;
                 const long long total = (long long)op.Cout * op.Cin;
                 long long blocks = (total + 255) / 256;
@@ -1200,6 +1225,7 @@ int xl_run_bwd_op(const xl_op &op, hipStream_t st)
             a.bco = reinterpret_cast<float *>(a.ncsums + (long long)op.B * op.Cin * 6);
             a.B = op.B; a.HW = op.Hi * op.Wi; a.C = op.Cin; a.ldX = op.ld_in; a.ldD = op.ld_aux; a.ldO = op.ld_out; a.ldDx = op.ld_in;
             a.ldAux = op.Cout > 0 ? op.Cout : op.ld_out; a.G = op.groups; a.nchunks2 = op.nchunks2; a.flags = op.flags;
+            a.amax = op.type == XL_OP_GNB_APPLY ? (unsigned *)op.scale : nullptr;      // (round 5: max |dx| for the pair GEMMs that read dx)
             if (op.type == XL_OP_GNB_STATS) {
                 const int T = gnb_threads(op.Cin);
                 if (T < 0 || T > 1024) return XL_ERR_ARG;
@@ -1251,8 +1277,12 @@ int xl_run_bwd_op(const xl_op &op, hipStream_t st)
             const long long items = (long long)op.B * op.Ho * op.Wo * (op.Cin / 2);
             long long blocks = (items + 255) / 256;
             if (blocks > 262144) blocks = 262144;
-            hipLaunchKernelGGL(m == 6 ? wino6_dy_kernel : wino4_dy_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float *)op.in, (float *)op.out,
-                               op.B, op.Hi, op.Wi, op.Cin, op.ld_in, op.Ho, op.Wo);
+            if (m == 6)
+                hipLaunchKernelGGL(wino6_dy_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float *)op.in, (float *)op.out,
+                                   op.B, op.Hi, op.Wi, op.Cin, op.ld_in, op.Ho, op.Wo, (unsigned *)op.scale);   // scale: max |dM| slot (optional)
+            else
+                hipLaunchKernelGGL(wino4_dy_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float *)op.in, (float *)op.out,
+                                   op.B, op.Hi, op.Wi, op.Cin, op.ld_in, op.Ho, op.Wo);
             return XL_OK;
         }
         case XL_OP_WINO_WFINAL: {

@@ -296,6 +296,8 @@ struct PairConvArgs {
     int tile0, ntiles;                               // the launch's range of the (z, m-tile, n-tile) order
     const float *res; int ldRes;                     // RES (with NORM): a residual added behind the normalisation, then ReLU
     const float *uInv; const float *aScale;          // [Z] inverse weight scales; {s, 1 / s} of the activations
+    int amaxShift;                                   // >= 0 (XL_CONV_PAIR_AMAX): aScale points at the float bits of max |operand source| and the
+                                                     // scale is derived here: max 2^e in [2^(14 - shift), 2^(15 - shift))
     int var;                                         // measurement switches (XL_PAIR_VAR)
 };
 
@@ -356,7 +358,15 @@ __device__ __forceinline__ void pair_conv1x1_body(const PairConvArgs &a)
 
     const long long rowU = (long long)a.C * 4;
     const int nk = ZB == 2 ? 32 : a.C / 16;
-    const float aS = a.aScale[0], aInv = a.aScale[1];
+    float aS, aInv;
+    if (a.amaxShift >= 0) {
+        const unsigned bits = reinterpret_cast<const unsigned *>(a.aScale)[0];
+        int e = 0;
+        if (bits >> 23) e = 14 - ((int)(bits >> 23) - 127) - a.amaxShift;
+        e = e > 120 ? 120 : (e < -120 ? -120 : e);
+        aS = __builtin_bit_cast(float, (unsigned)(e + 127) << 23);
+        aInv = __builtin_bit_cast(float, (unsigned)(127 - e) << 23);
+    } else { aS = a.aScale[0]; aInv = a.aScale[1]; }
 
     // ---- streams: weights by LDS-DMA three K-steps ahead of the multiplies (2 instructions per wave and step), activations into
     // registers two steps ahead (row tid >> 1, channels 8 (tid & 1) .. + 7 of the step; two register sets, by the parity of the step)
@@ -764,7 +774,7 @@ static int xl_run_pair_gemm(const xl_op &op, hipStream_t st)
 {
     const int T = op.B * op.Ho * op.Wo, Z = op.nchunks2;
     if (op.ksize != 1 || op.stride != 1 || Z < 1 || op.Cin % 16 != 0 || op.Cout % 256 != 0 || op.ld_in != op.Cin || op.ld_out != op.Cout ||
-        op.bias || op.stats || (op.flags & (XL_CONV_ACCUMULATE | XL_CONV_NORM_IN | XL_CONV_M_TILE_MAJOR)) || !op.in || !op.w || !op.out || !op.scale ||
+        op.bias || op.stats || (op.flags & (XL_CONV_ACCUMULATE | XL_CONV_NORM_IN | XL_CONV_M_TILE_MAJOR | XL_CONV_PAIR_AMAX)) || !op.in || !op.w || !op.out || !op.scale ||
         (((uintptr_t)op.in | (uintptr_t)op.w | (uintptr_t)op.out) & 15))
         return XL_ERR_ARG;
     // 32-bit offsets inside one GEMM's operands / result (each z has its own buffer descriptor)
@@ -880,8 +890,8 @@ static int xl_run_pair_conv1x1(const xl_op &op, hipStream_t st)
     a.res = nullptr; a.ldRes = 0;
     a.uInv = reinterpret_cast<const float *>(a.u + (long long)Z * op.Cout * op.Cin * 4) + Z;
     a.aScale = (const float *)op.scale;
-    static const int var = getenv("XL_PAIR_VAR") ? atoi(getenv("XL_PAIR_VAR")) : 0;
-    a.var = var;
+    a.amaxShift = (op.flags & XL_CONV_PAIR_AMAX) ? (Z > 1 ? 8 : 0) : -1;
+    a.var = 0;
     if (op.flags & XL_CONV_NORM_ADD) {
         if (!norm || !(op.flags & XL_CONV_NORM_RELU) || !op.aux || op.ld_aux < op.Cin || (op.ld_aux & 3) || ((uintptr_t)op.aux & 15) || Z > 1 ||
             256LL * op.ld_aux * 4 >= 0x7fffffffLL) return XL_ERR_ARG;

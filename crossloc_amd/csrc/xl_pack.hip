@@ -6,6 +6,7 @@
 
 #include "../../include/crossloc_cnn.h"
 #include "../../include/crossloc_dsac.h"   // status codes
+#include "xl_common.h"
 
 namespace {
 
@@ -198,6 +199,11 @@ void pair_weight_kernel(const float *__restrict__ src, uint16_t *__restrict__ ds
     unsigned m = 0u;
     const float sc = PASS ? pair_scale_of_max(maxBits[0]) : 1.f;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        if (PASS == 0) {                                               // (the maximum does not care about the order: a linear read)
+            const unsigned b = __builtin_bit_cast(unsigned, fabsf(src[i]));
+            m = b > m ? b : m;
+            continue;
+        }
         const int r = (int)(i / K), k = (int)(i - (long long)r * K);
         float v;
         if (taps == 1) v = src[i];
@@ -212,7 +218,7 @@ void pair_weight_kernel(const float *__restrict__ src, uint16_t *__restrict__ ds
             if (i == 0) invScale[0] = 1.f / sc;
         }
     }
-    if (PASS == 0 && m) atomicMax(maxBits, m);
+    if (PASS == 0) xl_wave_max_commit(__builtin_bit_cast(float, m), maxBits);      // (one atomic per wave at most)
 }
 
 // activation pairs [rows][K/8][2][8] fp16 {hi, (x - hi) * 2^11} of x = src * scale[0] (the layout the Winograd input transform writes)

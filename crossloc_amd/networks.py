@@ -38,6 +38,8 @@ CONV_SPLIT_ACT = 1024
 CONV_M_TILE_MAJOR = 2048
 CONV_NORM_ADD = 4096
 CONV_PAIR_F16 = 8192
+CONV_PAIR_AMAX = 16384
+XL_OP_FILL0 = 21
 XL_ERR_UNSUPPORTED = -4            # include/crossloc_dsac.h
 
 
@@ -263,6 +265,7 @@ class _Plan:
         assert not getattr(self, "pending_fold", None), "a folded GroupNorm apply was never consumed"
         if train:
             self._lower_backward()
+            self._update_pair_scales()          # (the backward GEMMs may be the plan's first pair operands: small maps)
 
     # -- workspace
     def alloc(self, numel):
@@ -451,7 +454,7 @@ class _Plan:
         |gn(x)| <= sqrt(N - 1) |gamma| + |beta|, an activation is a GroupNorm output plus residuals that are activations
         themselves (the sum over ALL layers bounds any chain), and |B^T d B| <= 225 max|d| for F(6x6,3x3).  One tiny launch
         reading the live parameters - no host synchronisation, so a training loop can call it every step."""
-        if not self.packed_pair and not getattr(self, "pair_ops", 0):
+        if not self.pair_ok():
             return
         if not hasattr(self, "_pair_gn"):
             layers = self._gn_layers()
@@ -464,26 +467,27 @@ class _Plan:
         stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         _check(_bind().xl_cnn_pair_scales(g, b, c, r, n, self.pair_scales.data_ptr(), stream))
 
-    def pack_conv_wino_pair(self, conv, m):
+    def pack_conv_wino_pair(self, conv, m, dgrad=False):
         """The transformed weights of pack_conv_wino as fp16 pairs {hi, lo} [(m+2)^2][Cout][Cin/16][2][16], each frequency scaled by its
-        own power of two, + 2 (m+2)^2 floats (scratch, inverse scales)."""
-        key = (id(conv.weight), "wino%d_pair" % m)
+        own power of two, + 2 (m+2)^2 floats (scratch, inverse scales).  dgrad: the data-gradient operand [(m+2)^2][Cin][Cout/16]..."""
+        key = (id(conv.weight), "wino%d%s_pair" % (m, "d" if dgrad else ""))
         if key not in self.packed_pair:
             src = conv.weight.detach().to(device=self.device, dtype=torch.float32).contiguous()   # aliases the live parameter
             nf = (m + 2) ** 2
             planes = torch.empty(2 * nf * src.shape[0] * src.shape[1] + 4 * nf, dtype=torch.int16, device=self.device)
-            self.packed_pair[key] = (planes, src, m)
-            self._pack_pair(planes, src, m)
+            self.packed_pair[key] = (planes, src, m, "d" if dgrad else "")
+            self._pack_pair(*self.packed_pair[key])
         return self.packed_pair[key][0]
 
-    def pack_conv_1x1_pair(self, conv):
-        """[Cout][Cin/16][2][16] fp16 pairs {hi, lo} of a 1x1 convolution's weight (one power-of-two scale) + 2 floats."""
-        key = (id(conv.weight), "1x1_pair")
+    def pack_conv_1x1_pair(self, conv, transposed=False):
+        """[Cout][Cin/16][2][16] fp16 pairs {hi, lo} of a 1x1 convolution's weight (one power-of-two scale) + 2 floats;
+        `transposed`: [Cin][Cout/16][2][16], the operand of its data gradient."""
+        key = (id(conv.weight), "1x1_pair" + ("_t" if transposed else ""))
         if key not in self.packed_pair:
             src = conv.weight.detach().to(device=self.device, dtype=torch.float32).contiguous()   # aliases the live parameter
             planes = torch.empty(2 * src.numel() + 4, dtype=torch.int16, device=self.device)
-            self.packed_pair[key] = (planes, src, 0)
-            self._pack_pair(planes, src, 0)
+            self.packed_pair[key] = (planes, src, 0, "t" if transposed else "")
+            self._pack_pair(*self.packed_pair[key])
         return self.packed_pair[key][0]
 
     def pack_conv_stem_pair(self, conv):
@@ -492,14 +496,17 @@ class _Plan:
         if key not in self.packed_pair:
             src = conv.weight.detach().to(device=self.device, dtype=torch.float32).contiguous()   # aliases the live parameter
             planes = torch.empty(2 * src.numel() + 4, dtype=torch.int16, device=self.device)
-            self.packed_pair[key] = (planes, src, 0)
-            self._pack_pair(planes, src, 0)
+            self.packed_pair[key] = (planes, src, 0, "")
+            self._pack_pair(*self.packed_pair[key])
         return self.packed_pair[key][0]
 
-    def _pack_pair(self, planes, src, m):
+    def _pack_pair(self, planes, src, m, mode=""):
         stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         if m:
-            _check(_bind().xl_cnn_pack_wino_weight_pair(src.data_ptr(), planes.data_ptr(), src.shape[0], src.shape[1], m, 0, stream))
+            _check(_bind().xl_cnn_pack_wino_weight_pair(src.data_ptr(), planes.data_ptr(), src.shape[0], src.shape[1], m,
+                                                        1 if mode == "d" else 0, stream))
+        elif mode == "t":                             # [Cin][Cout]: rows and K swapped
+            _check(_bind().xl_cnn_pair_weight(src.data_ptr(), planes.data_ptr(), src.shape[1], src.shape[0], 0, stream))
         elif src.dim() == 4 and src.shape[2] == 3:
             _check(_bind().xl_cnn_pair_weight(src.data_ptr(), planes.data_ptr(), src.shape[0], src.shape[1] * 9, 9, stream))
         else:
@@ -1685,6 +1692,23 @@ class _Plan:
         patch_f, patch_d = [], []
         self.conv1_wgrad_indices = []
         producers = {self._key(e["raw"]): e for e in self.tape if e["kind"] in ("conv", "conv1")}
+        # round 5: backward GEMMs as fp16 pairs (XL_TRAIN_PAIR_BWD=0: six-pass bf16).  A gradient has no static bound: every
+        # GroupNorm-backward apply pass records max |dx| (a float's bits, atomicMax) in a slot of its own, and so does the dY
+        # transform of a Winograd weight gradient; the GEMMs that read those tensors derive their power-of-two scale from the
+        # slot.  The slots are zeroed by the first op of the list.
+        pair_bwd = self.pair_ok() and os.environ.get("XL_TRAIN_PAIR_BWD", "1") not in ("", "0")
+        self.bwd_amax = torch.zeros(1024, dtype=torch.int32, device=dev)
+        amax_n = [0]
+        gamax = {}                # conv-output key -> byte address of the slot holding max |its gradient|
+
+        def new_slot():
+            assert amax_n[0] < 1024
+            amax_n[0] += 1
+            return self.bwd_amax.data_ptr() + 4 * (amax_n[0] - 1)
+        if pair_bwd:
+            z = XlOp()
+            z.type, z.Cin, z.out = XL_OP_FILL0, 4 * 1024, self.bwd_amax.data_ptr()
+            bops.append(z)
 
         # every parameter gradient is a slice of ONE flat buffer (16-byte aligned slices): a backward pass hands its result
         # out with one device-to-device copy of that buffer instead of one clone per parameter (run_backward)
@@ -1785,6 +1809,8 @@ class _Plan:
                     op.aux2 = e["out"][0].data_ptr() + 4 * e["out"][5]
                     if typ == XL_OP_GNB_APPLY:
                         op.out = dx.data_ptr()
+                        if pair_bwd and prod is not None:
+                            gamax[self._key(e["raw"])] = op.scale = new_slot()
                         if daux is not None:
                             op.out2 = daux[0].data_ptr() + 4 * daux[2]
                             op.Cout = daux[1]                  # pixel stride of the d(residual) tensor
@@ -1813,6 +1839,7 @@ class _Plan:
                 dy = graw.pop(self._key(e["raw"]), None)
                 if dy is None:
                     continue
+                dy_amax = gamax.pop(self._key(e["raw"]), None)
                 k, s = conv.kernel_size[0], conv.stride[0]
                 bo = 128 if Cout % 128 == 0 else 64
                 bc = 128 if C % 128 == 0 else (64 if C % 64 == 0 else 32)
@@ -1844,6 +1871,9 @@ class _Plan:
                     wd.type, wd.ksize = XL_OP_WINO_DY, wm
                     wd.B, wd.Hi, wd.Wi, wd.Cin, wd.Ho, wd.Wo, wd.ld_in = B, H, W, Cout, Th, Tw, Cout
                     wd.in_, wd.out = dy.data_ptr(), dMb.data_ptr()
+                    wg_pair = pair_bwd and wm == 6 and self.wgrad_split_ok(C, Cout)
+                    if wg_pair:
+                        wd.scale = new_slot()                          # max |dM|: the scale of the weight-gradient GEMMs' dY operand
                     bops.append(wd)
                     dU = self.alloc(nfw * Cout * C)
                     tiles = nfw * (Cout // bo) * (C // bc)
@@ -1863,6 +1893,9 @@ class _Plan:
                         # on the split pipe (csrc/xl_wgrad_split.hip): 256 x 256 tiles, one workgroup per CU
                         wg.flags = CONV_SPLIT_BF16
                         splits = self.wgrad_splits(nfw * (Cout // 256) * (C // 256), Tw4)
+                        if wg_pair:                                    # csrc/xl_wgrad_pair.hip: V at the plan's scale, dM at its own
+                            wg.flags |= CONV_PAIR_F16
+                            wg.scale, wg.out2 = self.pair_scales.data_ptr() + 8, wd.scale
                     wg.ksize, wg.stride, wg.ld_in, wg.ld_aux, wg.groups, wg.nchunks2 = 1, 1, C, Cout, nfw, splits
                     wg.in_, wg.aux, wg.out = Vb.data_ptr(), dMb.data_ptr(), dU.data_ptr()
                     scratch_f = max(scratch_f, nfw * splits * Cout * C)
@@ -1904,6 +1937,9 @@ class _Plan:
                 if k == 1 and s == 1 and not wino_w and self.wgrad_split_ok(C, Cout) and ld % 4 == 0 and off % 4 == 0:
                     op.flags = CONV_SPLIT_BF16
                     splits = self.wgrad_splits((Cout // 256) * (C // 256), M)
+                    if pair_bwd and dy_amax is not None:
+                        op.flags |= CONV_PAIR_F16
+                        op.scale, op.out2 = self.pair_scales.data_ptr(), dy_amax
                     if e.get("xnorm") is not None:                    # x is a raw conv output: normalise on load
                         op.flags |= CONV_NORM_IN | (CONV_NORM_RELU if e["xnorm"].flags & GN_RELU_IN else 0)
                         op.aux2 = e["xnorm"].aux2
@@ -1947,7 +1983,13 @@ class _Plan:
                     if self.wino_gemm_form(Cout, C, m, T)[2]:       # on the split pipe, V(dY) split inside the GEMM kernel
                         tile_major = CONV_M_TILE_MAJOR if (m == 6 and os.environ.get("XL_WINO_M_TILE_MAJOR")) else 0
                         gm.flags = CONV_SPLIT_BF16 | CONV_SPLIT_IL | CONV_SPLIT_ACT | tile_major
-                        gm.w = self.pack_conv_wino_split(conv, m, True, dgrad=True).data_ptr()
+                        if pair_bwd and dy_amax is not None and not tile_major:
+                            # V(dY) stays fp32; the pairs are formed in the GEMM at the scale of max |dY| / 256 (|B^T d B| <= 225 max|d|)
+                            gm.flags |= CONV_PAIR_F16 | CONV_PAIR_AMAX
+                            gm.w = self.pack_conv_wino_pair(conv, m, dgrad=True).data_ptr()
+                            gm.scale = dy_amax
+                        else:
+                            gm.w = self.pack_conv_wino_split(conv, m, True, dgrad=True).data_ptr()
                     else:
                         gm.w = self.pack_conv_wino(conv, m, dgrad=True).data_ptr()
                         if -(-T // 128) * (C // 128) * nf <= 256:
@@ -1993,7 +2035,12 @@ class _Plan:
                     # dX = dY W on the split pipe: a plain 1x1 "convolution" of dY with the transposed weight matrix, split
                     # once per weight version; a second producer of the gradient accumulates in the epilogue
                     op.flags = CONV_SPLIT_BF16 | CONV_SPLIT_IL | (op.flags & CONV_ACCUMULATE)
-                    op.w = self.pack_conv_1x1_split(conv, transposed=True).data_ptr()
+                    if pair_bwd and dy_amax is not None:
+                        op.flags |= CONV_PAIR_F16 | CONV_PAIR_AMAX
+                        op.w = self.pack_conv_1x1_pair(conv, transposed=True).data_ptr()
+                        op.scale = dy_amax
+                    else:
+                        op.w = self.pack_conv_1x1_split(conv, transposed=True).data_ptr()
                     op.reserved_i = 256
                 else:
                     op.w = self.pack_conv(conv, dgrad=True).data_ptr()

@@ -86,6 +86,9 @@ enum {
                                csrc/xl_stem_dgrad.hip: in = dY [B,Hi,Wi,Cin] (Cin = the layer's output channels, 64 or 128), w = weight
                                fragments [9 taps][Cin/16][3 planes][Cout/32][64 lanes][8] bf16 (networks._Plan.s2_dgrad_fragments),
                                out = dX [B,Ho,Wo,Cout] (Cout = 32 or 64, overwritten), stats = two int32, zero (tile queue) */
+    XL_OP_FILL0 = 21,       /* round 5: `Cin` bytes at `out` set to zero on the stream (the slots of the gradient maxima, zeroed at the
+                               head of a backward op list: XL_OP_GNB_APPLY / XL_OP_WINO_DY with `scale` set record max |result| there
+                               as float bits; the pair GEMMs that read those results take XL_CONV_PAIR_AMAX) */
     XL_OP_GN_FINAL = 11  /* per-(image, channel) GroupNorm scale/shift [B][C][2] from the partial sums (out);
                             GN_APPLY with aux2 = that buffer skips its own finalisation.  out2 (training plans):
                             [B][C][2] {mean, rstd} for the GroupNorm backward ops.  reserved_i = rows per producer tile (0: all
@@ -134,6 +137,11 @@ enum {
                                   fp32 and the kernel forms the pairs on the operand's way into LDS (1x1 layers, normalise-on-load).
                                   xl_op.scale must be set; |a * scale| <= 65504 is the caller's contract (crossloc_amd/networks.py
                                   derives the scale from the GroupNorm bound |gn(x)| <= sqrt(N - 1) |gamma| + |beta|) */
+#define XL_CONV_PAIR_AMAX 16384 /* with XL_CONV_PAIR_F16 on an XL_OP_CONV whose fp32 activation operand is a GRADIENT (data gradients of
+                                  training plans): `scale` points at the float bits of max |activation| recorded by the pass that wrote the
+                                  operand (or its untransformed source: Winograd launches, nchunks2 > 1, allow for |B^T d B| <= 225 max|d|)
+                                  and the kernel derives the power-of-two scale itself.  On XL_OP_WGRAD (csrc/xl_wgrad_pair.hip) the dY
+                                  operand always works this way: out2 = that slot, scale = {s, 1 / s} of the `in` operand */
 /* xl_op.flags for XL_OP_CONV */
 #define XL_CONV_DGRAD 1        /* data gradient: `in` is dY (Hi x Wi x Cin = forward output), result is dX; weights
                                   packed with xl_cnn_pack_conv_weight_dgrad; `stride` is the forward stride */
