@@ -2521,6 +2521,14 @@ int run_op(const xl_op &op, hipStream_t st)
         }
         case XL_OP_GN_FINAL: {
             if (op.groups > 32 || op.Cin % op.groups != 0) return XL_ERR_ARG;
+            if (op.reserved_i != 0) {
+                // one entry (x stride) per producer tile overlapping an image: they must fit the nchunks slots the producer wrote,
+                // or the finalisation sums the next image's entries / stale memory
+                const long long rows = op.reserved_i < 0 ? -op.reserved_i : op.reserved_i, hw = (long long)op.Hi * op.Wi;
+                const long long perTile = op.stride > 1 ? op.stride : 1;
+                const long long tiles = op.reserved_i < 0 ? (hw + rows - 1) / rows : (hw + rows - 1) / rows + 1;
+                if (tiles * perTile > op.nchunks) return XL_ERR_ARG;
+            }
             hipLaunchKernelGGL(gn_final_kernel, dim3(op.B), dim3(256), 0, st, (const double *)op.stats, (const float *)op.w,
                                (const float *)op.bias, (float *)op.out, op.Hi * op.Wi, op.Cin, op.groups, op.nchunks, op.eps,
                                op.reserved_i, (float *)op.out2, op.reserved_i != 0 && op.stride > 1 ? op.stride : 1);

@@ -191,7 +191,9 @@ void wgrad_pair_kernel(WgPairArgs a)
             if (kk + 2 < nk) load_regs(kk + 2);                        // (the registers are free again)
             // my LDS writes are done, every wave has read this step's stage - but NOT vmcnt(0) (see csrc/xl_wgrad_split.hip)
             __builtin_amdgcn_s_waitcnt(0x0070 | 0xC00F);               // lgkmcnt(0)
-            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);                         // (nothing of the next step may move above the barrier, nothing of
+            __builtin_amdgcn_s_barrier();                              //  this one below it: the bare s_barrier carries no fence - ADVICE r4)
+            __builtin_amdgcn_sched_barrier(0);
             mma(fb[0], fa[0]);                                         // hi x hi
             __builtin_amdgcn_sched_barrier(0);
         }

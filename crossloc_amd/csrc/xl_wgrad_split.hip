@@ -201,7 +201,9 @@ void wgrad_split_kernel(WgSplitArgs a)
             // all eight waves until the loads just issued are back, a memory latency per K-step with nothing under it;
             // their wait belongs to the conversion one step later (the compiler counts it there)
             __builtin_amdgcn_s_waitcnt(0x0070 | 0xC00F);               // lgkmcnt(0)
-            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);                         // (nothing of the next step may move above the barrier, nothing of
+            __builtin_amdgcn_s_barrier();                              //  this one below it: the bare s_barrier carries no fence - ADVICE r4)
+            __builtin_amdgcn_sched_barrier(0);
             mma_term(0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }

@@ -530,8 +530,10 @@ class _Plan:
         """The weight gradient of this F(m x m,3x3) layer will be a Winograd one (the conditions of _lower_backward): it then
         reads the normalised V and never the layer's input tensor."""
         Cout = conv.out_channels
+        # (ADVICE r4: the SAME conditions _lower_backward applies - including H * W >= 64 - and, when the apply is left to this
+        #  layer, the backward pass takes the forward's tile size `wm` instead of re-deriving one: see `xnorm` there)
         return (not conv.weight.requires_grad) or (
-            m in (4, 6) and C % 64 == 0 and Cout % 128 == 0 and self.B * -(-H // m) * -(-W // m) >= 64
+            m in (4, 6) and C % 64 == 0 and Cout % 128 == 0 and H * W >= 64 and self.B * -(-H // m) * -(-W // m) >= 64
             and not os.environ.get("XL_NO_WINOGRAD") and not os.environ.get("XL_NO_WINOGRAD_TRAIN")
             and not os.environ.get("XL_NO_WINOGRAD_WGRAD"))
 
@@ -1848,7 +1850,8 @@ class _Plan:
                         and not os.environ.get("XL_NO_WINOGRAD") and not os.environ.get("XL_NO_WINOGRAD_TRAIN")
                         and not os.environ.get("XL_NO_WINOGRAD_WGRAD")):
                     # a V kept by the forward pass fixes the tile size; otherwise the cheapest form for this map
-                    wm = e.get("wm", 0) if e.get("v") is not None else self.wino_pick(H, W, max(C, Cout))
+                    # (a deferred GroupNorm - xnorm - was accepted by wino_wgrad_ok() for the FORWARD tile size: keep it, V kept or not)
+                    wm = e.get("wm", 0) if (e.get("v") is not None or e.get("xnorm") is not None) else self.wino_pick(H, W, max(C, Cout))
                 Tw4 = B * -(-H // wm) * -(-W // wm) if wm else 0          # tiles = K dimension of the GEMMs
                 wino_w = wm in (4, 6) and Tw4 >= 64
                 nfw = (wm + 2) ** 2
@@ -2196,6 +2199,11 @@ def _sole_owner(buf):
     try:
         return torch._C._storage_Use_Count(buf.untyped_storage()._cdata) <= 2
     except (AttributeError, RuntimeError, TypeError):
+        if not getattr(_sole_owner, "warned", False):
+            _sole_owner.warned = True
+            import warnings
+            warnings.warn("crossloc_amd: torch._C._storage_Use_Count is unavailable in this PyTorch: every backward pass allocates a fresh "
+                          "gradient buffer (correct, but the fused optimizer rebuilds its pointer tables each step)")
         return False
 
 

@@ -105,3 +105,22 @@ def test_concurrent_imports_with_a_stale_stamp_leave_one_loadable_library():
         assert f.read().strip() == build.source_hash()
     assert not [d for d in os.listdir(os.path.dirname(build.LIB)) if d.startswith(".build.")]     # no leftovers
     ctypes.CDLL(build.LIB)
+
+
+def test_storage_use_count_semantics_the_gradient_buffers_rely_on():
+    """crossloc_amd.networks._sole_owner: a result buffer of the backward pass is reused only when NOTHING else
+    references its storage.  That reads torch's private storage use count with a threshold of 2 (the tensor + the storage object the
+    query creates): pinned here for the PyTorch in use - alone: sole owner; with a live view, or a second tensor on the storage: not."""
+    torch = pytest.importorskip("torch")
+    from crossloc_amd.networks import _sole_owner
+    buf = torch.zeros(64)
+    assert _sole_owner(buf)
+    view = buf[8:16]
+    assert not _sole_owner(buf)
+    del view
+    assert _sole_owner(buf)
+    keep = buf.view(8, 8)
+    assert not _sole_owner(buf)
+    del keep
+    assert _sole_owner(buf)
+    assert not getattr(_sole_owner, "warned", False)       # the private API exists in this PyTorch: no fallback warning
