@@ -425,3 +425,98 @@ def test_inference_plans_run_their_gemms_as_pairs_and_agree_with_the_six_pass_pl
         assert torch.isfinite(a).all()
         d = (a[:, :3] - b[:, :3]).abs().max().item()
         assert d <= 2e-4 * max(1.0, b[:, :3].abs().max().item()), (i, d)
+
+
+def _amax_slot(t):
+    """What the GroupNorm-backward apply pass leaves for the pair GEMMs that read its result: max |t| as float bits."""
+    return torch.tensor([t.abs().max().item()], dtype=torch.float32, device="cuda").view(torch.int32)
+
+
+@pytest.mark.parametrize("cin,cout,M,Z,splits,dmag,xmag,slack", [
+    (512, 512, 2 * 20 * 31, 1, 3, 1.0, 1.0, 5), (256, 512, 1500, 1, 1, 1e-7, 3.0, 9), (512, 256, 777, 4, 2, 2e3, 0.05, 3),
+    (512, 512, 2400, 36, 1, 1e-4, 10.0, 6), (256, 256, 300, 2, 5, 1.0, 1.0, 0)])
+def test_weight_gradient_products_as_fp16_pairs(cin, cout, M, Z, splits, dmag, xmag, slack):
+    """XL_OP_WGRAD with XL_CONV_SPLIT_BF16 | XL_CONV_PAIR_F16 (csrc/xl_wgrad_pair.hip): P_z = dY_z^T X_z, the pixels / Winograd tiles as
+    the K dimension, both operands converted in the kernel - dY at the scale of its recorded maximum (any magnitude: 1e-7 ... 2e3),
+    X at the plan's scale (looser than its data by 2^slack) - against float64, beside the six-pass bf16 and the fp32-MFMA kernels."""
+    g = torch.Generator().manual_seed(cin + cout + M + Z)
+    x = torch.randn(Z, M, cin, generator=g) * xmag
+    dy = torch.randn(Z, M, cout, generator=g) * dmag
+    dy[:, ::5] *= 1e-3                                                # gradients are heavy-tailed: most rows far below the maximum
+    ref = torch.einsum("zto,ztc->zoc", dy.double(), x.double())
+    xd, dyd = x.cuda(), dy.cuda()
+    xs, slot = _scale_for(x.abs().max().item(), slack), _amax_slot(dyd)
+
+    def run(flags, sp):
+        out = torch.full((Z, cout, cin), float("nan"), device="cuda")
+        scratch = torch.full((Z * sp * cout * cin,), float("nan"), device="cuda")
+        op = networks.XlOp()
+        op.type, op.flags = networks.XL_OP_WGRAD, flags
+        op.B, op.Hi, op.Wi, op.Cin, op.Ho, op.Wo, op.Cout = 1, M, 1, cin, M, 1, cout
+        op.ksize, op.stride, op.ld_in, op.ld_aux, op.groups, op.nchunks2 = 1, 1, cin, cout, Z, sp
+        op.in_, op.aux, op.out, op.stats2 = xd.data_ptr(), dyd.data_ptr(), out.data_ptr(), scratch.data_ptr()
+        op.scale, op.out2 = xs.data_ptr(), slot.data_ptr()
+        _run([op])
+        return out.cpu().double()
+    got = run(networks.CONV_SPLIT_BF16 | networks.CONV_PAIR_F16, splits)
+    scale = ref.abs().max().item()
+    esp = (got - ref).abs().max().item() / scale
+    e6 = (run(networks.CONV_SPLIT_BF16, splits) - ref).abs().max().item() / scale
+    e32 = (run(0, splits) - ref).abs().max().item() / scale
+    assert esp < 2e-6 and esp <= 1.5 * max(e6, e32) + 1e-7, (esp, e6, e32)
+
+
+@pytest.mark.parametrize("cin,cout,B,H,W,dmag", [(512, 512, 2, 20, 31, 1.0), (256, 512, 3, 16, 16, 3e-8), (512, 1024, 1, 24, 37, 4e3)])
+def test_conv1x1_data_gradient_as_fp16_pairs_with_the_scale_from_the_recorded_maximum(cin, cout, B, H, W, dmag):
+    """Training plans (round 5): dX = dY W of a 1x1 layer through pair_conv1x1_kernel with XL_CONV_PAIR_AMAX - the kernel derives its
+    power-of-two scale from max |dY| (float bits in a slot, as the GroupNorm-backward apply pass records it), the transposed weights
+    are pair-packed by xl_cnn_pair_weight(taps = 0); second producers accumulate.  Against float64, gradients from 3e-8 to 4e3."""
+    L = networks._bind()
+    g = torch.Generator().manual_seed(cin + cout + H)
+    w = torch.randn(cout, cin, generator=g) * (2.0 / cin) ** 0.5
+    dy = torch.randn(B, H, W, cout, generator=g) * dmag
+    dy[:, ::3] *= 1e-4
+    ref = torch.matmul(dy.double(), w.double())                      # [B,H,W,cin]
+    ws = w.cuda().contiguous()
+    wp = torch.zeros(2 * ws.numel() + 4, dtype=torch.int16, device="cuda")
+    networks._check(L.xl_cnn_pair_weight(ws.data_ptr(), wp.data_ptr(), cin, cout, 0, None))
+    dyd = dy.cuda()
+    slot = _amax_slot(dyd)
+    gx = torch.full((B, H, W, cin), float("nan"), device="cuda")
+    op = networks.XlOp()
+    op.type = networks.XL_OP_CONV
+    op.flags = PAIR | networks.CONV_PAIR_AMAX
+    op.B, op.Hi, op.Wi, op.Cin, op.Ho, op.Wo, op.Cout = B, H, W, cout, H, W, cin
+    op.ksize, op.stride, op.ld_in, op.ld_out, op.reserved_i = 1, 1, cout, cin, 256
+    op.in_, op.w, op.out, op.scale = dyd.data_ptr(), wp.data_ptr(), gx.data_ptr(), slot.data_ptr()
+    _run([op])
+    sc = ref.abs().max().item()
+    assert ((gx.cpu().double() - ref).abs().max() / sc).item() < 1e-6
+    op.flags |= networks.CONV_ACCUMULATE
+    _run([op, op])
+    assert ((gx.cpu().double() - 3 * ref).abs().max() / sc).item() < 3e-6
+
+
+def test_gradient_maxima_are_recorded_by_the_groupnorm_backward_pass():
+    """A training step leaves max |dx| of every GroupNorm-backward apply pass in the plan's slots (zeroed by XL_OP_FILL0 at the head of
+    the backward list): after a backward pass every slot a pair GEMM reads holds a positive finite float, and a second pass with
+    gradients 1000 times larger moves every one of them by that factor (to fp32 rounding) - the slots are re-derived, not accumulated."""
+    from crossloc_amd.weights import seeded_state_dict
+    net = networks.TransPoseNet(torch.tensor([-455.934, 417.50, 520.31]), False, False, 1, 1, 3, 1)
+    net.load_state_dict(seeded_state_dict(net, 77))
+    net = net.cuda().train()
+    x = torch.rand(2, 3, 256, 384, generator=torch.Generator().manual_seed(3)).cuda()
+    vals = []
+    for k in (1.0, 1000.0):
+        net.zero_grad(set_to_none=True)
+        (net(x) * k).sum().backward()
+        torch.cuda.synchronize()
+        plan = [p for p in net._plans.values() if p.train][0]
+        used = sorted({op.scale for op in plan.bwd_array if op.type == networks.XL_OP_CONV and (op.flags & networks.CONV_PAIR_AMAX)} |
+                      {op.out2 for op in plan.bwd_array if op.type == networks.XL_OP_WGRAD and (op.flags & networks.CONV_PAIR_F16)})
+        assert len(used) > 10
+        idx = [(a - plan.bwd_amax.data_ptr()) // 4 for a in used]
+        v = plan.bwd_amax.view(torch.float32)[idx].cpu()
+        assert torch.isfinite(v).all() and (v > 0).all()
+        vals.append(v)
+    assert torch.allclose(vals[1], vals[0] * 1000.0, rtol=1e-3)
