@@ -520,6 +520,7 @@ struct GnbArgs {
     float *bco;              // [B][C][3]: rstd*gamma, rstd*S1/m, rstd*S2/m (gnb_final_kernel)
     int B, HW, C, ldX, ldD, ldO, ldDx, ldAux, G, nchunks2, flags;
     unsigned *amax;          // gnb_apply (optional): max |dx| of the pass, as float bits (xl_amax_commit)
+    int rev;                 // gnb_stats: walk the images in descending order
 };
 
 // dv (gradient w.r.t. v = gn(x)) of one element
@@ -538,7 +539,10 @@ __global__ void gnb_stats_kernel(GnbArgs a)
     const int T = blockDim.x, tid = threadIdx.x;
     const int C4 = a.C >> 2;
     float *sCo = reinterpret_cast<float *>(smemD + (size_t)T * 12);          // mean, rstd, sc, sh per channel
-    const int n = blockIdx.y, chunk = blockIdx.x;
+    // images in DESCENDING order (a.rev; XL_GNB_REVERSE=0: ascending): the apply pass walks ascending and so starts with what this
+    // pass read last - its first reads are still on the die (apply 118.9 -> 114.7 us per launch at batch 16; this pass itself does
+    // not gain from meeting its producer's last writes: 85.7 -> 85.2)
+    const int n = a.rev ? (int)gridDim.y - 1 - (int)blockIdx.y : (int)blockIdx.y, chunk = blockIdx.x;
     {
         const float *scsh = a.fco + (long long)n * a.C * 2;
         const float *murs = a.fco + ((long long)a.B + n) * a.C * 2;
@@ -1225,6 +1229,8 @@ int xl_run_bwd_op(const xl_op &op, hipStream_t st)
             a.bco = reinterpret_cast<float *>(a.ncsums + (long long)op.B * op.Cin * 6);
             a.B = op.B; a.HW = op.Hi * op.Wi; a.C = op.Cin; a.ldX = op.ld_in; a.ldD = op.ld_aux; a.ldO = op.ld_out; a.ldDx = op.ld_in;
             a.ldAux = op.Cout > 0 ? op.Cout : op.ld_out; a.G = op.groups; a.nchunks2 = op.nchunks2; a.flags = op.flags;
+            static const int gnbRev = getenv("XL_GNB_REVERSE") ? atoi(getenv("XL_GNB_REVERSE")) : 1;
+            a.rev = gnbRev;
             a.amax = op.type == XL_OP_GNB_APPLY ? (unsigned *)op.scale : nullptr;      // (round 5: max |dx| for the pair GEMMs that read dx)
             if (op.type == XL_OP_GNB_STATS) {
                 const int T = gnb_threads(op.Cin);

@@ -1606,6 +1606,8 @@ int xl_dsac_forward_rgb_batch(const float *coords_dev, int64_t sb, int64_t sc, i
     while (S * 2 <= n_hyp / kWaves && (long long)B * S * 2 <= 512) S *= 2;
     static const char *noSplit = getenv("XL_DSAC_NO_SPLIT");
     if (noSplit) S = 1;
+    static const int forceS = getenv("XL_DSAC_SPLIT") ? atoi(getenv("XL_DSAC_SPLIT")) : 0;      // experiments: sub-blocks per image
+    if (forceS >= 1 && forceS * kWaves <= n_hyp) S = forceS;
     P.part = nullptr; P.S = S;
     static const int pairCells = getenv("XL_DSAC_PAIR_CELLS") ? atoi(getenv("XL_DSAC_PAIR_CELLS")) : 1;
     P.pairCells = pairCells;
