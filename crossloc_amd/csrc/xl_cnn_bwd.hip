@@ -799,6 +799,25 @@ __global__ void gnb_params_kernel(const double *ncsums, const float *gamma, int 
     if (dbias) dbias[c] = (cpg == 1) ? 0.f : (float)dbi;
 }
 
+// the same for a list of layers: blockIdx.y = layer (XL_OP_GNB_PARAMS_LIST)
+__global__ void gnb_params_list_kernel(const xl_gnb_params_item *__restrict__ items)
+{
+    const xl_gnb_params_item it = items[blockIdx.y];
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= it.C) return;
+    const int cpg = it.C / it.G;
+    const double m = (double)cpg * (double)it.HW;
+    const double gam = (double)it.gamma[c];
+    double dg = 0.0, db = 0.0, dbi = 0.0;
+    for (int n = 0; n < it.B; ++n) {
+        const double *o = it.sums + ((long long)n * it.C + c) * 6;
+        dg += o[1]; db += o[0];
+        dbi += o[5] * (gam * o[0] - ((double)it.HW * o[3] + o[4] * o[2]) / m);
+    }
+    it.dgamma[c] = (float)dg; it.dbeta[c] = (float)db;
+    if (it.dbias) it.dbias[c] = (cpg == 1) ? 0.f : (float)dbi;
+}
+
 // ---------------------------------------------------------------------------------------------- head backward
 
 // forward: s_o = w_o . x + b_o; out_o = s_o + mean (o < nTask); out_o = exp(clamp(s_o, lo, hi)) otherwise.
@@ -1200,6 +1219,13 @@ int xl_run_bwd_op(const xl_op &op, hipStream_t st)
         case XL_OP_WGRAD: {
             if (op.nchunks2 < 1 || op.ld_in % 4 != 0 || op.ld_aux % 4 != 0) return XL_ERR_ARG;
             if (op.flags & XL_CONV_SPLIT_BF16) {                      // 1x1 / batched Winograd products on the bf16 pipe
+                if (op.nchunks2 == 1) {
+                    // one split (the 64 batched products of a Winograd layer fill the chip without splitting K): the "partial"
+                    // tile IS the result, [z][Cout][Cin] - written in place, no reduce pass (it was a 134 MB copy per layer)
+                    xl_op direct = op;
+                    direct.stats2 = op.out;
+                    return (op.flags & XL_CONV_PAIR_F16) ? xl_run_wgrad_pair(direct, st) : xl_run_wgrad_split(direct, st);
+                }
                 const int rc = (op.flags & XL_CONV_PAIR_F16) ? xl_run_wgrad_pair(op, st) : xl_run_wgrad_split(op, st);
                 if (rc != XL_OK) return rc;
                 const long long total = (long long)op.Cout * op.Cin;
@@ -1227,6 +1253,8 @@ int xl_run_bwd_op(const xl_op &op, hipStream_t st)
             a.bstats = (double *)op.stats2; a.dx = (float *)op.out; a.daux = (float *)op.out2;
             a.ncsums = a.bstats + (long long)op.B * op.nchunks2 * op.Cin * 3;
             a.bco = reinterpret_cast<float *>(a.ncsums + (long long)op.B * op.Cin * 6);
+            // (XL_OP_GNB_PARAMS_LIST: the per-(image, channel) sums of this layer go to a buffer of its own, read at the end of the pass)
+            if (op.type == XL_OP_GNB_FINAL && op.scale) a.ncsums = (double *)const_cast<void *>(op.scale);
             a.B = op.B; a.HW = op.Hi * op.Wi; a.C = op.Cin; a.ldX = op.ld_in; a.ldD = op.ld_aux; a.ldO = op.ld_out; a.ldDx = op.ld_in;
             a.ldAux = op.Cout > 0 ? op.Cout : op.ld_out; a.G = op.groups; a.nchunks2 = op.nchunks2; a.flags = op.flags;
             static const int gnbRev = getenv("XL_GNB_REVERSE") ? atoi(getenv("XL_GNB_REVERSE")) : 1;
@@ -1256,6 +1284,12 @@ int xl_run_bwd_op(const xl_op &op, hipStream_t st)
             float *dbias = (op.flags & XL_GN_NO_CONV_BIAS) ? nullptr : (float *)op.aux2;
             hipLaunchKernelGGL(gnb_params_kernel, dim3((op.Cin + 63) / 64), dim3(64), 0, st, nc, (const float *)op.w, op.B,
                                op.Cin, op.groups, op.Hi * op.Wi, (float *)op.out, (float *)op.out2, dbias);
+            return XL_OK;
+        }
+        case XL_OP_GNB_PARAMS_LIST: {
+            if (op.Cin < 1 || op.Cin > 65535 || !op.in || op.Cout < 1) return XL_ERR_ARG;      // Cout = the largest channel count
+            hipLaunchKernelGGL(gnb_params_list_kernel, dim3((op.Cout + 63) / 64, op.Cin), dim3(64), 0, st,
+                               (const xl_gnb_params_item *)op.in);
             return XL_OK;
         }
         case XL_OP_HEAD_BWD: {

@@ -144,15 +144,25 @@ __device__ __forceinline__ void wino_u_of(const float *__restrict__ w, int Cin, 
 // PASS 0: the maxima per frequency; PASS 1: scale, split, store (and the inverse scales).  PASS 0 runs on few workgroups (a thread
 // keeps the running maxima of its elements in registers, the workgroup combines them through an LDS table - no atomics on
 // shared addresses - and issues one global atomicMax per frequency): a training loop re-packs every layer after every step.
+// One launch covers a LIST of matrices (blockIdx.y = entry of `items`, a device table - xl_cnn_repack_pairs: a training loop
+// re-packs every layer after every optimizer step, and 24 layers x (memset + two launches) of 25 us each were 1.4 ms of a
+// 35 ms step) or the single matrix `one` (items == nullptr).
+struct PairItem { const float *src; uint16_t *dst; int rows, K, kind, pad; };     // = xl_pair_item (include/crossloc_cnn.h)
+
 template <int M, int PASS>
 __global__ __launch_bounds__(256)
-void wino_weight_pair_kernel(const float *__restrict__ w, uint16_t *__restrict__ dst, unsigned *__restrict__ maxBits,
-                             float *__restrict__ invScale, int Cout, int Cin, int dgrad)
+void wino_weight_pair_kernel(const PairItem *__restrict__ items, PairItem one)
 {
     constexpr int N = M + 2, Z = N * N;
     extern __shared__ unsigned sTab[];                                // PASS 0: [256 threads][Z]
+    const PairItem it = items ? items[blockIdx.y] : one;              // rows = Cout, K = Cin, kind = dgrad
+    const float *__restrict__ w = it.src;
+    uint16_t *__restrict__ dst = it.dst;
+    const int Cout = it.rows, Cin = it.K, dgrad = it.kind;
     const int rows = dgrad ? Cin : Cout, K = dgrad ? Cout : Cin;
     const long long total = (long long)rows * K;
+    unsigned *__restrict__ maxBits = reinterpret_cast<unsigned *>(dst + (long long)Z * total * 2);
+    float *__restrict__ invScale = reinterpret_cast<float *>(maxBits + Z);
     unsigned mx[Z];
     if (PASS == 0) {
 #pragma unroll
@@ -189,12 +199,25 @@ void wino_weight_pair_kernel(const float *__restrict__ w, uint16_t *__restrict__
     }
 }
 
+// the maxima slots of a list of matrices (Z words behind each matrix' pairs) to zero: one launch instead of a memset per matrix
+__global__ void pair_zero_max_kernel(const PairItem *__restrict__ items, int Z)
+{
+    const PairItem it = items[blockIdx.x];
+    unsigned *maxBits = reinterpret_cast<unsigned *>(it.dst + (long long)Z * it.rows * it.K * 2);
+    for (int z = threadIdx.x; z < Z; z += blockDim.x) maxBits[z] = 0u;
+}
+
 template <int PASS>
 __global__ __launch_bounds__(256)
-void pair_weight_kernel(const float *__restrict__ src, uint16_t *__restrict__ dst, unsigned *__restrict__ maxBits, float *__restrict__ invScale,
-                        int rows, int K, int taps)
+void pair_weight_kernel(const PairItem *__restrict__ items, PairItem one)
 {
+    const PairItem it = items ? items[blockIdx.y] : one;              // kind = taps
+    const float *__restrict__ src = it.src;
+    uint16_t *__restrict__ dst = it.dst;
+    const int rows = it.rows, K = it.K, taps = it.kind;
     const long long total = (long long)rows * K;
+    unsigned *__restrict__ maxBits = reinterpret_cast<unsigned *>(dst + total * 2);
+    float *__restrict__ invScale = reinterpret_cast<float *>(maxBits + 1);
     const int Cin = taps > 0 ? K / taps : K;
     unsigned m = 0u;
     const float sc = PASS ? pair_scale_of_max(maxBits[0]) : 1.f;
@@ -209,14 +232,11 @@ void pair_weight_kernel(const float *__restrict__ src, uint16_t *__restrict__ ds
         if (taps == 1) v = src[i];
         else if (taps == 0) v = src[(long long)k * rows + r];
         else { const int tap = k / Cin, c = k - tap * Cin; v = src[((long long)r * Cin + c) * taps + tap]; }
-        if (PASS == 0) { const unsigned b = __builtin_bit_cast(unsigned, fabsf(v)); m = b > m ? b : m; }
-        else {
-            uint16_t hi, lo;
-            pair_hi_lo(v * sc, hi, lo);
-            const long long b0 = ((long long)r * (K >> 4) + (k >> 4)) * 32 + (k & 15);
-            dst[b0] = hi; dst[b0 + 16] = lo;
-            if (i == 0) invScale[0] = 1.f / sc;
-        }
+        uint16_t hi, lo;
+        pair_hi_lo(v * sc, hi, lo);
+        const long long b0 = ((long long)r * (K >> 4) + (k >> 4)) * 32 + (k & 15);
+        dst[b0] = hi; dst[b0 + 16] = lo;
+        if (i == 0) invScale[0] = 1.f / sc;
     }
     if (PASS == 0) xl_wave_max_commit(__builtin_bit_cast(float, m), maxBits);      // (one atomic per wave at most)
 }
@@ -272,6 +292,31 @@ void pair_scales_kernel(PairGnList L, float *__restrict__ out, int first, int la
     }
 }
 
+template <int M>
+int launch_wino_pairs(const PairItem *items, const PairItem &one, int n, long long maxTotal, hipStream_t st)
+{
+    constexpr int Z = (M + 2) * (M + 2);
+    long long blocks = (maxTotal + 255) / 256, blocks0 = blocks;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks0 > 256) blocks0 = 256;                             // PASS 0: one workgroup per CU, a few elements per thread
+    const size_t lds0 = sizeof(unsigned) * 256 * Z;
+    // (64 KB of dynamic LDS for m = 6: set on every call - idempotent, and cheaper than tracking the attribute per device here)
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(wino_weight_pair_kernel<M, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds0) != hipSuccess)
+        return XL_ERR_HIP;
+    hipLaunchKernelGGL((wino_weight_pair_kernel<M, 0>), dim3((unsigned)blocks0, n), dim3(256), lds0, st, items, one);
+    hipLaunchKernelGGL((wino_weight_pair_kernel<M, 1>), dim3((unsigned)blocks, n), dim3(256), 0, st, items, one);
+    return hipGetLastError() == hipSuccess ? XL_OK : XL_ERR_HIP;
+}
+int launch_plain_pairs(const PairItem *items, const PairItem &one, int n, long long maxTotal, hipStream_t st)
+{
+    long long blocks = (maxTotal + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    // (the maxima pass on few workgroups: thousands of waves arriving at once would all find the slot still empty and serialise
+    //  their atomics - 46 us for a 512 x 512 matrix against 5 for the split pass)
+    hipLaunchKernelGGL(pair_weight_kernel<0>, dim3((unsigned)(blocks < 32 ? blocks : 32), n), dim3(256), 0, st, items, one);
+    hipLaunchKernelGGL(pair_weight_kernel<1>, dim3((unsigned)blocks, n), dim3(256), 0, st, items, one);
+    return hipGetLastError() == hipSuccess ? XL_OK : XL_ERR_HIP;
+}
 }  // namespace
 
 extern "C" {
@@ -307,43 +352,36 @@ int xl_cnn_pack_wino_weight_pair(const float *w, void *dst, int Cout, int Cin, i
     const int K = dgrad ? Cout : Cin, Z = (m + 2) * (m + 2);
     if (K % 16 != 0) return XL_ERR_ARG;
     const long long total = (long long)Cout * Cin;
-    long long blocks = (total + 255) / 256, blocks0 = blocks;
-    if (blocks > 4096) blocks = 4096;
-    if (blocks0 > 256) blocks0 = 256;                             // PASS 0: one workgroup per CU, a few elements per thread
     hipStream_t st = (hipStream_t)stream;
     uint16_t *d = (uint16_t *)dst;
-    unsigned *maxBits = reinterpret_cast<unsigned *>(d + (long long)Z * total * 2);
-    float *inv = reinterpret_cast<float *>(maxBits + Z);
-    if (hipMemsetAsync(maxBits, 0, sizeof(unsigned) * Z, st) != hipSuccess) return XL_ERR_HIP;
-    const size_t lds0 = sizeof(unsigned) * 256 * Z;
-    if (m == 4) {
-        hipLaunchKernelGGL((wino_weight_pair_kernel<4, 0>), dim3((unsigned)blocks0), dim3(256), lds0, st, w, d, maxBits, inv, Cout, Cin, dgrad ? 1 : 0);
-        hipLaunchKernelGGL((wino_weight_pair_kernel<4, 1>), dim3((unsigned)blocks), dim3(256), 0, st, w, d, maxBits, inv, Cout, Cin, dgrad ? 1 : 0);
-    } else {
-        // (64 KB of dynamic LDS: set on every call - idempotent, and cheaper than tracking the attribute per device here)
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(wino_weight_pair_kernel<6, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds0) != hipSuccess) return XL_ERR_HIP;
-        hipLaunchKernelGGL((wino_weight_pair_kernel<6, 0>), dim3((unsigned)blocks0), dim3(256), lds0, st, w, d, maxBits, inv, Cout, Cin, dgrad ? 1 : 0);
-        hipLaunchKernelGGL((wino_weight_pair_kernel<6, 1>), dim3((unsigned)blocks), dim3(256), 0, st, w, d, maxBits, inv, Cout, Cin, dgrad ? 1 : 0);
-    }
-    return hipGetLastError() == hipSuccess ? XL_OK : XL_ERR_HIP;
+    if (hipMemsetAsync(d + (long long)Z * total * 2, 0, sizeof(unsigned) * Z, st) != hipSuccess) return XL_ERR_HIP;
+    const PairItem one = { w, d, Cout, Cin, dgrad ? 1 : 0, 0 };
+    return m == 4 ? launch_wino_pairs<4>(nullptr, one, 1, total, st) : launch_wino_pairs<6>(nullptr, one, 1, total, st);
 }
 
 int xl_cnn_pair_weight(const float *src, void *dst, int rows, int K, int taps, void *stream)
 {
     if (!src || !dst || rows < 1 || K < 16 || K % 16 != 0 || (taps != 0 && taps != 1 && taps != 9) || (taps > 0 && K % taps != 0)) return XL_ERR_ARG;
     const long long total = (long long)rows * K;
-    long long blocks = (total + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
     hipStream_t st = (hipStream_t)stream;
     uint16_t *d = (uint16_t *)dst;
-    unsigned *maxBits = reinterpret_cast<unsigned *>(d + total * 2);
-    float *inv = reinterpret_cast<float *>(maxBits + 1);
-    if (hipMemsetAsync(maxBits, 0, sizeof(unsigned), st) != hipSuccess) return XL_ERR_HIP;
-    // (the maxima pass on few workgroups: thousands of waves arriving at once would all find the slot still empty and serialise
-    //  their atomics - 46 us for a 512 x 512 matrix against 5 for the split pass)
-    hipLaunchKernelGGL(pair_weight_kernel<0>, dim3((unsigned)(blocks < 32 ? blocks : 32)), dim3(256), 0, st, src, d, maxBits, inv, rows, K, taps);
-    hipLaunchKernelGGL(pair_weight_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, src, d, maxBits, inv, rows, K, taps);
-    return hipGetLastError() == hipSuccess ? XL_OK : XL_ERR_HIP;
+    if (hipMemsetAsync(d + total * 2, 0, sizeof(unsigned), st) != hipSuccess) return XL_ERR_HIP;
+    const PairItem one = { src, d, rows, K, taps, 0 };
+    return launch_plain_pairs(nullptr, one, 1, total, st);
+}
+
+int xl_cnn_repack_pairs(const xl_pair_item *items_dev, int n, int m, long long max_elements, void *stream)
+{
+    static_assert(sizeof(xl_pair_item) == sizeof(PairItem), "xl_pair_item and the kernels' PairItem are one layout");
+    if (n == 0) return XL_OK;
+    if (!items_dev || n < 0 || n > 65535 || (m != 0 && m != 4 && m != 6) || max_elements < 1) return XL_ERR_ARG;
+    const PairItem *items = reinterpret_cast<const PairItem *>(items_dev);
+    hipStream_t st = (hipStream_t)stream;
+    const PairItem none = { nullptr, nullptr, 0, 0, 0, 0 };
+    hipLaunchKernelGGL(pair_zero_max_kernel, dim3(n), dim3(64), 0, st, items, m ? (m + 2) * (m + 2) : 1);
+    if (m == 6) return launch_wino_pairs<6>(items, none, n, max_elements, st);
+    if (m == 4) return launch_wino_pairs<4>(items, none, n, max_elements, st);
+    return launch_plain_pairs(items, none, n, max_elements, st);
 }
 
 int xl_cnn_pair_activation(const float *src, void *dst, long long rows, int K, const float *scale, void *stream)

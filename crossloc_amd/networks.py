@@ -40,6 +40,7 @@ CONV_NORM_ADD = 4096
 CONV_PAIR_F16 = 8192
 CONV_PAIR_AMAX = 16384
 XL_OP_FILL0 = 21
+XL_OP_GNB_PARAMS_LIST = 22
 XL_ERR_UNSUPPORTED = -4            # include/crossloc_dsac.h
 
 
@@ -70,6 +71,8 @@ def _bind():
         L.xl_cnn_pack_wino_weight_pair.argtypes = [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 4 + [ctypes.c_void_p]
         L.xl_cnn_pair_weight.restype = ctypes.c_int
         L.xl_cnn_pair_weight.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+        L.xl_cnn_repack_pairs.restype = ctypes.c_int
+        L.xl_cnn_repack_pairs.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_longlong, ctypes.c_void_p]
         L.xl_cnn_pair_activation.restype = ctypes.c_int
         L.xl_cnn_pair_activation.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
         L.xl_cnn_pair_scales.restype = ctypes.c_int
@@ -512,6 +515,45 @@ class _Plan:
         else:
             _check(_bind().xl_cnn_pair_weight(src.data_ptr(), planes.data_ptr(), src.shape[0], src.shape[1], 1, stream))
 
+    @staticmethod
+    def _pair_item(planes, src, m, mode=""):
+        """(list key, rows, K, kind) of a packed_pair entry for xl_cnn_repack_pairs - the arguments _pack_pair passes per matrix."""
+        if m:
+            return m, src.shape[0], src.shape[1], 1 if mode == "d" else 0
+        if mode == "t":
+            return 0, src.shape[1], src.shape[0], 0
+        if src.dim() == 4 and src.shape[2] == 3:
+            return 0, src.shape[0], src.shape[1] * 9, 9
+        return 0, src.shape[0], src.shape[1], 1
+
+    def _repack_pairs(self):
+        """Every fp16-pair operand again (refresh_weights) in three launches per list - the F(6x6,3x3) layers, the F(4x4,3x3) ones,
+        the plain matrices - instead of a memset and two launches per matrix (xl_cnn_repack_pairs; 24 + 23 matrices per step of
+        the batch-16 training plan).  The device tables hold pointers: they are rebuilt when an entry or an address changed."""
+        if not self.packed_pair:
+            return
+        if os.environ.get("XL_NO_BATCHED_REPACK"):
+            for entry in self.packed_pair.values():
+                self._pack_pair(*entry)
+            return
+        entries = list(self.packed_pair.values())
+        sig = tuple((e[0].data_ptr(), e[1].data_ptr()) for e in entries)
+        if getattr(self, "_pair_tables_sig", None) != sig:
+            import numpy as np
+            lists = {}
+            for planes, src, m, mode in entries:
+                key, rows, K, kind = self._pair_item(planes, src, m, mode)
+                lists.setdefault(key, []).append((src.data_ptr(), planes.data_ptr(), rows, K, kind, 0))
+            dt = np.dtype([("src", "<u8"), ("dst", "<u8"), ("rows", "<i4"), ("K", "<i4"), ("kind", "<i4"), ("pad", "<i4")])
+            self._pair_tables = []
+            for key, items in sorted(lists.items()):
+                table = torch.from_numpy(np.array(items, dtype=dt).view(np.uint8).copy()).to(self.device)
+                self._pair_tables.append((key, len(items), max(i[2] * i[3] for i in items), table))
+            self._pair_tables_sig = sig
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        for key, n, biggest, table in self._pair_tables:
+            _check(_bind().xl_cnn_repack_pairs(table.data_ptr(), n, key, biggest, stream))
+
     def wino_pick(self, H, W, chan_max, allowed=(6, 4)):
         """Output tile m of F(m x m, 3x3) for an H x W map: the allowed size (capped by XL_WINOGRAD) with the fewest
         multiplies, (m+2)^2 * ceil(H/m) * ceil(W/m); 0 if none.  The transformed tensors V / M hold (m+2)^2 independent
@@ -581,8 +623,7 @@ class _Plan:
             self._pack_wino_split(*entry)
         for entry in self.packed_1x1.values():
             self._split_weight(*entry)
-        for entry in self.packed_pair.values():
-            self._pack_pair(*entry)
+        self._repack_pairs()
         self._update_pair_scales()
         for key, (planes, src) in self.packed_c1.items():
             kind = key[1] if isinstance(key, tuple) else "c1"
@@ -698,17 +739,26 @@ class _Plan:
             self._split_weight(planes, src, transposed)
         return self.packed_1x1[key][0]
 
+    _conv1_fragment_index = {}                   # device -> gather indices of conv1_fragments
+
     @staticmethod
     def conv1_fragments(weight):
         """[3 planes][3 window rows][64 lanes][8] bf16 (int16 storage): the MFMA weight fragments of conv1_mfma_kernel.  Lane =
         32 * K-half + output channel; slot i of a lane = (dx = 2 * K-half + i // 4, c = i % 4), zero for c = 3 and dx = 3."""
         w = weight.detach().to(torch.float32)                                    # [32][3][ky][kx]
-        f = torch.zeros(3, 2, 32, 8, dtype=torch.float32, device=w.device)       # [dy][K-half][channel][slot]
-        for kh in range(2):
-            for i in range(8):
-                dx, c = 2 * kh + i // 4, i % 4
-                if c < 3 and dx < 3:
-                    f[:, kh, :, i] = w[:, c, :, dx].t()
+        # one gather through an index table (a training loop rebuilds the fragments after every step): slot (dy, K-half, channel,
+        # i) <- w[channel][c][dy][dx], or the zero appended behind the weights
+        idx = _Plan._conv1_fragment_index.get(w.device)
+        if idx is None:
+            host = torch.full((3, 2, 32, 8), 32 * 27, dtype=torch.int64)
+            for dy in range(3):
+                for kh in range(2):
+                    for i in range(8):
+                        dx, c = 2 * kh + i // 4, i % 4
+                        if c < 3 and dx < 3:
+                            host[dy, kh, :, i] = torch.arange(32) * 27 + c * 9 + dy * 3 + dx
+            idx = _Plan._conv1_fragment_index[w.device] = host.reshape(-1).to(w.device)
+        f = torch.cat([w.reshape(-1), w.new_zeros(1)])[idx]                      # [dy][K-half][channel][slot]
         planes = _Plan.split_bf16(f.reshape(3, 64, 8))                           # [3 planes][3 dy][64][8]
         return planes.contiguous()
 
@@ -745,10 +795,7 @@ class _Plan:
         to 16 bytes): the MFMA weight fragments of stem12_kernel<.., true> - the pair form of the 32 -> 64 stride-2 layer, cut
         from the operand xl_cnn_pair_weight packs for pair_conv3x3s2_kernel (same scale, same split: the fused and the
         two-kernel stem stay bitwise equal).  (int16 storage)"""
-        key = (id(conv.weight), "stem_pair")
-        if key in self.packed_pair:
-            self._pack_pair(*self.packed_pair[key])                             # (a refresh: the live weights first)
-        packed = self.pack_conv_stem_pair(conv)
+        packed = self.pack_conv_stem_pair(conv)                                  # (a refresh re-packs packed_pair first: _repack_pairs)
         n = 64 * 288
         frag = packed[:2 * n].view(2, 32, 18, 2, 2, 8).permute(2, 3, 0, 4, 1, 5).contiguous().reshape(-1)   # [kk][p][j][kh][fr][8]
         tail = torch.zeros(8, dtype=torch.int16, device=self.device)
@@ -1703,6 +1750,8 @@ class _Plan:
         amax_n = [0]
         gamax = {}                # conv-output key -> byte address of the slot holding max |its gradient|
 
+        params_list = None if os.environ.get("XL_GNB_PARAMS_PER_LAYER") else []
+
         def new_slot():
             assert amax_n[0] < 1024
             amax_n[0] += 1
@@ -1798,6 +1847,12 @@ class _Plan:
                 G = e["norm"].num_groups
                 nch2 = max(1, min(128, (H * W + 63) // 64))
                 scratch_d = max(scratch_d, B * nch2 * C * 3 + B * C * 6 + (B * C * 3 + 1) // 2)
+                # d gamma / d beta / d bias of ALL layers come from one launch at the end of the pass (XL_OP_GNB_PARAMS_LIST): the
+                # layer's per-(image, channel) sums then live in a buffer of their own (XL_GNB_PARAMS_PER_LAYER=1: one launch each)
+                sums = None
+                if params_list is not None:
+                    sums = torch.empty(B * C * 6, dtype=torch.float64, device=dev)
+                    self.keep.append(sums)
                 for typ in (XL_OP_GNB_STATS, XL_OP_GNB_FINAL, XL_OP_GNB_APPLY, XL_OP_GNB_PARAMS):
                     op = XlOp()
                     op.type = typ
@@ -1816,6 +1871,8 @@ class _Plan:
                         if daux is not None:
                             op.out2 = daux[0].data_ptr() + 4 * daux[2]
                             op.Cout = daux[1]                  # pixel stride of the d(residual) tensor
+                    elif typ == XL_OP_GNB_FINAL and sums is not None:
+                        op.scale = sums.data_ptr()
                     elif typ == XL_OP_GNB_PARAMS:
                         op.out = pgrad(e["norm"].weight).data_ptr()
                         op.out2 = pgrad(e["norm"].bias).data_ptr()
@@ -1823,6 +1880,10 @@ class _Plan:
                             op.aux2 = pgrad(prod["conv"].bias).data_ptr()
                         else:
                             op.flags = flags | GN_NO_CONV_BIAS
+                        if sums is not None:
+                            params_list.append((sums.data_ptr(), e["gamma"].data_ptr(), op.out, op.out2,
+                                                op.aux2 if prod is not None else 0, B, C, G, H * W))
+                            continue
                     patch_d.append(len(bops))
                     bops.append(op)
                 if self._key(e["out"]) in grads:                # dense, fully consumed: recycle (slices of the
@@ -2070,6 +2131,15 @@ class _Plan:
                 self.conv1_wgrad_indices.append(len(bops))
                 bops.append(op)
                 self.release_grad(dy)
+        if params_list:
+            import numpy as np
+            dt = np.dtype([("sums", "<u8"), ("gamma", "<u8"), ("dgamma", "<u8"), ("dbeta", "<u8"), ("dbias", "<u8"),
+                           ("B", "<i4"), ("C", "<i4"), ("G", "<i4"), ("HW", "<i4")])
+            self.gnb_params_table = torch.from_numpy(np.array(params_list, dtype=dt).view(np.uint8).copy()).to(dev)
+            op = XlOp()
+            op.type, op.Cin, op.Cout = XL_OP_GNB_PARAMS_LIST, len(params_list), max(i[6] for i in params_list)
+            op.in_ = self.gnb_params_table.data_ptr()
+            bops.append(op)
         self.bwd_scratch_f = torch.empty(max(scratch_f, 1), dtype=torch.float32, device=dev)
         self.bwd_scratch_d = torch.empty(max(scratch_d, 1), dtype=torch.float64, device=dev)
         self.bwd_array = (XlOp * len(bops))(*bops)

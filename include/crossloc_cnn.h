@@ -89,6 +89,10 @@ enum {
     XL_OP_FILL0 = 21,       /* round 5: `Cin` bytes at `out` set to zero on the stream (the slots of the gradient maxima, zeroed at the
                                head of a backward op list: XL_OP_GNB_APPLY / XL_OP_WINO_DY with `scale` set record max |result| there
                                as float bits; the pair GEMMs that read those results take XL_CONV_PAIR_AMAX) */
+    XL_OP_GNB_PARAMS_LIST = 22, /* XL_OP_GNB_PARAMS of a whole backward pass in ONE launch (28 launches of 10 us each per step of the
+                               reference's network): in = device array of `Cin` xl_gnb_params_item entries; the XL_OP_GNB_FINAL
+                               ops of those layers carry scale = the item's `sums` (a buffer of the layer's own: the shared
+                               scratch behind stats2 is reused by the next layer).  Bit-identical to the per-layer ops. */
     XL_OP_GN_FINAL = 11  /* per-(image, channel) GroupNorm scale/shift [B][C][2] from the partial sums (out);
                             GN_APPLY with aux2 = that buffer skips its own finalisation.  out2 (training plans):
                             [B][C][2] {mean, rstd} for the GroupNorm backward ops.  reserved_i = rows per producer tile (0: all
@@ -196,6 +200,10 @@ typedef struct xl_op {
                                       weights' own inverse scale) in the epilogue */
 } xl_op;
 
+/* one layer of XL_OP_GNB_PARAMS_LIST: sums = [B][C][6] doubles written by XL_OP_GNB_FINAL (its `scale`), gamma[C], results
+ * d gamma[C], d beta[C], d bias[C] of the preceding convolution (NULL: none) */
+typedef struct xl_gnb_params_item { const double *sums; const float *gamma; float *dgamma, *dbeta, *dbias; int32_t B, C, G, HW; } xl_gnb_params_item;
+
 /* Execute ops[0..n_ops) in order on `stream` (hipStream_t; NULL = default). Asynchronous.
  * Returns 0 or a negative xl status (include/crossloc_dsac.h); on error nothing further is launched. */
 int xl_cnn_run(const xl_op *ops, int n_ops, void *stream);
@@ -244,6 +252,13 @@ int xl_cnn_split_weight(const float *src_dev, void *dst_dev, int rows, int K, in
  * xl_cnn_pair_weight: a plain [rows][K] matrix (taps as xl_cnn_split_weight), one scale: rows*K*4 + 8 bytes. */
 int xl_cnn_pack_wino_weight_pair(const float *w_oihw_dev, void *dst_dev, int Cout, int Cin, int m, int dgrad, void *stream);
 int xl_cnn_pair_weight(const float *src_dev, void *dst_dev, int rows, int K, int taps, void *stream);
+
+/* The same packs for a LIST of matrices in three launches (a training loop re-packs every layer after every optimizer step):
+ * items_dev = device array of n entries; m = 6 / 4: every entry a Winograd layer (src = OIHW weights, rows = Cout, K = Cin,
+ * kind = dgrad, dst as xl_cnn_pack_wino_weight_pair); m = 0: plain matrices (rows, K, kind = taps, dst as xl_cnn_pair_weight).
+ * max_elements = the largest rows*K (Cout*Cin) of the list.  Results are bit-identical to the per-matrix calls. */
+typedef struct xl_pair_item { const float *src; void *dst; int rows, K, kind, pad; } xl_pair_item;
+int xl_cnn_repack_pairs(const xl_pair_item *items_dev, int n, int m, long long max_elements, void *stream);
 /* fp32 [rows][K] -> activation pairs [rows][K/8][2][8] fp16 of src * scale[0] (tests, tools; K % 16 == 0) */
 int xl_cnn_pair_activation(const float *src_dev, void *dst_dev, long long rows, int K, const float *scale_dev, void *stream);
 /* The activation scale of a plan: out[0..1] = {s, 1/s} for GroupNorm outputs, out[2..3] = {s/256, 256/s} for their Winograd

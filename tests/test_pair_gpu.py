@@ -520,3 +520,77 @@ def test_gradient_maxima_are_recorded_by_the_groupnorm_backward_pass():
         assert torch.isfinite(v).all() and (v > 0).all()
         vals.append(v)
     assert torch.allclose(vals[1], vals[0] * 1000.0, rtol=1e-3)
+
+
+def test_batched_repack_is_bitwise_the_per_matrix_packs():
+    """xl_cnn_repack_pairs (what a training loop calls after every optimizer step): a list of F(6x6,3x3) layers (forward and data-
+    gradient operands, different sizes), a list of F(4x4,3x3) ones and a list of plain matrices (1x1, transposed, 3x3 tap-major) in
+    three launches per list - every byte of every destination, the scratch maxima and the inverse scales included, equals what
+    xl_cnn_pack_wino_weight_pair / xl_cnn_pair_weight write for that matrix alone."""
+    import numpy as np
+    L = networks._bind()
+    g = torch.Generator().manual_seed(11)
+    dt = np.dtype([("src", "<u8"), ("dst", "<u8"), ("rows", "<i4"), ("K", "<i4"), ("kind", "<i4"), ("pad", "<i4")])
+
+    def check(m, specs):
+        srcs, single, batch, items = [], [], [], []
+        for cout, cin, kind, mag in specs:
+            if m:
+                w = (torch.randn(cout, cin, 3, 3, generator=g) * mag).cuda()
+                n16 = (m + 2) ** 2 * cout * cin * 2 + 4 * (m + 2) ** 2
+                rows, K = cout, cin
+            elif kind == 9:
+                w = (torch.randn(cout, cin, 3, 3, generator=g) * mag).cuda()
+                n16, rows, K = cout * cin * 9 * 2 + 4, cout, cin * 9
+            elif kind == 0:
+                w = (torch.randn(cin, cout, generator=g) * mag).cuda()            # [K][rows]: the transpose is packed
+                n16, rows, K = cout * cin * 2 + 4, cout, cin
+            else:
+                w = (torch.randn(cout, cin, generator=g) * mag).cuda()
+                n16, rows, K = cout * cin * 2 + 4, cout, cin
+            a = torch.full((n16,), 0x5555, dtype=torch.int16, device="cuda")
+            b = torch.full((n16,), 0x2222, dtype=torch.int16, device="cuda")
+            if m:
+                networks._check(L.xl_cnn_pack_wino_weight_pair(w.data_ptr(), a.data_ptr(), cout, cin, m, kind, None))
+            else:
+                networks._check(L.xl_cnn_pair_weight(w.data_ptr(), a.data_ptr(), rows, K, kind, None))
+            srcs.append(w); single.append(a); batch.append(b)
+            items.append((w.data_ptr(), b.data_ptr(), rows, K, kind, 0))
+        table = torch.from_numpy(np.array(items, dtype=dt).view(np.uint8).copy()).cuda()
+        networks._check(L.xl_cnn_repack_pairs(table.data_ptr(), len(items), m, max(i[2] * i[3] for i in items), None))
+        torch.cuda.synchronize()
+        for a, b in zip(single, batch):
+            assert torch.equal(a, b)
+    check(6, [(512, 512, 0, 0.02), (512, 512, 1, 0.02), (256, 128, 0, 3.0), (128, 256, 1, 1e-6), (64, 64, 0, 0.0)])
+    check(4, [(128, 128, 0, 0.05), (256, 128, 1, 0.5)])
+    check(0, [(512, 512, 1, 0.03), (256, 512, 0, 0.03), (1024, 512, 1, 2.0), (128, 64, 9, 0.1), (64, 32, 9, 1e-5), (256, 256, 0, 0.0)])
+    assert L.xl_cnn_repack_pairs(None, 0, 6, 1, None) == 0                      # an empty list is not an error
+    assert L.xl_cnn_repack_pairs(None, 3, 6, 1, None) != 0 and L.xl_cnn_repack_pairs(1, 3, 5, 1, None) != 0
+
+
+def test_refresh_weights_batched_and_per_matrix_leave_identical_operands(monkeypatch):
+    """A training plan's refresh_weights after an in-place parameter update: the batched re-pack (default) and the per-matrix one
+    (XL_NO_BATCHED_REPACK=1) write identical pair operands, and both differ from the operands of the old weights."""
+    from crossloc_amd.weights import seeded_state_dict
+    net = networks.TransPoseNet(torch.tensor([-455.934, 417.50, 520.31]), False, False, 1, 1, 3, 1)
+    net.load_state_dict(seeded_state_dict(net, 5))
+    net = net.cuda().train()
+    x = torch.rand(2, 3, 256, 384, generator=torch.Generator().manual_seed(4)).cuda()
+    net(x).sum().backward()
+    plan = [p for p in net._plans.values() if p.train][0]
+    assert len(plan.packed_pair) > 20
+    before = [e[0].clone() for e in plan.packed_pair.values()]
+    with torch.no_grad():
+        for p in net.parameters():
+            p.mul_(1.0 + 0.01 * torch.rand_like(p))
+    plan.refresh_weights()
+    torch.cuda.synchronize()
+    batched = [e[0].clone() for e in plan.packed_pair.values()]
+    assert any(not torch.equal(a, b) for a, b in zip(before, batched))
+    for e in plan.packed_pair.values():
+        e[0].fill_(0x1111)
+    monkeypatch.setenv("XL_NO_BATCHED_REPACK", "1")
+    plan.refresh_weights()
+    torch.cuda.synchronize()
+    for a, e in zip(batched, plan.packed_pair.values()):
+        assert torch.equal(a, e[0])

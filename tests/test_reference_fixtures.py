@@ -105,7 +105,7 @@ def _loss16(mod, on_gpu):
             yield "%s_%s" % (task, mode or "plain"), float(loss.item()), float(rate), dp, du
 
 
-def _check_loss16(mod, on_gpu, rel_loss, rel_mom, rel_s):
+def _check_loss16(mod, on_gpu, rel_loss, rel_mom, rel_s, abs_s=1e-4):
     for tag, loss, rate, dp, du in _loss16(mod, on_gpu):
         assert loss == pytest.approx(float(L16[tag + "_loss"]), rel=rel_loss), tag
         assert rate == pytest.approx(float(L16[tag + "_rate"]), abs=2e-5), tag
@@ -121,7 +121,7 @@ def _check_loss16(mod, on_gpu, rel_loss, rel_mom, rel_s):
             # and reprojection terms leaves single elements of the fp32 reference 2e-2 off; measured on the MI355X: the kernel
             # lands closer to the float64 value than the fp32 reference does)
             ref64 = L16["%s_%s_sample64" % (tag, nm)].astype(np.float64)
-            atol = 1e-4 * max(np.abs(ref_s).max(), 1e-30)
+            atol = abs_s * max(np.abs(ref_s).max(), 1e-30)
             excess = np.abs(s - ref64) - rel_s * np.abs(ref64) - 2.0 * np.abs(ref_s - ref64)
             i = np.unravel_index(np.argmax(excess), excess.shape)
             assert excess[i] <= atol, (tag, nm, "worst element", i, float(s[i]), float(ref_s[i]), float(ref64[i]), "excess / atol",
@@ -130,7 +130,10 @@ def _check_loss16(mod, on_gpu, rel_loss, rel_mom, rel_s):
 
 def test_loss_oracle_at_batch16_vs_reference_fixture():
     from oracle import loss_oracle
-    _check_loss16(loss_oracle, False, 2e-6, 1e-5, 1e-4)
+    # (abs_s: the oracle is PyTorch CPU fp32, whose vectorised kernels differ between hosts in their last bits - on the GPU box's
+    #  host one near-cancelling element of d pred lands 1.4e-4 of the largest sample off, in the build container below 1e-4; the HIP kernel,
+    #  which accumulates those terms in a fixed order, is held to 1e-4 on every host)
+    _check_loss16(loss_oracle, False, 2e-6, 1e-5, 1e-4, abs_s=3e-4)
 
 
 # ------------------------------------------------------------------------------------------ GPU: the HIP path
