@@ -1714,7 +1714,10 @@ __global__ void gn_stats_kernel(const float *__restrict__ x, double *__restrict_
     }
 }
 
-// per-(image, channel) scale/shift from the fp64 partial sums, fixed summation order.  grid (B), 256 threads.
+// per-(image, channel) scale/shift from the fp64 partial sums, fixed summation order.  grid (B, slices), 256 threads: a workgroup
+// finalises G / slices consecutive groups of one image.  slices > 1 for long entry lists only (the stem: conv2 leaves 2760 entries
+// per image and group, 1.4 MB that ONE workgroup read in 41 us whatever the number of loads in flight - a single CU's miss queue -
+// out of a single frame's 1.46 ms); the launcher derives it from the layer's geometry, never from the batch.
 __global__ __launch_bounds__(256)
 void gn_final_kernel(const double *__restrict__ stats, const float *__restrict__ gamma, const float *__restrict__ beta,
                      float *__restrict__ coeff, int HW, int C, int G, int nchunks, float eps, int statTile,
@@ -1723,6 +1726,7 @@ void gn_final_kernel(const double *__restrict__ stats, const float *__restrict__
     __shared__ double sG[2 * 64];
     const int n = blockIdx.x, tid = threadIdx.x;
     const int cpg = C / G;
+    const int Gw = G / (int)gridDim.y, g0 = (int)blockIdx.y * Gw;     // this workgroup's groups
     int valid = nchunks;
     if (statTile > 0)          // statistics came from a conv epilogue: one entry per conv tile overlapping image n
         valid = (int)((((long long)(n + 1) * HW - 1) / statTile) - (((long long)n * HW) / statTile)) + 1;
@@ -1733,12 +1737,12 @@ void gn_final_kernel(const double *__restrict__ stats, const float *__restrict__
     // a contiguous slice of the chunks, then the P slices are added as a fixed binary tree.  P depends on the layer only.
     __shared__ double sP[256 * 2];
     int gp = 1;
-    while (gp < G) gp <<= 1;
+    while (gp < Gw) gp <<= 1;
     const int P = 256 / gp;
     {
-        const int g = tid / P, part = tid - g * P;
+        const int gl = tid / P, part = tid - gl * P, g = g0 + gl;
         double a = 0.0, b = 0.0;
-        if (g < G) {
+        if (gl < Gw) {
             const int per = (valid + P - 1) / P;
             int k0 = part * per, k1 = k0 + per;
             if (k1 > valid) k1 = valid;
@@ -1769,7 +1773,7 @@ void gn_final_kernel(const double *__restrict__ stats, const float *__restrict__
         }
     }
     __syncthreads();
-    for (int g = tid; g < G; g += 256) {
+    for (int g = tid; g < Gw; g += 256) {                              // (sG: indexed by the group's number within the workgroup)
         const double a = sP[2 * (g * P)], b = sP[2 * (g * P) + 1];
         const double cnt = (double)HW * (double)cpg;
         const double mean = a / cnt;
@@ -1778,8 +1782,8 @@ void gn_final_kernel(const double *__restrict__ stats, const float *__restrict__
         sG[2 * g] = mean; sG[2 * g + 1] = 1.0 / sqrt(var + (double)eps);
     }
     __syncthreads();
-    for (int c = tid; c < C; c += 256) {
-        const int g = c / cpg;
+    for (int c = g0 * cpg + tid; c < (g0 + Gw) * cpg; c += 256) {
+        const int g = c / cpg - g0;
         const double sc = (double)gamma[c] * sG[2 * g + 1];
         coeff[((long long)n * C + c) * 2] = (float)sc;
         coeff[((long long)n * C + c) * 2 + 1] = (float)((double)beta[c] - sG[2 * g] * sc);
@@ -2529,7 +2533,17 @@ int run_op(const xl_op &op, hipStream_t st)
                 const long long tiles = op.reserved_i < 0 ? (hw + rows - 1) / rows : (hw + rows - 1) / rows + 1;
                 if (tiles * perTile > op.nchunks) return XL_ERR_ARG;
             }
-            hipLaunchKernelGGL(gn_final_kernel, dim3(op.B), dim3(256), 0, st, (const double *)op.stats, (const float *)op.w,
+            // entries per image and group (an upper estimate from the layer's geometry): long lists are split over workgroups by
+            // groups - 4 slices above 256 entries, 8 above 1024 (the stem; every other layer: one workgroup per image, as ever)
+            long long entries = op.nchunks;
+            if (op.reserved_i != 0) {
+                const long long rows = op.reserved_i < 0 ? -op.reserved_i : op.reserved_i;
+                entries = (((long long)op.Hi * op.Wi + rows - 1) / rows + 1) * (op.stride > 1 ? op.stride : 1);
+            }
+            int slices = entries > 1024 ? 8 : entries > 256 ? 4 : 1;
+            static const char *noSlices = getenv("XL_GN_FINAL_ONE_WG");
+            if (op.groups % slices != 0 || noSlices) slices = 1;
+            hipLaunchKernelGGL(gn_final_kernel, dim3(op.B, slices), dim3(256), 0, st, (const double *)op.stats, (const float *)op.w,
                                (const float *)op.bias, (float *)op.out, op.Hi * op.Wi, op.Cin, op.groups, op.nchunks, op.eps,
                                op.reserved_i, (float *)op.out2, op.reserved_i != 0 && op.stride > 1 ? op.stride : 1);
             return XL_OK;
