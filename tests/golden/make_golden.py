@@ -232,7 +232,11 @@ def full_size_goldens():
         x = golden_inputs.full_size_image(tag)
         with torch.no_grad():
             y = net(torch.from_numpy(x))
+            # the same module evaluated in float64 (round 5): how far the reference's OWN fp32 forward is from it is the yardstick
+            # the HIP forward - fp16-pair GEMMs, Winograd - is held to (tests/test_reference_fixtures.py)
+            y64 = net.to(torch.float64)(torch.from_numpy(x).to(torch.float64))
         out[tag + "_y"] = y.numpy()
+        out[tag + "_y64"] = y64.numpy()
         out[tag + "_x_checksum"] = np.array(golden_inputs.checksum(x))
     np.savez_compressed(os.path.join(HERE, "full_size.npz"), **out)
     _print("full_size.npz", {k: v.shape for k, v in out.items()})
