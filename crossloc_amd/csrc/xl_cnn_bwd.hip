@@ -1076,9 +1076,15 @@ void partial_sum_kernel(const float *__restrict__ partial, float *__restrict__ o
 // output channel per thread (3 per read) the kernel sat on the LDS pipe at 6x its HBM time.
 // A block walks `rowsPerBlock` output rows of one image two at a time; the 4 image rows (with halo, channels padded
 // to a float4) they touch are staged in LDS.  partial [gridDim.y * gridDim.x][28][32]
+// FOLD (round 5): `dy` is the gradient w.r.t. the GroupNorm(+ReLU) OUTPUT of conv1 and `x` conv1's raw output: the apply pass of
+// the GroupNorm backward (dx = k1 dv - k2 - xhat k3, the arithmetic of gnb_apply_kernel - same operations, same order, same bits)
+// runs on load, from the forward table `fco` and the coefficients `bco` XL_OP_GNB_FINAL left.  conv1 has no data gradient: its dx
+// had this kernel as only reader, and the apply pass read and wrote 2.1 GB for it at batch 16.
+template <bool FOLD>
 __global__ __launch_bounds__(256)
 void conv1_wgrad_kernel(const float *__restrict__ img, const float *__restrict__ dy, float *__restrict__ partial,
-                        int B, int Cin, int H, int W, int ldY, int rowsPerBlock)
+                        int B, int Cin, int H, int W, int ldY, int rowsPerBlock,
+                        const float *__restrict__ x, int ldX, const float *__restrict__ fco, const float *__restrict__ bco, int reluIn)
 {
     constexpr int R = 2, CO = 32;
     extern __shared__ __attribute__((aligned(16))) float sDyn[];
@@ -1092,6 +1098,28 @@ void conv1_wgrad_kernel(const float *__restrict__ img, const float *__restrict__
     f32x4 acc[28];                                                 // [tap*3 + c] (27: bias) x 4 output channels
 #pragma unroll
     for (int k = 0; k < 28; ++k) acc[k] = f32x4{ 0.f, 0.f, 0.f, 0.f };
+    f32x4 kMu, kRs, kSc, kSh, k1, k2, k3;                          // FOLD: this thread's four channels of image n
+    if constexpr (FOLD) {
+        const float *scsh = fco + ((long long)n * CO + 4 * og) * 2, *murs = fco + (((long long)B + n) * CO + 4 * og) * 2;
+        const float *bo = bco + ((long long)n * CO + 4 * og) * 3;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            kSc[j] = scsh[2 * j]; kSh[j] = scsh[2 * j + 1]; kMu[j] = murs[2 * j]; kRs[j] = murs[2 * j + 1];
+            k1[j] = bo[3 * j]; k2[j] = bo[3 * j + 1]; k3[j] = bo[3 * j + 2];
+        }
+    }
+    auto grad_of = [&](const f32x4 &d4, const f32x4 &xv) {
+        if constexpr (!FOLD) return d4;
+        f32x4 dx;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float v = xv[j] * kSc[j] + kSh[j];
+            const float xh = (xv[j] - kMu[j]) * kRs[j];
+            const float dv = (reluIn && !(v > 0.f)) ? 0.f : d4[j];
+            dx[j] = k1[j] * dv - k2[j] - xh * k3[j];
+        }
+        return dx;
+    };
     const int W2 = W + 2;
     for (int y0 = yBeg; y0 < yEnd; y0 += R) {
         __syncthreads();
@@ -1121,17 +1149,24 @@ void conv1_wgrad_kernel(const float *__restrict__ img, const float *__restrict__
         // rows y0.. are consecutive in memory: pixel p of the step is dyRow + p*ldY.  The load of the next pixel is
         // issued before the FMAs of the current one (one HBM round trip per iteration otherwise).
         const float *dyRow = dy + ((long long)n * H + y0) * W * ldY + 4 * og;
+        const float *xRow = FOLD ? x + ((long long)n * H + y0) * W * ldX + 4 * og : nullptr;
         const int np = rows * W;
-        f32x4 gNext = f32x4{ 0.f, 0.f, 0.f, 0.f };
-        if (pl < np) gNext = *reinterpret_cast<const f32x4 *>(dyRow + (long long)pl * ldY);
+        f32x4 gNext = f32x4{ 0.f, 0.f, 0.f, 0.f }, xNext = f32x4{ 0.f, 0.f, 0.f, 0.f };
+        if (pl < np) {
+            gNext = *reinterpret_cast<const f32x4 *>(dyRow + (long long)pl * ldY);
+            if constexpr (FOLD) xNext = *reinterpret_cast<const f32x4 *>(xRow + (long long)pl * ldX);
+        }
         for (int p = pl; p < np; p += 32) {
-            const int ry = p / W, x = p - ry * W;
-            const f32x4 g = gNext;
-            if (p + 32 < np) gNext = *reinterpret_cast<const f32x4 *>(dyRow + (long long)(p + 32) * ldY);
+            const int ry = p / W, xcol = p - ry * W;
+            const f32x4 g = grad_of(gNext, xNext);
+            if (p + 32 < np) {
+                gNext = *reinterpret_cast<const f32x4 *>(dyRow + (long long)(p + 32) * ldY);
+                if constexpr (FOLD) xNext = *reinterpret_cast<const f32x4 *>(xRow + (long long)(p + 32) * ldX);
+            }
             acc[27] += g;
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
-                const f32x4 *row = sImg + (ry + ky) * W2 + x;
+                const f32x4 *row = sImg + (ry + ky) * W2 + xcol;
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
                     const f32x4 v = row[kx];
@@ -1374,8 +1409,17 @@ int xl_run_bwd_op(const xl_op &op, hipStream_t st)
             size_t lds = sizeof(float) * (size_t)4 * (op.Wi + 2) * 4;
             if (lds < sizeof(float) * (size_t)4 * op.Cout * 28) lds = sizeof(float) * (size_t)4 * op.Cout * 28;
             if (lds > 64 * 1024) return XL_ERR_UNSUPPORTED;
-            hipLaunchKernelGGL(conv1_wgrad_kernel, dim3(rb, op.B), dim3(256), lds, st, (const float *)op.in, (const float *)op.aux,
-                               (float *)op.stats2, op.B, op.Cin, op.Hi, op.Wi, op.ld_aux, rowsPerBlock);
+            if (op.aux2) {
+                // GroupNorm-backward apply on load: aux2 = conv1's raw output (ld_in), w = the layer's forward table (XL_OP_GN_FINAL
+                // with out2), bias = the coefficients [B][Cout][3] of XL_OP_GNB_FINAL, flags = the GroupNorm's XL_GN_RELU_IN
+                if (!op.w || !op.bias || op.ld_in % 4 != 0) return XL_ERR_ARG;
+                hipLaunchKernelGGL(conv1_wgrad_kernel<true>, dim3(rb, op.B), dim3(256), lds, st, (const float *)op.in, (const float *)op.aux,
+                                   (float *)op.stats2, op.B, op.Cin, op.Hi, op.Wi, op.ld_aux, rowsPerBlock, (const float *)op.aux2, op.ld_in,
+                                   (const float *)op.w, (const float *)op.bias, (op.flags & XL_GN_RELU_IN) ? 1 : 0);
+            } else
+                hipLaunchKernelGGL(conv1_wgrad_kernel<false>, dim3(rb, op.B), dim3(256), lds, st, (const float *)op.in, (const float *)op.aux,
+                                   (float *)op.stats2, op.B, op.Cin, op.Hi, op.Wi, op.ld_aux, rowsPerBlock, (const float *)nullptr, 0,
+                                   (const float *)nullptr, (const float *)nullptr, 0);
             hipLaunchKernelGGL(conv1_wgrad_reduce_kernel, dim3(28), dim3(256), 0, st,
                                (const float *)op.stats2, (float *)op.out, (float *)op.out2, blocks, op.Cin);
             return XL_OK;

@@ -1751,6 +1751,7 @@ class _Plan:
         gamax = {}                # conv-output key -> byte address of the slot holding max |its gradient|
 
         params_list = None if os.environ.get("XL_GNB_PARAMS_PER_LAYER") else []
+        c1_fold, patch_bco = {}, []
 
         def new_slot():
             assert amax_n[0] < 1024
@@ -1833,8 +1834,14 @@ class _Plan:
                 gout = find_grad(e["out"])
                 if gout is None:
                     continue                                   # output unused downstream of any trainable path
-                dx = self.alloc(B * H * W * C)
                 flags = e["flags"]
+                prod = producers.get(self._key(e["raw"]))
+                # conv1's GroupNorm: its dx has ONE reader, conv1's weight gradient (the image needs no data gradient) - that kernel
+                # applies the backward pass on load and the apply pass (2.1 GB read and written at batch 16) is not run
+                fold_c1 = (prod is not None and prod["kind"] == "conv1" and e["aux"] is None and C == 32
+                           and not (flags & (GN_ADD | GN_RELU_OUT)) and ld % 4 == 0 and off % 4 == 0
+                           and not os.environ.get("XL_NO_CONV1_WGRAD_FOLD"))
+                dx = None if fold_c1 else self.alloc(B * H * W * C)
                 daux = None
                 if e["aux"] is not None:
                     daux = find_grad(e["aux"])
@@ -1843,7 +1850,6 @@ class _Plan:
                     else:
                         daux = (self.alloc(B * H * W * C), C, 0)
                         grads[self._key(e["aux"])] = daux
-                prod = producers.get(self._key(e["raw"]))
                 G = e["norm"].num_groups
                 nch2 = max(1, min(128, (H * W + 63) // 64))
                 scratch_d = max(scratch_d, B * nch2 * C * 3 + B * C * 6 + (B * C * 3 + 1) // 2)
@@ -1854,6 +1860,8 @@ class _Plan:
                     sums = torch.empty(B * C * 6, dtype=torch.float64, device=dev)
                     self.keep.append(sums)
                 for typ in (XL_OP_GNB_STATS, XL_OP_GNB_FINAL, XL_OP_GNB_APPLY, XL_OP_GNB_PARAMS):
+                    if typ == XL_OP_GNB_APPLY and fold_c1:
+                        continue
                     op = XlOp()
                     op.type = typ
                     op.B, op.Hi, op.Wi, op.Cin, op.groups = B, H, W, C, G
@@ -1886,6 +1894,13 @@ class _Plan:
                             continue
                     patch_d.append(len(bops))
                     bops.append(op)
+                if fold_c1:
+                    # (the gradient w.r.t. the GroupNorm output stays alive until conv1's weight gradient has read it)
+                    c1_fold[self._key(e["raw"])] = dict(dout=gout, x=(t, ld, off), fco=e["table"], flags=flags,
+                                                       bco_off=B * nch2 * C * 3 + B * C * 6,
+                                                       release=grads.pop(self._key(e["out"]), (None,))[0])
+                    graw[self._key(e["raw"])] = gout[0]
+                    continue
                 if self._key(e["out"]) in grads:                # dense, fully consumed: recycle (slices of the
                     self.release_grad(grads.pop(self._key(e["out"]))[0])   # concat gradient stay until the end)
                 if prod is not None:
@@ -2120,6 +2135,14 @@ class _Plan:
                 op.type = XL_OP_CONV1_WGRAD
                 op.B, op.Hi, op.Wi, op.Cin, op.Cout, op.ld_aux = B, H, W, conv.in_channels, Cout, Cout
                 op.aux = dy.data_ptr()
+                fold = c1_fold.pop(self._key(e["raw"]), None)
+                if fold is not None:                                # the GroupNorm-backward apply pass on load (see the "gn" branch)
+                    gt, gld, goff = fold["dout"]
+                    xt, xld, xoff = fold["x"]
+                    op.aux, op.ld_aux = gt.data_ptr() + 4 * goff, gld
+                    op.aux2, op.ld_in = xt.data_ptr() + 4 * xoff, xld
+                    op.w, op.flags = fold["fco"].data_ptr(), fold["flags"]
+                    patch_bco.append((len(bops), fold["bco_off"]))
                 op.out = pgrad(conv.weight).data_ptr()
                 # the bias gradient of conv1 comes from the GroupNorm backward sums (fp64 closed form); the sum this
                 # kernel also produces goes to a scratch vector
@@ -2130,7 +2153,10 @@ class _Plan:
                 patch_f.append(len(bops))
                 self.conv1_wgrad_indices.append(len(bops))
                 bops.append(op)
-                self.release_grad(dy)
+                if fold is None:
+                    self.release_grad(dy)
+                elif fold["release"] is not None:
+                    self.release_grad(fold["release"])
         if params_list:
             import numpy as np
             dt = np.dtype([("sums", "<u8"), ("gamma", "<u8"), ("dgamma", "<u8"), ("dbeta", "<u8"), ("dbias", "<u8"),
@@ -2147,6 +2173,8 @@ class _Plan:
             self.bwd_array[i].stats2 = self.bwd_scratch_f.data_ptr()
         for i in patch_d:
             self.bwd_array[i].stats2 = self.bwd_scratch_d.data_ptr()
+        for i, off_d in patch_bco:                                  # conv1's folded apply: the coefficients its GNB_FINAL op left
+            self.bwd_array[i].bias = self.bwd_scratch_d.data_ptr() + 8 * off_d
 
     GRAPH_MAX_BATCH = 8            # plans of at most this many frames replay their op list as one HIP graph (XL_CNN_GRAPH)
 

@@ -47,7 +47,11 @@ enum {
     XL_OP_GNB_PARAMS = 8,/* d gamma, d beta and the bias gradient of the preceding conv */
     XL_OP_HEAD_BWD = 9,  /* backward of XL_OP_HEAD: d(input) NHWC, d(fc3 weight), d(fc3 bias) */
     XL_OP_CONV1_WGRAD = 10, /* weight + bias gradient of the NCHW-input first conv (Cout 32); reserved_i = image rows per
-                               workgroup (default 16), stats2 = scratch of B*ceil(Hi/rows)*28*Cout floats */
+                               workgroup (default 16), stats2 = scratch of B*ceil(Hi/rows)*28*Cout floats.  aux2 != NULL (round 5):
+                               aux is the gradient w.r.t. the layer's GroupNorm(+ReLU) OUTPUT and the backward apply pass runs on
+                               load - aux2 = conv1's raw output (ld_in), w = the forward table of XL_OP_GN_FINAL (out, out2),
+                               bias = the coefficients [B][Cout][3] XL_OP_GNB_FINAL left, flags = XL_GN_RELU_IN of that layer;
+                               no XL_OP_GNB_APPLY is run for it (conv1 has no data gradient: its dx has no other reader) */
     XL_OP_WINO_IN = 12,     /* Winograd input transform: in [B,Hi,Wi,Cin] -> out V [(m+2)^2][B*Ho*Wo][Cin] with Ho x Wo tiles
                                of m x m outputs; ksize = m: 2 = F(2x2,3x3) (Hi, Wi even), 4 = F(4x4,3x3) (Ho = ceil(Hi/4)), 6 = F(6x6,3x3)
                                (Ho = ceil(Hi/6)).

@@ -195,3 +195,32 @@ def test_rccl_collectives_on_a_one_rank_group():
         assert torch.equal(out, vals)
     finally:
         dist.destroy_process_group()
+
+
+def test_backward_launch_reductions_do_not_change_a_bit(monkeypatch):
+    """Round 5's training-step launch reductions against the forms they replace, same network, same batch: conv1's GroupNorm-backward
+    apply folded into its weight-gradient kernel (XL_NO_CONV1_WGRAD_FOLD=1: the apply pass), the GroupNorm parameter gradients of
+    the pass in one launch (XL_GNB_PARAMS_PER_LAYER=1: one launch per layer) and the batched re-pack (covered in test_pair_gpu) -
+    every parameter gradient (90 tensors of the 1 + 1 extra-block network) is bitwise the same."""
+    def grads(env):
+        for k in ("XL_NO_CONV1_WGRAD_FOLD", "XL_GNB_PARAMS_PER_LAYER"):
+            monkeypatch.delenv(k, raising=False)
+        for k in env:
+            monkeypatch.setenv(k, "1")
+        net = networks.TransPoseNet(torch.tensor(synth.SCENE_MEAN, dtype=torch.float32), False, False, 1, 1, 3, 1)
+        net.load_state_dict(seeded_state_dict(net, 31))
+        net = net.cuda().train()
+        x = torch.rand(2, 3, 128, 192, generator=torch.Generator().manual_seed(9)).cuda()
+        pred = net(x)
+        w = torch.rand(pred.shape, generator=torch.Generator().manual_seed(10)).cuda()
+        (pred * w).sum().backward()
+        plan = [p for p in net._plans.values() if p.train][0]
+        folded = any(op.type == networks.XL_OP_CONV1_WGRAD and op.aux2 for op in plan.bwd_array)
+        listed = any(op.type == networks.XL_OP_GNB_PARAMS_LIST for op in plan.bwd_array)
+        return {n: p.grad.clone() for n, p in net.named_parameters()}, folded, listed
+    new, folded, listed = grads(())
+    old, folded0, listed0 = grads(("XL_NO_CONV1_WGRAD_FOLD", "XL_GNB_PARAMS_PER_LAYER"))
+    assert folded and listed and not folded0 and not listed0
+    assert len(new) == 90
+    for n in new:
+        assert torch.equal(new[n], old[n]), n
