@@ -41,6 +41,11 @@ CONV_PAIR_F16 = 8192
 CONV_PAIR_AMAX = 16384
 XL_OP_FILL0 = 21
 XL_OP_GNB_PARAMS_LIST = 22
+# entries of the device tables of xl_cnn_repack_pairs / XL_OP_GNB_PARAMS_LIST (include/crossloc_cnn.h: xl_pair_item, xl_gnb_params_item)
+import numpy as _np   # noqa: E402
+PAIR_ITEM_DTYPE = _np.dtype([("src", "<u8"), ("dst", "<u8"), ("rows", "<i4"), ("K", "<i4"), ("kind", "<i4"), ("pad", "<i4")])
+GNB_PARAMS_ITEM_DTYPE = _np.dtype([("sums", "<u8"), ("gamma", "<u8"), ("dgamma", "<u8"), ("dbeta", "<u8"), ("dbias", "<u8"),
+                                   ("B", "<i4"), ("C", "<i4"), ("G", "<i4"), ("HW", "<i4")])
 XL_ERR_UNSUPPORTED = -4            # include/crossloc_dsac.h
 
 
@@ -85,6 +90,11 @@ def _bind():
         L.xl_cnn_graph_destroy.restype = ctypes.c_int
         L.xl_cnn_graph_destroy.argtypes = [ctypes.c_void_p]
         L.xl_cnn_last_error.restype = ctypes.c_char_p
+        L.xl_cnn_item_size.restype = ctypes.c_int
+        L.xl_cnn_item_size.argtypes = [ctypes.c_int]
+        if (L.xl_cnn_item_size(0), L.xl_cnn_item_size(1)) != (PAIR_ITEM_DTYPE.itemsize, GNB_PARAMS_ITEM_DTYPE.itemsize):
+            raise _lib.XlError("device-table entry layout mismatch: C %d / %d vs numpy %d / %d" % (
+                L.xl_cnn_item_size(0), L.xl_cnn_item_size(1), PAIR_ITEM_DTYPE.itemsize, GNB_PARAMS_ITEM_DTYPE.itemsize))
         if L.xl_cnn_op_size() != ctypes.sizeof(XlOp):
             raise _lib.XlError("xl_op layout mismatch: C %d vs ctypes %d" % (L.xl_cnn_op_size(), ctypes.sizeof(XlOp)))
         L._cnn_bound = True
@@ -544,7 +554,7 @@ class _Plan:
             for planes, src, m, mode in entries:
                 key, rows, K, kind = self._pair_item(planes, src, m, mode)
                 lists.setdefault(key, []).append((src.data_ptr(), planes.data_ptr(), rows, K, kind, 0))
-            dt = np.dtype([("src", "<u8"), ("dst", "<u8"), ("rows", "<i4"), ("K", "<i4"), ("kind", "<i4"), ("pad", "<i4")])
+            dt = PAIR_ITEM_DTYPE
             self._pair_tables = []
             for key, items in sorted(lists.items()):
                 table = torch.from_numpy(np.array(items, dtype=dt).view(np.uint8).copy()).to(self.device)
@@ -2159,8 +2169,7 @@ class _Plan:
                     self.release_grad(fold["release"])
         if params_list:
             import numpy as np
-            dt = np.dtype([("sums", "<u8"), ("gamma", "<u8"), ("dgamma", "<u8"), ("dbeta", "<u8"), ("dbias", "<u8"),
-                           ("B", "<i4"), ("C", "<i4"), ("G", "<i4"), ("HW", "<i4")])
+            dt = GNB_PARAMS_ITEM_DTYPE
             self.gnb_params_table = torch.from_numpy(np.array(params_list, dtype=dt).view(np.uint8).copy()).to(dev)
             op = XlOp()
             op.type, op.Cin, op.Cout = XL_OP_GNB_PARAMS_LIST, len(params_list), max(i[6] for i in params_list)

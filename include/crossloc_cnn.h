@@ -215,6 +215,9 @@ int xl_cnn_run(const xl_op *ops, int n_ops, void *stream);
 /* sizeof(xl_op) as compiled, so a binding can verify its struct layout. */
 int xl_cnn_op_size(void);
 
+/* sizeof of the device-table entries a binding builds: which = 0: xl_pair_item, 1: xl_gnb_params_item (-1: unknown). */
+int xl_cnn_item_size(int which);
+
 /* The same op list as ONE executable HIP graph: xl_cnn_graph_capture records the launches of ops[0..n_ops) on `stream`
  * (a created stream, not NULL; nothing executes during the capture, and every kernel of the list must have run once
  * before - the first launch of a kernel configures it) and returns an opaque handle; xl_cnn_graph_launch replays it on a

@@ -530,7 +530,7 @@ def test_batched_repack_is_bitwise_the_per_matrix_packs():
     import numpy as np
     L = networks._bind()
     g = torch.Generator().manual_seed(11)
-    dt = np.dtype([("src", "<u8"), ("dst", "<u8"), ("rows", "<i4"), ("K", "<i4"), ("kind", "<i4"), ("pad", "<i4")])
+    dt = networks.PAIR_ITEM_DTYPE
 
     def check(m, specs):
         srcs, single, batch, items = [], [], [], []
