@@ -2603,11 +2603,6 @@ int xl_cnn_run(const xl_op *ops, int n_ops, void *stream)
 
 int xl_cnn_op_size(void) { return (int)sizeof(xl_op); }
 
-int xl_cnn_item_size(int which)
-{
-    return which == 0 ? (int)sizeof(xl_pair_item) : which == 1 ? (int)sizeof(xl_gnb_params_item) : -1;
-}
-
 // ---- the op list of a plan as ONE executable HIP graph (latency path: a single frame is ~95 short launches, and the host
 // side of an eager launch costs about as much as the shortest kernels run)
 int xl_cnn_graph_capture(const xl_op *ops, int n_ops, void *stream, void **graph_out)

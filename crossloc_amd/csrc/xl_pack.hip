@@ -370,6 +370,11 @@ int xl_cnn_pair_weight(const float *src, void *dst, int rows, int K, int taps, v
     return launch_plain_pairs(nullptr, one, 1, total, st);
 }
 
+int xl_cnn_item_size(int which)
+{
+    return which == 0 ? (int)sizeof(xl_pair_item) : which == 1 ? (int)sizeof(xl_gnb_params_item) : -1;
+}
+
 int xl_cnn_repack_pairs(const xl_pair_item *items_dev, int n, int m, long long max_elements, void *stream)
 {
     static_assert(sizeof(xl_pair_item) == sizeof(PairItem), "xl_pair_item and the kernels' PairItem are one layout");
