@@ -159,6 +159,28 @@ __device__ __forceinline__ void project(const Pose &p, double X, double Y, doubl
     v = (float)(y * cam.f + cam.cy);
 }
 
+// (cell i = y * Wo + x; the loops that walk the cells at a fixed stride carry (y, x) along instead of dividing: CellWalk)
+__device__ __forceinline__ float cell_err_at(const Pose &p, const Coords &co, int i, int y, int x, const Cam &cam)
+{
+    double X, Y, Z;
+    co.fetch(i, X, Y, Z);
+    float u, v;
+    project(p, X, Y, Z, cam, u, v);
+    float px = (float)(x * cam.sub + cam.sub / 2), py = (float)(y * cam.sub + cam.sub / 2);
+    float dx = px - u, dy = py - v;
+    double n = sqrt((double)dx * (double)dx + (double)dy * (double)dy);
+    float a = (float)n;
+    return (cam.maxReproj < a) ? cam.maxReproj : a;
+}
+
+// row / column of a cell index that advances by a constant stride: one division at the start, then adds and compares (an integer
+// division by the run-time grid width is ~25 of a cell's ~160 instructions in the scoring loop)
+struct CellWalk {
+    int y, x, sy, sx, Wo;
+    __device__ __forceinline__ CellWalk(int i0, int stride, int wo) : y(i0 / wo), x(i0 - (i0 / wo) * wo), sy(stride / wo), sx(stride - (stride / wo) * wo), Wo(wo) {}
+    __device__ __forceinline__ void step() { y += sy; x += sx; if (x >= Wo) { x -= Wo; ++y; } }
+};
+
 __device__ __forceinline__ float cell_err(const Pose &p, const Coords &co, int i, const Cam &cam)
 {
     int y = i / cam.Wo, x = i - y * cam.Wo;
@@ -608,6 +630,7 @@ struct Params {
     int S;                        // sub-blocks per image in the split launch
     float thr, focal, ppx, ppy, alpha, maxReproj;
     int pairCells;                // scoring loop: two cells per lane and trip (same bits, more instruction-level parallelism)
+    int cellWalk;                 // scoring loop: row / column carried along instead of divided out (XL_DSAC_CELL_WALK=0: divide)
 };
 
 // LDS carve (all dynamic, 16-byte aligned pieces)
@@ -781,9 +804,16 @@ void xl_dsac_forward_kernel(Params P)
         // cell, same order of the additions into `acc`: the bits do not change (XL_DSAC_PAIR_CELLS=0: one cell per trip)
         double acc = 0.0;
         int i = lane;
+        CellWalk w0(lane, 128, cam.Wo), w1(lane + 64, 128, cam.Wo);
         if (P.pairCells)
         for (; i + 64 < N; i += 128) {
-            const float e0 = cell_err(pose, co, i, cam), e1 = cell_err(pose, co, i + 64, cam);
+            float e0, e1;
+            if (P.cellWalk) {
+                e0 = cell_err_at(pose, co, i, w0.y, w0.x, cam); e1 = cell_err_at(pose, co, i + 64, w1.y, w1.x, cam);
+                w0.step(); w1.step();
+            } else {
+                e0 = cell_err(pose, co, i, cam); e1 = cell_err(pose, co, i + 64, cam);
+            }
             double st0 = (double)(beta * (e0 - cam.thr)), st1 = (double)(beta * (e1 - cam.thr));
             st0 = 1.0 / (1.0 + det_exp(-st0));
             st1 = 1.0 / (1.0 + det_exp(-st1));
@@ -1611,6 +1641,8 @@ int xl_dsac_forward_rgb_batch(const float *coords_dev, int64_t sb, int64_t sc, i
     P.part = nullptr; P.S = S;
     static const int pairCells = getenv("XL_DSAC_PAIR_CELLS") ? atoi(getenv("XL_DSAC_PAIR_CELLS")) : 1;
     P.pairCells = pairCells;
+    static const int cellWalk = getenv("XL_DSAC_CELL_WALK") ? atoi(getenv("XL_DSAC_CELL_WALK")) : 1;
+    P.cellWalk = cellWalk;
     if (S == 1) {
         hipLaunchKernelGGL(xl_dsac_forward_kernel<0>, dim3(B), dim3(kThreads), lds, st, P);
     } else {
@@ -1716,7 +1748,7 @@ int xl_dsac_backward_rgb_batch(const float *coords_dev, int64_t sb, int64_t sc, 
     P.nHyp = n_hyp; P.Ho = Ho; P.Wo = Wo; P.sub = sub; P.Npad = (N + 3) & ~3;
     P.thr = thr; P.focal = focal; P.ppx = ppx; P.ppy = ppy; P.alpha = alpha; P.maxReproj = max_reproj;
     P.part = part; P.S = S;
-    P.pairCells = 1;
+    P.pairCells = 1; P.cellWalk = 1;
     BwdParams Q;
     Q.coords = coords_dev; Q.sb = sb; Q.sc = sc; Q.sy = sy; Q.sx = sx;
     Q.grad = grad_dev; Q.gsb = gsb; Q.gsc = gsc; Q.gsy = gsy; Q.gsx = gsx;
