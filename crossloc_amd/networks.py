@@ -856,8 +856,10 @@ class _Plan:
             op.reserved_i = 64                        # (the normalise-on-load form exists with 128-row tiles only)
         if split and k == 3:                          # stride-2 stem layer on the split pipe (no statistics epilogue)
             op.flags |= CONV_SPLIT_BF16 | CONV_SPLIT_IL
-            if self.pair_ok() and norm_in is not None and not os.environ.get("XL_NO_PAIR_STEM"):
-                # round 5: fp16 pairs, three passes (csrc/xl_stem_pair.hip); the operand is a GroupNorm output normalised on load
+            if (self.pair_ok() and (norm_in is not None or (self.train and os.environ.get("XL_TRAIN_PAIR_STEM", "1") not in ("", "0")))
+                    and not os.environ.get("XL_NO_PAIR_STEM")):
+                # round 5: fp16 pairs, three passes (csrc/xl_stem_pair.hip); the operand is a GroupNorm output normalised on load -
+                # or, in training plans, the materialised GroupNorm + ReLU output: the same bound holds
                 op.flags |= CONV_PAIR_F16
                 op.w = self.pack_conv_stem_pair(conv).data_ptr()
                 op.scale = self.pair_scales.data_ptr()

@@ -594,3 +594,30 @@ def test_refresh_weights_batched_and_per_matrix_leave_identical_operands(monkeyp
     torch.cuda.synchronize()
     for a, e in zip(batched, plan.packed_pair.values()):
         assert torch.equal(a, e[0])
+
+
+def test_training_plans_run_the_stride2_stem_layers_as_pairs():
+    """conv3 / conv4 of a TRAINING plan (inputs: materialised GroupNorm + ReLU outputs - the bound that makes the static scale safe
+    holds for them as for the on-load form of inference plans) carry XL_CONV_PAIR_F16 (XL_TRAIN_PAIR_STEM=0: the six-pass kernels),
+    and the forward of the two plans agrees to the pair GEMMs' accuracy."""
+    from crossloc_amd.weights import seeded_state_dict
+    outs = []
+    for env in ("1", "0"):
+        os.environ["XL_TRAIN_PAIR_STEM"] = env
+        try:
+            net = networks.TransPoseNet(torch.tensor([-455.934, 417.50, 520.31]), False, False, 1, 1, 3, 1)
+            net.load_state_dict(seeded_state_dict(net, 5))
+            net = net.cuda().train()
+            x = torch.rand(2, 3, 256, 384, generator=torch.Generator().manual_seed(4)).cuda()
+            y = net(x)
+            plan = [p for p in net._plans.values() if p.train][0]
+            stem = [op for op in plan.ops if op.type == networks.XL_OP_CONV and op.ksize == 3 and op.stride == 2]
+            assert len(stem) >= 2
+            assert all(bool(op.flags & networks.CONV_PAIR_F16) == (env == "1") for op in stem)
+            outs.append(y.detach().cpu().double())
+        finally:
+            os.environ.pop("XL_TRAIN_PAIR_STEM", None)
+    ref = outs[1]
+    rng = (ref[:, :3] - torch.tensor([-455.934, 417.50, 520.31]).double()[None, :, None, None]).abs().max().item()
+    assert (outs[0][:, :3] - ref[:, :3]).abs().max().item() <= 2e-4 * max(1.0, rng)
+    assert torch.allclose(outs[0][:, 3], ref[:, 3], rtol=2e-3)
