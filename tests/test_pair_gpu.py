@@ -597,9 +597,9 @@ def test_refresh_weights_batched_and_per_matrix_leave_identical_operands(monkeyp
 
 
 def test_training_plans_run_the_stride2_stem_layers_as_pairs():
-    """conv3 / conv4 of a TRAINING plan (inputs: materialised GroupNorm + ReLU outputs - the bound that makes the static scale safe
-    holds for them as for the on-load form of inference plans) carry XL_CONV_PAIR_F16 (XL_TRAIN_PAIR_STEM=0: the six-pass kernels),
-    and the forward of the two plans agrees to the pair GEMMs' accuracy."""
+    """conv3 / conv4 of a TRAINING plan under XL_TRAIN_PAIR_STEM=1 (inputs: materialised GroupNorm + ReLU outputs - the bound that
+    makes the static scale safe holds for them as for the on-load form of inference plans) carry XL_CONV_PAIR_F16 (the default, 0:
+    the six-pass kernels), and the forward of the two plans agrees to the pair GEMMs' accuracy."""
     from crossloc_amd.weights import seeded_state_dict
     outs = []
     for env in ("1", "0"):
