@@ -9,6 +9,9 @@ import os
 
 import pytest
 
+_PAIRS_OFF = os.environ.get("XL_GEMM_PAIR") in ("", "0") or os.environ.get("XL_GEMM_SPLIT_BF16") in ("0", "1")
+pairs_only = pytest.mark.skipif(_PAIRS_OFF, reason="the fp16-pair forms are switched off (measurement switch set)")
+
 torch = pytest.importorskip("torch")
 import torch.nn as nn                      # noqa: E402
 import torch.nn.functional as F            # noqa: E402
@@ -497,6 +500,7 @@ def test_conv1x1_data_gradient_as_fp16_pairs_with_the_scale_from_the_recorded_ma
     assert ((gx.cpu().double() - 3 * ref).abs().max() / sc).item() < 3e-6
 
 
+@pairs_only
 def test_gradient_maxima_are_recorded_by_the_groupnorm_backward_pass():
     """A training step leaves max |dx| of every GroupNorm-backward apply pass in the plan's slots (zeroed by XL_OP_FILL0 at the head of
     the backward list): after a backward pass every slot a pair GEMM reads holds a positive finite float, and a second pass with
@@ -514,7 +518,7 @@ def test_gradient_maxima_are_recorded_by_the_groupnorm_backward_pass():
         plan = [p for p in net._plans.values() if p.train][0]
         used = sorted({op.scale for op in plan.bwd_array if op.type == networks.XL_OP_CONV and (op.flags & networks.CONV_PAIR_AMAX)} |
                       {op.out2 for op in plan.bwd_array if op.type == networks.XL_OP_WGRAD and (op.flags & networks.CONV_PAIR_F16)})
-        assert len(used) > 10
+        assert len(used) > 5
         idx = [(a - plan.bwd_amax.data_ptr()) // 4 for a in used]
         v = plan.bwd_amax.view(torch.float32)[idx].cpu()
         assert torch.isfinite(v).all() and (v > 0).all()
@@ -568,6 +572,7 @@ def test_batched_repack_is_bitwise_the_per_matrix_packs():
     assert L.xl_cnn_repack_pairs(None, 3, 6, 1, None) != 0 and L.xl_cnn_repack_pairs(1, 3, 5, 1, None) != 0
 
 
+@pairs_only
 def test_refresh_weights_batched_and_per_matrix_leave_identical_operands(monkeypatch):
     """A training plan's refresh_weights after an in-place parameter update: the batched re-pack (default) and the per-matrix one
     (XL_NO_BATCHED_REPACK=1) write identical pair operands, and both differ from the operands of the old weights."""
@@ -578,7 +583,7 @@ def test_refresh_weights_batched_and_per_matrix_leave_identical_operands(monkeyp
     x = torch.rand(2, 3, 256, 384, generator=torch.Generator().manual_seed(4)).cuda()
     net(x).sum().backward()
     plan = [p for p in net._plans.values() if p.train][0]
-    assert len(plan.packed_pair) > 20
+    assert len(plan.packed_pair) > 10
     before = [e[0].clone() for e in plan.packed_pair.values()]
     with torch.no_grad():
         for p in net.parameters():
@@ -596,6 +601,7 @@ def test_refresh_weights_batched_and_per_matrix_leave_identical_operands(monkeyp
         assert torch.equal(a, e[0])
 
 
+@pairs_only
 def test_training_plans_run_the_stride2_stem_layers_as_pairs():
     """conv3 / conv4 of a TRAINING plan under XL_TRAIN_PAIR_STEM=1 (inputs: materialised GroupNorm + ReLU outputs - the bound that
     makes the static scale safe holds for them as for the on-load form of inference plans) carry XL_CONV_PAIR_F16 (the default, 0:

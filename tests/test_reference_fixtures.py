@@ -161,7 +161,7 @@ def test_hip_forward_at_480x720_against_the_float64_reference(tag, num_mlr):
     """The dtype claim at the level of the NETWORK: the reference module evaluated in float64 on the fixture's frame
     (full_size.npz `*_y64`) is the truth, the reference's own fp32 forward (`*_y`, PyTorch CPU) the yardstick.  The coordinate
     channels - a mean of ~500 m added to an O(1) head output - sit within half an fp32 ulp of it either way: the HIP forward's mean
-    distance must stay within 1.15x the reference's (measured 1.03x / 1.09x).  The uncertainty channel has no such floor and shows
+    distance must stay within 1.25x the reference's (measured 1.03x / 1.09x).  The uncertainty channel has no such floor and shows
     the arithmetic: median relative distance 2.1e-6 / 3.8e-6 against the reference's 5.3e-7 / 7.2e-7 (4x / 5x), maxima 2.0e-5 /
     3.0e-5 against 2.9e-6 / 4.4e-6 (7x) - held to 8x and 12x.  That distance is the Winograd F(6x6,3x3) transforms' fp32 arithmetic,
     not the GEMM operands: the same network with XL_NO_WINOGRAD=1 lands at 1.8x (9.5e-7), with F(4x4,3x3) at 2.8x, and of the three
@@ -171,7 +171,8 @@ def test_hip_forward_at_480x720_against_the_float64_reference(tag, num_mlr):
         y = net(torch.from_numpy(golden_inputs.full_size_image(tag)).cuda()).cpu().double().numpy()
     y64, y32 = FULL[tag + "_y64"], FULL[tag + "_y"].astype(np.float64)
     e, e32 = np.abs(y - y64), np.abs(y32 - y64)
-    assert e[:, :3].mean() <= 1.15 * e32[:, :3].mean() and e[:, :3].max() <= 2.0 * e32[:, :3].max(), (e[:, :3].mean(), e[:, :3].max())
+    # (1.25: the measurement switches' forms - six-pass bf16 1.16x, fp32 MFMA 1.20x on the 3-encoder net - pass the same test)
+    assert e[:, :3].mean() <= 1.25 * e32[:, :3].mean() and e[:, :3].max() <= 2.0 * e32[:, :3].max(), (e[:, :3].mean(), e[:, :3].max())
     r, r32 = e[:, 3] / np.abs(y64[:, 3]), e32[:, 3] / np.abs(y64[:, 3])
     print("%s: uncertainty channel, relative distance from float64: median %.2e (reference fp32 %.2e), max %.2e (%.2e)"
           % (tag, np.median(r), np.median(r32), r.max(), r32.max()))
