@@ -1597,6 +1597,19 @@ int hip_fail(hipError_t e, const char *what)
 
 extern "C" {
 
+int xl_dsac_forward_sub_blocks(int B, int n_hyp)
+{
+    if (B <= 0 || n_hyp <= 0) return 0;
+    // sub-blocks per image: fill ~2 workgroups per CU, at least one hypothesis per wavefront
+    int S = 1;
+    while (S * 2 <= n_hyp / kWaves && (long long)B * S * 2 <= 512) S *= 2;
+    static const char *noSplit = getenv("XL_DSAC_NO_SPLIT");
+    if (noSplit) S = 1;
+    static const int forceS = getenv("XL_DSAC_SPLIT") ? atoi(getenv("XL_DSAC_SPLIT")) : 0;      // experiments: sub-blocks per image
+    if (forceS >= 1 && forceS * kWaves <= n_hyp) S = forceS;
+    return S;
+}
+
 int xl_dsac_forward_rgb_batch(const float *coords_dev, int64_t sb, int64_t sc, int64_t sy, int64_t sx,
                               int B, int Ho, int Wo, float *out_poses_dev,
                               int n_hyp, float thr, float focal, float ppx, float ppy,
@@ -1631,13 +1644,7 @@ int xl_dsac_forward_rgb_batch(const float *coords_dev, int64_t sb, int64_t sc, i
         configured.done(lds, cfgDev);
     }
     hipStream_t st = (hipStream_t)stream;
-    // sub-blocks per image: fill ~2 workgroups per CU, at least one hypothesis per wavefront
-    int S = 1;
-    while (S * 2 <= n_hyp / kWaves && (long long)B * S * 2 <= 512) S *= 2;
-    static const char *noSplit = getenv("XL_DSAC_NO_SPLIT");
-    if (noSplit) S = 1;
-    static const int forceS = getenv("XL_DSAC_SPLIT") ? atoi(getenv("XL_DSAC_SPLIT")) : 0;      // experiments: sub-blocks per image
-    if (forceS >= 1 && forceS * kWaves <= n_hyp) S = forceS;
+    const int S = xl_dsac_forward_sub_blocks(B, n_hyp);
     P.part = nullptr; P.S = S;
     static const int pairCells = getenv("XL_DSAC_PAIR_CELLS") ? atoi(getenv("XL_DSAC_PAIR_CELLS")) : 1;
     P.pairCells = pairCells;

@@ -69,7 +69,23 @@ struct PairArgs {
     const float *aScale;         // {s, 1 / s} of the activations
     int T, C, N, Z, nbm, nbn;
     long long *clk;              // diagnostics (XL_PAIR_CLK=1): per-wave shader-tick sums of the four phases of a K-step
+    int stagger;                 // > 0: the workgroups start spread over this many ticks of the 100 MHz clock (see stagger_start)
+    int var;                     // measurement switches (XL_PAIR_VAR)
 };
+
+// A persistent launch gives every CU the same tiles of the same size: all 256 workgroups reach their epilogues together, the chip
+// alternates between a phase in which nothing is stored (and the matrix pipes draw all the power) and one in which 64 MB of
+// stores queue at the memory side with every matrix pipe idle.  Spreading the START of the workgroups over one tile period puts
+// the CUs out of phase: at any moment a fraction of them stores while the others multiply.  The phase of a workgroup is a
+// fixed function of its index (a golden-ratio hash: neighbouring indices - the same XCD - far apart).
+__device__ __forceinline__ void stagger_start(int ticks)
+{
+    if (ticks <= 0) return;
+    const unsigned h = (blockIdx.x * 0x9E3779B1u) >> 24;
+    const long long d = ((long long)ticks * h) >> 8;
+    const long long t0 = wall_clock64();
+    while ((long long)wall_clock64() - t0 < d) __builtin_amdgcn_s_sleep(8);
+}
 
 __device__ __forceinline__ f16x8 scale_hs(f16x8 hi) { return hi * (_Float16)0.00048828125f; }      // hi * 2^-11: 4 x v_pk_mul_f16
 
@@ -100,6 +116,7 @@ void pair_gemm_kernel(PairArgs a)
     const int runLen = q8 + (xcd < r8 ? 1 : 0);
     const int myCount = runLen > local ? (runLen - local + nloc - 1) / nloc : 0;
     if (myCount == 0) return;
+    stagger_start(a.stagger);
 
     const long long rowB = (long long)a.C * 4;                        // bytes per operand row (both operands)
     const int nk = CT ? CT / 16 : a.C / 16;
@@ -186,7 +203,7 @@ void pair_gemm_kernel(PairArgs a)
     const int rhalf = (lane >> 5) * 4;
     const float aInv = a.aScale[1];
     dmaOn = false; readOn = false;
-    long long cPre = 0, cVm = 0, cBar = 0, cTail = 0, cT = 0;
+    long long cPre = 0, cVm = 0, cBar = 0, cTail = 0, cT = 0, cEpi = 0, cVm2 = 0;
     if (a.clk) cT = clock64();
     for (int ti = 0; ti < myCount; ++ti) {
 #pragma unroll
@@ -225,10 +242,11 @@ void pair_gemm_kernel(PairArgs a)
             __builtin_amdgcn_sched_barrier(0);
             if (a.clk) { const long long t = clock64(); cPre += t - cT; cT = t; }
             if (!(DBG & 4)) {
-                if (kk < 2 && ti > 0) __builtin_amdgcn_s_waitcnt(0x8F70 | 8);   // vmcnt(40): + the 32 stores of the tile before
+                if ((DBG & 8) && kk < 2 && ti > 0) __builtin_amdgcn_s_waitcnt(0x0F70 | 9);   // (one store per tile)
+            else if (kk < 2 && ti > 0) __builtin_amdgcn_s_waitcnt(0x8F70 | 8);   // vmcnt(40): + the 32 stores of the tile before
                 else __builtin_amdgcn_s_waitcnt(0x0F70 | 8);
             }
-            if (a.clk) { const long long t = clock64(); cVm += t - cT; cT = t; }
+            if (a.clk) { const long long t = clock64(); cVm += t - cT; if (kk < 2 && ti > 0) cVm2 += t - cT; cT = t; }
             if (!(DBG & 4)) __builtin_amdgcn_s_barrier();
             if (a.clk) { const long long t = clock64(); cBar += t - cT; cT = t; }
             __builtin_amdgcn_sched_barrier(0);
@@ -251,6 +269,37 @@ void pair_gemm_kernel(PairArgs a)
         const int m0 = mt * 256, n0 = nt * 256;
         const float inv = aInv * a.uInv[z];                              // (powers of two: the un-scaling is exact)
         const __amdgpu_buffer_rsrc_t srdO = __builtin_amdgcn_make_buffer_rsrc((void *)(a.out + (long long)z * a.T * a.N), 0, (int)((long long)a.T * a.N * 4), 0x00020000);
+        if (!(a.var & 4) && !(DBG & (8 | 48))) {
+            // A lane of the 32 x 32 accumulator block holds 4 x 4 consecutive channels of ONE row (8 apart, the other 4 of each 8 in lane
+            // + 32): stored as they lie, an instruction writes 32 bytes into each of 32 rows - 32 requests of half a 64-byte L2
+            // request each, and the CU's store path takes ~440 ticks per instruction (14000 per tile: round 6, XL_PAIR_CLK).  Neighbouring
+            // lanes (rows m, m + 1) trade one channel quad of each pair, so that an instruction writes 64 contiguous bytes into each of 16
+            // rows: even rows in the first instruction of a pair, odd rows in the second.  Same values, same number of stores.
+            const bool odd = lane & 1;
+            const int mE = m0 + wm * 128 + ((lane & 31) & ~1), cL = n0 + wn * 64 + 8 * (lane & 1) + rhalf;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const unsigned rowOff0 = (unsigned)((long long)(mE + i * 32) * a.N * 4) + (unsigned)cL * 4u;
+                const unsigned rowOff1 = rowOff0 + (unsigned)a.N * 4u;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int pq = 0; pq < 2; ++pq) {
+                        f32x4 o0, o1;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float x0 = acc[i][j][8 * pq + e] * inv, x1 = acc[i][j][8 * pq + 4 + e] * inv;
+                            const float give = odd ? x0 : x1;
+                            const float recv = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, give), 0xB1, 0xF, 0xF, true));
+                            o0[e] = odd ? recv : x0;
+                            o1[e] = odd ? x1 : recv;
+                        }
+                        const unsigned cOff = (unsigned)(j * 32 + pq * 16) * 4u;
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o0), srdO, (int)(rowOff0 + cOff), 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o1), srdO, (int)(rowOff1 + cOff), 0, 0);
+                    }
+            }
+        } else
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             // (exactly 32 stores per wave and tile, counted by the vmcnt arithmetic above: rows past T fall outside the
@@ -264,13 +313,35 @@ void pair_gemm_kernel(PairArgs a)
                     const int n = n0 + wn * 64 + j * 32 + rhalf + 8 * q;
                     const unsigned off = rowOff + (unsigned)n * 4u;
                     const f32x4 v = f32x4{ acc[i][j][4 * q] * inv, acc[i][j][4 * q + 1] * inv, acc[i][j][4 * q + 2] * inv, acc[i][j][4 * q + 3] * inv };
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), srdO, (int)off, 0, 0);
+                    if (DBG & 8) continue;                                   // (measurement: no stores)
+                    if (DBG & 48) {
+                        // (measurement, garbage results: the same bytes per instruction laid out as 8 rows x 128 B (16) or 16 rows x
+                        //  64 B (32) instead of 32 rows x 32 B - what the store pattern itself costs)
+                        const int rr = (DBG & 16) ? q * 8 + (lane >> 3) : (q & 1) * 16 + (lane >> 2);
+                        const int cc = (DBG & 16) ? (lane & 7) * 4 : (q >> 1) * 16 + (lane & 3) * 4;
+                        const unsigned o2 = (unsigned)((long long)(m0 + wm * 128 + i * 32 + rr) * a.N * 4) + (unsigned)(n0 + wn * 64 + j * 32 + cc) * 4u;
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), srdO, (int)o2, 0, 0);
+                        continue;
+                    }
+                    if (a.var & 2) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), srdO, (int)off, 0, 2);
+                    else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), srdO, (int)off, 0, 0);
                 }
         }
+        if (DBG & 8) {                                                   // keep the accumulators alive: one store per tile
+            f32x4 v = f32x4{ 0.f, 0.f, 0.f, 0.f };
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r & 3] += acc[i][j][r];
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), srdO, (int)((unsigned)((long long)(m0 + wm * 128 + (lane & 31)) * a.N * 4) + (unsigned)(n0 + wn * 64 + rhalf) * 4u), 0, 0);
+        }
+        if (a.clk) { const long long t = clock64(); cEpi += t - cT; cT = t; }
     }
     if (a.clk && lane == 0) {
         long long *c = a.clk + ((long long)blockIdx.x * 8 + wave) * 8;
-        c[0] = cPre; c[1] = cVm; c[2] = cBar; c[3] = cTail; c[4] = (long long)myCount * nk;
+        c[0] = cPre; c[1] = cVm; c[2] = cBar; c[3] = cTail; c[4] = (long long)myCount * nk; c[5] = cEpi; c[6] = cVm2; c[7] = myCount;
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);                             // vmcnt(0)
 }
@@ -299,6 +370,7 @@ struct PairConvArgs {
     int amaxShift;                                   // >= 0 (XL_CONV_PAIR_AMAX): aScale points at the float bits of max |operand source| and the
                                                      // scale is derived here: max 2^e in [2^(14 - shift), 2^(15 - shift))
     int var;                                         // measurement switches (XL_PAIR_VAR)
+    int stagger;                                     // as PairArgs.stagger
 };
 
 template <bool NORM, bool ACC, int NW, int ZB, int BN, bool RES>               // ACC: out += result
@@ -339,6 +411,7 @@ __device__ __forceinline__ void pair_conv1x1_body(const PairConvArgs &a)
     const int runLen = q8 + (xcd < r8 ? 1 : 0);
     const int myCount = runLen > local ? (runLen - local + nloc - 1) / nloc : 0;
     if (myCount == 0) return;
+    stagger_start(a.stagger);
     auto tile_z = [&](int i) { return (runStart + local + i * nloc) / (a.nbm * a.nbn); };
     auto tile_at = [&](int i, int &m0, int &n0) {
         int t = runStart + local + i * nloc;
@@ -787,12 +860,15 @@ static int xl_run_pair_gemm(const xl_op &op, hipStream_t st)
     a.T = T; a.C = op.Cin; a.N = op.Cout; a.Z = Z;
     a.nbm = (T + 255) / 256; a.nbn = op.Cout / 256;
     a.clk = nullptr;
+    static const int stagger = getenv("XL_PAIR_STAGGER") ? atoi(getenv("XL_PAIR_STAGGER")) : 0;
+    static const int pvar = getenv("XL_PAIR_VAR") ? atoi(getenv("XL_PAIR_VAR")) : 0;
+    a.stagger = stagger; a.var = pvar;
     const size_t lds = 4 * (size_t)(256 * kPA + 256 * kPB);         // 128 KB: one workgroup per CU
     auto kernel = op.Cin == 512 ? pair_gemm_kernel<512> : pair_gemm_kernel<0>;
     static const int dbg = getenv("XL_PAIR_DBG") ? atoi(getenv("XL_PAIR_DBG")) : 0;
     if (dbg && op.Cin == 512)
         kernel = dbg == 1 ? pair_gemm_kernel<512, 1> : dbg == 2 ? pair_gemm_kernel<512, 2> : dbg == 3 ? pair_gemm_kernel<512, 3> : dbg == 4 ? pair_gemm_kernel<512, 4>
-               : dbg == 7 ? pair_gemm_kernel<512, 7> : pair_gemm_kernel<512, 5>;
+               : dbg == 7 ? pair_gemm_kernel<512, 7> : dbg == 8 ? pair_gemm_kernel<512, 8> : dbg == 15 ? pair_gemm_kernel<512, 15> : dbg == 16 ? pair_gemm_kernel<512, 16> : dbg == 32 ? pair_gemm_kernel<512, 32> : dbg == 23 ? pair_gemm_kernel<512, 23> : pair_gemm_kernel<512, 5>;
     static XlLdsLimit configured[3];
     int cfgDev;
     const int slot = dbg ? 2 : op.Cin == 512 ? 1 : 0;
@@ -809,8 +885,10 @@ static int xl_run_pair_gemm(const xl_op &op, hipStream_t st)
     if (clkDbg) {
         std::vector<long long> h((size_t)64 * grid);
         if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(h.data(), a.clk, sizeof(long long) * 64 * grid, hipMemcpyDeviceToHost) == hipSuccess) {
-            double v[2][4] = { { 0 } }; double steps = 0;
-            for (int i = 0; i < 8 * grid; ++i) { const int r = (i & 7) < 4 ? 0 : 1; for (int c = 0; c < 4; ++c) v[r][c] += h[8 * (size_t)i + c]; steps += h[8 * (size_t)i + 4]; }
+            double v[2][4] = { { 0 } }; double steps = 0, epi = 0, vm2 = 0, tiles = 0;
+            for (int i = 0; i < 8 * grid; ++i) { const int r = (i & 7) < 4 ? 0 : 1; for (int c = 0; c < 4; ++c) v[r][c] += h[8 * (size_t)i + c]; steps += h[8 * (size_t)i + 4];
+                                                 epi += h[8 * (size_t)i + 5]; vm2 += h[8 * (size_t)i + 6]; tiles += h[8 * (size_t)i + 7]; }
+            fprintf(stderr, "[pair clk] per wave and tile: epilogue (un-scale + store issue) %.0f ticks, DMA wait of the first two K-steps behind it %.0f\n", epi / tiles, vm2 / tiles);
             steps /= 2;                                         // per wave group
             for (int r = 0; r < 2; ++r)
                 fprintf(stderr, "[pair clk] waves %d-%d, ticks per K-step: reads + terms 0-1 + DMA issue %.0f, wait for DMAs %.0f, barrier %.0f, prefetch + term 2 %.0f\n",
@@ -891,7 +969,8 @@ static int xl_run_pair_conv1x1(const xl_op &op, hipStream_t st)
     a.uInv = reinterpret_cast<const float *>(a.u + (long long)Z * op.Cout * op.Cin * 4) + Z;
     a.aScale = (const float *)op.scale;
     a.amaxShift = (op.flags & XL_CONV_PAIR_AMAX) ? (Z > 1 ? 8 : 0) : -1;
-    a.var = 0;
+    static const int stagger = getenv("XL_PAIR_STAGGER1") ? atoi(getenv("XL_PAIR_STAGGER1")) : 0;
+    a.var = 0; a.stagger = stagger;
     if (op.flags & XL_CONV_NORM_ADD) {
         if (!norm || !(op.flags & XL_CONV_NORM_RELU) || !op.aux || op.ld_aux < op.Cin || (op.ld_aux & 3) || ((uintptr_t)op.aux & 15) || Z > 1 ||
             256LL * op.ld_aux * 4 >= 0x7fffffffLL) return XL_ERR_ARG;

@@ -1616,6 +1616,13 @@ class _Plan:
         # (c is consumed by the addition below only: when that addition is folded into the next block's input transform, so is
         #  c's own GroupNorm + ReLU)
         aux_fold = last_out is None and self.fold_ok() and not os.environ.get("XL_NO_AUX_FOLD")
+        if enc.tiny:
+            # networks.py:245-250 with tiny=True: no projection on the skip path - res2 closes like res1, relu(res + x)
+            c = self.cgr(b, enc.res2_conv3, enc.res2_norm3, GN_RELU_IN | GN_ADD | GN_RELU_OUT, aux=res,
+                         share=last_out is None, out=last_out)
+            self.release(b[0]); self.release(res[0])
+            res = c
+            return self._encoder_add_blocks(enc, res, out)
         c = self.cgr(b, enc.res2_conv3, enc.res2_norm3, defer=aux_fold); self.release(b[0])
         if aux_fold:
             self._aux_defer(c)
@@ -1630,6 +1637,11 @@ class _Plan:
             self.release(c[0])
             if res[0] is not sk[0]:
                 self.release(sk[0])
+        return self._encoder_add_blocks(enc, res, out)
+
+    def _encoder_add_blocks(self, enc, res, out=None):
+        """networks.py:252-254: the encoder's additional residual blocks; the last one writes into `out` if given."""
+        n_add = len(enc.enc_add_res_block_ls)
         for i, block in enumerate(enc.enc_add_res_block_ls):
             if i == n_add - 1 and out is not None:
                 # (round 4: like every other block - GroupNorm applies deferred to the consumer, the last 3x3 layer as
@@ -2377,8 +2389,6 @@ class TransPoseNet(nn.Module):
         # result bitwise independent of the batch it is in (default: conv-epilogue statistics, ~4 % faster, equal to
         # the last fp32 bit or two).  Set before the first forward.
         self.batch_invariant = False
-        if tiny:
-            raise NotImplementedError("tiny=True is never instantiated by CrossLoc (utils/learning.py:302-305)")
         mean = torch.as_tensor(mean, dtype=torch.float32)
         self.register_buffer('mean', mean.clone())
         self.tiny, self.grayscale = tiny, grayscale

@@ -31,6 +31,12 @@ extern "C" {
 #define XL_DSAC_MAX_HYP_TRIES 1000000u     /* dsacstar.cpp:48 */
 #define XL_DSAC_DBG_DOUBLES 28             /* per-image debug record, layout below */
 
+/* The launch form xl_dsac_forward_rgb_batch selects for a batch of B images and n_hyp hypotheses: 1 = one fused launch (a
+ * workgroup per image: sample, score, select, refine), S > 1 = the split form (S sub-blocks per image sample and score, a second
+ * launch selects and refines).  Results are bit-identical across forms; parity tests assert which one they exercised.
+ * No reference counterpart (the reference loops over hypotheses with OpenMP, dsacstar.cpp:112-130). */
+int xl_dsac_forward_sub_blocks(int B, int n_hyp);
+
 /*
  * Batched forward_rgb: replaces dsacstar_rgb_forward (dsacstar.cpp:63-178) for B independent
  * images in one launch (the reference supports batch 1 only, dsacstar_util.h:161).

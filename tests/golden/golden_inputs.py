@@ -15,6 +15,19 @@ def full_size_image(tag):
     return rng.uniform(0.0, 1.0, size=(1, 3, FULL_H, FULL_W)).astype(np.float32)
 
 
+TINY_CASES = {                   # tag -> (num_mlr, extra residual blocks per side, weight seed, input shape)
+    "tiny": (0, 2, 77, (2, 3, 64, 96)),
+    "tiny_mlr3": (3, 1, 78, (2, 3, 64, 96)),
+    "tiny_full": (0, 2, 77, (1, 3, FULL_H, FULL_W)),
+}
+
+
+def tiny_input(tag):
+    """Input of the tiny=True fixtures (net_forward_tiny.npz): uniform [0,1) frames."""
+    _, _, seed, shape = TINY_CASES[tag]
+    return np.random.default_rng(seed + 100 + len(tag)).uniform(0.0, 1.0, size=shape).astype(np.float32)
+
+
 GRAD_B, GRAD_H, GRAD_W, GRAD_FOCAL = 2, 64, 96, 60.0
 
 

@@ -95,6 +95,29 @@ def net_goldens():
     _print("net_forward.npz", {k: v.shape for k, v in out.items()})
 
 
+def tiny_goldens():
+    """tiny=True (test_single_task.py:43 `--tiny`, :253, :299 -> utils/evaluation.py:106 -> networks.py:133-135, 194-198, 245-247):
+    128-channel residual blocks, no projection on the res2 skip path.  Single-task (2 + 2 extra blocks) and the 3-encoder fusion
+    (1 + 1) at 64x96 x 2, single-task at 480x720 x 1; fp32 and float64 outputs of the reference module."""
+    mean = torch.tensor([-455.934, 417.50, 520.31])
+    out = {}
+    for tag, (num_mlr, add, seed, shape) in golden_inputs.TINY_CASES.items():
+        net = quiet(TransPoseNet, mean, True, False, add, add, 3, 1, 32, num_mlr, 0, False)
+        net.load_state_dict(seeded_state_dict(net, seed=seed), strict=True)
+        net.eval()
+        x = torch.from_numpy(golden_inputs.tiny_input(tag))
+        with torch.no_grad():
+            y = net(x)
+            y64 = net.double()(x.double())
+        out[tag + "_x_checksum"] = np.array(golden_inputs.checksum(x.numpy()))
+        out[tag + "_y"] = y.numpy()
+        out[tag + "_y64"] = y64.numpy()
+        out[tag + "_nparams"] = np.array(sum(p.numel() for p in net.parameters()))
+        out[tag + "_keys"] = np.array(["%s:%s" % (k, "x".join(map(str, v.shape))) for k, v in net.state_dict().items()])
+    np.savez_compressed(os.path.join(HERE, "net_forward_tiny.npz"), **out)
+    _print("net_forward_tiny.npz", {k: v.shape for k, v in out.items()})
+
+
 def net4_goldens():
     """The 4-encoder (CrossLoc-SE) variant, 1+1 extra residual blocks to keep the fixture generation short."""
     mean = torch.tensor([-455.934, 417.50, 520.31])
@@ -394,7 +417,9 @@ def loss_b16_goldens():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["net", "net4", "loss", "semantics", "full", "grads", "loss16", "gradsfull"]
+    which = sys.argv[1:] or ["net", "net4", "loss", "semantics", "full", "grads", "loss16", "gradsfull", "tiny"]
+    if "tiny" in which:
+        tiny_goldens()
     if "gradsfull" in which:
         grad_full_goldens()
     if "net" in which:

@@ -54,8 +54,29 @@ def test_forward_requires_gpu_no_fallback():
     net = networks.TransPoseNet(MEAN, False, False, 0, 0)
     with pytest.raises(RuntimeError):
         net(torch.zeros(1, 3, 64, 96))
-    with pytest.raises(NotImplementedError):
-        networks.TransPoseNet(MEAN, True, False)
+
+
+TINY = np.load(os.path.join(os.path.dirname(__file__), "golden", "net_forward_tiny.npz"))
+
+
+@pytest.mark.parametrize("tag", ["tiny", "tiny_mlr3", "tiny_full"])
+def test_tiny_variant_keys_and_oracle_match_reference_golden(tag):
+    """tiny=True (test_single_task.py:43, :253, :299 -> networks.py:133-135, 194-198, 245-247): 128-channel blocks, no res2 skip
+    projection.  Fixture net_forward_tiny.npz = the imported reference's fp32 and float64 outputs (make_golden.py tiny)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    import golden_inputs
+    num_mlr, add, seed, shape = golden_inputs.TINY_CASES[tag]
+    net = networks.TransPoseNet(MEAN, True, False, add, add, 3, 1, 32, num_mlr, 0, False)
+    ours = ["%s:%s" % (k, "x".join(map(str, v.shape))) for k, v in net.state_dict().items()]
+    assert ours == list(TINY[tag + "_keys"])
+    assert sum(p.numel() for p in net.parameters()) == int(TINY[tag + "_nparams"])
+    x = golden_inputs.tiny_input(tag)
+    assert golden_inputs.checksum(x) == float(TINY[tag + "_x_checksum"])
+    y = cnn_oracle.transposenet_forward(seeded_state_dict(net, seed=seed), torch.from_numpy(x), num_mlr, add, add)
+    ref = torch.from_numpy(TINY[tag + "_y"])
+    assert torch.allclose(y[:, :3] - MEAN[None, :, None, None], ref[:, :3] - MEAN[None, :, None, None], atol=2e-4)
+    assert torch.allclose(y[:, 3], ref[:, 3], rtol=1e-4)
 
 
 SEM = np.load(os.path.join(os.path.dirname(__file__), "golden", "semantics.npz"))

@@ -155,6 +155,34 @@ def test_hip_forward_at_480x720_vs_reference_fixture(tag, num_mlr):
         assert any(op.flags & networks.CONV_SPLIT_BF16 for op in plan.ops if op.type == networks.XL_OP_CONV)
 
 
+TINY = np.load(os.path.join(HERE, "golden", "net_forward_tiny.npz"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["tiny", "tiny_mlr3", "tiny_full"])
+def test_hip_forward_of_the_tiny_variant_vs_reference_fixture(tag):
+    """`--tiny` (test_single_task.py:43, :253 '-tiny' in the folder name, :299 -> utils/evaluation.py:106): the 128-channel
+    network of networks.py:133-135, 194-198 whose res2 block closes without the skip projection (:245-247).  Single-task and
+    3-encoder at 64x96 x 2, single-task at 480x720, against the reference module's fp32 output and - the yardstick - its float64
+    one: the HIP forward's distance from float64 within 8x / 12x (median / max) of the reference's own fp32 distance on the
+    uncertainty channel, as the 512-channel network is held."""
+    num_mlr, add, seed, shape = golden_inputs.TINY_CASES[tag]
+    net = networks.TransPoseNet(MEAN, True, False, add, add, 3, 1, 32, num_mlr, 0, False)
+    net.load_state_dict(seeded_state_dict(net, seed=seed), strict=True)
+    net = net.cuda().eval()
+    with torch.no_grad():
+        y = net(torch.from_numpy(golden_inputs.tiny_input(tag)).cuda()).cpu()
+    assert tuple(y.shape) == tuple(TINY[tag + "_y"].shape)
+    err = _check_forward(y, TINY[tag + "_y"])
+    y, y64, y32 = y.double().numpy(), TINY[tag + "_y64"], TINY[tag + "_y"].astype(np.float64)
+    e, e32 = np.abs(y - y64), np.abs(y32 - y64)
+    r, r32 = e[:, 3] / np.abs(y64[:, 3]), e32[:, 3] / np.abs(y64[:, 3])
+    print("%s: max coordinate error vs the reference %.2e m; uncertainty channel vs float64: median %.2e (reference fp32 %.2e), "
+          "max %.2e (%.2e)" % (tag, err, np.median(r), np.median(r32), r.max(), r32.max()))
+    assert e[:, :3].mean() <= 1.25 * e32[:, :3].mean() + 1e-6 and e[:, :3].max() <= 2.0 * e32[:, :3].max() + 1e-5
+    assert np.median(r) <= 8.0 * np.median(r32) and r.max() <= 12.0 * r32.max(), (np.median(r), r.max())
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("tag,num_mlr", [("single", 0), ("mlr3", 3)])
 def test_hip_forward_at_480x720_against_the_float64_reference(tag, num_mlr):
@@ -205,14 +233,17 @@ def test_hip_training_step_gradients_vs_reference_fixture():
     _check_param_grads(net, GRADS, "64x96 x 2")
 
 
-def _check_param_grads(net, G, tag):
+def _check_param_grads(net, G, tag, tensor_abs=1e-2, tensor_rel=5.0, max_over_1e3=None):
     """All 114 parameter gradients of `net` against the fixture `G` - the reference module's autograd gradients with the network
     in float64.  Per tensor: relative L2 error of a strided 256-element sample and relative error of the L2 norm.  The yardstick
     is the reference's OWN fp32 run of the same step, stored beside the float64 one (round 5): fp32 arithmetic through 29
     GroupNorm layers sits 1e-3 (64x96: 96-pixel maps) / 3e-5 (480x720) from the float64 gradients in the median, and the HIP
     path adds the rounding of its F(6x6,3x3) transforms (~1e-5 per layer where a direct fp32 convolution has 2e-7).  Asserted:
       median over the tensors  <= max(1e-3, 5 x the reference's fp32 median);
-      every tensor             <= max(1e-2, 5 x that tensor's own fp32 error) on the sample, <= 2e-2 on the norm."""
+      every tensor             <= max(tensor_abs, tensor_rel x that tensor's own fp32 error) on the sample - and never above 5e-2,
+                                  whatever the reference's fp32 run does (ADVICE r5) -, <= 2e-2 on the norm;
+      the tail (round 6)       at most `max_over_1e3` tensors above 1e-3 (480x720: the typical tensor is at 1e-5 - a systematic
+                                  0.9 % error in one tensor must not pass; there tensor_abs = 3e-3, tensor_rel = 3)."""
     names = [n.split(":")[0] for n in G["param_names"]]
     params = dict(net.named_parameters())
     assert names == list(params.keys()) and len(names) == 114
@@ -245,7 +276,12 @@ def _check_param_grads(net, G, tag):
         print("   %-40s sample %.2e (reference fp32 %.2e) norm %.2e" % (t[3], t[0], t[2], t[1]))
     assert median <= max(1e-3, 5.0 * med32), (median, med32)
     for e2, en, r2, name in table:
-        assert e2 <= max(1e-2, 5.0 * r2) and en <= 2e-2, (name, e2, r2, en)
+        bound = min(5e-2, max(tensor_abs, tensor_rel * r2))
+        assert e2 <= bound and en <= 2e-2, "%s: sample error %.2e (bound %.2e = %.1fx the measured value; reference fp32 %.2e), norm %.2e" % (
+            name, e2, bound, bound / max(e2, 1e-30), r2, en)
+    if max_over_1e3 is not None:
+        over = [(name, e2) for e2, en, r2, name in table if e2 > 1e-3]
+        assert len(over) <= max_over_1e3, "tensors above 1e-3: %d (limit %d): %s" % (len(over), max_over_1e3, over)
 
 
 @pytest.mark.gpu
@@ -271,7 +307,7 @@ def test_hip_training_step_gradients_at_480x720_vs_reference_fixture():
     dref = GF["dpred"].astype(np.float64)
     dgot = pred.grad.double().cpu().numpy()
     assert np.linalg.norm(dgot - dref) <= 2e-3 * np.linalg.norm(dref)
-    _check_param_grads(net, GF, "480x720 x 1")
+    _check_param_grads(net, GF, "480x720 x 1", tensor_abs=3e-3, tensor_rel=3.0, max_over_1e3=30)
 
 
 @pytest.mark.gpu

@@ -45,7 +45,7 @@ def op(kind):
 
 
 st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-kinds = ["pair_dma", "pair_act", "six_act"] + (["f32"] if B <= 47 else [])
+kinds = ["pair_dma"] if os.environ.get("XL_PAIR_ONLY_DMA") else ["pair_dma", "pair_act", "six_act"] + (["f32"] if B <= 47 else [])
 if os.environ.get("XL_PAIR_CLK"):               # (the phase clocks synchronise after every launch: their own run)
     for _ in range(3):
         networks._check(L.xl_cnn_run(op("pair_dma"), 1, st))
