@@ -1915,9 +1915,9 @@ void head_kernel(const float *__restrict__ in, const float *__restrict__ w, cons
     const int lane = threadIdx.x & 63;
     const int waveGlobal = (blockIdx.x * 256 + threadIdx.x) >> 6;
     const int nWaves = (gridDim.x * 256) >> 6;
-    const int nq = Cin >> 8;                                  // float4 per lane (Cin / 256), <= 8
+    const int nq = (Cin + 255) >> 8;                          // float4 per lane (256 channels per trip), <= 8
     const long long total = (long long)B * HW;
-    if (nq == 2 && Cout <= 4) {
+    if (Cin == 512 && Cout <= 4) {
         // the coordinate head (512 -> 4): the lane's 8 x 4 weights stay in registers across the pixel loop (re-reading
         // them per pixel made 8 of the 10 loads of a pixel weight loads), two pixels in flight per iteration
         f32x4 wr[4][2];
@@ -1998,6 +1998,7 @@ void head_kernel(const float *__restrict__ in, const float *__restrict__ w, cons
         for (int o = 0; o < COUT_MAX; ++o) acc[o] = 0.f;
         for (int q = 0; q < nq; ++q) {
             const int c = q * 256 + lane * 4;
+            if (c >= Cin) break;                                  // (Cin = 128 - the tiny network: lanes 32 .. 63 hold nothing)
             const f32x4 v = *reinterpret_cast<const f32x4 *>(in + p * ldIn + c);
 #pragma unroll
             for (int o = 0; o < COUT_MAX; ++o) {
@@ -2549,7 +2550,7 @@ int run_op(const xl_op &op, hipStream_t st)
             return XL_OK;
         }
         case XL_OP_HEAD: {
-            if (op.Cin % 256 != 0 || op.Cin > 2048 || op.Cout > 8 || op.Cout < 1 || op.ld_in % 4 != 0) return XL_ERR_ARG;
+            if (op.Cin % 4 != 0 || op.Cin < 4 || op.Cin > 2048 || op.Cout > 8 || op.Cout < 1 || op.ld_in % 4 != 0) return XL_ERR_ARG;
             const long long pix = (long long)op.B * op.Hi * op.Wi;
             long long blocks = (pix + 3) / 4;
             if (blocks > 4096) blocks = 4096;
@@ -2580,6 +2581,15 @@ int run_op(const xl_op &op, hipStream_t st)
 
 extern "C" {
 
+// which op of a list a launcher refused (the launchers return a bare status): read back through xl_cnn_last_error()
+static void note_failed_op(const xl_op &op, int index, int rc)
+{
+    if (rc == XL_ERR_HIP && g_err[0]) return;                             // (a HIP error already carries its own text)
+    snprintf(g_err, sizeof(g_err), "op %d refused (type %d, k%d s%d, %d -> %d channels, in %dx%d out %dx%d, B %d, ld %d/%d, flags 0x%x, Z %d, form %d)",
+             index, op.type, op.ksize, op.stride, op.Cin, op.Cout, op.Hi, op.Wi, op.Ho, op.Wo, op.B, op.ld_in, op.ld_out, (unsigned)op.flags,
+             op.nchunks2, op.reserved_i);
+}
+
 int xl_cnn_run(const xl_op *ops, int n_ops, void *stream)
 {
     if (!ops || n_ops < 0) return XL_ERR_ARG;
@@ -2589,7 +2599,7 @@ int xl_cnn_run(const xl_op *ops, int n_ops, void *stream)
                          ops[i].nchunks2 >= g_profMinBatched;
         if (rec) (void)hipEventRecord(g_prof[g_profCount].a, st);
         const int rc = run_op(ops[i], st);
-        if (rc != XL_OK) return rc;
+        if (rc != XL_OK) { note_failed_op(ops[i], i, rc); return rc; }
         if (rec) {
             (void)hipEventRecord(g_prof[g_profCount].b, st);
             g_prof[g_profCount].opIndex = i; g_prof[g_profCount].type = ops[i].type;
@@ -2613,7 +2623,10 @@ int xl_cnn_graph_capture(const xl_op *ops, int n_ops, void *stream, void **graph
     g_profOn = false;                                                      // event records are not part of a graph
     if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) { g_profOn = prof; return XL_ERR_HIP; }
     int rc = XL_OK;
-    for (int i = 0; i < n_ops && rc == XL_OK; ++i) rc = run_op(ops[i], st);
+    for (int i = 0; i < n_ops && rc == XL_OK; ++i) {
+        rc = run_op(ops[i], st);
+        if (rc != XL_OK) note_failed_op(ops[i], i, rc);
+    }
     hipGraph_t g = nullptr;
     const hipError_t e = hipStreamEndCapture(st, &g);
     g_profOn = prof;

@@ -832,7 +832,7 @@ void head_bwd_kernel(const float *__restrict__ x, const float *__restrict__ w, c
     const int lane = threadIdx.x & 63;
     const int waveGlobal = (blockIdx.x * 256 + threadIdx.x) >> 6;
     const int nWaves = (gridDim.x * 256) >> 6;
-    const int nq = Cin >> 8;
+    const int nq = (Cin + 255) >> 8;                          // (trips of 256 channels; lanes past Cin hold nothing)
     const long long total = (long long)B * HW;
     const float elo = expf(lo), ehi = expf(hi);
     f32x4 aw[COUT_MAX][NQ_MAX];
@@ -863,7 +863,7 @@ void head_bwd_kernel(const float *__restrict__ x, const float *__restrict__ w, c
         }
 #pragma unroll
         for (int q = 0; q < NQ_MAX; ++q) {
-            if (q < nq) {
+            if (q < nq && q * 256 + lane * 4 < Cin) {
                 const int c = q * 256 + lane * 4;
                 const f32x4 xv = *reinterpret_cast<const f32x4 *>(x + p * ldX + c);
                 f32x4 d = { 0.f, 0.f, 0.f, 0.f };
@@ -884,7 +884,8 @@ void head_bwd_kernel(const float *__restrict__ x, const float *__restrict__ w, c
         if (o < Cout) {
 #pragma unroll
             for (int q = 0; q < NQ_MAX; ++q)
-                if (q < nq) *reinterpret_cast<f32x4 *>(pW + ((long long)waveGlobal * Cout + o) * Cin + q * 256 + lane * 4) = aw[o][q];
+                if (q < nq && q * 256 + lane * 4 < Cin)
+                    *reinterpret_cast<f32x4 *>(pW + ((long long)waveGlobal * Cout + o) * Cin + q * 256 + lane * 4) = aw[o][q];
             if (lane == 0) pB[(long long)waveGlobal * Cout + o] = ab[o];
         }
     }
@@ -1328,7 +1329,7 @@ int xl_run_bwd_op(const xl_op &op, hipStream_t st)
             return XL_OK;
         }
         case XL_OP_HEAD_BWD: {
-            if (op.Cin % 256 != 0 || op.Cin > 1024 || op.Cout > 4 || op.Cout < 1) return XL_ERR_ARG;
+            if (op.Cin % 4 != 0 || op.Cin < 4 || op.Cin > 1024 || op.Cout > 4 || op.Cout < 1) return XL_ERR_ARG;
             const long long pix = (long long)op.B * op.Hi * op.Wi;
             long long blocks = (pix + 63) / 64;
             if (blocks > 256) blocks = 256;

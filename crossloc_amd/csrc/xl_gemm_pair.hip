@@ -87,6 +87,26 @@ __device__ __forceinline__ void stagger_start(int ticks)
     while ((long long)wall_clock64() - t0 < d) __builtin_amdgcn_s_sleep(8);
 }
 
+// Epilogue stores (round 6).  A lane of a 32 x 32 accumulator block (swapped operands) holds 4 x 4 consecutive channels of ONE
+// row, 8 apart (the other 4 of each 8 in lane + 32): stored as they lie, an instruction writes 32 bytes into each of 32 rows - 32
+// requests of half a 64-byte L2 request each, and the CU's store path takes ~440 ticks per instruction (14000 per 256 x 256 tile,
+// XL_PAIR_CLK).  Neighbouring lanes (rows m, m + 1) trade one channel quad of each pair (quad_perm [1,0,3,2]): the first
+// instruction of a pair then writes 64 contiguous bytes into each of the 16 EVEN rows, the second into the odd rows - 7900 ticks
+// per tile, dominant launch 1.65 -> 1.56 ms on random data.  Same values, same number of stores.
+// pair PQ of the block: o0 = (row m & ~1, channels 16 PQ + 8 (m & 1) + 4 (lane >> 5) ..+3), o1 = the same channels of row m | 1.
+template <int PQ>
+__device__ __forceinline__ void lane_pair_exchange(const f32x16 &c, bool odd, f32x4 &o0, f32x4 &o1)
+{
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float x0 = c[8 * PQ + e], x1 = c[8 * PQ + 4 + e];
+        const float give = odd ? x0 : x1;
+        const float recv = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, give), 0xB1, 0xF, 0xF, true));
+        o0[e] = odd ? recv : x0;
+        o1[e] = odd ? x1 : recv;
+    }
+}
+
 __device__ __forceinline__ f16x8 scale_hs(f16x8 hi) { return hi * (_Float16)0.00048828125f; }      // hi * 2^-11: 4 x v_pk_mul_f16
 
 // vmcnt bookkeeping (in order, per wave): a wave issues 4 DMA instructions per K-step (2 per operand), all in front of the step's
@@ -270,11 +290,7 @@ void pair_gemm_kernel(PairArgs a)
         const float inv = aInv * a.uInv[z];                              // (powers of two: the un-scaling is exact)
         const __amdgpu_buffer_rsrc_t srdO = __builtin_amdgcn_make_buffer_rsrc((void *)(a.out + (long long)z * a.T * a.N), 0, (int)((long long)a.T * a.N * 4), 0x00020000);
         if (!(a.var & 4) && !(DBG & (8 | 48))) {
-            // A lane of the 32 x 32 accumulator block holds 4 x 4 consecutive channels of ONE row (8 apart, the other 4 of each 8 in lane
-            // + 32): stored as they lie, an instruction writes 32 bytes into each of 32 rows - 32 requests of half a 64-byte L2
-            // request each, and the CU's store path takes ~440 ticks per instruction (14000 per tile: round 6, XL_PAIR_CLK).  Neighbouring
-            // lanes (rows m, m + 1) trade one channel quad of each pair, so that an instruction writes 64 contiguous bytes into each of 16
-            // rows: even rows in the first instruction of a pair, odd rows in the second.  Same values, same number of stores.
+            // (lane_pair_exchange: 64-byte pieces, even rows then odd rows)
             const bool odd = lane & 1;
             const int mE = m0 + wm * 128 + ((lane & 31) & ~1), cL = n0 + wn * 64 + 8 * (lane & 1) + rhalf;
 #pragma unroll
@@ -282,22 +298,16 @@ void pair_gemm_kernel(PairArgs a)
                 const unsigned rowOff0 = (unsigned)((long long)(mE + i * 32) * a.N * 4) + (unsigned)cL * 4u;
                 const unsigned rowOff1 = rowOff0 + (unsigned)a.N * 4u;
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < 2; ++j) {
+                    f32x4 o[4];
+                    const f32x16 c = acc[i][j] * inv;
+                    lane_pair_exchange<0>(c, odd, o[0], o[1]);
+                    lane_pair_exchange<1>(c, odd, o[2], o[3]);
 #pragma unroll
-                    for (int pq = 0; pq < 2; ++pq) {
-                        f32x4 o0, o1;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float x0 = acc[i][j][8 * pq + e] * inv, x1 = acc[i][j][8 * pq + 4 + e] * inv;
-                            const float give = odd ? x0 : x1;
-                            const float recv = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, give), 0xB1, 0xF, 0xF, true));
-                            o0[e] = odd ? recv : x0;
-                            o1[e] = odd ? x1 : recv;
-                        }
-                        const unsigned cOff = (unsigned)(j * 32 + pq * 16) * 4u;
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o0), srdO, (int)(rowOff0 + cOff), 0, 0);
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o1), srdO, (int)(rowOff1 + cOff), 0, 0);
-                    }
+                    for (int q = 0; q < 4; ++q)
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o[q]), srdO,
+                                                               (int)(((q & 1) ? rowOff1 : rowOff0) + (unsigned)(j * 32 + (q >> 1) * 16) * 4u), 0, 0);
+                }
             }
         } else
 #pragma unroll
@@ -778,28 +788,37 @@ __device__ __forceinline__ void pair_conv1x1_body(const PairConvArgs &a)
         // (every wave issues exactly NS stores per tile - the vmcnt arithmetic of the next step counts them)
         const __amdgpu_buffer_rsrc_t srdO = __builtin_amdgcn_make_buffer_rsrc((void *)(a.out + tile_z(ti) * a.zOut + (long long)m0 * a.ldOut), 0,
                                                                               tile_rows(m0) * a.ldOut * 4, 0x00020000);
+        {
+            // (lane_pair_exchange: 64-byte pieces, even rows then odd rows; rows past the tile fall outside the descriptor)
+            const bool odd = lane & 1;
+            const unsigned colL = (unsigned)(n0 + wn * 64 + 8 * (lane & 1) + rhalf) * 4u;
 #pragma unroll
-        for (int i = 0; i < RI; ++i) {
-            const unsigned rowOff = (unsigned)((wm * (32 * RI) + i * 32 + fr) * a.ldOut * 4);
-            f32x4 old[2][4];
-            if constexpr (ACC) {                                       // (8 loads in flight per 32-row block; rows past the tile read 0)
+            for (int i = 0; i < RI; ++i) {
+                const unsigned rowOff0 = (unsigned)((wm * (32 * RI) + i * 32 + (fr & ~1)) * a.ldOut * 4) + colL;
+                const unsigned rowOff1 = rowOff0 + (unsigned)a.ldOut * 4u;
+                f32x4 old[2][4];
+                if constexpr (ACC) {                                   // (8 loads in flight per 32-row block; rows past the tile read 0)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                    for (int j = 0; j < 2; ++j)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        old[j][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                            srdO, (int)(rowOff + (unsigned)(n0 + wn * 64 + j * 32 + rhalf + 8 * q) * 4u), 0, 0));
-            }
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int n = n0 + wn * 64 + j * 32 + rhalf + 8 * q;
-                    const unsigned off = rowOff + (unsigned)n * 4u;
-                    f32x4 v = f32x4{ acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3] };
-                    if constexpr (ACC) v += old[j][q];
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), srdO, (int)off, 0, 0);
+                        for (int q = 0; q < 4; ++q)
+                            old[j][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                srdO, (int)(((q & 1) ? rowOff1 : rowOff0) + (unsigned)(j * 32 + (q >> 1) * 16) * 4u), 0, 0));
                 }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    f32x4 o[4];
+                    lane_pair_exchange<0>(acc[i][j], odd, o[0], o[1]);
+                    lane_pair_exchange<1>(acc[i][j], odd, o[2], o[3]);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        f32x4 v = o[q];
+                        if constexpr (ACC) v += old[j][q];
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), srdO,
+                                                               (int)(((q & 1) ? rowOff1 : rowOff0) + (unsigned)(j * 32 + (q >> 1) * 16) * 4u), 0, 0);
+                    }
+                }
+            }
         }
         if (ti + 1 < myCount) {
             tile_at(ti + 1, m0, n0);

@@ -58,16 +58,18 @@ def _check_direct_form(worst, worst2):
 
 
 @pytest.mark.parametrize("form", ["direct", "winograd"])
-@pytest.mark.parametrize("B,H,W,enc_add,dec_add", [(2, 64, 96, 1, 1), (1, 128, 192, 2, 2), (3, 40, 56, 0, 0)])
-def test_parameter_gradients_vs_autograd(B, H, W, enc_add, dec_add, form, monkeypatch):
+@pytest.mark.parametrize("B,H,W,enc_add,dec_add,tiny", [(2, 64, 96, 1, 1, False), (1, 128, 192, 2, 2, False), (3, 40, 56, 0, 0, False),
+                                                        (2, 64, 96, 1, 1, True), (1, 128, 192, 0, 2, True)])
+def test_parameter_gradients_vs_autograd(B, H, W, enc_add, dec_add, tiny, form, monkeypatch):
     """form: training plans run the stride-1 3x3 layers (forward and data gradient) as Winograd F(4x4,3x3) by default;
     "direct" pins the direct implicit-GEMM kernels (XL_NO_WINOGRAD_TRAIN=1, read when the plan is built).  Winograd's
     forward rounding noise is ~10x the direct form's, so more pre-activations land on the other side of ReLU'(0) than
     in the float64 reference: the max-norm criterion stays on the direct form, the Winograd form is held to a relative
-    L2 error per tensor (a flipped mask moves a few elements; a wiring error moves the whole tensor)."""
+    L2 error per tensor (a flipped mask moves a few elements; a wiring error moves the whole tensor).
+    tiny (round 6): the 128-channel network of `--tiny` (networks.py:133-135, 194-198, 245-247)."""
     if form == "direct":
         monkeypatch.setenv("XL_NO_WINOGRAD_TRAIN", "1")
-    net = networks.TransPoseNet(MEAN, False, False, enc_add, dec_add, 3, 1)
+    net = networks.TransPoseNet(MEAN, tiny, False, enc_add, dec_add, 3, 1)
     net.load_state_dict(seeded_state_dict(net, seed=11))
     g = torch.Generator().manual_seed(B * 100 + H)
     x = torch.rand(B, 3, H, W, generator=g)
