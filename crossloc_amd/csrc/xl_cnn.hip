@@ -363,18 +363,23 @@ void conv1_mfma_kernel(const float *__restrict__ in, const c1_u32x4 *__restrict_
         }
     }
     if (kStats) {
-        // per-lane fp32 partials (8 pixels each) -> fp64 over the 128 lanes that hold a channel, fixed order
+        // per-lane fp32 partials (8 pixels each) -> fp64 over the 128 lanes that hold a channel, fixed order.
+        // Staging layout [value][thread] (round 6): with [thread][32 values] every lane of a ds_write_b32 hit the same bank - 32 writes
+        // of 64 LDS cycles each per wave, four times the LDS time of the whole convolution loop, and the kernel was bound by it
+        // (0.40 of its LDS cycles were conflict cycles).  The readers start at different lanes (l + c) so that they, too, spread
+        // over the banks; an fp64 sum of 128 fp32 values of one sign-mixed magnitude range is exact, the order is fixed anyway.
         float *sRed = reinterpret_cast<float *>(smem);
         __syncthreads();                                             // every wave is done with the halo
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { sRed[tid * 32 + r] = s[r]; sRed[tid * 32 + 16 + r] = q[r]; }
+        for (int r = 0; r < 16; ++r) { sRed[r * 256 + tid] = s[r]; sRed[(16 + r) * 256 + tid] = q[r]; }
         __syncthreads();
         if (tid < 64) {
             const int c = tid & 31, half = tid >> 5;
             const int khc = (c >> 2) & 1, r = ((c >> 3) << 2) | (c & 3);
+            const float *src = sRed + (half * 16 + r) * 256 + khc * 32;
             double a = 0.0;
             for (int wq = 0; wq < 4; ++wq)
-                for (int l = 0; l < 32; ++l) a += (double)sRed[(wq * 64 + khc * 32 + l) * 32 + half * 16 + r];
+                for (int l = 0; l < 32; ++l) a += (double)src[wq * 64 + ((l + c) & 31)];
             stats[(((long long)n * gridDim.x + blockIdx.x) * CO + c) * 2 + half] = a;
         }
     }

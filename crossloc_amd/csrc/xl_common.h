@@ -55,9 +55,21 @@ __device__ __forceinline__ float xl_wave_sum_top(float v)
 // the wave, then lane 63 issues the atomicMax only when its value beats what the slot already holds (a plain load first: thousands of
 // waves on one address otherwise serialise in L2 - measured +0.05 ms per GroupNorm-backward launch; after the first few arrivals
 // almost every wave skips the atomic).  slot may be nullptr.
+// PRECONDITIONS (every caller - gnb_apply, wino6_dy, pair_weight_kernel<0> - meets them): blockDim.x is a multiple of 64 and
+// ALL 64 lanes of the wave reach this call with values >= 0 (no early return in front of it; an out-of-range thread passes 0): the
+// DPP tree reads neighbours' registers and lane 63 commits.  A wave that arrives with lanes switched off falls back to one
+// atomicMax per live lane - slower, never wrong.  NaN: fmaxf drops it in the tree; a wave of NaNs commits nothing, and the
+// fallback's integer compare would order a NaN's bits ABOVE every finite value - so the fallback commits finite values only (a
+// non-finite gradient leaves the slot at the finite maximum: the scale then saturates the operand to fp16 inf, which the
+// training loop's own non-finite loss check sees).
 __device__ __forceinline__ void xl_wave_max_commit(float m, unsigned *slot)
 {
     if (slot == nullptr) return;
+    if (__builtin_amdgcn_read_exec() != ~0ull) {                       // partial wave: no tree
+        const unsigned b = __builtin_bit_cast(unsigned, m);
+        if (m >= 0.f && b < 0x7f800000u && b > __atomic_load_n(slot, __ATOMIC_RELAXED)) atomicMax(slot, b);
+        return;
+    }
     m = fmaxf(m, xl_dpp_f32<0xB1>(m));
     m = fmaxf(m, xl_dpp_f32<0x4E>(m));
     m = fmaxf(m, xl_dpp_f32<0x141>(m));

@@ -115,17 +115,23 @@ __device__ __forceinline__ f16x8 scale_hs(f16x8 hi) { return hi * (_Float16)0.00
 // first TWO steps of a tile that follows another one (the 32 stores of its epilogue lie between).
 // DBG (XL_PAIR_DBG, measurement only - the results are garbage): 1 = no DMA after the prologue, 2 = no fragment reads in the loop,
 // 4 = no barrier / vmcnt wait: what each piece costs under the chip's power limit.
-template <int CT, int DBG = 0>                                         // compile-time channel count (0: a.C)
-__global__ __launch_bounds__(512)
+// WM = 1 (round 6, XL_PAIR_PP=1: "ping-pong"): the workgroup is ONE row of four waves - 128 x 256 tiles, 256 threads, a ring of THREE
+// stages of 24 KB - and two of them share a CU, each with its own barrier: a SIMD holds one wave of each, and while one workgroup
+// stores a tile, waits at its barrier or issues its DMAs, the other one multiplies.  Price: the weights' tile is fetched by twice
+// as many workgroups (6 DMA instructions per wave and K-step for the same 24 MFMAs instead of 4).
+template <int CT, int DBG = 0, int WM = 2>                             // compile-time channel count (0: a.C)
+__global__ __launch_bounds__(256 * WM, 2 / WM)
 void pair_gemm_kernel(PairArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
     typedef __attribute__((address_space(3))) void lds_void;
-    constexpr int kOpA = 256 * kPA, kOpB = 256 * kPB, kStage = kOpA + kOpB;     // 16 + 16 = 32 KB per stage
-    constexpr int NST = 4;
+    constexpr int BMT = 128 * WM;                                     // tile rows
+    constexpr int kOpA = BMT * kPA, kOpB = 256 * kPB, kStage = kOpA + kOpB;     // 16 (8) + 16 KB per stage
+    constexpr int NST = WM == 2 ? 4 : 3;
+    constexpr int NA = 2, NB = 4 / WM, ND = NA + NB;                  // DMA instructions per wave and K-step: activations, weights
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;                          // 2 x 4 waves of 128 x 64
+    const int wm = WM == 2 ? wave >> 2 : 0, wn = wave & 3;            // WM x 4 waves of 128 x 64
 
     // tiles of this workgroup: XCD x (= block % 8) owns a contiguous run of the (z, m-tile, n-tile) order, its workgroups
     // take every nloc-th tile of the run, so the workgroups of an XCD work on neighbouring tiles at any time
@@ -145,11 +151,16 @@ void pair_gemm_kernel(PairArgs a)
     // offset inside a tile never changes (row and slot of the 16 x 4 piece); the tile is the descriptor's base, and rows past the
     // end of an operand - or a tile past the end of my list - fall outside the descriptor's extent and read as zero
     __amdgpu_buffer_rsrc_t srdV, srdU;
-    unsigned lOff[2];
+    unsigned lOffA[NA], lOffB[NB];
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int row = (wave * 2 + q) * 16 + (lane >> 2);
-        lOff[q] = (unsigned)(row * (int)rowB + (((lane & 3) ^ swz(row)) * 16));
+    for (int q = 0; q < NA; ++q) {
+        const int row = (wave * NA + q) * 16 + (lane >> 2);
+        lOffA[q] = (unsigned)(row * (int)rowB + (((lane & 3) ^ swz(row)) * 16));
+    }
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+        const int row = (wave * NB + q) * 16 + (lane >> 2);
+        lOffB[q] = (unsigned)(row * (int)rowB + (((lane & 3) ^ swz(row)) * 16));
     }
     int dTile = 0, dK = 0;                                            // position of the stream: tile of my list, K-step
     auto set_dma_tile = [&](int i) {
@@ -157,17 +168,17 @@ void pair_gemm_kernel(PairArgs a)
         const int z = t / (a.nbm * a.nbn);
         t -= z * (a.nbm * a.nbn);
         const int mt = t / a.nbn, nt = t - mt * a.nbn;
-        const int m0 = mt * 256, n0 = nt * 256;
-        const int rowsA = i < myCount ? (a.T - m0 < 256 ? a.T - m0 : 256) : 0, rowsB = i < myCount ? 256 : 0;
+        const int m0 = mt * BMT, n0 = nt * 256;
+        const int rowsA = i < myCount ? (a.T - m0 < BMT ? a.T - m0 : BMT) : 0, rowsB = i < myCount ? 256 : 0;
         srdV = __builtin_amdgcn_make_buffer_rsrc((void *)(a.v + ((long long)z * a.T + m0) * rowB), 0, (int)(rowsA * rowB), 0x00020000);
         srdU = __builtin_amdgcn_make_buffer_rsrc((void *)(a.u + ((long long)z * a.N + n0) * rowB), 0, (int)(rowsB * rowB), 0x00020000);
     };
     bool dmaOn = true;
-    auto dma_instr = [&](int q, int stage) {                          // instruction q of 4 of the stream's current step
+    auto dma_instr = [&](int q, int stage) {                          // instruction q of ND of the stream's current step
         if ((DBG & 1) && !dmaOn) return;
-        unsigned char *base = dsm + stage * kStage + (wave * 2 + (q & 1)) * 1024;
-        if (q < 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(srdV, (lds_void *)base, 16, (int)lOff[q], dK * kPA, 0, 0);
-        else __builtin_amdgcn_raw_ptr_buffer_load_lds(srdU, (lds_void *)(base + kOpA), 16, (int)lOff[q - 2], dK * kPB, 0, 0);
+        unsigned char *base = dsm + stage * kStage;
+        if (q < NA) __builtin_amdgcn_raw_ptr_buffer_load_lds(srdV, (lds_void *)(base + (wave * NA + q) * 1024), 16, (int)lOffA[q], dK * kPA, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(srdU, (lds_void *)(base + kOpA + (wave * NB + q - NA) * 1024), 16, (int)lOffB[q - NA], dK * kPB, 0, 0);
     };
     auto advance_dma = [&]() {
         if (++dK == nk) { dK = 0; ++dTile; set_dma_tile(dTile); }
@@ -204,22 +215,23 @@ void pair_gemm_kernel(PairArgs a)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[j], v[i], acc[i][j], 0, 0, 0);
     };
 
-    // ---- prologue: steps 0, 1 and 2 of the stream
+    // ---- prologue: steps 0 .. NST - 2 of the stream
     set_dma_tile(0);
 #pragma unroll
-    for (int st = 0; st < 3; ++st) {
+    for (int st = 0; st < NST - 1; ++st) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) dma_instr(q, st);
+        for (int q = 0; q < ND; ++q) dma_instr(q, st);
         advance_dma();
     }
-    __builtin_amdgcn_s_waitcnt(0x0F70 | 8);
+    constexpr int kYoung = ND * (NST - 2);                            // DMAs younger than the step a barrier needs: 8 (6)
+    __builtin_amdgcn_s_waitcnt(0x0F70 | kYoung);
     // (a bare s_barrier: the workgroup fence of __syncthreads() makes the compiler wait for EVERY outstanding LDS-DMA)
     __builtin_amdgcn_s_barrier();
 #pragma unroll
     for (int j = 0; j < 2; ++j) fbN[j] = ldB(dsm, 0, j);
 #pragma unroll
     for (int i = 0; i < 4; ++i) faN[i] = ldA(dsm, 1, i);
-    int sc = 0, sd = 3;                                               // stage being multiplied / being filled
+    int sc = 0, sd = NST - 1;                                         // stage being multiplied / being filled
     const int rhalf = (lane >> 5) * 4;
     const float aInv = a.aScale[1];
     dmaOn = false; readOn = false;
@@ -234,14 +246,14 @@ void pair_gemm_kernel(PairArgs a)
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
         for (int kk = 0; kk < nk; ++kk) {
             const unsigned char *sb = dsm + sc * kStage;
-            const int next = (sc + 1) & (NST - 1);
+            const int next = sc + 1 == NST ? 0 : sc + 1;
             // The two waves of a SIMD (wm = 0: the older one, which wins the matrix pipe's arbitration) take their four DMA
             // instructions at opposite ends of the phase: an LDS-DMA costs its wave 100-200 ticks of issue in which it multiplies
             // nothing, and with both waves in the same order those windows coincide (measured, XL_PAIR_CLK: the phase took the
             // younger waves 1837 ticks for 1024 of MFMA work per SIMD).  Now one wave multiplies while the other issues.
             if (wm) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) dma_instr(q, sd);
+                for (int q = 0; q < ND; ++q) dma_instr(q, sd);
                 __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
@@ -257,14 +269,16 @@ void pair_gemm_kernel(PairArgs a)
             __builtin_amdgcn_sched_barrier(0);
             if (!wm) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) dma_instr(q, sd);
+                for (int q = 0; q < ND; ++q) dma_instr(q, sd);
             }
             __builtin_amdgcn_sched_barrier(0);
             if (a.clk) { const long long t = clock64(); cPre += t - cT; cT = t; }
             if (!(DBG & 4)) {
-                if ((DBG & 8) && kk < 2 && ti > 0) __builtin_amdgcn_s_waitcnt(0x0F70 | 9);   // (one store per tile)
-            else if (kk < 2 && ti > 0) __builtin_amdgcn_s_waitcnt(0x8F70 | 8);   // vmcnt(40): + the 32 stores of the tile before
-                else __builtin_amdgcn_s_waitcnt(0x0F70 | 8);
+                // (vmcnt is a 6-bit field: bits 3:0 and 15:14 of the immediate)
+                constexpr int kS = kYoung + 32, kS1 = kYoung + 1;
+                if ((DBG & 8) && kk < NST - 2 && ti > 0) __builtin_amdgcn_s_waitcnt(0x0F70 | kS1);          // (one store per tile)
+                else if (kk < NST - 2 && ti > 0) __builtin_amdgcn_s_waitcnt(0x0F70 | (kS & 15) | ((kS >> 4) << 14));   // + the 32 stores of the tile before
+                else __builtin_amdgcn_s_waitcnt(0x0F70 | kYoung);
             }
             if (a.clk) { const long long t = clock64(); cVm += t - cT; if (kk < 2 && ti > 0) cVm2 += t - cT; cT = t; }
             if (!(DBG & 4)) __builtin_amdgcn_s_barrier();
@@ -278,7 +292,7 @@ void pair_gemm_kernel(PairArgs a)
             mma(fb[0], fa[0]);                                          // hi x hi
             advance_dma();
             sc = next;
-            sd = (sd + 1) & (NST - 1);
+            sd = sd + 1 == NST ? 0 : sd + 1;
             if (a.clk) { const long long t = clock64(); cTail += t - cT; cT = t; }
         }
         // ---- epilogue of tile ti (swapped operands): row = lane & 31, channels (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
@@ -286,7 +300,7 @@ void pair_gemm_kernel(PairArgs a)
         const int z = t / (a.nbm * a.nbn);
         t -= z * (a.nbm * a.nbn);
         const int mt = t / a.nbn, nt = t - mt * a.nbn;
-        const int m0 = mt * 256, n0 = nt * 256;
+        const int m0 = mt * BMT, n0 = nt * 256;
         const float inv = aInv * a.uInv[z];                              // (powers of two: the un-scaling is exact)
         const __amdgpu_buffer_rsrc_t srdO = __builtin_amdgcn_make_buffer_rsrc((void *)(a.out + (long long)z * a.T * a.N), 0, (int)((long long)a.T * a.N * 4), 0x00020000);
         if (!(a.var & 4) && !(DBG & (8 | 48))) {
@@ -877,30 +891,33 @@ static int xl_run_pair_gemm(const xl_op &op, hipStream_t st)
     a.uInv = reinterpret_cast<const float *>(a.u + (long long)Z * op.Cout * op.Cin * 4) + Z;
     a.aScale = (const float *)op.scale;
     a.T = T; a.C = op.Cin; a.N = op.Cout; a.Z = Z;
-    a.nbm = (T + 255) / 256; a.nbn = op.Cout / 256;
+    static const bool pingPong = getenv("XL_PAIR_PP") && atoi(getenv("XL_PAIR_PP")) != 0;
+    const bool pp = pingPong && op.Cin == 512;
+    a.nbm = pp ? (T + 127) / 128 : (T + 255) / 256; a.nbn = op.Cout / 256;
     a.clk = nullptr;
     static const int stagger = getenv("XL_PAIR_STAGGER") ? atoi(getenv("XL_PAIR_STAGGER")) : 0;
     static const int pvar = getenv("XL_PAIR_VAR") ? atoi(getenv("XL_PAIR_VAR")) : 0;
     a.stagger = stagger; a.var = pvar;
-    const size_t lds = 4 * (size_t)(256 * kPA + 256 * kPB);         // 128 KB: one workgroup per CU
-    auto kernel = op.Cin == 512 ? pair_gemm_kernel<512> : pair_gemm_kernel<0>;
+    const size_t lds = pp ? 3 * (size_t)(128 * kPA + 256 * kPB)     // 72 KB: two workgroups per CU
+                          : 4 * (size_t)(256 * kPA + 256 * kPB);    // 128 KB: one workgroup per CU
+    auto kernel = pp ? pair_gemm_kernel<512, 0, 1> : op.Cin == 512 ? pair_gemm_kernel<512> : pair_gemm_kernel<0>;
     static const int dbg = getenv("XL_PAIR_DBG") ? atoi(getenv("XL_PAIR_DBG")) : 0;
-    if (dbg && op.Cin == 512)
+    if (dbg && op.Cin == 512 && !pp)
         kernel = dbg == 1 ? pair_gemm_kernel<512, 1> : dbg == 2 ? pair_gemm_kernel<512, 2> : dbg == 3 ? pair_gemm_kernel<512, 3> : dbg == 4 ? pair_gemm_kernel<512, 4>
                : dbg == 7 ? pair_gemm_kernel<512, 7> : dbg == 8 ? pair_gemm_kernel<512, 8> : dbg == 15 ? pair_gemm_kernel<512, 15> : dbg == 16 ? pair_gemm_kernel<512, 16> : dbg == 32 ? pair_gemm_kernel<512, 32> : dbg == 23 ? pair_gemm_kernel<512, 23> : pair_gemm_kernel<512, 5>;
-    static XlLdsLimit configured[3];
+    static XlLdsLimit configured[4];
     int cfgDev;
-    const int slot = dbg ? 2 : op.Cin == 512 ? 1 : 0;
+    const int slot = pp ? 3 : dbg ? 2 : op.Cin == 512 ? 1 : 0;
     if (configured[slot].needs(lds, &cfgDev)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return XL_ERR_HIP;
         configured[slot].done(lds, cfgDev);
     }
     const int nwg = a.nbm * a.nbn * Z;
-    int grid = 256;
+    int grid = pp ? 512 : 256;
     if (grid > ((nwg + 7) & ~7)) grid = (nwg + 7) & ~7;
     static const bool clkDbg = getenv("XL_PAIR_CLK") != nullptr;
     if (clkDbg && hipMalloc(&a.clk, sizeof(long long) * 64 * grid) != hipSuccess) return XL_ERR_HIP;
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(512), lds, st, a);
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(pp ? 256 : 512), lds, st, a);
     if (clkDbg) {
         std::vector<long long> h((size_t)64 * grid);
         if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(h.data(), a.clk, sizeof(long long) * 64 * grid, hipMemcpyDeviceToHost) == hipSuccess) {

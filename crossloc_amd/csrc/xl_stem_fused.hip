@@ -56,7 +56,13 @@ template <int TH, bool PAIR = false> struct S12 {
     static constexpr int kPH = 2 * TH + 1, kHH = kPH + 2;
     static constexpr int kNPix = kPH * kPW, kBlocks = (kNPix + 31) / 32;
     static constexpr int kPixB = PAIR ? kPixPair : kPix;
-    static constexpr int kPatchBytes = kNPix * kPixB, kHaloPix = kHH * kHW, kHaloBytes = 3 * kHaloPix * 8;
+    // Patch rows are padded to a multiple of 128 bytes (round 6).  A ds_read_b128 is serviced in lane groups {0-3, 12-15, 20-27}, ...:
+    // lanes 20-27 of conv2's fragment reads sit on the SECOND tile row of their wave (two patch rows further), and with the dense
+    // pitch (33 records: 297 / 429 slots of 16 bytes) their slots collided with those of lanes 12-15 - every fragment read took 8
+    // LDS cycles instead of 4 (SQ_LDS_BANK_CONFLICT 0.40 of the kernel's LDS cycles in round 5).  With 2 x pitch = 0 mod 256 bytes
+    // the 16 lanes of a group fall on 16 distinct slots of the bank row whatever the tap.
+    static constexpr int kPitch = kPW * kPixB + (PAIR ? 112 : 48);
+    static constexpr int kPatchBytes = kPH * kPitch, kHaloPix = kHH * kHW, kHaloBytes = 3 * kHaloPix * 8;
     static constexpr int kE = (kHaloPix + 255) / 256;                // halo pixels per thread
     static constexpr int kPB = TH / 2;                               // 32-pixel blocks per tile (4 waves: kPB x 4 / kPB column blocks)
 };
@@ -110,12 +116,12 @@ struct Stem12Args {
 // the raw conv2 output stays bitwise what the two-kernel path produces): conv1's normalised output times the plan's scale goes
 // into the patch as {hi, lo'} (144 bytes per pixel), conv2's weights arrive as {hi, lo} fragments of the scaled matrix, hs = hi 2^-11
 // in registers.  conv1 itself - its operand is the IMAGE, for which there is no bound - keeps the three bf16 terms.
-template <int TH, bool PAIR = false>
-__global__ __launch_bounds__(256, TH == 8 ? 1 : 2)
+template <int TH, bool PAIR = false, int WGS = (TH == 8 ? 1 : 2)>
+__global__ __launch_bounds__(256, WGS)
 void stem12_kernel(Stem12Args a)
 {
     typedef S12<TH, PAIR> K;
-    constexpr int kPixB = K::kPixB, NPL = PAIR ? 2 : 3;
+    constexpr int kPixB = K::kPixB, NPL = PAIR ? 2 : 3, kPitch = K::kPitch;
     constexpr int kTH = TH, kHH = K::kHH, kNPix = K::kNPix, kBlocks = K::kBlocks, kPatchBytes = K::kPatchBytes;
     constexpr int kHaloPix = K::kHaloPix, kE = K::kE, kPB = K::kPB, kNJ = kPB == 4 ? 2 : 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
@@ -161,7 +167,7 @@ void stem12_kernel(Stem12Args a)
 
     // conv2: my output pixel inside the tile and the byte offset of its patch record (tap (0, 0), plane 0)
     const int oyl = 2 * pxb + (fr >> 4), oxl = fr & 15;
-    const unsigned aBase = (unsigned)(((2 * oyl) * kPW + oxl) * kPixB + kh * 16);
+    const unsigned aBase = (unsigned)((2 * oyl) * kPitch + oxl * kPixB + kh * 16);
     float aS = 1.f, unscale = 1.f;
     if constexpr (PAIR) {
         aS = a.aScale[0];
@@ -259,7 +265,7 @@ void stem12_kernel(Stem12Args a)
             const int iy = 2 * oy0 - 1 + pr, ix = 2 * ox0 - 1 + x;
             const bool inimg = ((unsigned)iy < (unsigned)a.H) & ((unsigned)ix < (unsigned)a.W);
             const float lo = inimg ? a.normLo : 0.f, hi = inimg ? __builtin_inff() : 0.f;
-            unsigned char *dst = sPatch + Lc * kPixB + kh * 8;
+            unsigned char *dst = sPatch + pr * kPitch + idx * kPixB + kh * 8;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const f32x4 sc4 = *reinterpret_cast<const f32x4 *>(sTab + 8 * q + 4 * kh), sh4 = *reinterpret_cast<const f32x4 *>(sTab + 32 + 8 * q + 4 * kh);
@@ -301,7 +307,7 @@ void stem12_kernel(Stem12Args a)
 #pragma unroll
         for (int kk = 0; kk < 18; ++kk) {
             const int tap = kk >> 1, c = kk & 1, ky = tap / 3, kx = tap - 3 * ky;
-            const unsigned off = (unsigned)((ky * kPW + (kx & 1) * kEven + (kx >> 1)) * kPixB + c * 32);
+            const unsigned off = (unsigned)(ky * kPitch + ((kx & 1) * kEven + (kx >> 1)) * kPixB + c * 32);
             const int slot = kk % D;
             if constexpr (PAIR) {
                 f16x8 fa[2];
@@ -435,7 +441,17 @@ int xl_run_stem12(const xl_op &op, hipStream_t st)
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return XL_ERR_HIP;
         configured[cslot].done(lds, cfgDev);
     }
-    int grid = tileRows == 8 ? 256 : 512;                             // persistent: one / two workgroups per CU
+    // (XL_STEM12_WGS=3, pair form with 4-row tiles: three workgroups per CU - 53 KB of LDS and at most 168 registers each)
+    static const bool wg3 = getenv("XL_STEM12_WGS") && atoi(getenv("XL_STEM12_WGS")) == 3;
+    const bool three = wg3 && pair && tileRows == 4 && 3 * lds <= 160 * 1024;
+    if (three) {
+        static XlLdsLimit configured3;
+        if (configured3.needs(lds, &cfgDev)) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(stem12_kernel<4, true, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return XL_ERR_HIP;
+            configured3.done(lds, cfgDev);
+        }
+    }
+    int grid = tileRows == 8 ? 256 : three ? 768 : 512;               // persistent: one / two (three) workgroups per CU
     if (grid > total) grid = (int)total;
     static const bool clkDbg = getenv("XL_STEM12_CLK") != nullptr;
     a.clk = nullptr;
@@ -444,7 +460,8 @@ int xl_run_stem12(const xl_op &op, hipStream_t st)
         if (pair) hipLaunchKernelGGL((stem12_kernel<8, true>), dim3(grid), dim3(256), lds, st, a);
         else hipLaunchKernelGGL((stem12_kernel<8, false>), dim3(grid), dim3(256), lds, st, a);
     } else {
-        if (pair) hipLaunchKernelGGL((stem12_kernel<4, true>), dim3(grid), dim3(256), lds, st, a);
+        if (three) hipLaunchKernelGGL((stem12_kernel<4, true, 3>), dim3(grid), dim3(256), lds, st, a);
+        else if (pair) hipLaunchKernelGGL((stem12_kernel<4, true>), dim3(grid), dim3(256), lds, st, a);
         else hipLaunchKernelGGL((stem12_kernel<4, false>), dim3(grid), dim3(256), lds, st, a);
     }
     if (clkDbg) {

@@ -246,7 +246,7 @@ int xl_run_wgrad_pair(const xl_op &op, hipStream_t st)
     a.xBytes = (unsigned)xb; a.dyBytes = (unsigned)yb;
     a.coef = (const float *)op.aux2; a.HW = op.Ho * op.Wo;
     a.normLo = (op.flags & XL_CONV_NORM_RELU) ? 0.f : -__builtin_inff();
-    const size_t lds = 4 * (size_t)kOperand;                          // two stages of two operands: 96 KB
+    const size_t lds = 4 * (size_t)kOperand;                          // two stages of two operands: 4 x 16 KB = 64 KB
     static XlLdsLimit configured[2];
     int cfgDev;
     if (configured[norm].needs(lds, &cfgDev)) {

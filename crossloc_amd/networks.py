@@ -456,10 +456,24 @@ class _Plan:
                 seen[op.w] = max(seen.get(op.w, 0), n)
         out = []
         for mod in self.net.modules():
-            if isinstance(mod, nn.GroupNorm) and mod.weight is not None:
-                g, b = self.dev(mod.weight), self.dev(mod.bias)
+            if not isinstance(mod, nn.GroupNorm):
+                continue
+            if mod.weight is None:
+                # affine=False (no reference network has one): gamma = 1, beta = 0 in the bound - constants of the plan
+                if not hasattr(self, "_unit_gn"):
+                    self._unit_gn = {}
+                if mod.num_channels not in self._unit_gn:
+                    self._unit_gn[mod.num_channels] = (torch.ones(mod.num_channels, dtype=torch.float32, device=self.device),
+                                                       torch.zeros(mod.num_channels, dtype=torch.float32, device=self.device))
+                g, b = self._unit_gn[mod.num_channels]
+                n = (mod.num_channels // mod.num_groups) * self.H * self.W
+            else:
+                # (not self.dev(): this runs with every weight refresh and must not grow the plan's keep list - the tensors alias the
+                #  live parameters and are held by the caller's table)
+                g = mod.weight.detach().to(device=self.device, dtype=torch.float32).contiguous()
+                b = mod.bias.detach().to(device=self.device, dtype=torch.float32).contiguous()
                 n = seen.get(g.data_ptr(), (mod.num_channels // mod.num_groups) * self.H * self.W)
-                out.append((g, b, mod.num_channels, float(n) ** 0.5))
+            out.append((g, b, mod.num_channels, float(n) ** 0.5))
         return out
 
     def _update_pair_scales(self):
@@ -469,8 +483,13 @@ class _Plan:
         reading the live parameters - no host synchronisation, so a training loop can call it every step."""
         if not self.pair_ok():
             return
-        if not hasattr(self, "_pair_gn"):
-            layers = self._gn_layers()
+        # (the table holds raw device pointers of gamma / beta: rebuilt whenever a parameter's storage moved - net.to(),
+        #  load_state_dict(assign=True) -, as _repack_pairs re-validates its own tables; ADVICE r5)
+        layers = self._gn_layers()
+        sig = tuple((g.data_ptr(), b.data_ptr()) for g, b, _, _ in layers)
+        if getattr(self, "_pair_gn_sig", None) != sig:
+            self._pair_gn_keep = [(g, b) for g, b, _, _ in layers]
+            self._pair_gn_sig = sig
             n = len(layers)
             self._pair_gn = ((ctypes.c_void_p * n)(*[g.data_ptr() for g, _, _, _ in layers]),
                              (ctypes.c_void_p * n)(*[b.data_ptr() for _, b, _, _ in layers]),

@@ -1,10 +1,11 @@
 # Round-5 evidence (one gpurun call from the repo root).  Order matters: the PMC passes come first, their HBM-side bytes go
 # into profiles/traffic.json (keyed by the hash of the kernel sources), and the bench line written afterwards reads
 # `roofline.traffic` from that record.  Counter passes are separate --pmc passes with kernel tracing only.
-set -x
-cd $GRAFT_REPO_ROOT
-OUT=$GRAFT_REPO_ROOT/gpurun_out/r5
-rm -rf $OUT; mkdir -p $OUT
+set -ux
+: "${GRAFT_REPO_ROOT:?run under gpurun (or export GRAFT_REPO_ROOT)}"
+cd "$GRAFT_REPO_ROOT"
+OUT="$GRAFT_REPO_ROOT/gpurun_out/r5"
+rm -rf "$OUT"; mkdir -p "$OUT"
 B="python $GRAFT_REPO_ROOT/bench.py --no-secondary --no-cpu-baseline"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 -i $GRAFT_REPO_ROOT/tools/pmc_r5.txt --kernel-trace --output-format csv -d $OUT/pmc -- $B --steps 2 --warmup 1 > $OUT/pmc.log 2>&1
