@@ -62,6 +62,23 @@ def lookup_traffic(form, frames):
     return None, "no record for %s at %d frames per launch in profiles/traffic.json" % (form, frames)
 
 
+PEAK_F64_VALU_TFLOPS = 78.65        # fp64 vector FMA: half of the fp32 vector rate (157.3 TFLOP/s, MI355X_MICROARCH.md)
+
+
+def solver_valu_roofline(frames, n_hyp, cells, ms):
+    """The solver against the roof that bounds it - fp64 VALU issue - from the time measured in this run; the issue-side counters
+    (share of cycles a SIMD issued VALU work, fp64 share of it) come from the committed PMC record like `dsac_pmc`."""
+    flop = float(frames) * n_hyp * cells * 60.0
+    achieved = flop / (ms * 1e-3) / 1e12
+    pmc = lookup_solver_counters() or {}
+    return {"bound": "fp64 VALU issue", "algorithmic_fp64_GFLOP_per_batch": round(flop / 1e9, 3), "achieved": round(achieved, 3),
+            "peak": PEAK_F64_VALU_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F64_VALU_TFLOPS, 4),
+            "valu_busy_sample_and_score": pmc.get("sample_and_score_valu_busy"),
+            "fp64_share_of_valu_instructions": pmc.get("sample_and_score_fp64_share_of_valu"),
+            "note": "60 FLOP per (hypothesis, cell) is the useful arithmetic; the kernel's fp64 instruction stream also holds the "
+                    "polynomial exp, divisions as Newton steps and the reductions - valu_busy x fp64 share is the issue-side view"}
+
+
 def lookup_solver_counters():
     """VALU-issue figures of the solver kernels from the committed PMC record (None when there is none)."""
     try:
@@ -549,6 +566,11 @@ def main():
                        "dsac_hbm_roofline_frac": round(B * (NH * 5400 * 12 + 64) / (dsac_ms * 1e-3) / 8e12, 5),
                        # ... which says little for an LDS-resident fp64 kernel: the VALU-issue fraction from the PMC record
                        "dsac_pmc": lookup_solver_counters(),
+                       # the roof that does bound it (round 6): fp64 vector FMA issue.  Algorithmic work = SURVEY.md 8(d)'s scoring count,
+                       # nHyp * N * 60 FLOP per image (projection, residual, soft-inlier sigmoid; sampling, P3P and the LM refinement are
+                       # not counted), all of it fp64 on the device; peak = 78.65 TFLOP/s (half the fp32 vector rate of the guide:
+                       # 157.3 / 2).  Measured on the side stream, i.e. while the next batch's CNN shares the chip
+                       "dsac_valu_roofline": solver_valu_roofline(B, NH, 5400, dsac_ms),
                        # direct-convolution FLOP count of the network over the CNN time; with the Winograd
                        # layers fewer multiplies are executed, so this "algorithmic" rate may exceed the MFMA peak
                        "cnn_fwd_algorithmic_tflops": round((FWD_GFLOP_PER_IMAGE_3ENC if args.mlr else FWD_GFLOP_PER_IMAGE) * B / cnn_ms, 2),

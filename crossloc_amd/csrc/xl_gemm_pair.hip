@@ -69,23 +69,8 @@ struct PairArgs {
     const float *aScale;         // {s, 1 / s} of the activations
     int T, C, N, Z, nbm, nbn;
     long long *clk;              // diagnostics (XL_PAIR_CLK=1): per-wave shader-tick sums of the four phases of a K-step
-    int stagger;                 // > 0: the workgroups start spread over this many ticks of the 100 MHz clock (see stagger_start)
-    int var;                     // measurement switches (XL_PAIR_VAR)
+    int var;                     // measurement switch (XL_PAIR_VAR=4: the epilogue stores as the accumulators lie, 32-byte pieces)
 };
-
-// A persistent launch gives every CU the same tiles of the same size: all 256 workgroups reach their epilogues together, the chip
-// alternates between a phase in which nothing is stored (and the matrix pipes draw all the power) and one in which 64 MB of
-// stores queue at the memory side with every matrix pipe idle.  Spreading the START of the workgroups over one tile period puts
-// the CUs out of phase: at any moment a fraction of them stores while the others multiply.  The phase of a workgroup is a
-// fixed function of its index (a golden-ratio hash: neighbouring indices - the same XCD - far apart).
-__device__ __forceinline__ void stagger_start(int ticks)
-{
-    if (ticks <= 0) return;
-    const unsigned h = (blockIdx.x * 0x9E3779B1u) >> 24;
-    const long long d = ((long long)ticks * h) >> 8;
-    const long long t0 = wall_clock64();
-    while ((long long)wall_clock64() - t0 < d) __builtin_amdgcn_s_sleep(8);
-}
 
 // Epilogue stores (round 6).  A lane of a 32 x 32 accumulator block (swapped operands) holds 4 x 4 consecutive channels of ONE
 // row, 8 apart (the other 4 of each 8 in lane + 32): stored as they lie, an instruction writes 32 bytes into each of 32 rows - 32
@@ -114,7 +99,9 @@ __device__ __forceinline__ f16x8 scale_hs(f16x8 hi) { return hi * (_Float16)0.00
 // have landed - issued in step s - 2; younger are the 4 DMAs of step s - 1 and the 4 of step s: vmcnt(8), and vmcnt(40) in the
 // first TWO steps of a tile that follows another one (the 32 stores of its epilogue lie between).
 // DBG (XL_PAIR_DBG, measurement only - the results are garbage): 1 = no DMA after the prologue, 2 = no fragment reads in the loop,
-// 4 = no barrier / vmcnt wait: what each piece costs under the chip's power limit.
+// 4 = no barrier / vmcnt wait, 8 = no epilogue stores (round 6): what each piece costs under the chip's power limit.
+// Round 6 (random data, 95 frames, one box): full kernel 1.65 ms; no stores 1.35; no DMA 1.36; MFMAs + stores only 1.20; MFMAs only
+// 1.00.  The stores' 0.30 ms was the store PATTERN as much as the bytes: see lane_pair_exchange (1.65 -> 1.56).
 // WM = 1 (round 6, XL_PAIR_PP=1: "ping-pong"): the workgroup is ONE row of four waves - 128 x 256 tiles, 256 threads, a ring of THREE
 // stages of 24 KB - and two of them share a CU, each with its own barrier: a SIMD holds one wave of each, and while one workgroup
 // stores a tile, waits at its barrier or issues its DMAs, the other one multiplies.  Price: the weights' tile is fetched by twice
@@ -142,7 +129,6 @@ void pair_gemm_kernel(PairArgs a)
     const int runLen = q8 + (xcd < r8 ? 1 : 0);
     const int myCount = runLen > local ? (runLen - local + nloc - 1) / nloc : 0;
     if (myCount == 0) return;
-    stagger_start(a.stagger);
 
     const long long rowB = (long long)a.C * 4;                        // bytes per operand row (both operands)
     const int nk = CT ? CT / 16 : a.C / 16;
@@ -303,7 +289,7 @@ void pair_gemm_kernel(PairArgs a)
         const int m0 = mt * BMT, n0 = nt * 256;
         const float inv = aInv * a.uInv[z];                              // (powers of two: the un-scaling is exact)
         const __amdgpu_buffer_rsrc_t srdO = __builtin_amdgcn_make_buffer_rsrc((void *)(a.out + (long long)z * a.T * a.N), 0, (int)((long long)a.T * a.N * 4), 0x00020000);
-        if (!(a.var & 4) && !(DBG & (8 | 48))) {
+        if (!(a.var & 4) && !(DBG & 8)) {
             // (lane_pair_exchange: 64-byte pieces, even rows then odd rows)
             const bool odd = lane & 1;
             const int mE = m0 + wm * 128 + ((lane & 31) & ~1), cL = n0 + wn * 64 + 8 * (lane & 1) + rhalf;
@@ -338,17 +324,7 @@ void pair_gemm_kernel(PairArgs a)
                     const unsigned off = rowOff + (unsigned)n * 4u;
                     const f32x4 v = f32x4{ acc[i][j][4 * q] * inv, acc[i][j][4 * q + 1] * inv, acc[i][j][4 * q + 2] * inv, acc[i][j][4 * q + 3] * inv };
                     if (DBG & 8) continue;                                   // (measurement: no stores)
-                    if (DBG & 48) {
-                        // (measurement, garbage results: the same bytes per instruction laid out as 8 rows x 128 B (16) or 16 rows x
-                        //  64 B (32) instead of 32 rows x 32 B - what the store pattern itself costs)
-                        const int rr = (DBG & 16) ? q * 8 + (lane >> 3) : (q & 1) * 16 + (lane >> 2);
-                        const int cc = (DBG & 16) ? (lane & 7) * 4 : (q >> 1) * 16 + (lane & 3) * 4;
-                        const unsigned o2 = (unsigned)((long long)(m0 + wm * 128 + i * 32 + rr) * a.N * 4) + (unsigned)(n0 + wn * 64 + j * 32 + cc) * 4u;
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), srdO, (int)o2, 0, 0);
-                        continue;
-                    }
-                    if (a.var & 2) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), srdO, (int)off, 0, 2);
-                    else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), srdO, (int)off, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), srdO, (int)off, 0, 0);
                 }
         }
         if (DBG & 8) {                                                   // keep the accumulators alive: one store per tile
@@ -393,8 +369,7 @@ struct PairConvArgs {
     const float *uInv; const float *aScale;          // [Z] inverse weight scales; {s, 1 / s} of the activations
     int amaxShift;                                   // >= 0 (XL_CONV_PAIR_AMAX): aScale points at the float bits of max |operand source| and the
                                                      // scale is derived here: max 2^e in [2^(14 - shift), 2^(15 - shift))
-    int var;                                         // measurement switches (XL_PAIR_VAR)
-    int stagger;                                     // as PairArgs.stagger
+    int var;                                         // measurement switches (unused)
 };
 
 template <bool NORM, bool ACC, int NW, int ZB, int BN, bool RES>               // ACC: out += result
@@ -435,7 +410,6 @@ __device__ __forceinline__ void pair_conv1x1_body(const PairConvArgs &a)
     const int runLen = q8 + (xcd < r8 ? 1 : 0);
     const int myCount = runLen > local ? (runLen - local + nloc - 1) / nloc : 0;
     if (myCount == 0) return;
-    stagger_start(a.stagger);
     auto tile_z = [&](int i) { return (runStart + local + i * nloc) / (a.nbm * a.nbn); };
     auto tile_at = [&](int i, int &m0, int &n0) {
         int t = runStart + local + i * nloc;
@@ -895,16 +869,15 @@ static int xl_run_pair_gemm(const xl_op &op, hipStream_t st)
     const bool pp = pingPong && op.Cin == 512;
     a.nbm = pp ? (T + 127) / 128 : (T + 255) / 256; a.nbn = op.Cout / 256;
     a.clk = nullptr;
-    static const int stagger = getenv("XL_PAIR_STAGGER") ? atoi(getenv("XL_PAIR_STAGGER")) : 0;
     static const int pvar = getenv("XL_PAIR_VAR") ? atoi(getenv("XL_PAIR_VAR")) : 0;
-    a.stagger = stagger; a.var = pvar;
+    a.var = pvar;
     const size_t lds = pp ? 3 * (size_t)(128 * kPA + 256 * kPB)     // 72 KB: two workgroups per CU
                           : 4 * (size_t)(256 * kPA + 256 * kPB);    // 128 KB: one workgroup per CU
     auto kernel = pp ? pair_gemm_kernel<512, 0, 1> : op.Cin == 512 ? pair_gemm_kernel<512> : pair_gemm_kernel<0>;
     static const int dbg = getenv("XL_PAIR_DBG") ? atoi(getenv("XL_PAIR_DBG")) : 0;
     if (dbg && op.Cin == 512 && !pp)
         kernel = dbg == 1 ? pair_gemm_kernel<512, 1> : dbg == 2 ? pair_gemm_kernel<512, 2> : dbg == 3 ? pair_gemm_kernel<512, 3> : dbg == 4 ? pair_gemm_kernel<512, 4>
-               : dbg == 7 ? pair_gemm_kernel<512, 7> : dbg == 8 ? pair_gemm_kernel<512, 8> : dbg == 15 ? pair_gemm_kernel<512, 15> : dbg == 16 ? pair_gemm_kernel<512, 16> : dbg == 32 ? pair_gemm_kernel<512, 32> : dbg == 23 ? pair_gemm_kernel<512, 23> : pair_gemm_kernel<512, 5>;
+               : dbg == 7 ? pair_gemm_kernel<512, 7> : dbg == 8 ? pair_gemm_kernel<512, 8> : dbg == 15 ? pair_gemm_kernel<512, 15> : pair_gemm_kernel<512, 5>;
     static XlLdsLimit configured[4];
     int cfgDev;
     const int slot = pp ? 3 : dbg ? 2 : op.Cin == 512 ? 1 : 0;
@@ -1005,8 +978,7 @@ static int xl_run_pair_conv1x1(const xl_op &op, hipStream_t st)
     a.uInv = reinterpret_cast<const float *>(a.u + (long long)Z * op.Cout * op.Cin * 4) + Z;
     a.aScale = (const float *)op.scale;
     a.amaxShift = (op.flags & XL_CONV_PAIR_AMAX) ? (Z > 1 ? 8 : 0) : -1;
-    static const int stagger = getenv("XL_PAIR_STAGGER1") ? atoi(getenv("XL_PAIR_STAGGER1")) : 0;
-    a.var = 0; a.stagger = stagger;
+    a.var = 0;
     if (op.flags & XL_CONV_NORM_ADD) {
         if (!norm || !(op.flags & XL_CONV_NORM_RELU) || !op.aux || op.ld_aux < op.Cin || (op.ld_aux & 3) || ((uintptr_t)op.aux & 15) || Z > 1 ||
             256LL * op.ld_aux * 4 >= 0x7fffffffLL) return XL_ERR_ARG;

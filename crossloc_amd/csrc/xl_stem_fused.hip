@@ -231,14 +231,36 @@ void stem12_kernel(Stem12Args a)
 #pragma unroll
         for (int kk = 0; kk < D; ++kk) load_b(kk, kk);
 
-        // ---- 2. conv1 on the patch: blocks of 32 patch pixels (linear index L = row * 33 + de-interleaved column)
+        // ---- 2. conv1 on the patch: blocks of 32 patch pixels (linear index L = row * 33 + de-interleaved column).
+        // (round 6: the image fragments of a wave's NEXT block are read while the MFMAs of the current one execute and in front of its
+        //  conversion arithmetic - a block used to be one dependent chain reads -> 18 MFMAs -> conversion -> writes)
+        auto block_pixel = [&](int blk, bool &valid, int &pr, int &idx, int &x) {
+            const int L = blk * 32 + fr;
+            valid = L < kNPix;
+            const int Lc = valid ? L : kNPix - 1;
+            pr = Lc / kPW; idx = Lc - pr * kPW;
+            x = idx < kEven ? 2 * idx : 2 * (idx - kEven) + 1;                    // patch column
+        };
+        auto load_pf = [&](bf16x8 (&pf)[3][3], int pr, int x) {
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) {
+                    const u32x2 *src = sH + p * kHaloPix + (pr + dy) * kHW + x + 2 * kh;
+                    const u32x2 v0 = src[0], v1 = src[1];
+                    pf[p][dy] = __builtin_bit_cast(bf16x8, u32x4{ v0[0], v0[1], v1[0], v1[1] });
+                }
+        };
+        bf16x8 pfN[3][3];
+        {
+            bool v0; int pr0, idx0, x0;
+            block_pixel(wave, v0, pr0, idx0, x0);
+            load_pf(pfN, pr0, x0);
+        }
 #pragma unroll 1
         for (int blk = wave; blk < kBlocks; blk += 4) {
-            const int L = blk * 32 + fr;
-            const bool valid = L < kNPix;
-            const int Lc = valid ? L : kNPix - 1;
-            const int pr = Lc / kPW, idx = Lc - pr * kPW;
-            const int x = idx < kEven ? 2 * idx : 2 * (idx - kEven) + 1;          // patch column
+            bool valid; int pr, idx, x;
+            block_pixel(blk, valid, pr, idx, x);
             f32x16 acc;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -250,17 +272,18 @@ void stem12_kernel(Stem12Args a)
 #pragma unroll
             for (int p = 0; p < 3; ++p)
 #pragma unroll
-                for (int dy = 0; dy < 3; ++dy) {
-                    const u32x2 *src = sH + p * kHaloPix + (pr + dy) * kHW + x + 2 * kh;
-                    const u32x2 v0 = src[0], v1 = src[1];
-                    pf[p][dy] = __builtin_bit_cast(bf16x8, u32x4{ v0[0], v0[1], v1[0], v1[1] });
-                }
+                for (int dy = 0; dy < 3; ++dy) pf[p][dy] = pfN[p][dy];
             constexpr int PW_[6] = { 2, 1, 0, 1, 0, 0 }, PP_[6] = { 0, 1, 2, 0, 1, 0 };   // smallest terms first (conv1_mfma_kernel)
 #pragma unroll
             for (int tm = 0; tm < 6; ++tm)
 #pragma unroll
                 for (int dy = 0; dy < 3; ++dy)
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[PW_[tm]][dy], pf[PP_[tm]][dy], acc, 0, 0, 0);
+            if (blk + 4 < kBlocks) {
+                bool vN; int prN, idxN, xN;
+                block_pixel(blk + 4, vN, prN, idxN, xN);
+                load_pf(pfN, prN, xN);
+            }
             // GroupNorm + ReLU; a conv1 pixel outside the image is conv2's zero padding
             const int iy = 2 * oy0 - 1 + pr, ix = 2 * ox0 - 1 + x;
             const bool inimg = ((unsigned)iy < (unsigned)a.H) & ((unsigned)ix < (unsigned)a.W);
@@ -304,15 +327,29 @@ void stem12_kernel(Stem12Args a)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc2[j][4 * q + e] = b4[e];
             }
+        // (round 6: the activation fragments of K-step kk + 1 are read in front of the MFMAs of step kk - the step used to open with
+        //  its own two reads and wait out their latency with the matrix pipe idle: one accumulator, nothing else to issue)
+        auto tap_off = [&](int kk) {
+            const int tap = kk >> 1, c = kk & 1, ky = tap / 3, kx = tap - 3 * ky;
+            return (unsigned)(ky * kPitch + ((kx & 1) * kEven + (kx >> 1)) * kPixB + c * 32);
+        };
+        f16x8 faN[2];
+        if constexpr (PAIR) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p) faN[p] = *reinterpret_cast<const f16x8 *>(sPatch + aBase + tap_off(0) + p * 64);
+        }
 #pragma unroll
         for (int kk = 0; kk < 18; ++kk) {
-            const int tap = kk >> 1, c = kk & 1, ky = tap / 3, kx = tap - 3 * ky;
-            const unsigned off = (unsigned)(ky * kPitch + ((kx & 1) * kEven + (kx >> 1)) * kPixB + c * 32);
+            const unsigned off = tap_off(kk);
             const int slot = kk % D;
             if constexpr (PAIR) {
                 f16x8 fa[2];
 #pragma unroll
-                for (int p = 0; p < 2; ++p) fa[p] = *reinterpret_cast<const f16x8 *>(sPatch + aBase + off + p * 64);
+                for (int p = 0; p < 2; ++p) fa[p] = faN[p];
+                if (kk + 1 < 18) {
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) faN[p] = *reinterpret_cast<const f16x8 *>(sPatch + aBase + tap_off(kk + 1) + p * 64);
+                }
                 // hs x lo', lo x hi, hi x hi: pair_conv3x3s2_kernel's terms and order
 #pragma unroll
                 for (int j = 0; j < kNJ; ++j) {
@@ -431,7 +468,9 @@ int xl_run_stem12(const xl_op &op, hipStream_t st)
     const long long total = (long long)op.B * a.tilesX * a.tilesY;
     if (total >= 0x7fffffffLL || (op.stats && op.nchunks != a.tilesX * a.tilesY * (tileRows / 2))) return XL_ERR_ARG;
     const size_t lds = (tileRows == 8 ? (pair ? S12<8, true>::kPatchBytes : S12<8>::kPatchBytes) + S12<8>::kHaloBytes
-                                      : (pair ? S12<4, true>::kPatchBytes : S12<4>::kPatchBytes) + S12<4>::kHaloBytes) + 1024;
+                                      : (pair ? S12<4, true>::kPatchBytes : S12<4>::kPatchBytes) + S12<4>::kHaloBytes) + 960;
+    // (tables: 192 floats + the queue's two ints = 776 bytes.  960, not 1024: LDS is handed out in 512-byte granules, and three
+    //  workgroups of the pair form fit a CU only up to 106 granules = 54272 bytes each - 43776 + 9504 + 960 = 54240)
     const void *fn = tileRows == 8 ? (pair ? reinterpret_cast<const void *>(stem12_kernel<8, true>) : reinterpret_cast<const void *>(stem12_kernel<8>))
                                    : (pair ? reinterpret_cast<const void *>(stem12_kernel<4, true>) : reinterpret_cast<const void *>(stem12_kernel<4>));
     static XlLdsLimit configured[4];
