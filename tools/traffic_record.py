@@ -52,7 +52,8 @@ def main():
         assert int(r["dispatches_per_pass"]) % 9 == 0, "9 layers of that shape per forward pass: %s dispatches" % r["dispatches_per_pass"]
         recs.append(record("splitact64", r["kernel"], r))
     # round 5: the same launches as fp16 pairs, both operands by DMA (pair_gemm_kernel<512,0>: Cin = 512, one launch shape)
-    cand = [r for r in rows if r["kernel"].replace(" ", "") == "pair_gemm_kernel<512,0>"]
+    # (round 6: the kernel has a third template argument - <512,0,2> = the 8-wave workgroup; <512,0,1> is the XL_PAIR_PP=1 form)
+    cand = [r for r in rows if r["kernel"].replace(" ", "") in ("pair_gemm_kernel<512,0>", "pair_gemm_kernel<512,0,2>")]
     assert len(cand) <= 1, "the dominant kernel must be one row (one launch shape)"
     if cand:
         r = cand[0]
