@@ -2269,11 +2269,19 @@ class _Plan:
             self.graph, self.graph_stream = h, stream
             weakref.finalize(self, L.xl_cnn_graph_destroy, h)
         self.graph_in.copy_(image)
-        if private is not None:
+        if private is not None and not getattr(self, "graph_on_null_stream", True):
             caller = torch.cuda.current_stream()
             private.wait_stream(caller)                     # the copy-in (and whatever produced the image) before the graph
             rc = L.xl_cnn_graph_launch(self.graph, ctypes.c_void_p(private.cuda_stream))
             caller.wait_stream(private)                     # the caller's next operation - the result copy - behind the graph
+        elif private is not None:
+            # round 6: a graph CAPTURED on the private stream may be LAUNCHED on the default stream - only capture is refused
+            # there - so the copy-in, the graph and the result copy are simply in stream order: no events, four driver calls
+            # fewer per frame.  A runtime that refuses falls back to the bracketed form for the life of the plan.
+            rc = L.xl_cnn_graph_launch(self.graph, ctypes.c_void_p(0))
+            if rc != 0 and rc != XL_ERR_UNSUPPORTED:
+                self.graph_on_null_stream = False
+                return self._run_graph_retry(image, stream)
         else:
             rc = L.xl_cnn_graph_launch(self.graph, ctypes.c_void_p(stream))
         if rc == XL_ERR_UNSUPPORTED:                        # per-op profiling is on: this call runs eagerly
@@ -2281,6 +2289,10 @@ class _Plan:
         if rc != 0:
             return self._graph_give_up("launch", rc)
         return self.graph_out.clone()
+
+    def _run_graph_retry(self, image, stream):
+        self.graph_runs -= 1                                 # (this call was counted already)
+        return self._run_graph(image, stream)
 
     def _graph_give_up(self, what, rc):
         """A capture / launch failure must not make small-batch inference unusable where the eager path works (a call inside the

@@ -1082,7 +1082,9 @@ def test_small_batch_forward_as_a_hip_graph_and_small_tile_form(monkeypatch):
 @pytest.mark.skipif(os.environ.get("XL_GEMM_SPLIT_BF16") in ("0", "1") or os.environ.get("XL_CNN_GRAPH") == "0", reason="graph path switched off")
 def test_default_stream_calls_replay_the_graph_on_a_private_stream(monkeypatch):
     """Round 5 (the reference's unchanged loop, test_single_task.py:347: `network(image.cuda())` on the DEFAULT stream): HIP
-    cannot capture on the default stream, so the plan captures and replays its graph on a private stream bracketed by events.
+    cannot capture on the default stream, so the plan captures its graph on a private stream - and (round 6) LAUNCHES it on the
+    default stream itself: copy-in, graph and result copy in stream order, no event brackets (the bracketed replay on the private
+    stream stays as the fallback for a runtime that refuses, and is exercised here by switching the plan to it).
     Bitwise the eager op list, new images picked up, the result usable at once by default-stream work and by `.cpu()`; a call
     from a created stream afterwards falls back to the eager list (one stream per plan)."""
     net = networks.TransPoseNet(MEAN, False, False, 1, 1, 3, 1)
@@ -1110,6 +1112,11 @@ def test_default_stream_calls_replay_the_graph_on_a_private_stream(monkeypatch):
         y = net(xs[1])
     st.synchronize()
     assert torch.equal(y, want[1]) and plan.graph_runs == 5
+    assert getattr(plan, "graph_on_null_stream", True)                  # the direct launch was accepted
+    plan.graph_on_null_stream = False                                   # the round-5 form: replay on the private stream between events
+    with torch.no_grad():
+        y = net(xs[2])
+    assert torch.equal((y * 2.0).cpu(), (want[2] * 2.0).cpu()) and plan.graph_runs == 6
 
 
 @pytest.mark.skipif(bool(os.environ.get("XL_NO_WINOGRAD")), reason="asserts the Winograd forms of the default plans (measurement switch set)")

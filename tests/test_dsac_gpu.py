@@ -135,6 +135,62 @@ def test_reference_shaped_call_cpu_and_gpu_tensors(oracle, binding):
         dsacstar.backward_rgbd()
 
 
+def test_host_call_keeps_its_buffers_across_sizes_and_threads(oracle):
+    """Round 6: the host entry point (the reference's per-frame call shape) keeps a per-thread staging workspace between calls.
+    Grids that grow and shrink from call to call, non-contiguous host tensors and two threads calling at once must all give the
+    oracle's pose bit for bit."""
+    import threading
+    import crossloc_amd.dsacstar as shim
+    scenes = [synth.make_scene(60 + i, noise=0.3, outlier_ratio=0.2, Ho=h, Wo=w) for i, (h, w) in enumerate([(8, 12), (60, 90), (33, 17), (60, 90)])]
+
+    def run(sc, image, n_hyp=32):
+        coords = torch.from_numpy(sc["coords"])[None]
+        shim.set_image_index(image)
+        out = torch.zeros((4, 4))
+        shim.forward_rgb(coords, out, n_hyp, 10.0, 480.0, float(sc["ppx"]), float(sc["ppy"]), 100.0, 100.0, 8)
+        ref = oracle.forward_rgb(sc["coords"], n_hyp, 10.0, 480.0, sc["ppx"], sc["ppy"], 100.0, 100.0, 8, image=image)
+        assert np.array_equal(out.numpy(), ref), (sc["coords"].shape, image)
+
+    for i, sc in enumerate(scenes):
+        run(sc, 100 + i)
+    # a strided host view (every second column of a wider buffer)
+    sc = scenes[1]
+    wide = np.zeros((3, 60, 180), np.float32)
+    wide[:, :, ::2] = sc["coords"]
+    view = torch.from_numpy(wide)[None][:, :, :, ::2]
+    assert not view.is_contiguous()
+    shim.set_image_index(7)
+    out = torch.zeros((4, 4))
+    shim.forward_rgb(view, out, 32, 10.0, 480.0, float(sc["ppx"]), float(sc["ppy"]), 100.0, 100.0, 8)
+    assert np.array_equal(out.numpy(), oracle.forward_rgb(sc["coords"], 32, 10.0, 480.0, sc["ppx"], sc["ppy"], 100.0, 100.0, 8, image=7))
+    # two threads, each with its own workspace and stream (the C entry point directly: the module's image counter is per process)
+    from crossloc_amd import _lib
+    L = _lib.lib()
+    errors = []
+
+    def worker(k):
+        try:
+            for rep in range(6):
+                s = scenes[(k + rep) % len(scenes)]
+                c = np.ascontiguousarray(s["coords"])
+                pose = np.zeros((4, 4), np.float32)
+                N = c.shape[1] * c.shape[2]
+                rc = L.xl_dsac_forward_rgb_host(ctypes.c_void_p(c.ctypes.data), N, c.shape[2], 1, c.shape[1], c.shape[2],
+                                                ctypes.c_void_p(pose.ctypes.data), 16, 10.0, 480.0, s["ppx"], s["ppy"], 100.0, 100.0, 8,
+                                                1305, 1000 * k + rep, 1000000, None, None, None, None)
+                assert rc == 0
+                ref = oracle.forward_rgb(s["coords"], 16, 10.0, 480.0, s["ppx"], s["ppy"], 100.0, 100.0, 8, image=1000 * k + rep)
+                assert np.array_equal(pose, ref)
+        except Exception as e:                                            # noqa: BLE001
+            errors.append(e)
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+
+
 def test_full_size_batch_properties():
     """BASELINE size (256 hypotheses, 60x90) on a larger batch: size-independent properties."""
     B = 64
