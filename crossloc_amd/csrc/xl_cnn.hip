@@ -2589,16 +2589,19 @@ extern "C" {
 // which op of a list a launcher refused (the launchers return a bare status): read back through xl_cnn_last_error()
 static void note_failed_op(const xl_op &op, int index, int rc)
 {
-    if (rc == XL_ERR_HIP && g_err[0]) return;                             // (a HIP error already carries its own text)
-    snprintf(g_err, sizeof(g_err), "op %d refused (type %d, k%d s%d, %d -> %d channels, in %dx%d out %dx%d, B %d, ld %d/%d, flags 0x%x, Z %d, form %d)",
-             index, op.type, op.ksize, op.stride, op.Cin, op.Cout, op.Hi, op.Wi, op.Ho, op.Wo, op.B, op.ld_in, op.ld_out, (unsigned)op.flags,
-             op.nchunks2, op.reserved_i);
+    (void)rc;
+    char why[160];
+    snprintf(why, sizeof(why), "%s", g_err);                              // (a launcher's own text - cleared at the head of the list - stays in front)
+    snprintf(g_err, sizeof(g_err), "%s%sop %d refused (type %d, k%d s%d, %d -> %d channels, in %dx%d out %dx%d, B %d, ld %d/%d, flags 0x%x, Z %d, form %d)",
+             why, why[0] ? "; " : "", index, op.type, op.ksize, op.stride, op.Cin, op.Cout, op.Hi, op.Wi, op.Ho, op.Wo, op.B, op.ld_in, op.ld_out,
+             (unsigned)op.flags, op.nchunks2, op.reserved_i);
 }
 
 int xl_cnn_run(const xl_op *ops, int n_ops, void *stream)
 {
     if (!ops || n_ops < 0) return XL_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
+    g_err[0] = 0;
     for (int i = 0; i < n_ops; ++i) {
         const bool rec = g_profOn && g_profCount < g_profCap && (g_profType < 0 || ops[i].type == g_profType) &&
                          ops[i].nchunks2 >= g_profMinBatched;
@@ -2627,6 +2630,7 @@ int xl_cnn_graph_capture(const xl_op *ops, int n_ops, void *stream, void **graph
     const bool prof = g_profOn;
     g_profOn = false;                                                      // event records are not part of a graph
     if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) { g_profOn = prof; return XL_ERR_HIP; }
+    g_err[0] = 0;
     int rc = XL_OK;
     for (int i = 0; i < n_ops && rc == XL_OK; ++i) {
         rc = run_op(ops[i], st);

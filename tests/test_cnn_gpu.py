@@ -459,6 +459,28 @@ def test_head_vs_torch():
     assert (got[:, 3] >= np.exp(-16.10) * 0.999).all() and (got[:, 3] <= np.exp(13.82) * 1.001).all()
 
 
+def test_a_refused_op_is_named_in_the_error():
+    """Round 6: a launcher that refuses an op returns a bare status; xl_cnn_run says WHICH op of the list it was (index, type,
+    shapes, flags) - the tiny network's head (128 channels) was found that way - and keeps a launcher's own text in front."""
+    from crossloc_amd import _lib
+    x = torch.zeros(1, 8, 12, 6, device="cuda")
+    op = networks.XlOp()
+    op.type = networks.XL_OP_HEAD
+    op.B, op.Hi, op.Wi, op.Cin, op.Ho, op.Wo, op.Cout, op.n_task, op.n_pos, op.ld_in = 1, 8, 12, 6, 8, 12, 4, 3, 1, 6    # Cin % 4 != 0
+    op.in_ = op.w = op.bias = op.aux = op.out = x.data_ptr()
+    good = networks.XlOp()
+    good.type = networks.XL_OP_HEAD
+    good.B, good.Hi, good.Wi, good.Cin, good.Ho, good.Wo, good.Cout, good.n_task, good.n_pos, good.ld_in = 1, 2, 3, 8, 2, 3, 4, 3, 1, 8
+    buf = torch.zeros(256, device="cuda")
+    good.in_ = good.w = good.bias = good.aux = buf.data_ptr()
+    good.out = torch.zeros(64, device="cuda").data_ptr()
+    with pytest.raises(_lib.XlError) as e:
+        _run([good, op])
+    msg = str(e.value)
+    assert "op 1 refused" in msg and "type %d" % networks.XL_OP_HEAD in msg and "6 -> 4 channels" in msg, msg
+    _run([good])                                                          # (and the library is usable afterwards)
+
+
 @pytest.mark.parametrize("tag,num_mlr", [("single", 0), ("mlr3", 3)])
 def test_network_matches_reference_golden(tag, num_mlr):
     net = networks.TransPoseNet(MEAN, False, False, 2, 2, 3, 1, 32, num_mlr, 0, False)
