@@ -2454,8 +2454,8 @@ class TransPoseNet(nn.Module):
 
     def _tensors(self):
         """(parameters, version) - the parameter list of the module tree and the sum of all parameter / buffer version counters.
-        `nn.Module.parameters()` walks the tree with a de-duplicating generator: ~0.1 ms per call for this network, paid twice per
-        forward - a twentieth of a single frame's 2 ms in the reference's per-frame loop (round 6).  The (owner, name, tensor) triples
+        `nn.Module.parameters()` / `.buffers()` walk the tree with de-duplicating generators: 0.35 ms of host time per forward for this
+        network (versions + the parameter list) - a sixth of a single frame's 2 ms in the reference's per-frame loop (round 6), now 0.02.  The (owner, name, tensor) triples
         are cached; every call re-checks each slot by identity (a replaced parameter object, a moved module: the cache is rebuilt),
         which is a dictionary look-up per tensor instead of a tree walk."""
         cache = self.__dict__.get("_tensor_cache")
@@ -2478,7 +2478,6 @@ class TransPoseNet(nn.Module):
                     seen.add(id(t)); cache.append((mod, name, t, False))
         self.__dict__["_tensor_cache"] = cache
         self.__dict__["_param_list"] = list(self.parameters())            # (the order autograd's inputs are bound in)
-        self.__dict__["_n_modules"] = sum(1 for _ in self.modules())
         return self.__dict__["_param_list"], sum(t._version for _, _, t, _ in cache)
 
     def _version(self):
