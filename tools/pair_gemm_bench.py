@@ -22,6 +22,13 @@ U6 = torch.zeros(3 * nf * N * C, dtype=torch.int16, device="cuda")
 networks._check(L.xl_cnn_pack_wino_weight(Wt.data_ptr(), U6.data_ptr(), N, C, 6, 0, 2, None))
 U32 = torch.zeros(nf * N * C, device="cuda")
 networks._check(L.xl_cnn_pack_wino_weight(Wt.data_ptr(), U32.data_ptr(), N, C, 6, 0, 0, None))
+# XL_PAIR_LO_MASK=k (experiment, round 6): clear the k low mantissa bits of every LOW term (lo' of V, lo of U) - does the matrix
+# pipe draw less power, and so clock higher, on operands with fewer set bits?  (error vs float64 printed below)
+_k = int(os.environ.get("XL_PAIR_LO_MASK", "0"))
+if _k:
+    m = torch.tensor(-(1 << _k), dtype=torch.int16, device="cuda")
+    Vp.view(-1, 2, 8)[:, 1, :] &= m
+    Up[: 2 * nf * N * C].view(-1, 2, 16)[:, 1, :] &= m
 outs = {}
 
 
